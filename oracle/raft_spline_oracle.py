@@ -1,0 +1,543 @@
+"""CPU ORACLE for the RAFT-spline inference hot path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+This file is a functional, torch-CPU (fp32) restatement of the reference algorithm
+(uzh-rpg/bflow).  It exists to check the HIP path; only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.  The product
+package (`bflow_amd`) never imports anything from `oracle/`.
+
+Pinning: the reference ships no tests / golden vectors for this path, so the
+oracle is pinned against OUTPUTS OF THE REFERENCE ITSELF, run in the build container:
+  * live   : tests/test_oracle_vs_reference.py (runs whenever /root/reference is present)
+  * frozen : tests/golden/*.npz, produced by tests/golden/make_golden.py from the reference.
+
+Every function cites the reference file:line it restates (paths relative to the reference root).
+The model is expressed over a flat state dict {reference parameter name: tensor} instead of
+nn.Modules, so there is exactly one code path per op and no hidden module state.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+StateDict = Dict[str, Tensor]
+
+LOOKUP_RADIUS = 4  # hard-coded in the reference: models/raft_spline/raft.py:40, raft_utils/corr.py:279
+
+
+# --------------------------------------------------------------------------------------
+# Parameter inventory + deterministic weights
+# --------------------------------------------------------------------------------------
+def _encoder_shapes(prefix: str, c_in: int, c_out: int, norm: str, out: Dict[str, Tuple[int, ...]]):
+    """Parameter names/shapes of BasicEncoder (models/raft_utils/extractor.py:58-100)."""
+
+    def conv(name, co, ci, kh, kw):
+        out[f"{prefix}.{name}.weight"] = (co, ci, kh, kw)
+        out[f"{prefix}.{name}.bias"] = (co,)
+
+    def bn(name, c):
+        if norm != "batch":
+            return  # InstanceNorm2d has no parameters (affine=False), extractor.py:27-31
+        out[f"{prefix}.{name}.weight"] = (c,)
+        out[f"{prefix}.{name}.bias"] = (c,)
+        out[f"{prefix}.{name}.running_mean"] = (c,)
+        out[f"{prefix}.{name}.running_var"] = (c,)
+        out[f"{prefix}.{name}.num_batches_tracked"] = ()
+
+    bn("norm1", 64)
+    conv("conv1", 64, c_in, 7, 7)
+    cin = 64
+    for li, (dim, stride) in enumerate(((64, 1), (96, 2), (128, 2)), start=1):
+        for bi in range(2):
+            p = f"layer{li}.{bi}"
+            s = stride if bi == 0 else 1
+            conv(f"{p}.conv1", dim, cin, 3, 3)
+            conv(f"{p}.conv2", dim, dim, 3, 3)
+            bn(f"{p}.norm1", dim)
+            bn(f"{p}.norm2", dim)
+            if s != 1:
+                bn(f"{p}.norm3", dim)  # registered twice: as .norm3 and as .downsample.1 (extractor.py:43-44)
+                conv(f"{p}.downsample.0", dim, cin, 1, 1)
+                bn(f"{p}.downsample.1", dim)
+            cin = dim
+    conv("conv2", c_out, 128, 1, 1)
+
+
+def num_corr_planes(cfg: Dict[str, Any]) -> int:
+    """models/raft_spline/update.py:69-86 (_num_cor_planes)."""
+    corr = cfg["correlation"]
+    n = 0
+    if cfg["use_events"]:
+        for lvl, rad in zip(corr["ev"]["levels"], corr["ev"]["radius"]):
+            n += lvl * (2 * rad + 1) ** 2
+    if cfg["use_boundary_images"]:
+        n += corr["img"]["levels"] * (2 * corr["img"]["radius"] + 1) ** 2
+    return n
+
+
+def param_shapes(cfg: Dict[str, Any]) -> Dict[str, Tuple[int, ...]]:
+    """All state-dict entries of RAFTSpline (models/raft_spline/raft.py:15-73), in module order."""
+    out: Dict[str, Tuple[int, ...]] = {}
+    hdim, cdim = cfg["hidden"]["dim"], cfg["context"]["dim"]
+    fdim = cfg["feature"]["dim"]
+    ctx_in = 0
+    if cfg["use_boundary_images"]:
+        _encoder_shapes("fnet_img", 3, fdim, cfg["feature"]["norm"], out)
+        ctx_in += 3
+    if cfg["use_events"]:
+        _encoder_shapes("fnet_ev", cfg["num_bins"]["correlation"], fdim, cfg["feature"]["norm"], out)
+        ctx_in += cfg["num_bins"]["context"]
+    _encoder_shapes("cnet", ctx_in, hdim + cdim, cfg["context"]["norm"], out)
+    deg2 = 2 * cfg["bezier_degree"]
+    mdim = cfg["motion"]["dim"]
+
+    def conv(name, co, ci, kh, kw):
+        out[f"update_block.{name}.weight"] = (co, ci, kh, kw)
+        out[f"update_block.{name}.bias"] = (co,)
+
+    conv("encoder.convc1", 256, num_corr_planes(cfg), 1, 1)   # update.py:56
+    conv("encoder.convc2", 192, 256, 3, 3)                    # update.py:58
+    conv("encoder.convf1", 128, deg2, 7, 7)                   # update.py:62
+    conv("encoder.convf2", 64, 128, 3, 3)                     # update.py:64
+    conv("encoder.conv", mdim - deg2, 64 + 192, 3, 3)         # update.py:67
+    gin = hdim + cdim + mdim
+    conv("gru.convz1", hdim, gin, 1, 5)
+    conv("gru.convr1", hdim, gin, 1, 5)
+    conv("gru.convq1", hdim, gin, 1, 5)
+    conv("gru.convz2", hdim, gin, 5, 1)
+    conv("gru.convr2", hdim, gin, 5, 1)
+    conv("gru.convq2", hdim, gin, 5, 1)
+    conv("bezier_head.conv1", 256, hdim, 3, 3)
+    conv("bezier_head.conv2", deg2, 256, 3, 3)
+    conv("mask.0", 256, hdim, 3, 3)
+    conv("mask.2", 64 * 9, 256, 1, 1)
+    return out
+
+
+# Per-layer gains that keep the recurrent loop in a numerically meaningful regime with random weights
+# (un-saturated GRU state, ~0.3 px/iteration updates at 1/8 resolution so look-ups stay inside the volume).
+_LAYER_GAINS = (("update_block.bezier_head.conv2.", 0.1), ("update_block.gru.", 0.2),
+                ("update_block.encoder.convc1.", 0.1), ("cnet.conv2.", 0.1))
+
+
+def make_state_dict(cfg: Dict[str, Any], seed: int = 0, gain: float = 1.0) -> StateDict:
+    """Deterministic weights, independent of the torch RNG: numpy RandomState(seed), tensors filled in
+    SORTED name order.  Conv weights ~ N(0, sqrt(2/fan_out)) (the encoder's kaiming fan_out init,
+    extractor.py:85-87, applied everywhere), biases ~ U(-0.05, 0.05), BN affine near identity, BN running
+    stats non-trivial.  `.norm3` and `.downsample.1` of a BatchNorm residual block are the same module in the
+    reference (extractor.py:43-44) and therefore get identical values."""
+    shapes = param_shapes(cfg)
+    rs = np.random.RandomState(seed)
+    sd: StateDict = {}
+    for name in sorted(shapes):
+        shp = shapes[name]
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.tensor(100, dtype=torch.int64)
+            continue
+        if ".downsample.1." in name:
+            continue  # aliased below
+        leaf = name.rsplit(".", 1)[1]
+        if len(shp) == 4:
+            fan_out = shp[0] * shp[2] * shp[3]
+            g = gain
+            for pfx, lg in _LAYER_GAINS:
+                if name.startswith(pfx):
+                    g = g * lg
+            arr = rs.standard_normal(shp) * math.sqrt(2.0 / fan_out) * g
+        elif leaf == "running_var":
+            arr = rs.uniform(0.5, 1.5, shp)
+        elif leaf == "running_mean":
+            arr = rs.uniform(-0.1, 0.1, shp)
+        elif leaf == "weight":  # BN gamma
+            arr = rs.uniform(0.9, 1.1, shp)
+        else:  # conv bias / BN beta
+            arr = rs.uniform(-0.05, 0.05, shp)
+        sd[name] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+    for name in shapes:
+        if ".downsample.1." in name:
+            sd[name] = sd[name.replace(".downsample.1.", ".norm3.")]
+    return {k: sd[k] for k in shapes}
+
+
+# --------------------------------------------------------------------------------------
+# K4: feature / context encoder
+# --------------------------------------------------------------------------------------
+def _norm(sd: StateDict, name: str, x: Tensor, kind: str) -> Tensor:
+    if kind == "instance":  # nn.InstanceNorm2d defaults: eps=1e-5, no affine, no running stats
+        return F.instance_norm(x, eps=1e-5)
+    if kind == "batch":     # eval mode (Lightning validate -> eval; raft.py:75-78 freeze_bn)
+        return F.batch_norm(x, sd[f"{name}.running_mean"], sd[f"{name}.running_var"],
+                            sd[f"{name}.weight"], sd[f"{name}.bias"], training=False, eps=1e-5)
+    if kind == "none":
+        return x
+    raise NotImplementedError(kind)
+
+
+def _conv(sd: StateDict, name: str, x: Tensor, stride=1, padding=0) -> Tensor:
+    return F.conv2d(x, sd[f"{name}.weight"], sd[f"{name}.bias"], stride=stride, padding=padding)
+
+
+def _residual_block(sd: StateDict, p: str, x: Tensor, kind: str, stride: int) -> Tensor:
+    """models/raft_utils/extractor.py:47-55."""
+    y = torch.relu(_norm(sd, f"{p}.norm1", _conv(sd, f"{p}.conv1", x, stride=stride, padding=1), kind))
+    y = torch.relu(_norm(sd, f"{p}.norm2", _conv(sd, f"{p}.conv2", y, padding=1), kind))
+    if stride != 1:
+        x = _norm(sd, f"{p}.norm3", _conv(sd, f"{p}.downsample.0", x, stride=stride), kind)
+    return torch.relu(x + y)
+
+
+def encoder(sd: StateDict, prefix: str, x: Union[Tensor, Sequence[Tensor]], kind: str):
+    """BasicEncoder.forward, models/raft_utils/extractor.py:103-125.  A list input is concatenated along the
+    batch axis (:106-110) and split again (:122-123)."""
+    is_list = isinstance(x, (list, tuple))
+    if is_list:
+        nb, length = x[0].shape[0], len(x)
+        x = torch.cat(list(x), dim=0)
+    x = torch.relu(_norm(sd, f"{prefix}.norm1", _conv(sd, f"{prefix}.conv1", x, stride=2, padding=3), kind))
+    for li, stride in ((1, 1), (2, 2), (3, 2)):
+        x = _residual_block(sd, f"{prefix}.layer{li}.0", x, kind, stride)
+        x = _residual_block(sd, f"{prefix}.layer{li}.1", x, kind, 1)
+    x = _conv(sd, f"{prefix}.conv2", x)
+    if is_list:
+        return list(torch.split(x, [nb] * length, dim=0))
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# K5 / K6: all-pairs correlation volume + pyramid
+# --------------------------------------------------------------------------------------
+def corr_volume(fmap1: Tensor, fmap2: Tensor) -> Tensor:
+    """CorrComputation._corr_dot_prod_util, models/raft_utils/corr.py:264-272.
+    fmap1: (B,D,h,w) [1-to-N, :237-246] or (T,B,D,h,w) [M-to-N, :248-262];  fmap2: (T,B,D,h,w).
+    Returns (T, B*h*w, 1, h, w)."""
+    T, B, D, h, w = fmap2.shape
+    f2 = fmap2.reshape(T, B, D, h * w)
+    if fmap1.ndim == 4:
+        f1 = fmap1.reshape(B, D, h * w)
+    else:
+        f1 = fmap1.reshape(T, B, D, h * w)
+    corr = f1.transpose(-1, -2) @ f2
+    corr = corr / torch.sqrt(torch.tensor(D).float())
+    return corr.reshape(T, B * h * w, 1, h, w)
+
+
+def corr_pyramid(volume: Tensor, levels_per_target: Sequence[int]) -> List[Tuple[Tensor, List[int]]]:
+    """CorrBlockParallelMultiTarget.__init__, corr.py:297-305 + CorrData.get_downsampled :108-125.
+    Returns [(corr_L (T_L, B*N, 1, h_L, w_L), base-target indices living at level L)] for L = 0..max-1."""
+    levels_per_target = [int(v) for v in levels_per_target]
+    pyr = [(volume, list(range(volume.shape[0])))]
+    for num_levels in range(2, max(levels_per_target) + 1):
+        prev, prev_idx = pyr[-1]
+        keep = [t for t, lv in enumerate(levels_per_target) if lv >= num_levels]
+        sel = prev[[prev_idx.index(t) for t in keep]]
+        tn, bhw, _, ht, wd = sel.shape
+        down = F.avg_pool2d(sel.reshape(-1, 1, ht, wd), 2, stride=2)   # floor on odd sizes (corr.py:119)
+        pyr.append((down.reshape(tn, bhw, 1, down.shape[-2], down.shape[-1]), keep))
+    return pyr
+
+
+def bilinear_sampler(img: Tensor, coords: Tensor) -> Tensor:
+    """models/raft_utils/utils.py:5-21: pixel coords -> [-1,1] -> grid_sample(bilinear, zeros, align_corners=True)."""
+    H, W = img.shape[-2:]
+    xg, yg = coords.split([1, 1], dim=-1)
+    xg = 2 * xg / (W - 1) - 1
+    yg = 2 * yg / (H - 1) - 1
+    return F.grid_sample(img, torch.cat([xg, yg], dim=-1), align_corners=True)
+
+
+def corr_lookup(pyramid: List[Tuple[Tensor, List[int]]], coords: Union[Tensor, Sequence[Tensor]],
+                radius: int = LOOKUP_RADIUS) -> Tensor:
+    """CorrBlockParallelMultiTarget.__call__, corr.py:307-351.  coords: (T,B,2,h,w) -> (B, P*(2r+1)^2, h, w).
+    Window channel order: x (dx) varies fastest (corr.py:328-331)."""
+    if isinstance(coords, (list, tuple)):
+        coords = torch.stack(list(coords), dim=0)
+    coords = coords.permute(0, 1, 3, 4, 2)
+    T, B, h1, w1, _ = coords.shape
+    r = radius
+    d = torch.linspace(-r, r, 2 * r + 1)
+    dyy, dxx = torch.meshgrid(d, d, indexing="ij")
+    delta = torch.stack([dxx, dyy], dim=-1).view(1, 2 * r + 1, 2 * r + 1, 2)  # [...,0]=x, [...,1]=y
+    outs = []
+    for lvl, (corr, tidx) in enumerate(pyramid):
+        sel = coords[tidx]
+        nt = len(tidx)
+        centroid = sel.reshape(nt * B * h1 * w1, 1, 1, 2) / 2 ** lvl
+        feat = bilinear_sampler(corr.reshape(-1, 1, corr.shape[-2], corr.shape[-1]), centroid + delta)
+        outs.append(feat.view(nt, B, h1, w1, -1))
+    out = torch.cat(outs, dim=0).permute(1, 0, 4, 2, 3)
+    return out.reshape(B, -1, h1, w1).float()
+
+
+# --------------------------------------------------------------------------------------
+# K8 / K12 / K14: Bezier curves
+# --------------------------------------------------------------------------------------
+def bezier_coeffs(times: Sequence[float], degree: int) -> np.ndarray:
+    """(len(times), degree) float64 matrix  C(deg,i) (1-t)^(deg-i) t^i, i=1..deg.
+    models/raft_spline/bezier.py:141-163,175-178 (scipy.special.binom == math.comb for these integers)."""
+    ts = np.asarray(times, dtype="float64")
+    assert ts.size > 0 and ts.min() >= 0 and ts.max() <= 1
+    out = np.zeros((ts.size, degree))
+    for ti in range(ts.size):
+        for di in range(degree):
+            i = di + 1
+            out[ti, di] = float(math.comb(degree, i)) * ((1 - ts[ti]) ** (degree - i) * ts[ti] ** i)
+    return out
+
+
+def bezier_flow(params: Tensor, time: Union[float, int, Sequence[float]]) -> Tensor:
+    """BezierCurves.get_flow_from_reference, bezier.py:188-216 (+ :165-186).
+    params (B, 2*deg, h, w), channel = dim*deg + (i-1) (:134-135).  Scalar time -> (B,2,h,w); list -> (T,B,2,h,w)."""
+    B, C, h, w = params.shape
+    deg = C // 2
+    pv = params.view(B, 2, deg, h, w)
+    scalar = isinstance(time, (int, float))
+    if scalar:
+        assert 0.0 <= time <= 1.0
+        if time == 1:
+            return pv[:, :, -1]
+        if time == 0:
+            return torch.zeros((B, 2, h, w), dtype=params.dtype)
+        time = [time]
+    coeffs = torch.from_numpy(bezier_coeffs(time, deg)).float()
+    flow = torch.einsum("bdphw,tp->tbdhw", pv, coeffs)
+    return flow[0] if scalar else flow
+
+
+def coords_grid(batch: int, ht: int, wd: int) -> Tensor:
+    """models/raft_utils/utils.py:24-30: channel 0 = x, channel 1 = y."""
+    ys, xs = torch.meshgrid(torch.arange(ht), torch.arange(wd), indexing="ij")
+    return torch.stack([xs, ys], dim=0).float()[None].repeat(batch, 1, 1, 1)
+
+
+def cvx_upsample(data: Tensor, mask: Tensor) -> Tensor:
+    """models/raft_utils/utils.py:33-48: softmax over the 9 taps, 3x3 unfold of 8*data, pixel shuffle x8."""
+    N, dim, H, W = data.shape
+    m = torch.softmax(mask.view(N, 1, 9, 8, 8, H, W), dim=2)
+    up = F.unfold(8 * data, [3, 3], padding=1).view(N, dim, 9, 1, 1, H, W)
+    up = torch.sum(m * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(N, dim, 8 * H, 8 * W)
+
+
+# --------------------------------------------------------------------------------------
+# K9-K11: update block
+# --------------------------------------------------------------------------------------
+def motion_encoder(sd: StateDict, bezier: Tensor, corr: Tensor) -> Tensor:
+    """BasicMotionEncoder.forward, models/raft_spline/update.py:88-97."""
+    p = "update_block.encoder"
+    cor = torch.relu(_conv(sd, f"{p}.convc1", corr))
+    cor = torch.relu(_conv(sd, f"{p}.convc2", cor, padding=1))
+    bez = torch.relu(_conv(sd, f"{p}.convf1", bezier, padding=3))
+    bez = torch.relu(_conv(sd, f"{p}.convf2", bez, padding=1))
+    out = torch.relu(_conv(sd, f"{p}.conv", torch.cat([cor, bez], dim=1), padding=1))
+    return torch.cat([out, bezier], dim=1)
+
+
+def sep_conv_gru(sd: StateDict, h: Tensor, x: Tensor) -> Tensor:
+    """SepConvGRU.forward, update.py:33-48: horizontal (1x5) then vertical (5x1) GRU step."""
+    p = "update_block.gru"
+    for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(_conv(sd, f"{p}.convz{sfx}", hx, padding=pad))
+        r = torch.sigmoid(_conv(sd, f"{p}.convr{sfx}", hx, padding=pad))
+        q = torch.tanh(_conv(sd, f"{p}.convq{sfx}", torch.cat([r * h, x], dim=1), padding=pad))
+        h = (1 - z) * h + z * q
+    return h
+
+
+def update_block(sd: StateDict, net: Tensor, inp: Tensor, corr: Tensor, bezier: Tensor):
+    """BasicUpdateBlock.forward, update.py:116-126 -> (net, mask, delta_bezier)."""
+    mf = motion_encoder(sd, bezier, corr)
+    net = sep_conv_gru(sd, net, torch.cat([inp, mf], dim=1))
+    p = "update_block.bezier_head"
+    delta = _conv(sd, f"{p}.conv2", torch.relu(_conv(sd, f"{p}.conv1", net, padding=1)), padding=1)
+    m = _conv(sd, "update_block.mask.2", torch.relu(_conv(sd, "update_block.mask.0", net, padding=1)))
+    return net, 0.25 * m, delta
+
+
+# --------------------------------------------------------------------------------------
+# RAFTSpline.forward
+# --------------------------------------------------------------------------------------
+def lookup_times(cfg: Dict[str, Any]) -> List[float]:
+    """models/raft_spline/raft.py:156,170-177."""
+    ts: List[float] = []
+    if cfg["use_events"]:
+        dt = 1 / (cfg["num_bins"]["context"] - 1)
+        ts += [dt * t for t in cfg["correlation"]["ev"]["target_indices"]]
+    if cfg["use_boundary_images"]:
+        ts.append(1)
+    return ts
+
+
+def forward(sd: StateDict, cfg: Dict[str, Any], voxel_grid: Optional[Tensor] = None,
+            images: Optional[List[Tensor]] = None, iters: int = 12, flow_init: Optional[Tensor] = None,
+            test_mode: bool = False, return_intermediates: bool = False):
+    """RAFTSpline.forward, models/raft_spline/raft.py:101-200.
+    Returns (bezier_low_params, bezier_up_params) if test_mode else [bezier_up_params per iteration]
+    (the reference wraps these tensors in BezierCurves)."""
+    assert voxel_grid is not None or images is not None
+    assert iters > 0
+    hdim, cdim = cfg["hidden"]["dim"], cfg["context"]["dim"]
+    nctx, ncorr = cfg["num_bins"]["context"], cfg["num_bins"]["correlation"]
+    fnorm, cnorm = cfg["feature"]["norm"], cfg["context"]["norm"]
+    groups = []   # [(fmap1 (B,D,h,w), fmap2 (T,B,D,h,w), levels)]
+    context_input = None
+    if cfg["use_events"]:
+        assert voxel_grid is not None
+        voxel_grid = voxel_grid.contiguous()
+        assert nctx + ncorr - 1 == voxel_grid.shape[-3]                      # raft.py:90
+        idxs = [0] + list(cfg["correlation"]["ev"]["target_indices"])        # raft.py:93-94
+        grids = [voxel_grid[:, i:i + ncorr] for i in idxs]
+        context_input = voxel_grid[:, -nctx:]
+        fm = [x.float() for x in encoder(sd, "fnet_ev", grids, fnorm)]
+        groups.append((fm[0], torch.stack(fm[1:], dim=0), list(cfg["correlation"]["ev"]["levels"])))
+    if cfg["use_boundary_images"]:
+        assert len(images) == 2
+        images = [2 * (x.float().contiguous() / 255) - 1 for x in images]    # raft.py:134
+        fi = encoder(sd, "fnet_img", images, fnorm)
+        groups.append((fi[0], fi[1].unsqueeze(0), [int(cfg["correlation"]["img"]["levels"])]))
+        context_input = images[0] if context_input is None else torch.cat((context_input, images[0]), dim=-3)
+    cnet = encoder(sd, "cnet", context_input, cnorm)
+    net, inp = torch.split(cnet, [hdim, cdim], dim=1)
+    net, inp = torch.tanh(net), torch.relu(inp)
+
+    B, _, H, W = context_input.shape
+    assert H % 8 == 0 and W % 8 == 0                                         # bezier.py:67-68
+    h, w = H // 8, W // 8
+    coords0 = coords_grid(B, h, w)
+    bezier = torch.zeros(B, 2 * cfg["bezier_degree"], h, w)
+    if flow_init is not None:
+        bezier = bezier + flow_init
+
+    # corr.py:223-262: 1-to-N for a single reference, M-to-N (fmap1 expanded per target) otherwise
+    if len(groups) == 1:
+        volume = corr_volume(groups[0][0], groups[0][1])
+    else:
+        f1 = torch.cat([g[0].unsqueeze(0).expand(g[1].shape[0], -1, -1, -1, -1) for g in groups], dim=0)
+        volume = corr_volume(f1, torch.cat([g[1] for g in groups], dim=0))
+    levels = sum((g[2] for g in groups), [])
+    pyramid = corr_pyramid(volume, levels)
+    times = lookup_times(cfg)
+
+    ups = []
+    inter = []
+    bezier_up = None
+    for itr in range(iters):
+        flows = bezier_flow(bezier, times)
+        coords1 = coords0 + flows
+        corr_feat = corr_lookup(pyramid, coords1)
+        net, up_mask, delta = update_block(sd, net, inp, corr_feat, bezier)
+        bezier = bezier + delta                                              # bezier.py:137-139
+        if return_intermediates:
+            inter.append(dict(corr=corr_feat, net=net, delta=delta))
+        if (not test_mode) or itr == iters - 1:
+            bezier_up = cvx_upsample(bezier, up_mask)                        # bezier.py:81-84
+            ups.append(bezier_up)
+    if return_intermediates:
+        return bezier, bezier_up, dict(volume=volume, pyramid=pyramid, iters=inter, net0=torch.tanh(cnet[:, :hdim]))
+    if test_mode:
+        return bezier, bezier_up
+    return ups
+
+
+# --------------------------------------------------------------------------------------
+# K1 / K2: event voxel grid
+# --------------------------------------------------------------------------------------
+def voxel_grid_convert(x: Tensor, y: Tensor, pol: Tensor, time: Tensor, channels: int, height: int, width: int,
+                       t0_center: Optional[int] = None, t1_center: Optional[int] = None) -> Tensor:
+    """VoxelGrid.convert, data/utils/representations.py:64-111.  Float x/y: trilinear over 8 neighbours
+    (:96-109); integer x/y: linear over the 2 temporal neighbours (:85-94).  Sequential accumulation."""
+    assert x.shape == y.shape == pol.shape == time.shape and x.ndim == 1
+    assert not torch.is_floating_point(time)
+    is_int_xy = not torch.is_floating_point(x)
+    grid = torch.zeros((channels, height, width), dtype=torch.float)
+    ch, ht, wd = channels, height, width
+    t0c = t0_center if t0_center is not None else time[0]
+    t1c = t1_center if t1_center is not None else time[-1]
+    t_norm = (time - t0c) / (t1c - t0c) * (ch - 1)                            # :58
+    t0 = t_norm.floor().int()
+    value = 2 * pol.float() - 1
+    if is_int_xy:
+        for tl in (t0, t0 + 1):
+            m = (tl >= 0) & (tl < ch)
+            wgt = value * (1 - (tl - t_norm).abs())
+            idx = ht * wd * tl.long() + wd * y.long() + x.long()
+            grid.put_(idx[m], wgt[m], accumulate=True)
+    else:
+        x0, y0 = x.floor().int(), y.floor().int()
+        for xl in (x0, x0 + 1):
+            for yl in (y0, y0 + 1):
+                for tl in (t0, t0 + 1):
+                    m = (xl < wd) & (xl >= 0) & (yl < ht) & (yl >= 0) & (tl >= 0) & (tl < ch)
+                    wgt = value * (1 - (xl - x).abs()) * (1 - (yl - y).abs()) * (1 - (tl - t_norm).abs())
+                    idx = ht * wd * tl.long() + wd * yl.long() + xl.long()
+                    grid.put_(idx[m], wgt[m], accumulate=True)
+    return grid
+
+
+def extended_time_window(t0_center: int, t1_center: int, channels: int) -> Tuple[int, int]:
+    """VoxelGrid.get_extended_time_window, representations.py:35-39."""
+    dt = (t1_center - t0_center) / (channels - 1)
+    return math.floor(t0_center - dt), math.ceil(t1_center + dt)
+
+
+def norm_voxel_grid(grid: Tensor) -> Tensor:
+    """representations.py:9-18: zero-mean / unit (unbiased) std over the non-zero entries, in place."""
+    mask = torch.nonzero(grid, as_tuple=True)
+    if mask[0].size()[0] > 0:
+        mean = grid[mask].mean()
+        std = grid[mask].std()
+        if std > 0:
+            grid[mask] = (grid[mask] - mean) / std
+        else:
+            grid[mask] = grid[mask] - mean
+    return grid
+
+
+# --------------------------------------------------------------------------------------
+# K15: end-point error
+# --------------------------------------------------------------------------------------
+def epe_masked(source: Tensor, target: Tensor, valid_mask: Optional[Tensor] = None) -> Optional[Tensor]:
+    """utils/metrics.py:196-213."""
+    assert source.ndim > 2 and source.shape == target.shape
+    epe = torch.sqrt(torch.square(source - target).sum(1))
+    if valid_mask is not None:
+        assert valid_mask.dtype == torch.bool and epe.shape == valid_mask.shape
+        den = valid_mask.sum()
+        if den == 0:
+            return None
+        return epe[valid_mask].sum() / den
+    return torch.mean(epe)
+
+
+# --------------------------------------------------------------------------------------
+# Configs of BASELINE.json
+# --------------------------------------------------------------------------------------
+def model_config(name: str) -> Dict[str, Any]:
+    """The `config['model']` dict Hydra composes for the four shipped experiments
+    (config/model/{base,raft_base,raft-spline}.yaml + config/experiment/**), with num_bins.correlation
+    back-filled as the DataModule does (modules/data_loading.py:63-68)."""
+    base = dict(name="raft-spline", detach_bezier=False, use_gma=False, num_iter=dict(train=12, test=12),
+                hidden=dict(dim=128), context=dict(dim=128, norm="batch"),
+                feature=dict(dim=256, norm="instance"), motion=dict(dim=128))
+    if name in ("E_LU4_BD2", "E_I_LU4_BD2"):
+        img = name.startswith("E_I")
+        base.update(num_bins=dict(context=5, correlation=5), bezier_degree=2, use_boundary_images=img,
+                    use_events=True,
+                    correlation=dict(use_cosine_sim=False,
+                                     ev=dict(target_indices=[1, 2, 3, 4], levels=[1, 1, 1, 4], radius=[4, 4, 4, 4]),
+                                     img=dict(levels=4 if img else None, radius=4 if img else None)))
+    elif name in ("E_LU5_BD10", "E_I_LU5_BD10"):
+        img = name.startswith("E_I")
+        base.update(num_bins=dict(context=41, correlation=25), bezier_degree=10, use_boundary_images=img,
+                    use_events=True,
+                    correlation=dict(use_cosine_sim=False,
+                                     ev=dict(target_indices=[8, 16, 24, 32, 40], levels=[1, 1, 1, 1, 4],
+                                             radius=[4, 4, 4, 4, 4]),
+                                     img=dict(levels=4, radius=4)))
+    else:
+        raise KeyError(name)
+    return base

@@ -1,0 +1,162 @@
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE (uzh-rpg/bflow, mounted
+read-only at /root/reference) in the build container.  Fixtures hold data only: inputs (or the seeds that
+regenerate them) and the reference's outputs.  Re-run:  python tests/golden/make_golden.py
+
+Weights come from oracle.raft_spline_oracle.make_state_dict (numpy RandomState, independent of torch's RNG);
+inputs from bflow_amd.synthetic.  Both are loaded INTO the reference modules; every stored output is computed
+by reference code only.
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import refshim  # noqa: E402
+from bflow_amd import synthetic  # noqa: E402
+from oracle import raft_spline_oracle as O  # noqa: E402
+
+# (config, B, H, W, iters) -- frames sized so that the 4-level pyramid exercises odd-size flooring
+E2E_CASES = {
+    "e2e_E_LU4_BD2": ("E_LU4_BD2", 1, 176, 208, 12),
+    "e2e_E_I_LU4_BD2": ("E_I_LU4_BD2", 2, 176, 208, 6),
+    "e2e_E_LU5_BD10": ("E_LU5_BD10", 1, 144, 176, 4),
+    "e2e_E_I_LU5_BD10": ("E_I_LU5_BD10", 1, 144, 176, 3),
+}
+
+
+def e2e_inputs(cfg, B, H, W):
+    C = cfg["num_bins"]["context"] + cfg["num_bins"]["correlation"] - 1
+    vox = torch.from_numpy(synthetic.voxel_grid(B, C, H, W, seed=1234))
+    imgs = None
+    if cfg["use_boundary_images"]:
+        a, b = synthetic.image_pair(B, H, W, seed=4321)
+        imgs = [torch.from_numpy(a), torch.from_numpy(b)]
+    return vox, imgs
+
+
+def corr_case_inputs(seed, B, D, h, w, T):
+    rs = np.random.RandomState(seed)
+    f1 = rs.standard_normal((B, D, h, w)).astype(np.float32)
+    f2 = rs.standard_normal((T, B, D, h, w)).astype(np.float32)
+    # coords: grid + flow with large excursions (out of bounds on all four sides, negative, fractional)
+    ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    base = np.stack([xs, ys], 0).astype(np.float32)
+    flow = (rs.standard_normal((T, B, 2, h, w)) * 3.0).astype(np.float32)
+    flow[:, :, :, 0, 0] = -50.0      # far outside
+    flow[:, :, :, -1, -1] = 40.0
+    flow[:, :, :, 1, 1] = 0.0        # exactly integer coordinates
+    coords = base[None, None] + flow
+    return f1, f2, coords.astype(np.float32)
+
+
+def main():
+    ns = refshim.import_reference()
+    torch.manual_seed(0)
+    out_dir = HERE
+
+    # ---------------- end-to-end ----------------
+    for fname, (cname, B, H, W, iters) in E2E_CASES.items():
+        cfg = O.model_config(cname)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ns.RAFTSpline(cfg).eval()
+        model.load_state_dict(O.make_state_dict(cfg, seed=0))
+        vox, imgs = e2e_inputs(cfg, B, H, W)
+        with torch.inference_mode():
+            low, up = model(voxel_grid=vox, images=imgs, iters=iters, test_mode=True)
+            flow1 = up.get_flow_from_reference(1.0)
+            flow_half = up.get_flow_from_reference(0.5)
+        np.savez_compressed(os.path.join(out_dir, fname + ".npz"),
+                            config=cname, B=B, H=H, W=W, iters=iters,
+                            bezier_low=low.get_params().numpy(),
+                            flow_t1=flow1.numpy(), flow_t05=flow_half.numpy(),
+                            bezier_up_sub=up.get_params()[:, :, ::4, ::4].numpy())
+        print(fname, "flow |mean|", float(flow1.abs().mean()))
+
+    # ---------------- correlation volume / pyramid / lookup ----------------
+    with torch.inference_mode():
+        # 1-to-N, levels [1,2,3]
+        f1, f2, coords = corr_case_inputs(11, 2, 32, 10, 12, 3)
+        cc = ns.CorrComputation(torch.from_numpy(f1), torch.from_numpy(f2), num_levels_per_target=[1, 2, 3])
+        blk = ns.CorrBlockParallelMultiTarget(corr_computation_events=cc)
+        look = blk(torch.from_numpy(coords))
+        pyr = {f"pyr{L}": d.corr.numpy() for L, d in enumerate(blk._corr_pyramid)}
+        np.savez_compressed(os.path.join(out_dir, "corr_1toN.npz"), f1=f1, f2=f2, coords=coords,
+                            levels=np.array([1, 2, 3]), lookup=look.numpy(), **pyr)
+        # M-to-N: events [1,1,1,4] + frames 4 ; odd sizes 18x22 -> 9x11 -> 4x5 -> 2x2
+        f1e, f2e, coords = corr_case_inputs(12, 1, 16, 18, 22, 5)
+        rs = np.random.RandomState(13)
+        f1i = rs.standard_normal(f1e.shape).astype(np.float32)
+        cce = ns.CorrComputation(torch.from_numpy(f1e), torch.from_numpy(f2e[:4]), num_levels_per_target=[1, 1, 1, 4])
+        cci = ns.CorrComputation(torch.from_numpy(f1i), torch.from_numpy(f2e[4]), num_levels_per_target=4)
+        blk = ns.CorrBlockParallelMultiTarget(corr_computation_events=cce, corr_computation_frames=cci)
+        look = blk(list(torch.from_numpy(coords)))
+        pyr = {f"pyr{L}": d.corr.numpy() for L, d in enumerate(blk._corr_pyramid) if L > 0}
+        pyr["pyr0_rows7"] = blk._corr_pyramid[0].corr.numpy()[:, ::7]   # every 7th query pixel (fixture size)
+        np.savez_compressed(os.path.join(out_dir, "corr_MtoN.npz"), f1_ev=f1e, f2_ev=f2e[:4], f1_img=f1i,
+                            f2_img=f2e[4], coords=coords, levels=np.array([1, 1, 1, 4, 4]), lookup=look.numpy(), **pyr)
+
+        # ---------------- bezier ----------------
+        bz = {}
+        for deg in (2, 10):
+            rs = np.random.RandomState(20 + deg)
+            p = rs.standard_normal((2, 2 * deg, 5, 6)).astype(np.float32)
+            curves = ns.BezierCurves(torch.from_numpy(p))
+            ts = [0.25, 0.5, 0.75, 1.0] if deg == 2 else [0.2, 0.4, 0.6, 0.8, 1.0, 1]
+            bz[f"params_d{deg}"] = p
+            bz[f"times_d{deg}"] = np.array(ts, dtype=np.float64)
+            bz[f"flow_list_d{deg}"] = curves.get_flow_from_reference(ts).numpy()
+            bz[f"flow_0_d{deg}"] = curves.get_flow_from_reference(0.0).numpy()
+            bz[f"flow_1_d{deg}"] = curves.get_flow_from_reference(1.0).numpy()
+            bz[f"flow_03_d{deg}"] = curves.get_flow_from_reference(0.3).numpy()
+        np.savez_compressed(os.path.join(out_dir, "bezier.npz"), **bz)
+
+        # ---------------- convex upsampling ----------------
+        rs = np.random.RandomState(31)
+        data = rs.standard_normal((2, 4, 5, 6)).astype(np.float32)
+        mask = (rs.standard_normal((2, 576, 5, 6)) * 2).astype(np.float32)
+        np.savez_compressed(os.path.join(out_dir, "cvx_upsample.npz"), data=data, mask=mask,
+                            out=ns.cvx_upsample(torch.from_numpy(data), torch.from_numpy(mask)).numpy())
+
+        # ---------------- voxel grid + normalisation ----------------
+        vg = {}
+        C, Hh, Ww = 5, 24, 32
+        t0c, t1c = 1_000_000, 1_100_000
+        conv = ns.VoxelGrid(C, Hh, Ww)
+        ts, te = conv.get_extended_time_window(t0c, t1c)
+        vg["window"] = np.array([ts, te, t0c, t1c], dtype=np.int64)
+        for tag, int_xy in (("f", False), ("i", True)):
+            x, y, pol, t = synthetic.events(6000, Hh, Ww, ts - 3000, te + 3000, seed=41, int_xy=int_xy)
+            g = conv.convert(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(pol), torch.from_numpy(t), t0c, t1c)
+            vg[f"x_{tag}"], vg[f"y_{tag}"], vg[f"pol_{tag}"], vg[f"t_{tag}"] = x, y, pol, t
+            vg[f"grid_{tag}"] = g.numpy().copy()
+            vg[f"norm_{tag}"] = ns.norm_voxel_grid(g.clone()).numpy()
+        z = torch.zeros(3, 4, 5)
+        vg["norm_allzero"] = ns.norm_voxel_grid(z.clone()).numpy()
+        one = torch.zeros(3, 4, 5)
+        one[1, 2, 3] = 2.5
+        one[0, 0, 0] = 2.5          # two equal non-zeros -> std == 0 branch
+        vg["norm_std0_in"] = one.numpy().copy()
+        vg["norm_std0"] = ns.norm_voxel_grid(one.clone()).numpy()
+        np.savez_compressed(os.path.join(out_dir, "voxel.npz"), **vg)
+
+        # ---------------- EPE ----------------
+        rs = np.random.RandomState(51)
+        a = rs.standard_normal((3, 2, 9, 11)).astype(np.float32) * 4
+        b = rs.standard_normal((3, 2, 9, 11)).astype(np.float32) * 4
+        m = rs.uniform(size=(3, 9, 11)) < 0.6
+        np.savez_compressed(os.path.join(out_dir, "epe.npz"), a=a, b=b, mask=m,
+                            epe=ns.epe_masked(torch.from_numpy(a), torch.from_numpy(b)).numpy(),
+                            epe_masked=ns.epe_masked(torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(m)).numpy())
+    print("golden fixtures written to", out_dir)
+
+
+if __name__ == "__main__":
+    main()
