@@ -1,0 +1,166 @@
+"""Correlation volume, pyramid and look-up on the HIP kernels -- drop-in for models/raft_utils/corr.py:127-351.
+
+`CorrComputation` validates/collects the feature maps exactly like the reference (corr.py:128-185,223-227);
+`CorrBlockParallelMultiTarget` builds the (T, B, N, N) volume with the fp32-MFMA kernel (K5), the per-target pyramid
+with the pooling kernel (K6), and answers look-ups with the LDS-staged gather kernel (K7).  Layouts:
+
+    level 0 : one tensor (T, B*N, h, w)            == reference CorrData.corr (T, B*N, 1, h, w) without the unit dim
+    level L : one tensor (T_L, B*N, h>>L, w>>L)    for the targets with num_levels > L (floor on odd sizes)
+
+Everything is allocated with torch (caller-owned memory); the kernels only see pointers.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import hip
+
+_LIST_TYPES: Tuple[type, ...] = (list, tuple)
+try:  # omegaconf is optional (the reference passes ListConfig objects when driven by Hydra, corr.py:8,147)
+    from omegaconf import ListConfig as _ListConfig  # type: ignore
+    _LIST_TYPES = (list, tuple, _ListConfig)
+except Exception:  # pragma: no cover
+    pass
+
+
+class CorrComputation:
+    def __init__(self,
+                 fmap1: Union[torch.Tensor, List[torch.Tensor]],
+                 fmap2: Union[torch.Tensor, List[torch.Tensor]],
+                 num_levels_per_target: Union[int, List[int], List[torch.Tensor]]):
+        """fmap1: (B,D,h,w) or list of those; fmap2: (B,D,h,w) | (T,B,D,h,w) or list of (T,B,D,h,w);
+        num_levels_per_target: int | list[int] (len T) | list of int64 tensors (one per reference)."""
+        single = isinstance(fmap1, torch.Tensor)
+        if isinstance(num_levels_per_target, int):
+            num_levels_per_target = [num_levels_per_target]
+        else:
+            assert isinstance(num_levels_per_target, _LIST_TYPES)
+        if single:
+            assert fmap1.ndim == 4 and isinstance(fmap2, torch.Tensor)
+            if fmap2.ndim == 4:
+                fmap2 = fmap2.unsqueeze(0)
+            assert fmap2.ndim == 5 and fmap1.shape == fmap2.shape[1:]
+            assert len(num_levels_per_target) == fmap2.shape[0]
+            levels = [[int(v) for v in num_levels_per_target]]
+            fmap1, fmap2 = [fmap1], [fmap2]
+        else:
+            assert isinstance(fmap1, list) and isinstance(fmap2, list)
+            assert len(fmap1) == len(fmap2) == len(num_levels_per_target)
+            levels = []
+            for f1, f2, lv in zip(fmap1, fmap2, num_levels_per_target):
+                assert f1.ndim == 4 and f2.ndim == 5 and f1.shape == f2.shape[1:]
+                lv = [int(v) for v in (lv.tolist() if isinstance(lv, torch.Tensor) else lv)]
+                assert len(lv) == f2.shape[0]
+                levels.append(lv)
+        self._has_single_reference = single
+        self._fmap1, self._fmap2, self._levels = fmap1, fmap2, levels
+        self._bdhw = tuple(fmap1[0].shape)
+
+    batch = property(lambda self: self._bdhw[0])
+    dim = property(lambda self: self._bdhw[1])
+    height = property(lambda self: self._bdhw[2])
+    width = property(lambda self: self._bdhw[3])
+    num_references = property(lambda self: len(self._fmap1))
+    num_targets_per_reference = property(lambda self: [f.shape[0] for f in self._fmap2])
+    num_targets_overall = property(lambda self: sum(f.shape[0] for f in self._fmap2))
+
+    @property
+    def num_levels_per_target(self) -> List[torch.Tensor]:
+        return [torch.tensor(lv) for lv in self._levels]
+
+    @property
+    def num_levels_per_target_merged(self) -> torch.Tensor:
+        return torch.tensor(sum(self._levels, []))
+
+    def levels_flat(self) -> List[int]:
+        return sum(self._levels, [])
+
+    def __add__(self, other: "CorrComputation") -> "CorrComputation":
+        return CorrComputation(fmap1=self._fmap1 + other._fmap1, fmap2=self._fmap2 + other._fmap2,
+                               num_levels_per_target=[torch.tensor(lv) for lv in self._levels + other._levels])
+
+    def get_correlation_volume(self) -> torch.Tensor:
+        """(T, B*N, 1, h, w) fp32 -- corr.py:229-272.  One K5 launch per reference group, written straight into its
+        slice of the volume (the reference expands fmap1 per target and concatenates, corr.py:254-259)."""
+        B, D, h, w = self._bdhw
+        N = h * w
+        T = self.num_targets_overall
+        vol = torch.empty((T, B, N, N), dtype=torch.float32, device=self._fmap1[0].device)
+        t0 = 0
+        for f1, f2 in zip(self._fmap1, self._fmap2):
+            tg = f2.shape[0]
+            hip.corr_build_f32(f1.float().contiguous().view(B, D, N), f2.float().contiguous().view(tg, B, D, N), vol[t0:t0 + tg])
+            t0 += tg
+        return vol.view(T, B * N, 1, h, w)
+
+
+class CorrBlockParallelMultiTarget:
+    def __init__(self,
+                 corr_computation_events: Optional[CorrComputation] = None,
+                 corr_computation_frames: Optional[CorrComputation] = None,
+                 radius: int = 4):
+        assert corr_computation_events is not None or corr_computation_frames is not None
+        assert radius == hip.LOOKUP_RADIUS, "the look-up radius is 4 everywhere in the reference (raft.py:40, corr.py:279)"
+        if corr_computation_frames is None:
+            cc = corr_computation_events
+        elif corr_computation_events is None:
+            cc = corr_computation_frames
+        else:
+            cc = corr_computation_events + corr_computation_frames
+        levels = cc.levels_flat()
+        self._num_targets_base = len(levels)
+        self._radius = radius
+        self._batch = cc.batch
+        self._hw = (cc.height, cc.width)
+        B, h, w = cc.batch, cc.height, cc.width
+        N = h * w
+
+        base = cc.get_correlation_volume().view(len(levels), B * N, h, w)
+        # pyramid: corr.py:297-305 -- level L keeps the targets whose num_levels > L
+        self._pyramid: List[Tuple[torch.Tensor, List[int]]] = [(base, list(range(len(levels))))]
+        for num_levels in range(2, max(levels) + 1):
+            prev, prev_idx = self._pyramid[-1]
+            keep = [t for t, lv in enumerate(levels) if lv >= num_levels]
+            ph, pw = prev.shape[-2:]
+            cur = torch.empty((len(keep), B * N, ph // 2, pw // 2), dtype=torch.float32, device=base.device)
+            for k, t in enumerate(keep):
+                hip.corr_pool2x2(prev[prev_idx.index(t)], cur[k])
+            self._pyramid.append((cur, keep))
+        planes = []
+        for lvl, (tensor, tidx) in enumerate(self._pyramid):
+            for k, t in enumerate(tidx):
+                planes.append(dict(tensor=tensor[k], level=lvl, target=t))
+        self._planes = planes
+        self._table = hip.make_plane_table(planes)
+
+    @property
+    def num_planes(self) -> int:
+        return len(self._planes)
+
+    def pyramid_level(self, level: int) -> Tuple[torch.Tensor, List[int]]:
+        """(T_L, B*N, 1, h_L, w_L) tensor (reference CorrData.corr layout) and its base-target indices."""
+        t, idx = self._pyramid[level]
+        return t.unsqueeze(2), list(idx)
+
+    def new_output(self) -> torch.Tensor:
+        h, w = self._hw
+        return torch.empty((self._batch, self.num_planes * 81, h, w), dtype=torch.float32, device=self._pyramid[0][0].device)
+
+    def __call__(self, coords: Union[torch.Tensor, Sequence[torch.Tensor]], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """coords: (T, B, 2, h, w) tensor or list of T (B, 2, h, w) tensors -> (B, P*81, h, w)   (corr.py:307-351)."""
+        if isinstance(coords, (list, tuple)):
+            coords = torch.stack(list(coords), dim=0)
+        assert coords.ndim == 5 and coords.shape[0] == self._num_targets_base
+        out = self.new_output() if out is None else out
+        hip.corr_lookup(self._table, coords.float().contiguous(), out)
+        return out
+
+    def lookup_bezier(self, params: torch.Tensor, coef: np.ndarray, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Fused get_flow_from_reference + coords0 + look-up (raft.py:180-184): coords are never materialised."""
+        assert coef.shape[0] == self._num_targets_base
+        out = self.new_output() if out is None else out
+        hip.corr_lookup_bezier(self._table, params, coef, out)
+        return out

@@ -1,0 +1,46 @@
+// Library-level entry points: version, last-error string, host-side Bezier coefficients.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include "common.h"
+
+namespace bflow {
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+}  // namespace bflow
+
+extern "C" int bflow_version(void) { return BFLOW_ABI_VERSION; }
+
+extern "C" const char* bflow_last_error_string(void) { return bflow::g_err; }
+
+// models/raft_spline/bezier.py:141-180: binom(deg, i) * (1-t)^(deg-i) * t^i in float64, then cast to fp32.
+extern "C" int bflow_bezier_coeffs(const double* times, int T, int deg, float* coef_out) {
+    BFLOW_REQUIRE(times && coef_out && T > 0 && deg >= 1, BFLOW_E_ARG, "bezier_coeffs: bad arguments");
+    BFLOW_REQUIRE(deg <= BFLOW_MAX_DEGREE, BFLOW_E_LIMIT, "bezier_coeffs: degree %d > %d", deg, BFLOW_MAX_DEGREE);
+    for (int t = 0; t < T; ++t) {
+        const double tm = times[t];
+        BFLOW_REQUIRE(tm >= 0.0 && tm <= 1.0, BFLOW_E_ARG, "bezier_coeffs: time %g outside [0,1]", tm);
+        double binom = 1.0;  // C(deg, i), exact for these small integers
+        for (int i = 1; i <= deg; ++i) {
+            binom = binom * (double)(deg - i + 1) / (double)i;
+            const double c = std::round(binom) * (std::pow(1.0 - tm, (double)(deg - i)) * std::pow(tm, (double)i));
+            coef_out[t * deg + (i - 1)] = (float)c;
+        }
+    }
+    return 0;
+}

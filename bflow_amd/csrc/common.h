@@ -1,0 +1,48 @@
+// Shared helpers for the bflow HIP kernels (gfx950 / CDNA4 only: wave64, 256 CUs in 8 XCDs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bflow_hip.h"
+
+namespace bflow {
+
+void set_error(const char* fmt, ...);
+
+// Checks the launch that was just enqueued; returns the C-ABI status code.
+int launch_status(const char* what);
+
+constexpr int WAVE = 64;
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Grid size for HBM-bound streaming kernels: enough blocks to fill 256 CUs x 8, grid-stride the rest
+// (cdna_hip_programming.md guideline 11).
+static inline int stream_grid(long long work_items, int block) {
+    long long g = (work_items + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace bflow
+
+#define BFLOW_REQUIRE(cond, code, ...)            \
+    do {                                          \
+        if (!(cond)) {                            \
+            bflow::set_error(__VA_ARGS__);        \
+            return (code);                        \
+        }                                         \
+    } while (0)

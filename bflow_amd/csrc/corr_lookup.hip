@@ -1,0 +1,216 @@
+// K6: correlation pyramid (2x2 average pooling) and K7: 9x9 bilinear window look-up.
+// Reference: CorrData.get_downsampled (corr.py:108-125), CorrBlockParallelMultiTarget.__call__ (corr.py:307-351),
+// bilinear_sampler (raft_utils/utils.py:5-21; F.grid_sample bilinear / zeros / align_corners=True).
+//
+// Look-up design (HBM / gather bound):
+//   every query pixel owns a PRIVATE h_L x w_L plane of the 4-D volume, so nothing is shared between pixels;
+//   per (pixel, plane) the 81 samples touch one <= 12x12 patch.  A block takes 64 consecutive query pixels of
+//   one plane:
+//     phase 1  the 64 patches are fetched cooperatively, 16 lanes per patch row (48-B row segments instead of
+//              64 scattered dwords per wave load) with zero fill outside the plane (= grid_sample's zero padding),
+//              into LDS at an odd per-pixel stride (conflict-free for lane == pixel);
+//     phase 2  lane == pixel: each wave produces a quarter of the 81 window positions from LDS and writes
+//              out[b, p*81+k, pixel..pixel+63] as one coalesced 256-B row.
+//   The Bezier evaluation + coords0 (raft.py:180-181) is optionally fused in front (FUSED = true), which removes
+//   the `flows`/`coords1` tensors and one launch per GRU iteration.
+#include "common.h"
+
+namespace {
+
+constexpr int R = BFLOW_LOOKUP_RADIUS;   // 4
+constexpr int WIN = 2 * R + 1;           // 9
+constexpr int PATCH = 12;                // floor(c)-5 .. floor(c)+6 covers every bilinear corner incl. round-off flips
+constexpr int PSTRIDE = PATCH * PATCH + 1;  // 145 floats (odd -> bank-conflict free for lane == pixel)
+constexpr int TILE = 64;                 // query pixels per block
+constexpr int LTHREADS = 256;
+
+struct PlaneDev {
+    const float* base;
+    int h, w;
+    float inv_scale;  // 1 / 2^level (exact)
+    int target;
+};
+
+struct LookupArgs {
+    PlaneDev planes[BFLOW_MAX_PLANES];
+    float coef[BFLOW_MAX_TARGETS * BFLOW_MAX_DEGREE];
+    int P, T, deg;
+};
+
+// pixel coordinate -> the coordinate grid_sample actually samples at.  bilinear_sampler normalises
+// (utils.py:13-14: 2*x/(W-1) - 1) and grid_sample un-normalises ((g+1) * (W-1)/2, align_corners=True); the
+// round trip is reproduced so that floor()/fraction see the same round-off as the reference.
+__device__ __forceinline__ float roundtrip(float x, int size) {
+    const float sm1 = (float)(size - 1);
+    const float g = 2.0f * x / sm1 - 1.0f;
+    return (g + 1.0f) * (sm1 / 2.0f);
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, const float* __restrict__ src,
+                                                              float* __restrict__ out, int B, int h1, int w1) {
+    __shared__ float patch[TILE * PSTRIDE];
+    __shared__ float s_cx[TILE], s_cy[TILE];
+    __shared__ int s_ox[TILE], s_oy[TILE];
+
+    const int tid = threadIdx.x;
+    const int N = h1 * w1;
+    const int p = blockIdx.y;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * TILE;
+    const PlaneDev pl = args.planes[p];
+
+    if (tid < TILE) {
+        const int n = n0 + tid;
+        float cx = 0.f, cy = 0.f;
+        if (n < N) {
+            if (FUSED) {
+                // coords = coords0 + sum_i coef[t][i] * P_i   (bezier.py:185, raft.py:181); src = params (B, 2*deg, N)
+                const int deg = args.deg;
+                const float* pp = src + (long long)b * 2 * deg * N + n;
+                const float* cf = args.coef + pl.target * deg;
+                float fx = 0.f, fy = 0.f;
+                for (int i = 0; i < deg; ++i) {
+                    fx = fmaf(pp[(long long)i * N], cf[i], fx);
+                    fy = fmaf(pp[(long long)(deg + i) * N], cf[i], fy);
+                }
+                const int y = n / w1, x = n - y * w1;
+                cx = (float)x + fx;
+                cy = (float)y + fy;
+            } else {
+                // src = coords (T, B, 2, N)
+                const float* cc = src + ((long long)(pl.target * B + b) * 2) * N + n;
+                cx = cc[0];
+                cy = cc[N];
+            }
+            cx *= pl.inv_scale;  // corr.py:333  (division by 2^level == exact multiply)
+            cy *= pl.inv_scale;
+        }
+        s_cx[tid] = cx;
+        s_cy[tid] = cy;
+        // patch origin from the (clamped) centre; far-away centres give an all-zero patch, as zero padding demands
+        const float ccx = fminf(fmaxf(cx, -64.f), (float)pl.w + 64.f);
+        const float ccy = fminf(fmaxf(cy, -64.f), (float)pl.h + 64.f);
+        s_ox[tid] = (int)floorf(ccx) - (R + 1);
+        s_oy[tid] = (int)floorf(ccy) - (R + 1);
+    }
+    __syncthreads();
+
+    // ---- phase 1: gather 64 patches, 16 lanes per 12-wide patch row -------------------------------------
+    {
+        const int g = tid >> 4, c = tid & 15;
+        const long long plane_sz = (long long)pl.h * pl.w;
+        for (int rowid = g; rowid < TILE * PATCH; rowid += LTHREADS / 16) {
+            const int pix = rowid / PATCH, r = rowid - pix * PATCH;
+            const int n = n0 + pix;
+            if (c < PATCH) {
+                const int gy = s_oy[pix] + r, gx = s_ox[pix] + c;
+                float v = 0.f;
+                if (n < N && gy >= 0 && gy < pl.h && gx >= 0 && gx < pl.w)
+                    v = pl.base[((long long)b * N + n) * plane_sz + (long long)gy * pl.w + gx];
+                patch[pix * PSTRIDE + r * PATCH + c] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: lane == pixel, wave w produces window positions k = w, w+4, ... ----------------------
+    {
+        const int pix = tid & 63, wv = tid >> 6;
+        const int n = n0 + pix;
+        const float cx = s_cx[pix], cy = s_cy[pix];
+        const int ox = s_ox[pix], oy = s_oy[pix];
+        const float* pp = patch + pix * PSTRIDE;
+        float* o = out + ((long long)b * args.P * (WIN * WIN) + (long long)p * (WIN * WIN)) * N + n;
+        for (int k = wv; k < WIN * WIN; k += 4) {
+            const int ky = k / WIN, kx = k - ky * WIN;
+            float ix = roundtrip(cx + (float)(kx - R), pl.w);
+            float iy = roundtrip(cy + (float)(ky - R), pl.h);
+            ix = fminf(fmaxf(ix, -1.0e4f), 1.0e4f);
+            iy = fminf(fmaxf(iy, -1.0e4f), 1.0e4f);
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const float we = ix - fx0, ww = 1.f - we;  // weights of the east (x0+1) / west (x0) columns
+            const float ws = iy - fy0, wn = 1.f - ws;  // south (y0+1) / north (y0) rows
+            const int rx = (int)fx0 - ox, ry = (int)fy0 - oy;
+            float v = 0.f;
+            if (rx >= 0 && rx + 1 < PATCH && ry >= 0 && ry + 1 < PATCH) {
+                const float* q = pp + ry * PATCH + rx;
+                v = q[0] * (ww * wn);
+                v += q[1] * (we * wn);
+                v += q[PATCH] * (ww * ws);
+                v += q[PATCH + 1] * (we * ws);
+            }
+            if (n < N) o[(long long)k * N] = v;
+        }
+    }
+}
+
+int fill_args(LookupArgs& a, const bflow_plane_t* planes, int P, int T) {
+    BFLOW_REQUIRE(planes && P > 0 && T > 0, BFLOW_E_ARG, "corr_lookup: bad plane table");
+    BFLOW_REQUIRE(P <= BFLOW_MAX_PLANES, BFLOW_E_LIMIT, "corr_lookup: %d planes > %d", P, BFLOW_MAX_PLANES);
+    BFLOW_REQUIRE(T <= BFLOW_MAX_TARGETS, BFLOW_E_LIMIT, "corr_lookup: %d targets > %d", T, BFLOW_MAX_TARGETS);
+    a.P = P;
+    a.T = T;
+    a.deg = 0;
+    for (int p = 0; p < P; ++p) {
+        BFLOW_REQUIRE(planes[p].base && planes[p].h > 0 && planes[p].w > 0 && planes[p].level >= 0 && planes[p].level < 16 &&
+                          planes[p].target >= 0 && planes[p].target < T,
+                      BFLOW_E_ARG, "corr_lookup: bad descriptor for plane %d", p);
+        a.planes[p].base = planes[p].base;
+        a.planes[p].h = planes[p].h;
+        a.planes[p].w = planes[p].w;
+        a.planes[p].inv_scale = 1.0f / (float)(1 << planes[p].level);
+        a.planes[p].target = planes[p].target;
+    }
+    return 0;
+}
+
+// ---- K6 ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_pool2x2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           long long planes, int h, int w, int ho, int wo) {
+    const long long total = planes * ho * wo;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long pl = idx / (ho * wo);
+        const int rem = (int)(idx - pl * (ho * wo));
+        const int y = rem / wo, x = rem - y * wo;
+        const float* q = in + pl * h * w + (long long)(2 * y) * w + 2 * x;
+        // F.avg_pool2d accumulates the window row-major and divides by the window size (4: exact)
+        out[idx] = (((q[0] + q[1]) + q[w]) + q[w + 1]) * 0.25f;
+    }
+}
+
+}  // namespace
+
+extern "C" int bflow_corr_pool2x2(const float* in, float* out, long long planes, int h, int w, bflow_stream_t stream) {
+    BFLOW_REQUIRE(in && out && planes > 0 && h >= 2 && w >= 2, BFLOW_E_ARG, "corr_pool2x2: bad arguments");
+    const int ho = h / 2, wo = w / 2;
+    const long long total = planes * ho * wo;
+    hipLaunchKernelGGL(corr_pool2x2_kernel, dim3(bflow::stream_grid(total, 256) * 4), dim3(256), 0, (hipStream_t)stream, in, out,
+                       planes, h, w, ho, wo);
+    return bflow::launch_status("corr_pool2x2");
+}
+
+extern "C" int bflow_corr_lookup(const bflow_plane_t* planes, int P, const float* coords, float* out, int T, int B, int h1,
+                                 int w1, bflow_stream_t stream) {
+    LookupArgs a;
+    int rc = fill_args(a, planes, P, T);
+    if (rc) return rc;
+    BFLOW_REQUIRE(coords && out && B > 0 && h1 > 0 && w1 > 0, BFLOW_E_ARG, "corr_lookup: bad arguments");
+    dim3 grid(bflow::ceil_div((long long)h1 * w1, TILE), P, B);
+    hipLaunchKernelGGL(corr_lookup_kernel<false>, grid, dim3(LTHREADS), 0, (hipStream_t)stream, a, coords, out, B, h1, w1);
+    return bflow::launch_status("corr_lookup");
+}
+
+extern "C" int bflow_corr_lookup_bezier(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T,
+                                        int deg, float* out, int B, int h1, int w1, bflow_stream_t stream) {
+    LookupArgs a;
+    int rc = fill_args(a, planes, P, T);
+    if (rc) return rc;
+    BFLOW_REQUIRE(params && coef && out && B > 0 && h1 > 0 && w1 > 0, BFLOW_E_ARG, "corr_lookup_bezier: bad arguments");
+    BFLOW_REQUIRE(deg >= 1 && deg <= BFLOW_MAX_DEGREE, BFLOW_E_LIMIT, "corr_lookup_bezier: degree %d", deg);
+    a.deg = deg;
+    for (int i = 0; i < T * deg; ++i) a.coef[i] = coef[i];
+    dim3 grid(bflow::ceil_div((long long)h1 * w1, TILE), P, B);
+    hipLaunchKernelGGL(corr_lookup_kernel<true>, grid, dim3(LTHREADS), 0, (hipStream_t)stream, a, params, out, B, h1, w1);
+    return bflow::launch_status("corr_lookup_bezier");
+}

@@ -1,0 +1,80 @@
+// K13: convex x8 up-sampling of the Bezier parameters (reference: cvx_upsample, models/raft_utils/utils.py:33-48,
+// called once per forward in test mode, raft.py:193-195).
+//
+// HBM-bound: reads the (B,576,h,w) mask once (dominant: 2304 B per low-res pixel) and writes (B,C,8h,8w).
+// Thread = (low-res pixel x, sub-row i): lanes run over x so every mask read mask[b, k*64+i*8+j, y, x] is a
+// coalesced row, the 9-tap softmax lives in registers, and each lane writes 8 consecutive outputs (two float4),
+// i.e. a wave writes one contiguous 2-KB output row segment.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restrict__ data, const float* __restrict__ mask,
+                                                           const float* __restrict__ mask_bias, float mask_scale,
+                                                           float* __restrict__ out, int B, int C, int h, int w) {
+    const int N = h * w;
+    const long long total = (long long)B * 8 * N;   // (b, i, y, x) with x fastest
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % N);
+        const int bi = (int)(idx / N);
+        const int i = bi & 7, b = bi >> 3;
+        const int y = n / w, x = n - y * w;
+        const float* mb = mask + (long long)b * 576 * N + n;
+
+        // softmax over the 9 taps for the 8 sub-columns j of sub-row i   (utils.py:36-37)
+        float m[9][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int ch = k * 64 + i * 8 + j;
+                m[k][j] = mask_scale * (mb[(long long)ch * N] + (mask_bias ? mask_bias[ch] : 0.f));
+                mx = fmaxf(mx, m[k][j]);
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                m[k][j] = expf(m[k][j] - mx);
+                s += m[k][j];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) m[k][j] = m[k][j] / s;
+        }
+
+        for (int c = 0; c < C; ++c) {
+            const float* d = data + ((long long)b * C + c) * N;
+            float nb[9];  // 3x3 neighbourhood of 8*data, zero padded (F.unfold padding=1; utils.py:40)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = y + ky - 1, xx = x + kx - 1;
+                    nb[ky * 3 + kx] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? 8.f * d[yy * w + xx] : 0.f;
+                }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc += m[k][j] * nb[k];
+                o[j] = acc;
+            }
+            float* op = out + (((long long)b * C + c) * (8 * h) + (8 * y + i)) * (8LL * w) + 8 * x;
+            *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int bflow_cvx_upsample(const float* data, const float* mask, const float* mask_bias, float mask_scale, float* out, int B,
+                                  int C, int h, int w, bflow_stream_t stream) {
+    BFLOW_REQUIRE(data && mask && out && B > 0 && C > 0 && h > 0 && w > 0, BFLOW_E_ARG, "cvx_upsample: bad arguments");
+    BFLOW_REQUIRE(((uintptr_t)out & 15) == 0, BFLOW_E_ARG, "cvx_upsample: output must be 16-byte aligned");
+    const long long total = (long long)B * 8 * h * w;
+    hipLaunchKernelGGL(cvx_upsample_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, data, mask,
+                       mask_bias, mask_scale, out, B, C, h, w);
+    return bflow::launch_status("cvx_upsample");
+}

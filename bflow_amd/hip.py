@@ -1,0 +1,300 @@
+"""ctypes binding of libbflow_hip.so (include/bflow_hip.h) for PyTorch-ROCm tensors.
+
+This is the only place the package touches the C ABI.  Every wrapper
+  * requires CUDA(HIP)-resident, contiguous tensors of the declared dtype,
+  * passes raw `data_ptr()`s plus sizes, and torch's CURRENT stream (so launches are captured by hipGraph
+    stream capture and ordered with the MIOpen convolutions torch enqueues on the same stream),
+  * raises `BflowHipError` on a non-zero status.
+
+There is NO fallback: if the shared library is missing or a tensor lives on the CPU the call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libbflow_hip.so")
+
+MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
+ACT_NONE, ACT_RELU = 0, 1
+
+EXPORTS = (
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_corr_lookup_bezier", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
+    "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
+    "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
+)
+
+
+class BflowHipError(RuntimeError):
+    pass
+
+
+class PlaneDesc(ctypes.Structure):
+    """struct bflow_plane (include/bflow_hip.h)."""
+    _fields_ = [("base", ctypes.c_void_p), ("h", ctypes.c_int), ("w", ctypes.c_int),
+                ("level", ctypes.c_int), ("target", ctypes.c_int)]
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Loads libbflow_hip.so once.  Raises if it has not been built (python -m bflow_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(_LIB_PATH):
+        raise BflowHipError(f"{_LIB_PATH} is missing: build it with `python -m bflow_amd.build` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = ctypes.CDLL(_LIB_PATH)
+    vp, i, ll, f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+    L.bflow_version.restype = i
+    L.bflow_version.argtypes = []
+    L.bflow_last_error_string.restype = ctypes.c_char_p
+    L.bflow_last_error_string.argtypes = []
+    sig = {
+        "bflow_corr_build_f32": [vp, vp, vp, i, i, i, i, ll, vp],
+        "bflow_corr_pool2x2": [vp, vp, ll, i, i, vp],
+        "bflow_corr_lookup": [ctypes.POINTER(PlaneDesc), i, vp, vp, i, i, i, i, vp],
+        "bflow_corr_lookup_bezier": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, i, i, i, vp],
+        "bflow_bezier_coeffs": [ctypes.POINTER(ctypes.c_double), i, i, ctypes.POINTER(ctypes.c_float)],
+        "bflow_bezier_eval": [vp, ctypes.POINTER(ctypes.c_float), i, i, i, i, i, i, vp, vp],
+        "bflow_concat2_act": [vp, ll, i, vp, i, vp, ll, i, vp, i, vp, ll, vp, ll, i, i, vp],
+        "bflow_bias_act_inplace": [vp, ll, vp, i, i, i, i, vp],
+        "bflow_gru_rh": [vp, ll, vp, vp, ll, vp, ll, i, i, i, vp],
+        "bflow_gru_blend": [vp, ll, vp, vp, ll, vp, vp, ll, vp, ll, i, i, i, vp],
+        "bflow_tanh_relu_split": [vp, ll, vp, i, i, vp, ll, vp, ll, i, i, vp],
+        "bflow_add_delta": [vp, vp, vp, i, i, i, vp],
+        "bflow_cvx_upsample": [vp, vp, vp, f, vp, i, i, i, i, vp],
+        "bflow_voxel_scatter_f32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
+        "bflow_voxel_scatter_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
+        "bflow_voxel_norm": [vp, ll, vp, vp],
+        "bflow_epe_accumulate": [vp, vp, vp, i, i, ll, vp, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.restype = i
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().bflow_last_error_string().decode("utf-8", "replace")
+        raise BflowHipError(f"{what} failed (status {rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype=torch.float32, name: str = "tensor", contiguous: bool = True) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise BflowHipError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise BflowHipError(f"{name}: tensor is on {t.device}; the HIP path needs a GPU tensor (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise BflowHipError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if contiguous and not t.is_contiguous():
+        raise BflowHipError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _slice(t: torch.Tensor, name: str):
+    """(ptr, batch_stride) of a (B, C, ...) channel slice of a contiguous NCHW buffer."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise BflowHipError(f"{name}: needs a float32 GPU tensor")
+    B = t.shape[0]
+    inner = t[0] if B > 0 else t
+    if not inner.is_contiguous():
+        raise BflowHipError(f"{name}: per-sample (C, H, W) block must be contiguous")
+    return t.data_ptr(), (t.stride(0) if B > 1 else int(np.prod(t.shape[1:])))
+
+
+def _opt(t: Optional[torch.Tensor], name: str) -> Optional[int]:
+    return None if t is None else _dev(t, torch.float32, name)
+
+
+# ------------------------------------------------------------------------------------------------ K5 / K6 / K7
+def corr_build_f32(f1: torch.Tensor, f2: torch.Tensor, out: torch.Tensor):
+    """f1 (B,D,N) [shared] or (T,B,D,N); f2 (T,B,D,N); out (T,B,N,N)."""
+    T, B, D, N = f2.shape
+    if f1.dim() == 3:
+        assert f1.shape == (B, D, N)
+        tstride = 0
+    else:
+        assert f1.shape == (T, B, D, N)
+        tstride = B * D * N
+    assert out.shape == (T, B, N, N)
+    _check(lib().bflow_corr_build_f32(_dev(f1, name="f1"), _dev(f2, name="f2"), _dev(out, name="out"), T, B, D, N, tstride, _stream()),
+           "bflow_corr_build_f32")
+
+
+def corr_pool2x2(src: torch.Tensor, dst: torch.Tensor):
+    """src (..., h, w) -> dst (..., h//2, w//2)."""
+    h, w = src.shape[-2:]
+    planes = src.numel() // (h * w)
+    assert dst.shape[-2:] == (h // 2, w // 2) and dst.numel() == planes * (h // 2) * (w // 2)
+    _check(lib().bflow_corr_pool2x2(_dev(src, name="src"), _dev(dst, name="dst"), planes, h, w, _stream()), "bflow_corr_pool2x2")
+
+
+def make_plane_table(planes: Sequence[dict]):
+    """planes: [{tensor: (B*N, h, w) slab, level: int, target: int}] -> ctypes array (keeps no reference to tensors)."""
+    arr = (PlaneDesc * len(planes))()
+    for k, p in enumerate(planes):
+        t = p["tensor"]
+        arr[k].base = _dev(t, name=f"plane{k}")
+        arr[k].h, arr[k].w = int(t.shape[-2]), int(t.shape[-1])
+        arr[k].level, arr[k].target = int(p["level"]), int(p["target"])
+    return arr
+
+
+def corr_lookup(table, coords: torch.Tensor, out: torch.Tensor):
+    T, B, two, h1, w1 = coords.shape
+    assert two == 2
+    P = len(table)
+    assert out.shape == (B, P * 81, h1, w1)
+    _check(lib().bflow_corr_lookup(table, P, _dev(coords, name="coords"), _dev(out, name="out"), T, B, h1, w1, _stream()),
+           "bflow_corr_lookup")
+
+
+def corr_lookup_bezier(table, params: torch.Tensor, coef: np.ndarray, out: torch.Tensor):
+    B, C2, h1, w1 = params.shape
+    T, deg = coef.shape
+    assert C2 == 2 * deg and coef.dtype == np.float32 and coef.flags["C_CONTIGUOUS"]
+    P = len(table)
+    assert out.shape == (B, P * 81, h1, w1)
+    _check(lib().bflow_corr_lookup_bezier(table, P, _dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                          T, deg, _dev(out, name="out"), B, h1, w1, _stream()), "bflow_corr_lookup_bezier")
+
+
+# ------------------------------------------------------------------------------------------------ K8
+def bezier_coeffs(times: Sequence[float], degree: int) -> np.ndarray:
+    ts = np.ascontiguousarray(np.asarray(times, dtype=np.float64).reshape(-1))
+    out = np.empty((ts.size, degree), dtype=np.float32)
+    _check(lib().bflow_bezier_coeffs(ts.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ts.size, degree,
+                                     out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))), "bflow_bezier_coeffs")
+    return out
+
+
+def bezier_eval(params: torch.Tensor, coef: np.ndarray, add_coords0: bool = False) -> torch.Tensor:
+    B, C2, h, w = params.shape
+    T, deg = coef.shape
+    assert C2 == 2 * deg and coef.dtype == np.float32
+    coef = np.ascontiguousarray(coef)
+    out = torch.empty((T, B, 2, h, w), dtype=torch.float32, device=params.device)
+    _check(lib().bflow_bezier_eval(_dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), T, deg, B, h, w,
+                                   int(add_coords0), _dev(out), _stream()), "bflow_bezier_eval")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ K9 / K10 / K12
+def concat2_act(a: torch.Tensor, bias_a, act_a: int, b: Optional[torch.Tensor], bias_b, act_b: int,
+                dst1: torch.Tensor, dst2: Optional[torch.Tensor] = None):
+    B, Ca = a.shape[:2]
+    HW = int(np.prod(a.shape[2:]))
+    Cb = 0 if b is None else b.shape[1]
+    pa, sa = _slice(a, "a")
+    pb, sb = (None, 0) if b is None else _slice(b, "b")
+    p1, s1 = _slice(dst1, "dst1")
+    p2, s2 = (None, 0) if dst2 is None else _slice(dst2, "dst2")
+    assert dst1.shape[1] == Ca + Cb and (dst2 is None or dst2.shape[1] == Ca + Cb)
+    _check(lib().bflow_concat2_act(pa, sa, Ca, _opt(bias_a, "bias_a"), act_a, pb, sb, Cb, _opt(bias_b, "bias_b"), act_b,
+                                   p1, s1, p2, s2, B, HW, _stream()), "bflow_concat2_act")
+
+
+def bias_act_inplace(x: torch.Tensor, bias: Optional[torch.Tensor], act: int):
+    B, C = x.shape[:2]
+    px, sx = _slice(x, "x")
+    _check(lib().bflow_bias_act_inplace(px, sx, _opt(bias, "bias"), act, B, C, int(np.prod(x.shape[2:])), _stream()),
+           "bflow_bias_act_inplace")
+
+
+def gru_rh(r_pre: torch.Tensor, bias_r, h: torch.Tensor, rh: torch.Tensor):
+    B, C = h.shape[:2]
+    pr, sr = _slice(r_pre, "r_pre")
+    ph, sh = _slice(h, "h")
+    po, so = _slice(rh, "rh")
+    _check(lib().bflow_gru_rh(pr, sr, _opt(bias_r, "bias_r"), ph, sh, po, so, B, C, int(np.prod(h.shape[2:])), _stream()), "bflow_gru_rh")
+
+
+def gru_blend(z_pre: torch.Tensor, bias_z, q_pre: torch.Tensor, bias_q, h: torch.Tensor, h2: Optional[torch.Tensor] = None):
+    B, C = h.shape[:2]
+    pz, sz = _slice(z_pre, "z_pre")
+    pq, sq = _slice(q_pre, "q_pre")
+    ph, sh = _slice(h, "h")
+    p2, s2 = (None, 0) if h2 is None else _slice(h2, "h2")
+    _check(lib().bflow_gru_blend(pz, sz, _opt(bias_z, "bias_z"), pq, sq, _opt(bias_q, "bias_q"), ph, sh, p2, s2, B, C,
+                                 int(np.prod(h.shape[2:])), _stream()), "bflow_gru_blend")
+
+
+def tanh_relu_split(cnet: torch.Tensor, bias, c_h: int, c_i: int, net: torch.Tensor, inp: torch.Tensor):
+    B = cnet.shape[0]
+    pc, sc = _slice(cnet, "cnet")
+    pn, sn = _slice(net, "net")
+    pi, si = _slice(inp, "inp")
+    _check(lib().bflow_tanh_relu_split(pc, sc, _opt(bias, "bias"), c_h, c_i, pn, sn, pi, si, B, int(np.prod(cnet.shape[2:])), _stream()),
+           "bflow_tanh_relu_split")
+
+
+def add_delta(params: torch.Tensor, delta: torch.Tensor, bias: Optional[torch.Tensor]):
+    B, C = params.shape[:2]
+    assert params.shape == delta.shape
+    _check(lib().bflow_add_delta(_dev(params, name="params"), _dev(delta, name="delta"), _opt(bias, "bias"), B, C,
+                                 int(np.prod(params.shape[2:])), _stream()), "bflow_add_delta")
+
+
+# ------------------------------------------------------------------------------------------------ K13
+def cvx_upsample(data: torch.Tensor, mask: torch.Tensor, mask_bias: Optional[torch.Tensor] = None, mask_scale: float = 1.0) -> torch.Tensor:
+    B, C, h, w = data.shape
+    assert mask.shape == (B, 576, h, w)
+    out = torch.empty((B, C, 8 * h, 8 * w), dtype=torch.float32, device=data.device)
+    _check(lib().bflow_cvx_upsample(_dev(data, name="data"), _dev(mask, name="mask"), _opt(mask_bias, "mask_bias"), float(mask_scale),
+                                    _dev(out), B, C, h, w, _stream()), "bflow_cvx_upsample")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ K1 / K2
+def voxel_scatter(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.Tensor, t0_center: int, t1_center: int,
+                  grid: torch.Tensor):
+    C, H, W = grid.shape
+    n = x.numel()
+    ppol = _dev(pol, torch.int8, "pol")
+    pt = _dev(t, torch.int64, "time")
+    if x.dtype == torch.float32:
+        fn, px, py = lib().bflow_voxel_scatter_f32xy, _dev(x, torch.float32, "x"), _dev(y, torch.float32, "y")
+    elif x.dtype == torch.int16:
+        fn, px, py = lib().bflow_voxel_scatter_i16xy, _dev(x, torch.int16, "x"), _dev(y, torch.int16, "y")
+    else:
+        raise BflowHipError(f"voxel_scatter: x/y dtype {x.dtype} unsupported (float32 or int16)")
+    _check(fn(px, py, ppol, pt, n, int(t0_center), int(t1_center), _dev(grid, name="grid"), C, H, W, _stream()), "bflow_voxel_scatter")
+
+
+def voxel_norm(grid: torch.Tensor, workspace: Optional[torch.Tensor] = None):
+    if workspace is None:
+        workspace = torch.empty(4, dtype=torch.float64, device=grid.device)
+    _check(lib().bflow_voxel_norm(_dev(grid, name="grid"), grid.numel(), _dev(workspace, torch.float64, "workspace"), _stream()),
+           "bflow_voxel_norm")
+
+
+# ------------------------------------------------------------------------------------------------ K15
+def epe_accumulate(pred: torch.Tensor, gt: torch.Tensor, valid: Optional[torch.Tensor], acc: torch.Tensor):
+    B, C = pred.shape[:2]
+    HW = int(np.prod(pred.shape[2:]))
+    assert pred.shape == gt.shape
+    pv = None
+    if valid is not None:
+        assert valid.dtype in (torch.bool, torch.uint8) and valid.numel() == B * HW
+        pv = _dev(valid.view(torch.uint8) if valid.dtype == torch.bool else valid, torch.uint8, "valid")
+    _check(lib().bflow_epe_accumulate(_dev(pred, name="pred"), _dev(gt, name="gt"), pv, B, C, HW, _dev(acc, torch.float64, "acc"), _stream()),
+           "bflow_epe_accumulate")

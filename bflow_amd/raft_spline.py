@@ -1,0 +1,224 @@
+"""RAFTSpline -- MI355X-native drop-in for models/raft_spline/raft.py:14-200 (inference).
+
+Same constructor (`RAFTSpline(config['model'])`), same `forward(voxel_grid, images, iters, flow_init, test_mode)`
+signature and return types, same parameter names (`fnet_ev.*, fnet_img.*, cnet.*, update_block.*`) so the public
+checkpoints load through `load_state_dict`.  What differs is how the hot path is executed:
+
+    encoders            MIOpen convolutions via PyTorch-ROCm                                   (K4)
+    correlation volume  bflow_corr_build_f32: fp32-MFMA GEMM, one launch per reference group   (K5)
+    pyramid             bflow_corr_pool2x2                                                     (K6)
+    per iteration       bflow_corr_lookup_bezier (Bezier evaluation + coords0 + 9x9 gather fused), MIOpen convs with
+                        bias/activation/concat/GRU gates folded into the HIP element-wise kernels (K7-K12)
+    last iteration      mask head + bflow_cvx_upsample                                         (K13)
+
+The whole forward is free of host synchronisation, so `enable_hipgraph()` captures it once per input signature into
+a hipGraph (bflow_amd/graph.py) and replays it; eager execution stays available for debugging and stage timing.
+Inputs must live on the GPU: there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .bezier import BezierCurves, polynomial_coefficients
+from .corr import CorrBlockParallelMultiTarget, CorrComputation
+from .extractor import BasicEncoder
+from .timers import StageTimer
+from .update import BasicUpdateBlock
+
+
+class RAFTSpline(nn.Module):
+    def __init__(self, model_params: Dict[str, Any]):
+        super().__init__()
+        nbins_context = model_params["num_bins"]["context"]
+        nbins_correlation = model_params["num_bins"]["correlation"]
+        self.bezier_degree = model_params["bezier_degree"]
+        self.detach_bezier = model_params["detach_bezier"]
+        assert nbins_correlation is not None, "num_bins.correlation must be back-filled (modules/data_loading.py:63-68)"
+        assert nbins_correlation > 0 and nbins_context > 0
+        assert self.bezier_degree >= 1
+        self.nbins_context = nbins_context
+        self.nbins_corr = nbins_correlation
+
+        corr_params = model_params["correlation"]
+        self.corr_use_cosine_sim = corr_params["use_cosine_sim"]   # stored, never used (raft.py:33)
+        ev = corr_params["ev"]
+        self.ev_corr_target_indices = list(ev["target_indices"])
+        self.ev_corr_levels = list(ev["levels"])
+        self.ev_corr_radius = 4                                     # raft.py:38-40
+
+        self.img_corr_params = None
+        if model_params["use_boundary_images"]:
+            self.img_corr_params = corr_params["img"]
+            assert "levels" in self.img_corr_params and "radius" in self.img_corr_params
+
+        self.hidden_dim = hdim = model_params["hidden"]["dim"]
+        self.context_dim = cdim = model_params["context"]["dim"]
+        cnorm = model_params["context"]["norm"]
+        feature_dim = model_params["feature"]["dim"]
+        fnorm = model_params["feature"]["norm"]
+
+        context_dim = 0
+        self.fnet_img = None
+        if self.img_corr_params is not None:
+            self.fnet_img = BasicEncoder(input_dim=3, output_dim=feature_dim, norm_fn=fnorm)
+            context_dim += 3
+        self.fnet_ev = None
+        if model_params["use_events"]:
+            assert 0 not in self.ev_corr_target_indices
+            assert len(self.ev_corr_target_indices) > 0
+            assert max(self.ev_corr_target_indices) < self.nbins_context
+            assert len(self.ev_corr_target_indices) == len(self.ev_corr_levels)
+            self.fnet_ev = BasicEncoder(input_dim=nbins_correlation, output_dim=feature_dim, norm_fn=fnorm)
+            context_dim += nbins_context
+        assert self.fnet_ev is not None or self.fnet_img is not None
+        self.cnet = BasicEncoder(input_dim=context_dim, output_dim=hdim + cdim, norm_fn=cnorm)
+        self.update_block = BasicUpdateBlock(model_params, hidden_dim=hdim)
+
+        # look-up times are a property of the configuration (raft.py:156,170-177): build the Bezier coefficient table
+        # ONCE instead of re-deriving it in numpy and copying it host->device every iteration (bezier.py:176-180)
+        times: List[float] = []
+        if self.fnet_ev is not None:
+            dt = 1 / (self.nbins_context - 1)
+            times += [dt * t for t in self.ev_corr_target_indices]
+        if self.fnet_img is not None:
+            times.append(1)
+        self.lookup_timestamps = times
+        self._coef = None
+        self._graphs = None
+        self.stage_timer: Optional[StageTimer] = None
+
+    # ---------------------------------------------------------------------------------------- reference API
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def initialize_flow(self, input_: torch.Tensor):
+        """raft.py:80-86 (coords0 is implicit in the fused look-up; materialised here only for API parity)."""
+        N, _, H, W = input_.shape
+        ys, xs = torch.meshgrid(torch.arange(H // 8, device=input_.device), torch.arange(W // 8, device=input_.device), indexing="ij")
+        coords0 = torch.stack([xs, ys], dim=0).float()[None].repeat(N, 1, 1, 1)
+        return coords0, BezierCurves.create_from_voxel_grid(input_, downsample_factor=8, bezier_degree=self.bezier_degree)
+
+    def gen_voxel_grids(self, input_: torch.Tensor):
+        """raft.py:88-99: channel windows [idx, idx+nbins_corr) for idx in {0} + target indices; context = last bins."""
+        assert self.nbins_context + self.nbins_corr - 1 == input_.shape[-3]
+        grids = [input_[:, idx:idx + self.nbins_corr, ...] for idx in [0] + self.ev_corr_target_indices]
+        return grids, input_[:, -self.nbins_context:, ...]
+
+    # ---------------------------------------------------------------------------------------- execution control
+    def enable_hipgraph(self, enabled: bool = True):
+        """Replay the forward from a captured hipGraph (one graph per input signature)."""
+        from .graph import GraphCache
+        self._graphs = GraphCache(self) if enabled else None
+        return self
+
+    def enable_stage_timing(self, enabled: bool = True):
+        """hipEvent stage timers with the reference's hook names (raft.py:116-186, utils/timers.py); eager mode only."""
+        self.stage_timer = StageTimer() if enabled else None
+        return self
+
+    def _coefficients(self) -> np.ndarray:
+        if self._coef is None:
+            self._coef = polynomial_coefficients(self.lookup_timestamps, self.bezier_degree)
+        return self._coef
+
+    def forward(self,
+                voxel_grid: Optional[torch.Tensor] = None,
+                images: Optional[List[torch.Tensor]] = None,
+                iters: int = 12,
+                flow_init: Optional[BezierCurves] = None,
+                test_mode: bool = False):
+        assert voxel_grid is not None or images is not None
+        assert iters > 0
+        ref = voxel_grid if voxel_grid is not None else images[0]
+        if not ref.is_cuda:
+            raise hip.BflowHipError("RAFTSpline (bflow_amd) runs on MI355X only: move the inputs and the module to the GPU "
+                                    "(the CPU restatement lives in oracle/ and is test infrastructure)")
+        if self.training:
+            raise hip.BflowHipError("bflow_amd.RAFTSpline implements the inference path; call .eval() (training is out of scope)")
+        with torch.no_grad():
+            init = None if flow_init is None else flow_init.get_params()
+            if self._graphs is not None and self.stage_timer is None:
+                low, ups = self._graphs.run(voxel_grid, images, iters, init, test_mode)
+            else:
+                low, ups = self._forward_impl(voxel_grid, images, iters, init, test_mode)
+        if test_mode:
+            return BezierCurves(low), BezierCurves(ups[-1])
+        return [BezierCurves(u) for u in ups]
+
+    # ---------------------------------------------------------------------------------------- the hot path
+    def _forward_impl(self, voxel_grid, images, iters: int, flow_init: Optional[torch.Tensor], test_mode: bool):
+        """raft.py:101-200 on the HIP kernels.  No host<->device synchronisation anywhere (hipGraph-capturable)."""
+        hdim, cdim = self.hidden_dim, self.context_dim
+        tm = self.stage_timer
+        corr_ev = corr_img = None
+        context_input = None
+
+        if self.fnet_ev is not None:
+            assert voxel_grid is not None
+            if tm: tm.start("fnet_ev")
+            voxel_grid = voxel_grid.contiguous().float()
+            grids, context_input = self.gen_voxel_grids(voxel_grid)
+            B = voxel_grid.shape[0]
+            fm = self.fnet_ev(torch.cat(grids, dim=0)).float()             # ((T+1)*B, D, h, w): [reference | targets]
+            T = len(grids) - 1
+            fmap1 = fm[:B]
+            fmap2 = fm[B:].view(T, B, *fm.shape[1:])
+            corr_ev = CorrComputation(fmap1, fmap2, num_levels_per_target=self.ev_corr_levels)
+            if tm: tm.stop("fnet_ev")
+
+        if self.fnet_img is not None:
+            assert images is not None and len(images) == 2
+            if tm: tm.start("fnet_img")
+            images = [2 * (x.float().contiguous() / 255) - 1 for x in images]   # raft.py:134
+            B = images[0].shape[0]
+            fi = self.fnet_img(torch.cat(images, dim=0)).float()
+            corr_img = CorrComputation(fi[:B], fi[B:], num_levels_per_target=self.img_corr_params["levels"])
+            context_input = images[0] if context_input is None else torch.cat((context_input, images[0]), dim=-3)
+            if tm: tm.stop("fnet_img")
+        assert context_input is not None
+        B, _, H, W = context_input.shape
+        assert H % 8 == 0 and W % 8 == 0                                       # bezier.py:67-68
+        h, w = H // 8, W // 8
+        device = context_input.device
+
+        if tm: tm.start("cnet")
+        trunk = self.cnet(context_input.contiguous(), project=False)
+        cnet = torch.nn.functional.conv2d(trunk, self.cnet.conv2.weight)     # bias folded into the split kernel
+        ws = self.update_block.new_workspace(B, h, w, device)
+        ws.set_context(cnet, self.cnet.conv2.bias)
+        if tm: tm.stop("cnet")
+
+        bezier = torch.zeros((B, 2 * self.bezier_degree, h, w), dtype=torch.float32, device=device)   # raft.py:150
+        if flow_init is not None:
+            assert flow_init.shape == bezier.shape
+            bezier += flow_init                                               # raft.py:152-153
+
+        if tm: tm.start("corr computation")
+        corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img)
+        if tm: tm.stop("corr computation")
+
+        coef = self._coefficients()
+        corr_feat = corr_block.new_output()
+        ups: List[torch.Tensor] = []
+        if tm: tm.start("all iters")
+        for itr in range(iters):
+            if tm: tm.start("1 iter")
+            if tm: tm.start("corr lookup (per iter)")          # includes 'get_flow (per iter)': fused into the gather
+            corr_block.lookup_bezier(bezier, coef, out=corr_feat)
+            if tm: tm.stop("corr lookup (per iter)")
+            need_mask = (not test_mode) or itr == iters - 1
+            if tm: tm.start("update (per iter)")
+            raw_mask = self.update_block.step(ws, corr_feat, bezier, need_mask)
+            if need_mask:
+                ups.append(hip.cvx_upsample(bezier, raw_mask, self.update_block.mask[2].bias, 0.25))
+            if tm: tm.stop("update (per iter)")
+            if tm: tm.stop("1 iter")
+        if tm: tm.stop("all iters")
+        return bezier, ups

@@ -1,0 +1,160 @@
+"""Update block (K9-K11) -- drop-in for models/raft_spline/update.py:8-126 with the reference's parameter names.
+
+Inference only.  `BasicUpdateBlock.step()` runs one GRU/Bezier iteration on caller-provided workspaces with the
+dense convolutions on MIOpen (bias-free calls) and everything between them in the fused HIP element-wise kernels
+of csrc/update_ops.hip:
+  * no torch.cat: the convs read hx = [h | inp | motion] and rhx = [r*h | inp | motion] in place,
+  * convz and convr are one 256-channel convolution,
+  * conv bias + relu / sigmoid / tanh / GRU blend are folded into the element-wise kernels,
+  * the mask head only runs when its output is consumed (last iteration in test mode; raft.py:193-195).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+
+
+class BezierHead(nn.Module):
+    def __init__(self, bezier_degree: int, input_dim: int = 128, hidden_dim: int = 256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, bezier_degree * 2, 3, padding=1)
+
+
+class SepConvGRU(nn.Module):
+    def __init__(self, hidden_dim: int = 128, input_dim: int = 192 + 128):
+        super().__init__()
+        cin = hidden_dim + input_dim
+        for sfx, k, p in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
+            for gate in "zrq":
+                setattr(self, f"conv{gate}{sfx}", nn.Conv2d(cin, hidden_dim, k, padding=p))
+
+
+class BasicMotionEncoder(nn.Module):
+    def __init__(self, model_params: Dict[str, Any], output_dim: int = 128):
+        super().__init__()
+        cor_planes = self._num_cor_planes(model_params["correlation"], model_params["use_boundary_images"], model_params["use_events"])
+        bezier_planes = model_params["bezier_degree"] * 2
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(bezier_planes, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, output_dim - bezier_planes, 3, padding=1)
+
+    @staticmethod
+    def _num_cor_planes(corr_params: Dict[str, Any], use_boundary_images: bool, use_events: bool) -> int:
+        """update.py:69-86."""
+        assert use_events or use_boundary_images
+        out = 0
+        if use_events:
+            ev = corr_params["ev"]
+            assert len(ev["levels"]) > 0 and len(ev["levels"]) == len(ev["radius"])
+            for lvl, rad in zip(ev["levels"], ev["radius"]):
+                out += lvl * (2 * rad + 1) ** 2
+        if use_boundary_images:
+            out += corr_params["img"]["levels"] * (2 * corr_params["img"]["radius"] + 1) ** 2
+        return out
+
+
+class UpdateWorkspace:
+    """Caller-owned buffers of one forward: the two concatenated GRU inputs and the contiguous hidden state."""
+
+    def __init__(self, batch: int, hdim: int, cdim: int, mdim: int, h: int, w: int, device):
+        self.hdim, self.cdim, self.mdim = hdim, cdim, mdim
+        ctot = hdim + cdim + mdim
+        self.hx = torch.empty((batch, ctot, h, w), dtype=torch.float32, device=device)
+        self.rhx = torch.empty((batch, ctot, h, w), dtype=torch.float32, device=device)
+        self.net = torch.empty((batch, hdim, h, w), dtype=torch.float32, device=device)
+        self.corbez = torch.empty((batch, 256, h, w), dtype=torch.float32, device=device)
+
+    def set_context(self, cnet: torch.Tensor, bias: Optional[torch.Tensor]):
+        """net = tanh(cnet[:, :hdim]), inp = relu(cnet[:, hdim:])  (raft.py:145-147) written into hx; inp mirrored to rhx."""
+        h0, c0 = self.hdim, self.cdim
+        hip.tanh_relu_split(cnet, bias, h0, c0, self.hx[:, :h0], self.hx[:, h0:h0 + c0])
+        self.rhx[:, h0:h0 + c0].copy_(self.hx[:, h0:h0 + c0])
+        self.net.copy_(self.hx[:, :h0])
+
+
+class BasicUpdateBlock(nn.Module):
+    def __init__(self, model_params: Dict[str, Any], hidden_dim: int = 128):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.motion_dim = model_params["motion"]["dim"]
+        self.context_dim = model_params["context"]["dim"]
+        self.bezier_planes = model_params["bezier_degree"] * 2
+        self.encoder = BasicMotionEncoder(model_params, output_dim=self.motion_dim)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=self.context_dim + self.motion_dim)
+        self.bezier_head = BezierHead(model_params["bezier_degree"], input_dim=hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(nn.Conv2d(hidden_dim, 256, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(256, 64 * 9, 1, padding=0))
+        self._fused = None
+
+    # merged z|r weights; rebuilt when any source parameter changed (load_state_dict, .to(), ...)
+    def _fused_weights(self):
+        g = self.gru
+        key = tuple((p.data_ptr(), p._version) for p in (g.convz1.weight, g.convr1.weight, g.convz2.weight, g.convr2.weight))
+        if self._fused is None or self._fused[0] != key:
+            with torch.no_grad():
+                wzr1 = torch.cat([g.convz1.weight, g.convr1.weight], dim=0).contiguous()
+                wzr2 = torch.cat([g.convz2.weight, g.convr2.weight], dim=0).contiguous()
+            self._fused = (key, wzr1, wzr2)
+        return self._fused[1], self._fused[2]
+
+    def new_workspace(self, batch: int, h: int, w: int, device) -> UpdateWorkspace:
+        return UpdateWorkspace(batch, self.hidden_dim, self.context_dim, self.motion_dim, h, w, device)
+
+    def step(self, ws: UpdateWorkspace, corr: torch.Tensor, bezier: torch.Tensor, need_mask: bool):
+        """One iteration of update.py:116-126 on the workspace; `bezier` (B, 2*deg, h, w) is updated IN PLACE with the
+        predicted delta (bezier.py:137-139).  Returns the raw mask-head output (before bias and the 0.25 scale, both folded
+        into the up-sampling kernel) or None."""
+        enc, g = self.encoder, self.gru
+        h0, c0 = self.hidden_dim, self.context_dim
+        xo = h0 + c0  # first motion-feature channel inside hx / rhx
+        # ---- motion encoder (update.py:88-97)
+        c1 = F.conv2d(corr, enc.convc1.weight)
+        hip.bias_act_inplace(c1, enc.convc1.bias, hip.ACT_RELU)
+        c2 = F.conv2d(c1, enc.convc2.weight, padding=1)
+        f1 = F.conv2d(bezier, enc.convf1.weight, padding=3)
+        hip.bias_act_inplace(f1, enc.convf1.bias, hip.ACT_RELU)
+        f2 = F.conv2d(f1, enc.convf2.weight, padding=1)
+        hip.concat2_act(c2, enc.convc2.bias, hip.ACT_RELU, f2, enc.convf2.bias, hip.ACT_RELU, ws.corbez)
+        m = F.conv2d(ws.corbez, enc.conv.weight, padding=1)
+        hip.concat2_act(m, enc.conv.bias, hip.ACT_RELU, bezier, None, hip.ACT_NONE, ws.hx[:, xo:], ws.rhx[:, xo:])
+        # ---- separable conv-GRU (update.py:33-48): horizontal 1x5, then vertical 5x1
+        wzr1, wzr2 = self._fused_weights()
+        hview, rhview = ws.hx[:, :h0], ws.rhx[:, :h0]
+        for wzr, cz, cr, cq, pad, last in ((wzr1, g.convz1, g.convr1, g.convq1, (0, 2), False),
+                                           (wzr2, g.convz2, g.convr2, g.convq2, (2, 0), True)):
+            zr = F.conv2d(ws.hx, wzr, padding=pad)
+            hip.gru_rh(zr[:, h0:], cr.bias, hview, rhview)
+            q = F.conv2d(ws.rhx, cq.weight, padding=pad)
+            hip.gru_blend(zr[:, :h0], cz.bias, q, cq.bias, hview, ws.net if last else None)
+        # ---- heads (update.py:17-18,111-114,120-125)
+        d1 = F.conv2d(ws.net, self.bezier_head.conv1.weight, padding=1)
+        hip.bias_act_inplace(d1, self.bezier_head.conv1.bias, hip.ACT_RELU)
+        d2 = F.conv2d(d1, self.bezier_head.conv2.weight, padding=1)
+        hip.add_delta(bezier, d2, self.bezier_head.conv2.bias)
+        if not need_mask:
+            return None
+        m1 = F.conv2d(ws.net, self.mask[0].weight, padding=1)
+        hip.bias_act_inplace(m1, self.mask[0].bias, hip.ACT_RELU)
+        return F.conv2d(m1, self.mask[2].weight)
+
+    def forward(self, net, inp, corr, bezier):
+        """Reference-shaped call (update.py:116-126): returns (net, mask, delta_bezier) without mutating the inputs."""
+        B, _, h, w = net.shape
+        ws = self.new_workspace(B, h, w, net.device)
+        h0, c0 = self.hidden_dim, self.context_dim
+        ws.hx[:, :h0].copy_(net)
+        ws.hx[:, h0:h0 + c0].copy_(inp)
+        ws.rhx[:, h0:h0 + c0].copy_(inp)
+        ws.net.copy_(net)
+        before = bezier.clone()
+        after = bezier.clone()
+        raw = self.step(ws, corr.contiguous(), after, need_mask=True)
+        mask = 0.25 * (raw + self.mask[2].bias.view(1, -1, 1, 1))
+        return ws.net, mask, after - before

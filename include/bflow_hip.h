@@ -1,0 +1,173 @@
+/*
+ * bflow_hip.h -- C ABI of libbflow_hip.so: the MI355X (gfx950 / CDNA4) kernels of the RAFT-spline
+ * inference hot path of uzh-rpg/bflow.
+ *
+ * The reference is 100 % Python/PyTorch and has no native layer; each entry point
+ * below replaces the stock-PyTorch op sequence of the cited reference lines (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers unless stated otherwise, sizes are ints / long long, no torch types;
+ *   - the CALLER allocates every buffer; the library never allocates or frees device memory and keeps no
+ *     mutable global state (except a thread-local last-error string);
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*): no synchronisation, no
+ *     host reads of device data -> safe inside hipGraph stream capture;
+ *   - return value 0 = OK, > 0 = hipError_t of the failed launch, < 0 = argument error (BFLOW_E_*);
+ *     nothing throws across the ABI.  bflow_last_error_string() describes the last failure on this thread;
+ *   - tensors are dense, row-major ("NCHW contiguous") fp32 unless stated otherwise.
+ */
+#ifndef BFLOW_HIP_H
+#define BFLOW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only this ABI is exported */
+
+#define BFLOW_ABI_VERSION 1
+
+#define BFLOW_E_ARG      (-1)   /* bad size / null pointer / unsupported configuration */
+#define BFLOW_E_LIMIT    (-2)   /* exceeds a compile-time limit (BFLOW_MAX_*) */
+
+#define BFLOW_MAX_PLANES   16   /* (level, target) planes of one correlation pyramid            */
+#define BFLOW_MAX_TARGETS   8   /* correlation targets (event targets + image target)           */
+#define BFLOW_MAX_DEGREE   16   /* Bezier degree                                                */
+#define BFLOW_LOOKUP_RADIUS 4   /* hard-coded in the reference: raft.py:40, corr.py:279         */
+
+typedef void* bflow_stream_t;   /* hipStream_t */
+
+int         bflow_version(void);
+const char* bflow_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K5  all-pairs correlation volume ("feature_dot_product").
+ * Replaces CorrComputation._corr_dot_prod_util, models/raft_utils/corr.py:264-272 (+ the 1-to-N / M-to-N
+ * reshapes :237-262):  out[t,b,i,j] = sum_d f1[t?,b,d,i] * f2[t,b,d,j] / sqrt(D).
+ *   f1 : (B, D, N) when f1_target_stride == 0 (one reference shared by all T targets), else element
+ *        stride between the per-target (B, D, N) blocks (M-to-N; = B*D*N for a dense (T,B,D,N) tensor)
+ *   f2 : (T, B, D, N)          out: (T, B, N, N)  == the reference's (T, B*N, 1, h, w) layout
+ * fp32 in, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out.                                        */
+int bflow_corr_build_f32(const float* f1, const float* f2, float* out,
+                         int T, int B, int D, int N, long long f1_target_stride, bflow_stream_t stream);
+
+/* K6  one pyramid level: 2x2 average pooling, stride 2, floor on odd sizes, over the target plane.
+ * Replaces CorrData.get_downsampled (F.avg_pool2d), models/raft_utils/corr.py:108-125.
+ *   in : (planes, h, w)   out : (planes, h/2, w/2)                                                    */
+int bflow_corr_pool2x2(const float* in, float* out, long long planes, int h, int w, bflow_stream_t stream);
+
+/* K7  9x9 bilinear window look-up in the correlation pyramid (zero padding, align_corners=True).
+ * Replaces CorrBlockParallelMultiTarget.__call__, models/raft_utils/corr.py:307-351, and bilinear_sampler,
+ * models/raft_utils/utils.py:5-21.  Plane p is one (pyramid level, target) pair, in the reference's channel
+ * order (level-major, targets ascending inside a level); output channel = p*81 + (dy+4)*9 + (dx+4).   */
+typedef struct bflow_plane {
+    const float* base;   /* device: (B*N, h, w) slab of this level/target                               */
+    int h, w;            /* plane size at this level                                                     */
+    int level;           /* centroid = coords / 2^level                           (corr.py:333)          */
+    int target;          /* index into the T base targets (which coords / which Bezier time to use)     */
+} bflow_plane_t;
+
+/*   planes : HOST array of P descriptors (copied into the kernel arguments)
+ *   coords : (T, B, 2, h1, w1) pixel coordinates, channel 0 = x, 1 = y
+ *   out    : (B, P*81, h1, w1)                                                                         */
+int bflow_corr_lookup(const bflow_plane_t* planes, int P, const float* coords, float* out,
+                      int T, int B, int h1, int w1, bflow_stream_t stream);
+
+/* K8+K14+K7 fused: evaluates the Bezier curve at the look-up times inside the gather kernel, so neither
+ * `flows` nor `coords1` (raft.py:180-181) is materialised:
+ *   coords[t,b,:,y,x] = (x, y) + sum_i coef[t][i] * params[b, dim*deg + i, y, x]
+ *   params : (B, 2*deg, h1, w1)            coef : HOST (T, deg) fp32 row-major (bflow_bezier_coeffs)    */
+int bflow_corr_lookup_bezier(const bflow_plane_t* planes, int P, const float* params, const float* coef,
+                             int T, int deg, float* out, int B, int h1, int w1, bflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K8  Bezier polynomial coefficients C(deg,i) (1-t)^(deg-i) t^i, i = 1..deg, computed in fp64 on the HOST
+ * and rounded to fp32 exactly like BezierCurves._compute_flow_from_timestamps,
+ * models/raft_spline/bezier.py:141-180.  times: HOST (T) fp64 in [0,1]; coef_out: HOST (T, deg) fp32.  */
+int bflow_bezier_coeffs(const double* times, int T, int deg, float* coef_out);
+
+/* K8  flow[t,b,d,y,x] = sum_i coef[t][i] * params[b, d*deg+i, y, x]  (+ (x,y) when add_coords0 != 0).
+ * Replaces BezierCurves.get_flow_from_reference / einsum, bezier.py:185,188-216 and raft.py:181.
+ *   out : (T, B, 2, h, w)                                                                              */
+int bflow_bezier_eval(const float* params, const float* coef, int T, int deg, int B, int h, int w,
+                      int add_coords0, float* out, bflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K9/K10 element-wise pieces of the update block, written so that no torch.cat / bias-add / activation
+ * launch is needed: the convolutions (MIOpen, bias-free) read the channel-concatenated buffers
+ * hx = [h | x] and rhx = [r*h | x] directly, and every conv bias + activation is folded into the next
+ * element-wise kernel.  All tensors are (B, C, HW) slices addressed by an element batch stride; `bias_*`
+ * are per-channel device vectors or NULL.  act: 0 = identity, 1 = relu.
+ *
+ * bflow_concat2_act:  dst[b, c]      = act_a(a[b, c] + bias_a[c])            c <  Ca
+ *                     dst[b, Ca + c] = act_b(b[b, c] + bias_b[c])            c <  Cb
+ * written to dst1 and (if not NULL) dst2.  Used for cat([cor, bez]) (update.py:94), cat([out, bezier])
+ * (update.py:96-97) and cat([inp, motion_features]) (update.py:118).                                      */
+int bflow_concat2_act(const float* a, long long a_bs, int Ca, const float* bias_a, int act_a,
+                      const float* b, long long b_bs, int Cb, const float* bias_b, int act_b,
+                      float* dst1, long long dst1_bs, float* dst2, long long dst2_bs,
+                      int B, int HW, bflow_stream_t stream);
+
+/* bflow_bias_act_inplace:  x[b,c] = act(x[b,c] + bias[c])        (conv bias + F.relu, update.py:89-92,18) */
+int bflow_bias_act_inplace(float* x, long long x_bs, const float* bias, int act, int B, int C, int HW,
+                           bflow_stream_t stream);
+
+/* bflow_gru_rh:  rh = sigmoid(r_pre + bias_r) * h                         (update.py:36-37 / :43-44)    */
+int bflow_gru_rh(const float* r_pre, long long r_bs, const float* bias_r, const float* h, long long h_bs,
+                 float* rh, long long rh_bs, int B, int C, int HW, bflow_stream_t stream);
+
+/* bflow_gru_blend:  z = sigmoid(z_pre + bias_z); h = (1 - z) * h + z * tanh(q_pre + bias_q), in place
+ *                                                                           (update.py:35,37-38 / :42,44-45)
+ * h2 (may be NULL) receives a second copy of the new state.                                             */
+int bflow_gru_blend(const float* z_pre, long long z_bs, const float* bias_z, const float* q_pre, long long q_bs,
+                    const float* bias_q, float* h, long long h_bs, float* h2, long long h2_bs,
+                    int B, int C, int HW, bflow_stream_t stream);
+
+/* bflow_tanh_relu_split: net = tanh(cnet[:, :C_h] + bias), inp = relu(cnet[:, C_h:C_h+C_i] + bias)
+ *                                                                                     (raft.py:145-147) */
+int bflow_tanh_relu_split(const float* cnet, long long cnet_bs, const float* bias, int C_h, int C_i,
+                          float* net, long long net_bs, float* inp, long long inp_bs,
+                          int B, int HW, bflow_stream_t stream);
+
+/* K12  params[b,c] += delta[b,c] + bias[c]   (bias of the last head conv, update.py:18, folded into
+ * BezierCurves.delta_update_params, bezier.py:137-139).  Dense (B, C, HW) tensors.                       */
+int bflow_add_delta(float* params, const float* delta, const float* bias, int B, int C, int HW,
+                    bflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K13  convex up-sampling x8: softmax over the 9 taps of mask_scale*mask, 3x3 neighbourhood of 8*data,
+ * pixel shuffle.  Replaces cvx_upsample, models/raft_utils/utils.py:33-48 (+ the 0.25 of update.py:125).
+ * The mask logits are mask_scale * (mask + mask_bias[channel]); mask_bias (576) may be NULL.
+ *   data : (B, C, h, w)   mask : (B, 576, h, w)   out : (B, C, 8h, 8w)                                  */
+int bflow_cvx_upsample(const float* data, const float* mask, const float* mask_bias, float mask_scale,
+                       float* out, int B, int C, int h, int w, bflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K1  event voxel grid: signed tri-linear (float x/y) or temporal-linear (integer x/y) scatter-add.
+ * Replaces VoxelGrid.convert, data/utils/representations.py:64-111.  `grid` (C,H,W) must be zeroed by the
+ * caller (hipMemsetAsync); accumulation uses fp32 hardware atomics (order is not deterministic).
+ *   x,y : fp32 (f32xy) or int16 (i16xy);  pol : int8 in {0,1};  t : int64 microseconds                  */
+int bflow_voxel_scatter_f32xy(const float* x, const float* y, const signed char* pol, const long long* t,
+                              long long n_events, long long t0_center, long long t1_center,
+                              float* grid, int C, int H, int W, bflow_stream_t stream);
+int bflow_voxel_scatter_i16xy(const short* x, const short* y, const signed char* pol, const long long* t,
+                              long long n_events, long long t0_center, long long t1_center,
+                              float* grid, int C, int H, int W, bflow_stream_t stream);
+
+/* K2  in-place normalisation over the NON-ZERO entries: (v - mean) / std (unbiased), or v - mean if std == 0.
+ * Replaces norm_voxel_grid, representations.py:9-18.  workspace: device, >= 4 doubles, any contents.    */
+int bflow_voxel_norm(float* grid, long long n, double* workspace, bflow_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K15 end-point-error partial sums for epe_masked / the EPE metric state, utils/metrics.py:30-49,196-213:
+ *   acc[0] += sum over valid pixels of sqrt(sum_c (pred-gt)^2)   (fp64)
+ *   acc[1] += number of valid pixels                              (fp64)
+ *   pred, gt : (B, C, HW);  valid : (B, HW) uint8 or NULL (= all valid);  acc : device double[2], the caller
+ *   zeroes it.  The caller forms mean = acc[0]/acc[1] (per batch, then sums batch means like the metric). */
+int bflow_epe_accumulate(const float* pred, const float* gt, const unsigned char* valid,
+                         int B, int C, long long HW, double* acc, bflow_stream_t stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFLOW_HIP_H */

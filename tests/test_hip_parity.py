@@ -1,0 +1,319 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed reference goldens.
+Runs on the GPU box only (`-m gpu`).  Floating-point path: tolerances are written at every comparison; the
+north-star bar for the flow is 1e-3 px EPE (fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bflow_amd
+from bflow_amd import configs, hip, synthetic
+from bflow_amd.bezier import BezierCurves
+from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
+from bflow_amd.metrics import EPE, epe_masked
+from bflow_amd.representations import VoxelGrid, norm_voxel_grid
+from bflow_amd.weights import deterministic_state_dict
+from oracle import raft_spline_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+EPE_TOL = 1e-3   # px, BASELINE.json north_star
+
+
+def g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_library_loaded_from_tree():
+    assert hip.lib().bflow_version() == 1
+    assert os.path.samefile(os.path.dirname(hip.library_path()), os.path.join(os.path.dirname(bflow_amd.__file__), "lib"))
+
+
+# ------------------------------------------------------------------------------------------------- K5 / K6 / K7
+def test_corr_build_pool_lookup_1toN_golden(golden_dir):
+    d = g(golden_dir, "corr_1toN")
+    cc = CorrComputation(cu(d["f1"]), cu(d["f2"]), num_levels_per_target=d["levels"].tolist())
+    blk = CorrBlockParallelMultiTarget(corr_computation_events=cc)
+    for L in range(3):
+        t, idx = blk.pyramid_level(L)
+        # fp32 dot products of length 32, values O(6): 1e-5 abs covers MFMA-vs-MKL summation order
+        np.testing.assert_allclose(t.cpu().numpy(), d[f"pyr{L}"], rtol=1e-5, atol=2e-5)
+    out = blk(cu(d["coords"]))
+    np.testing.assert_allclose(out.cpu().numpy(), d["lookup"], rtol=1e-5, atol=5e-5)
+
+
+def test_corr_MtoN_odd_pyramid_golden(golden_dir):
+    d = g(golden_dir, "corr_MtoN")
+    cce = CorrComputation(cu(d["f1_ev"]), cu(d["f2_ev"]), num_levels_per_target=[1, 1, 1, 4])
+    cci = CorrComputation(cu(d["f1_img"]), cu(d["f2_img"]), num_levels_per_target=4)
+    blk = CorrBlockParallelMultiTarget(corr_computation_events=cce, corr_computation_frames=cci)
+    assert blk.num_planes == 11
+    np.testing.assert_allclose(blk.pyramid_level(0)[0].cpu().numpy()[:, ::7], d["pyr0_rows7"], rtol=1e-5, atol=2e-5)
+    for L in (1, 2, 3):
+        t, idx = blk.pyramid_level(L)
+        assert idx == [3, 4]
+        np.testing.assert_allclose(t.cpu().numpy(), d[f"pyr{L}"], rtol=1e-5, atol=2e-5)
+    out = blk(list(cu(d["coords"])))
+    np.testing.assert_allclose(out.cpu().numpy(), d["lookup"], rtol=1e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("B,D,h,w,T", [(1, 256, 60, 80, 2), (2, 64, 9, 11, 3), (1, 16, 33, 40, 1)])
+def test_corr_build_vs_oracle_shapes(B, D, h, w, T):
+    """DSEC-sized tile edges (N=4800 is not a multiple of the 128 tile), N % 4 != 0 (scalar-load path), shared and
+    per-target references.  Asymmetric operands: a transposed write would fail."""
+    rs = np.random.RandomState(0)
+    f1 = rs.standard_normal((B, D, h, w)).astype(np.float32)
+    f2 = rs.standard_normal((T, B, D, h, w)).astype(np.float32)
+    ref = O.corr_volume(torch.from_numpy(f1), torch.from_numpy(f2)).numpy().reshape(T, B, h * w, h * w)
+    out = torch.empty((T, B, h * w, h * w), device=DEV)
+    hip.corr_build_f32(cu(f1).view(B, D, -1), cu(f2).view(T, B, D, -1), out)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=3e-5 * np.sqrt(D / 16))
+    f1t = rs.standard_normal((T, B, D, h, w)).astype(np.float32)
+    ref = O.corr_volume(torch.from_numpy(f1t), torch.from_numpy(f2)).numpy().reshape(T, B, h * w, h * w)
+    hip.corr_build_f32(cu(f1t).view(T, B, D, -1), cu(f2).view(T, B, D, -1), out)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=3e-5 * np.sqrt(D / 16))
+
+
+def test_corr_build_full_size_properties():
+    """BASELINE config C2 size (T=4, D=256, N=4800): size-independent properties instead of a CPU recomputation.
+    (1) swapping the operands transposes the volume; (2) linearity in f2; (3) rows against an fp64 spot check."""
+    T, B, D, N = 4, 1, 256, 4800
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    f1 = torch.randn((B, D, N), generator=gen)
+    f2 = torch.randn((T, B, D, N), generator=gen)
+    a = torch.empty((T, B, N, N), device=DEV)
+    hip.corr_build_f32(f1.to(DEV), f2.to(DEV), a)
+    b = torch.empty((1, B, N, N), device=DEV)
+    hip.corr_build_f32(f2[0].to(DEV), f1.unsqueeze(0).to(DEV), b)
+    assert torch.equal(a[0, 0].t(), b[0, 0])                      # exact: same fmaf chain over d, transposed tile roles
+    c = torch.empty((1, B, N, N), device=DEV)
+    hip.corr_build_f32(f1.to(DEV), (f2[1] + f2[2]).unsqueeze(0).to(DEV), c)
+    assert (c[0] - (a[1] + a[2])).abs().max().item() < 2e-4      # linearity (fp32 round-off of values O(16))
+    rows = [0, 127, 128, 4095, 4799]
+    ref = (f1[0].double().t()[rows] @ f2[3, 0].double()) / 16.0
+    assert (a[3, 0][rows].cpu().double() - ref).abs().max().item() < 2e-5
+
+
+def test_lookup_integer_coords_returns_volume_entries():
+    """Identity property at DSEC size: with zero flow the window centre (k=40) of plane (level 0, target t) is corr[t,b,i,i]
+    and the k-th tap is the (dy,dx)-shifted entry (zero outside the plane)."""
+    T, B, D, h, w = 2, 1, 32, 60, 80
+    N = h * w
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    f1, f2 = torch.randn((B, D, h, w), generator=gen).to(DEV), torch.randn((T, B, D, h, w), generator=gen).to(DEV)
+    blk = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, [1, 1]))
+    vol = blk.pyramid_level(0)[0].view(T, B, N, h, w)
+    coords = O.coords_grid(B, h, w).to(DEV).unsqueeze(0).repeat(T, 1, 1, 1, 1)
+    out = blk(coords).view(B, T, 81, h, w)
+    ii = torch.arange(N, device=DEV)
+    centre = vol[:, 0].reshape(T, N, N)[:, ii, ii].view(T, h, w)
+    # the reference's normalise/un-normalise round trip leaves ~1e-5 px of coordinate noise -> 1e-3 abs on values O(6)
+    assert (out[0, :, 40] - centre).abs().max().item() < 2e-3
+    k = 4 * 9 + 7  # dy = 0, dx = +3
+    shifted = torch.zeros_like(centre)
+    vv = vol[:, 0].reshape(T, h, w, h, w)
+    ys, xs = torch.meshgrid(torch.arange(h, device=DEV), torch.arange(w - 3, device=DEV), indexing="ij")
+    shifted[:, :, : w - 3] = vv[:, ys, xs, ys, xs + 3]
+    assert (out[0, :, k] - shifted).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("deg", [2, 10])
+def test_lookup_fused_bezier_matches_unfused(deg):
+    T, B, D, h, w = 3, 2, 16, 18, 22
+    rs = np.random.RandomState(3)
+    f1, f2 = cu(rs.standard_normal((B, D, h, w)).astype(np.float32)), cu(rs.standard_normal((T, B, D, h, w)).astype(np.float32))
+    blk = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, [1, 2, 4]))
+    params = (rs.standard_normal((B, 2 * deg, h, w)) * 2).astype(np.float32)
+    times = [0.25, 0.5, 1.0]
+    coef = hip.bezier_coeffs(times, deg)
+    fused = blk.lookup_bezier(cu(params), coef)
+    coords = O.coords_grid(B, h, w) + O.bezier_flow(torch.from_numpy(params), times)
+    unfused = blk(coords.to(DEV))
+    assert (fused - unfused).abs().max().item() < 1e-3     # coordinates agree to ~1e-6 px; values O(4), gradients O(4)/px
+    pyr = O.corr_pyramid(O.corr_volume(f1.cpu(), f2.cpu()), [1, 2, 4])
+    ref = O.corr_lookup(pyr, coords)
+    np.testing.assert_allclose(unfused.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=5e-5)
+
+
+# ------------------------------------------------------------------------------------------------- K8 / K13
+@pytest.mark.parametrize("deg", [2, 10])
+def test_bezier_golden(golden_dir, deg):
+    d = g(golden_dir, "bezier")
+    curves = BezierCurves(cu(d[f"params_d{deg}"]))
+    ts = d[f"times_d{deg}"].tolist()
+    np.testing.assert_allclose(curves.get_flow_from_reference(ts).cpu().numpy(), d[f"flow_list_d{deg}"], rtol=1e-6, atol=2e-6)
+    np.testing.assert_array_equal(curves.get_flow_from_reference(0.0).cpu().numpy(), d[f"flow_0_d{deg}"])
+    np.testing.assert_array_equal(curves.get_flow_from_reference(1.0).cpu().numpy(), d[f"flow_1_d{deg}"])
+    np.testing.assert_allclose(curves.get_flow_from_reference(0.3).cpu().numpy(), d[f"flow_03_d{deg}"], rtol=1e-6, atol=2e-6)
+    np.testing.assert_array_equal(hip.bezier_coeffs(ts, deg), O.bezier_coeffs(ts, deg).astype(np.float32))
+
+
+def test_cvx_upsample_golden(golden_dir):
+    d = g(golden_dir, "cvx_upsample")
+    out = BezierCurves(cu(d["data"])).create_upsampled(cu(d["mask"])).get_params()
+    np.testing.assert_allclose(out.cpu().numpy(), d["out"], rtol=1e-5, atol=1e-5)
+    # bias and the 0.25 scale folded into the kernel == applying them first (update.py:125)
+    rs = np.random.RandomState(4)
+    bias = rs.standard_normal(576).astype(np.float32)
+    out2 = hip.cvx_upsample(cu(d["data"]), cu(d["mask"]), cu(bias), 0.25)
+    ref = O.cvx_upsample(torch.from_numpy(d["data"]), 0.25 * (torch.from_numpy(d["mask"]) + torch.from_numpy(bias).view(1, -1, 1, 1)))
+    np.testing.assert_allclose(out2.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------- K1 / K2 / K15
+@pytest.mark.parametrize("tag", ["f", "i"])
+def test_voxel_grid_golden(golden_dir, tag):
+    d = g(golden_dir, "voxel")
+    ts, te, t0c, t1c = d["window"].tolist()
+    vg = VoxelGrid(5, 24, 32)
+    assert vg.get_extended_time_window(t0c, t1c) == (ts, te)
+    grid = vg.convert(cu(d[f"x_{tag}"]), cu(d[f"y_{tag}"]), cu(d[f"pol_{tag}"]), cu(d[f"t_{tag}"]), t0c, t1c)
+    # atomics reorder the fp32 accumulation (<= ~10 events per voxel here): 1e-5 abs
+    np.testing.assert_allclose(grid.cpu().numpy(), d[f"grid_{tag}"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(norm_voxel_grid(cu(d[f"grid_{tag}"])).cpu().numpy(), d[f"norm_{tag}"], rtol=1e-5, atol=1e-5)
+
+
+def test_voxel_norm_edge_cases(golden_dir):
+    d = g(golden_dir, "voxel")
+    np.testing.assert_array_equal(norm_voxel_grid(torch.zeros(3, 4, 5, device=DEV)).cpu().numpy(), d["norm_allzero"])
+    np.testing.assert_allclose(norm_voxel_grid(cu(d["norm_std0_in"])).cpu().numpy(), d["norm_std0"], atol=1e-7)
+    empty = VoxelGrid(5, 24, 32).convert(*(torch.zeros(0, dtype=dt, device=DEV) for dt in (torch.float32, torch.float32, torch.int8, torch.int64)),
+                                         0, 100)
+    assert empty.shape == (5, 24, 32) and float(empty.abs().sum()) == 0
+
+
+def test_voxel_grid_dsec_size_vs_oracle():
+    """480x640x5 grid, 1M events (DSEC path, float x/y): total mass is conserved and the grid matches the oracle."""
+    C, H, W = 5, 480, 640
+    vg = VoxelGrid(C, H, W)
+    ts, te = vg.get_extended_time_window(0, 100000)
+    x, y, pol, t = synthetic.events(1_000_000, H, W, ts, te, seed=5, int_xy=False)
+    ref = O.voxel_grid_convert(*(torch.from_numpy(v) for v in (x, y, pol, t)), C, H, W, 0, 100000)
+    out = vg.convert(cu(x), cu(y), cu(pol), cu(t), 0, 100000)
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    assert abs(float(out.double().sum()) - float(ref.double().sum())) < 1e-2
+
+
+def test_epe_golden(golden_dir):
+    d = g(golden_dir, "epe")
+    a, b, m = cu(d["a"]), cu(d["b"]), cu(d["mask"])
+    np.testing.assert_allclose(epe_masked(a, b).cpu().numpy(), d["epe"], rtol=1e-6)
+    np.testing.assert_allclose(epe_masked(a, b, m).cpu().numpy(), d["epe_masked"], rtol=1e-6)
+    assert epe_masked(a, b, torch.zeros_like(m)) is None
+    metric = EPE(device=DEV)
+    metric.update(a, b)
+    metric.update(a, b, m)
+    np.testing.assert_allclose(float(metric.compute()), (float(d["epe"]) + float(d["epe_masked"])) / 2, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------- update block / encoder
+def _model(cname, seed=0):
+    cfg = configs.model_config(cname)
+    m = bflow_amd.RAFTSpline(cfg).eval()
+    sd = deterministic_state_dict(m, seed)
+    m.load_state_dict(sd)
+    return cfg, m.to(DEV), sd
+
+
+def test_update_block_step_vs_oracle():
+    cfg, m, sd = _model("E_LU4_BD2")
+    rs = np.random.RandomState(6)
+    B, h, w = 2, 22, 26
+    net = np.tanh(rs.standard_normal((B, 128, h, w))).astype(np.float32)
+    inp = np.maximum(rs.standard_normal((B, 128, h, w)), 0).astype(np.float32)
+    corr = (rs.standard_normal((B, 567, h, w)) * 5).astype(np.float32)
+    bez = rs.standard_normal((B, 4, h, w)).astype(np.float32)
+    with torch.no_grad():
+        n2, mask, delta = m.update_block(cu(net), cu(inp), cu(corr), cu(bez))
+        rn, rm, rd = O.update_block(sd, *(torch.from_numpy(v) for v in (net, inp, corr, bez)))
+    assert (n2.cpu() - rn).abs().max().item() < 5e-5
+    assert (delta.cpu() - rd).abs().max().item() < 5e-5
+    assert (mask.cpu() - rm).abs().max().item() < 5e-4
+
+
+def test_encoder_vs_oracle():
+    cfg, m, sd = _model("E_I_LU4_BD2")
+    x = torch.from_numpy(synthetic.voxel_grid(2, 5, 64, 96, seed=9))
+    with torch.no_grad():
+        a = m.fnet_ev(x.to(DEV)).cpu()
+        b = O.encoder(sd, "fnet_ev", x, "instance")
+        assert (a - b).abs().max().item() < 5e-4 * float(b.abs().max())
+        xc = torch.from_numpy(synthetic.voxel_grid(2, 8, 64, 96, seed=10))
+        a = m.cnet(xc.to(DEV)).cpu()
+        b = O.encoder(sd, "cnet", xc, "batch")
+        assert (a - b).abs().max().item() < 5e-4 * float(b.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------- end to end
+E2E = ["e2e_E_LU4_BD2", "e2e_E_I_LU4_BD2", "e2e_E_LU5_BD10", "e2e_E_I_LU5_BD10"]
+
+
+def _e2e_inputs(d, cfg):
+    B, H, W = int(d["B"]), int(d["H"]), int(d["W"])
+    C = cfg["num_bins"]["context"] + cfg["num_bins"]["correlation"] - 1
+    vox = cu(synthetic.voxel_grid(B, C, H, W, seed=1234))
+    imgs = None
+    if cfg["use_boundary_images"]:
+        imgs = [cu(a) for a in synthetic.image_pair(B, H, W, seed=4321)]
+    return vox, imgs
+
+
+@pytest.mark.parametrize("name", E2E)
+@pytest.mark.parametrize("graph", [False, True])
+def test_e2e_forward_vs_reference_golden(golden_dir, name, graph):
+    d = g(golden_dir, name)
+    cfg, m, sd = _model(str(d["config"]))
+    if graph:
+        m.enable_hipgraph()
+    vox, imgs = _e2e_inputs(d, cfg)
+    for _ in range(2 if graph else 1):     # second call of the graph variant is a pure replay
+        low, up = m(voxel_grid=vox, images=imgs, iters=int(d["iters"]), test_mode=True)
+    f1 = up.get_flow_from_reference(1.0)
+    f05 = up.get_flow_from_reference(0.5)
+    e1 = float(epe_masked(f1.contiguous(), cu(d["flow_t1"])))
+    e05 = float(epe_masked(f05.contiguous(), cu(d["flow_t05"])))
+    glow = torch.from_numpy(d["bezier_low"])
+    glow1 = glow.view(glow.shape[0], 2, glow.shape[1] // 2, *glow.shape[2:])[:, :, -1]
+    elow = float(O.epe_masked(low.get_flow_from_reference(1.0).cpu(), glow1))
+    print(f"{name} graph={graph}: EPE(t=1)={e1:.2e} EPE(t=.5)={e05:.2e} EPE(low)={elow:.2e}")
+    assert e1 < EPE_TOL and e05 < EPE_TOL and elow < EPE_TOL
+    assert (up.get_params()[:, :, ::4, ::4].cpu() - torch.from_numpy(d["bezier_up_sub"])).abs().max().item() < 2e-2
+
+
+def test_e2e_train_mode_list_and_flow_init():
+    cfg, m, sd = _model("E_LU4_BD2")
+    vox = torch.from_numpy(synthetic.voxel_grid(1, 9, 128, 160, seed=8))
+    init = torch.from_numpy(np.random.RandomState(2).standard_normal((1, 4, 16, 20)).astype(np.float32))
+    ups = m(voxel_grid=vox.to(DEV), iters=3, flow_init=BezierCurves(init.to(DEV)), test_mode=False)
+    with torch.inference_mode():
+        ref = O.forward(sd, cfg, vox, None, iters=3, flow_init=init, test_mode=False)
+    assert len(ups) == 3
+    for a, b in zip(ups, ref):
+        assert float(O.epe_masked(a.get_flow_from_reference(1.0).cpu(), O.bezier_flow(b, 1.0))) < EPE_TOL
+
+
+def test_e2e_full_size_dsec_vs_oracle():
+    """BASELINE config C2 at full size: 480x640, B=1, 12 iterations, hipGraph replay vs the CPU oracle."""
+    cfg, m, sd = _model("E_LU4_BD2")
+    m.enable_hipgraph()
+    vox = torch.from_numpy(synthetic.voxel_grid(1, 9, 480, 640, seed=1234))
+    low, up = m(voxel_grid=vox.to(DEV), iters=12, test_mode=True)
+    with torch.inference_mode():
+        rlow, rup = O.forward(sd, cfg, vox, None, iters=12, test_mode=True)
+    e = float(O.epe_masked(up.get_flow_from_reference(1.0).cpu(), O.bezier_flow(rup, 1.0)))
+    mag = float(O.bezier_flow(rup, 1.0).abs().mean())
+    print(f"full-size C2: EPE vs oracle = {e:.3e} px at mean |flow| = {mag:.2f} px")
+    assert e < EPE_TOL
+
+
+def test_cpu_inputs_fail_loudly():
+    cfg, m, sd = _model("E_LU4_BD2")
+    with pytest.raises(hip.BflowHipError):
+        m(voxel_grid=torch.zeros(1, 9, 64, 64), iters=1, test_mode=True)
+    with pytest.raises(hip.BflowHipError):
+        hip.corr_pool2x2(torch.zeros(1, 4, 4), torch.zeros(1, 2, 2))

@@ -1,0 +1,180 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/bflow_hip.h declares, host-side logic (config
+composition, parameter inventory / checkpoint compatibility, sharding, the N>1 exchange step over gloo), and that the
+product path refuses to run without a GPU.  No kernel is launched here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import bflow_amd
+from bflow_amd import configs, dist as bdist, hip
+from bflow_amd.bezier import BezierCurves
+from bflow_amd.corr import CorrComputation
+from bflow_amd.weights import deterministic_state_dict
+from oracle import raft_spline_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "bflow_hip.h")).read()
+    declared = set(re.findall(r"\b(bflow_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    lib = ctypes.CDLL(hip.library_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.lib().bflow_version() == 1
+    # only the C ABI is exported (built with -fvisibility=hidden)
+    syms = subprocess.run(["nm", "-D", "--defined-only", hip.library_path()], stdout=subprocess.PIPE, text=True).stdout
+    exported = {l.split()[-1] for l in syms.splitlines() if " T " in l}
+    assert exported == declared, exported ^ declared
+
+
+def test_host_side_abi_functions_and_error_reporting():
+    np.testing.assert_array_equal(hip.bezier_coeffs([0.25, 0.5, 0.75, 1.0], 2), O.bezier_coeffs([0.25, 0.5, 0.75, 1.0], 2).astype(np.float32))
+    np.testing.assert_array_equal(hip.bezier_coeffs([0.2, 0.4, 0.6, 0.8, 1.0, 1], 10), O.bezier_coeffs([0.2, 0.4, 0.6, 0.8, 1.0, 1], 10).astype(np.float32))
+    with pytest.raises(hip.BflowHipError, match="outside"):
+        hip.bezier_coeffs([1.5], 2)
+    with pytest.raises(hip.BflowHipError, match="degree"):
+        hip.bezier_coeffs([0.5], 99)
+
+
+def test_no_cpu_fallback():
+    cfg = configs.model_config("E_LU4_BD2")
+    m = bflow_amd.RAFTSpline(cfg).eval()
+    with pytest.raises(hip.BflowHipError, match="MI355X"):
+        m(voxel_grid=torch.zeros(1, 9, 64, 64), iters=1, test_mode=True)
+    with pytest.raises(hip.BflowHipError):
+        hip.corr_build_f32(torch.zeros(1, 16, 4), torch.zeros(1, 1, 16, 4), torch.zeros(1, 1, 4, 4))
+    with pytest.raises(hip.BflowHipError):
+        BezierCurves(torch.zeros(1, 4, 2, 2)).create_upsampled(torch.zeros(1, 576, 2, 2))
+    # the product package never imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "bflow_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+@pytest.mark.parametrize("name", list(configs.EXPERIMENTS))
+def test_config_tree_and_state_dict_compat(name):
+    cfg = configs.model_config(name)
+    ref = O.model_config(name)
+    for k in ("num_bins", "bezier_degree", "detach_bezier", "use_boundary_images", "use_events", "hidden", "context", "feature",
+              "motion", "num_iter"):
+        assert cfg[k] == ref[k], k
+    assert cfg["correlation"]["ev"] == ref["correlation"]["ev"] and cfg["correlation"]["use_cosine_sim"] is False
+    model = bflow_amd.RAFTSpline(cfg)
+    shapes = O.param_shapes(cfg)   # checked against the reference's own state dict in test_oracle_vs_reference.py
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+    a, b = deterministic_state_dict(model, 3), O.make_state_dict(cfg, 3)
+    assert all(torch.equal(a[k], b[k]) for k in b)
+    model.load_state_dict(a)
+    assert model.lookup_timestamps == O.lookup_times(cfg)
+
+
+def test_constructor_asserts_match_reference():
+    cfg = configs.model_config("E_LU4_BD2")
+    bad = {**cfg, "correlation": {**cfg["correlation"], "ev": {**cfg["correlation"]["ev"], "target_indices": [0, 1, 2, 3]}}}
+    with pytest.raises(AssertionError):
+        bflow_amd.RAFTSpline(bad)            # raft.py:64
+    bad = {**cfg, "correlation": {**cfg["correlation"], "ev": {**cfg["correlation"]["ev"], "target_indices": [1, 2, 3, 5]}}}
+    with pytest.raises(AssertionError):
+        bflow_amd.RAFTSpline(bad)            # raft.py:66
+    bad = {**cfg, "bezier_degree": 0}
+    with pytest.raises(AssertionError):
+        bflow_amd.RAFTSpline(bad)            # raft.py:24
+
+
+def test_corr_computation_bookkeeping():
+    f1 = torch.zeros(2, 8, 4, 6)
+    f2 = torch.zeros(3, 2, 8, 4, 6)
+    cc = CorrComputation(f1, f2, [1, 2, 3])
+    assert (cc.batch, cc.dim, cc.height, cc.width) == (2, 8, 4, 6)
+    assert cc.num_targets_overall == 3 and cc.num_levels_per_target_merged.tolist() == [1, 2, 3]
+    both = cc + CorrComputation(f1, f2[0], 4)
+    assert both.num_references == 2 and both.num_targets_per_reference == [3, 1] and both.levels_flat() == [1, 2, 3, 4]
+    with pytest.raises(AssertionError):
+        CorrComputation(f1, f2, [1, 2])      # corr.py:159
+    with pytest.raises(AssertionError):
+        CorrComputation(f1, torch.zeros(3, 2, 8, 4, 7), [1, 2, 3])   # corr.py:156
+
+
+def test_bezier_container_on_host():
+    p = torch.from_numpy(np.random.RandomState(0).standard_normal((2, 20, 3, 4)).astype(np.float32))
+    c = BezierCurves(p)
+    assert (c.degree, c.batch_size, c.dim, c.height, c.width) == (10, 2, 20, 3, 4)
+    assert torch.equal(c.get_flow_from_reference(1.0), O.bezier_flow(p, 1.0))
+    assert torch.equal(c.get_flow_from_reference(0), O.bezier_flow(p, 0))
+    np.testing.assert_allclose(c.get_flow_from_reference([0.2, 0.7]).numpy(), O.bezier_flow(p, [0.2, 0.7]).numpy(), rtol=1e-6, atol=1e-6)
+    c.delta_update_params(torch.ones_like(p))
+    assert torch.equal(c.get_params(), p + 1)
+    z = BezierCurves.create_from_voxel_grid(torch.zeros(2, 9, 64, 96), bezier_degree=2)
+    assert z.get_params().shape == (2, 4, 8, 12) and float(z.get_params().abs().sum()) == 0
+    with pytest.raises(AssertionError):
+        BezierCurves.create_from_voxel_grid(torch.zeros(1, 9, 60, 96))   # bezier.py:67-68
+
+
+def test_shard_ranges_cover_the_global_batch():
+    for G in (1, 7, 8, 64):
+        for Wd in (1, 2, 4, 8):
+            spans = [bdist.shard_range(G, r, Wd) for r in range(Wd)]
+            assert spans[0][0] == 0 and spans[-1][1] == G
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+import torch
+torch.set_num_threads(2)
+from bflow_amd import dist as bdist, synthetic
+from oracle import raft_spline_oracle as O
+rank, world, local = bdist.init_from_env("gloo")
+cfg = O.model_config("E_LU4_BD2")
+sd = O.make_state_dict(cfg, 0)
+G, H, W = 4, 128, 160
+def fwd(first, n):
+    vox = torch.from_numpy(synthetic.voxel_grid(n, 9, H, W, seed=1234, first_sample=first))
+    with torch.inference_mode():
+        low, up = O.forward(sd, cfg, vox, None, iters=2, test_mode=True)
+    return O.bezier_flow(up, 1.0)
+def gt(first, n):
+    return torch.from_numpy(synthetic.gt_flow(n, H, W, seed=99, first_sample=first))
+mean, s, c = bdist.evaluate_sharded(fwd, gt, O.epe_masked, G, 1, rank, world)
+if rank == 0:
+    print("RESULT " + json.dumps(dict(mean=float(mean), sum=float(s), count=float(c), world=world)))
+import torch.distributed as d
+if d.is_initialized():
+    d.barrier(); d.destroy_process_group()
+"""
+
+
+def _run_world(world: int, port: int):
+    code = _WORKER.format(root=ROOT)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    line = [l for l in outs[0].splitlines() if l.startswith("RESULT ")][0]
+    import json
+    return json.loads(line[len("RESULT "):])
+
+
+def test_two_rank_gloo_shard_equivalence():
+    """N-rank EPE == 1-rank EPE on the same global batch: contiguous shards, per-rank metric state,
+    one all-gather of the (epe_sum, count) record.  gloo on CPU with the oracle as the forward function."""
+    one = _run_world(1, 29631)
+    two = _run_world(2, 29632)
+    assert one["count"] == two["count"] == 4
+    assert abs(one["sum"] - two["sum"]) < 1e-9 and abs(one["mean"] - two["mean"]) < 1e-9
