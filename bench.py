@@ -60,11 +60,30 @@ def kernel_event_ms(launch, n):
     return float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU box exposes 256 logical CPUs
+    but caps the container at a 16-CPU quota; oversubscribing the quota makes the baseline ~100x slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(cfg, sd, vox_cpu, budget_s=25.0):
     """The CPU oracle (op-for-op restatement of the reference, pinned to it in the build container) on this host's cores.
     Bounded sample: 1 warm-up + up to 4 timed forwards of the same workload (one 640x480 frame, 12 iterations)."""
     from oracle import raft_spline_oracle as O   # checker / baseline only -- never on the product path
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     with torch.inference_mode():
         O.forward(sd, cfg, vox_cpu, None, iters=ITERS, test_mode=True)

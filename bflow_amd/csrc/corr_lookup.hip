@@ -22,7 +22,7 @@ constexpr int WIN = 2 * R + 1;           // 9
 constexpr int PATCH = 12;                // floor(c)-5 .. floor(c)+6 covers every bilinear corner incl. round-off flips
 constexpr int PSTRIDE = PATCH * PATCH + 1;  // 145 floats (odd -> bank-conflict free for lane == pixel)
 constexpr int TILE = 64;                 // query pixels per block
-constexpr int LTHREADS = 256;
+constexpr int LTHREADS = 192;           // 3 waves: each produces 3 of the 9 window rows in phase 2
 
 struct PlaneDev {
     const float* base;
@@ -97,50 +97,80 @@ __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, 
     __syncthreads();
 
     // ---- phase 1: gather 64 patches, 16 lanes per 12-wide patch row -------------------------------------
+    // 48 row segments per thread, issued in batches of 12 independent loads (memory-level parallelism: the gather is
+    // latency-bound, not bandwidth-bound, at batch 1) before any of them is written to LDS.
     {
         const int g = tid >> 4, c = tid & 15;
         const long long plane_sz = (long long)pl.h * pl.w;
-        for (int rowid = g; rowid < TILE * PATCH; rowid += LTHREADS / 16) {
-            const int pix = rowid / PATCH, r = rowid - pix * PATCH;
-            const int n = n0 + pix;
-            if (c < PATCH) {
+        const float* slab = pl.base + ((long long)b * N + n0) * plane_sz;
+        constexpr int ROWS_PER_PASS = LTHREADS / 16;            // 12
+        constexpr int PASSES = TILE * PATCH / ROWS_PER_PASS;    // 64
+        constexpr int BATCH = 16;
+        static_assert(TILE * PATCH % ROWS_PER_PASS == 0 && PASSES % BATCH == 0, "patch gather tiling");
+#pragma unroll
+        for (int p0 = 0; p0 < PASSES; p0 += BATCH) {
+            float v[BATCH];
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int rowid = (p0 + j) * ROWS_PER_PASS + g;
+                const int pix = rowid / PATCH, r = rowid - pix * PATCH;
                 const int gy = s_oy[pix] + r, gx = s_ox[pix] + c;
-                float v = 0.f;
-                if (n < N && gy >= 0 && gy < pl.h && gx >= 0 && gx < pl.w)
-                    v = pl.base[((long long)b * N + n) * plane_sz + (long long)gy * pl.w + gx];
-                patch[pix * PSTRIDE + r * PATCH + c] = v;
+                const bool ok = (c < PATCH) && (n0 + pix < N) && gy >= 0 && gy < pl.h && gx >= 0 && gx < pl.w;
+                v[j] = ok ? slab[pix * plane_sz + (long long)gy * pl.w + gx] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < BATCH; ++j) {
+                const int rowid = (p0 + j) * ROWS_PER_PASS + g;
+                const int pix = rowid / PATCH, r = rowid - pix * PATCH;
+                if (c < PATCH) patch[pix * PSTRIDE + r * PATCH + c] = v[j];
             }
         }
     }
     __syncthreads();
 
-    // ---- phase 2: lane == pixel, wave w produces window positions k = w, w+4, ... ----------------------
+    // ---- phase 2: lane == pixel, wave w produces window rows dy = 3w .. 3w+2 (27 of the 81 taps) ---------------
     {
         const int pix = tid & 63, wv = tid >> 6;
         const int n = n0 + pix;
         const float cx = s_cx[pix], cy = s_cy[pix];
         const int ox = s_ox[pix], oy = s_oy[pix];
+        // the 9 sample columns of the window: patch-relative west corner + east weight (shared by the 3 rows)
+        int rx[WIN];
+        float wx[WIN];
+#pragma unroll
+        for (int d = 0; d < WIN; ++d) {
+            float ix = roundtrip(cx + (float)(d - R), pl.w);
+            ix = fminf(fmaxf(ix, -1.0e4f), 1.0e4f);
+            const float fx0 = floorf(ix);
+            wx[d] = ix - fx0;
+            const int ax = (int)fx0 - ox;
+            rx[d] = (ax >= 0 && ax + 1 < PATCH) ? ax : -1;
+        }
         const float* pp = patch + pix * PSTRIDE;
         float* o = out + ((long long)b * args.P * (WIN * WIN) + (long long)p * (WIN * WIN)) * N + n;
-        for (int k = wv; k < WIN * WIN; k += 4) {
-            const int ky = k / WIN, kx = k - ky * WIN;
-            float ix = roundtrip(cx + (float)(kx - R), pl.w);
+#pragma unroll
+        for (int jr = 0; jr < 3; ++jr) {
+            const int ky = wv * 3 + jr;
             float iy = roundtrip(cy + (float)(ky - R), pl.h);
-            ix = fminf(fmaxf(ix, -1.0e4f), 1.0e4f);
             iy = fminf(fmaxf(iy, -1.0e4f), 1.0e4f);
-            const float fx0 = floorf(ix), fy0 = floorf(iy);
-            const float we = ix - fx0, ww = 1.f - we;  // weights of the east (x0+1) / west (x0) columns
-            const float ws = iy - fy0, wn = 1.f - ws;  // south (y0+1) / north (y0) rows
-            const int rx = (int)fx0 - ox, ry = (int)fy0 - oy;
-            float v = 0.f;
-            if (rx >= 0 && rx + 1 < PATCH && ry >= 0 && ry + 1 < PATCH) {
-                const float* q = pp + ry * PATCH + rx;
-                v = q[0] * (ww * wn);
-                v += q[1] * (we * wn);
-                v += q[PATCH] * (ww * ws);
-                v += q[PATCH + 1] * (we * ws);
+            const float fy0 = floorf(iy);
+            const float ws = iy - fy0, wn = 1.f - ws;   // south (y0+1) / north (y0) row weights
+            const int ay = (int)fy0 - oy;
+            const bool yok = (ay >= 0 && ay + 1 < PATCH);
+            const float* qrow = pp + (yok ? ay : 0) * PATCH;
+#pragma unroll
+            for (int kx = 0; kx < WIN; ++kx) {
+                const float we = wx[kx], ww = 1.f - we;
+                float v = 0.f;
+                if (yok && rx[kx] >= 0) {
+                    const float* q = qrow + rx[kx];
+                    v = q[0] * (ww * wn);
+                    v += q[1] * (we * wn);
+                    v += q[PATCH] * (ww * ws);
+                    v += q[PATCH + 1] * (we * ws);
+                }
+                if (n < N) o[(long long)(ky * WIN + kx) * N] = v;
             }
-            if (n < N) o[(long long)k * N] = v;
         }
     }
 }
