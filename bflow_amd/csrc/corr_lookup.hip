@@ -13,6 +13,7 @@
 //              out[b, p*81+k, pixel..pixel+63] as one coalesced 256-B row.
 //   The Bezier evaluation + coords0 (raft.py:180-181) is optionally fused in front (FUSED = true), which removes
 //   the `flows`/`coords1` tensors and one launch per GRU iteration.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -46,7 +47,7 @@ __device__ __forceinline__ float roundtrip(float x, int size) {
     return (g + 1.0f) * (sm1 / 2.0f);
 }
 
-template <bool FUSED>
+template <bool FUSED, int BATCH>
 __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, const float* __restrict__ src,
                                                               float* __restrict__ out, int B, int h1, int w1) {
     __shared__ float patch[TILE * PSTRIDE];
@@ -100,29 +101,29 @@ __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, 
     // 48 row segments per thread, issued in batches of 12 independent loads (memory-level parallelism: the gather is
     // latency-bound, not bandwidth-bound, at batch 1) before any of them is written to LDS.
     {
-        const int g = tid >> 4, c = tid & 15;
-        const long long plane_sz = (long long)pl.h * pl.w;
+        const int r = tid >> 4, c = tid & 15;                   // 12 row groups x 16 lanes: pass == pixel, group == patch row
+        const int plane_sz = pl.h * pl.w;                       // < 2^24 (checked on the host): 32-bit offsets inside the slab
         const float* slab = pl.base + ((long long)b * N + n0) * plane_sz;
         constexpr int ROWS_PER_PASS = LTHREADS / 16;            // 12
-        constexpr int PASSES = TILE * PATCH / ROWS_PER_PASS;    // 64
-        constexpr int BATCH = 16;
-        static_assert(TILE * PATCH % ROWS_PER_PASS == 0 && PASSES % BATCH == 0, "patch gather tiling");
+        static_assert(ROWS_PER_PASS == PATCH && TILE % BATCH == 0, "one pass gathers one 12x12 patch");
+        const int npix = min(TILE, N - n0);
 #pragma unroll
-        for (int p0 = 0; p0 < PASSES; p0 += BATCH) {
+        for (int p0 = 0; p0 < TILE; p0 += BATCH) {
             float v[BATCH];
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
-                const int rowid = (p0 + j) * ROWS_PER_PASS + g;
-                const int pix = rowid / PATCH, r = rowid - pix * PATCH;
+                const int pix = p0 + j;
                 const int gy = s_oy[pix] + r, gx = s_ox[pix] + c;
-                const bool ok = (c < PATCH) && (n0 + pix < N) && gy >= 0 && gy < pl.h && gx >= 0 && gx < pl.w;
-                v[j] = ok ? slab[pix * plane_sz + (long long)gy * pl.w + gx] : 0.f;
+                const bool ok = (c < PATCH) && (pix < npix) && gy >= 0 && gy < pl.h && gx >= 0 && gx < pl.w;
+                // branch-free: out-of-plane lanes read element 0 of the slab (always mapped) and are zeroed afterwards, so
+                // the BATCH loads issue back to back instead of one exec-masked branch + wait per load
+                const int off = ok ? (pix * plane_sz + gy * pl.w + gx) : 0;
+                const float ld = slab[off];
+                v[j] = ok ? ld : 0.f;
             }
+            if (c < PATCH) {
 #pragma unroll
-            for (int j = 0; j < BATCH; ++j) {
-                const int rowid = (p0 + j) * ROWS_PER_PASS + g;
-                const int pix = rowid / PATCH, r = rowid - pix * PATCH;
-                if (c < PATCH) patch[pix * PSTRIDE + r * PATCH + c] = v[j];
+                for (int j = 0; j < BATCH; ++j) patch[(p0 + j) * PSTRIDE + r * PATCH + c] = v[j];
             }
         }
     }
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, 
         }
         const float* pp = patch + pix * PSTRIDE;
         float* o = out + ((long long)b * args.P * (WIN * WIN) + (long long)p * (WIN * WIN)) * N + n;
+        if (n < N) {
 #pragma unroll
         for (int jr = 0; jr < 3; ++jr) {
             const int ky = wv * 3 + jr;
@@ -161,16 +163,16 @@ __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, 
 #pragma unroll
             for (int kx = 0; kx < WIN; ++kx) {
                 const float we = wx[kx], ww = 1.f - we;
-                float v = 0.f;
-                if (yok && rx[kx] >= 0) {
-                    const float* q = qrow + rx[kx];
-                    v = q[0] * (ww * wn);
-                    v += q[1] * (we * wn);
-                    v += q[PATCH] * (ww * ws);
-                    v += q[PATCH + 1] * (we * ws);
-                }
-                if (n < N) o[(long long)(ky * WIN + kx) * N] = v;
+                const bool ok = yok && rx[kx] >= 0;
+                const float* q = qrow + (ok ? rx[kx] : 0);     // branch-free: clamped LDS address, select afterwards
+                float v = q[0] * (ww * wn);
+                v += q[1] * (we * wn);
+                v += q[PATCH] * (ww * ws);
+                v += q[PATCH + 1] * (we * ws);
+                v = ok ? v : 0.f;
+                o[(long long)(ky * WIN + kx) * N] = v;
             }
+        }
         }
     }
 }
@@ -186,6 +188,7 @@ int fill_args(LookupArgs& a, const bflow_plane_t* planes, int P, int T) {
         BFLOW_REQUIRE(planes[p].base && planes[p].h > 0 && planes[p].w > 0 && planes[p].level >= 0 && planes[p].level < 16 &&
                           planes[p].target >= 0 && planes[p].target < T,
                       BFLOW_E_ARG, "corr_lookup: bad descriptor for plane %d", p);
+        BFLOW_REQUIRE((long long)planes[p].h * planes[p].w * TILE < (1LL << 30), BFLOW_E_LIMIT, "corr_lookup: plane %d too large", p);
         a.planes[p].base = planes[p].base;
         a.planes[p].h = planes[p].h;
         a.planes[p].w = planes[p].w;
@@ -193,6 +196,25 @@ int fill_args(LookupArgs& a, const bflow_plane_t* planes, int P, int T) {
         a.planes[p].target = planes[p].target;
     }
     return 0;
+}
+
+// Gather depth (independent loads in flight per thread) is a tunable: BFLOW_LOOKUP_BATCH in {16, 32, 64}.
+int lookup_batch() {
+    static int v = [] {
+        const char* e = getenv("BFLOW_LOOKUP_BATCH");
+        int b = e ? atoi(e) : 32;
+        return (b == 16 || b == 32 || b == 64) ? b : 32;
+    }();
+    return v;
+}
+
+template <bool FUSED>
+void launch_lookup(dim3 grid, hipStream_t s, const LookupArgs& a, const float* src, float* out, int B, int h1, int w1) {
+    switch (lookup_batch()) {
+        case 16: hipLaunchKernelGGL((corr_lookup_kernel<FUSED, 16>), grid, dim3(LTHREADS), 0, s, a, src, out, B, h1, w1); break;
+        case 64: hipLaunchKernelGGL((corr_lookup_kernel<FUSED, 64>), grid, dim3(LTHREADS), 0, s, a, src, out, B, h1, w1); break;
+        default: hipLaunchKernelGGL((corr_lookup_kernel<FUSED, 32>), grid, dim3(LTHREADS), 0, s, a, src, out, B, h1, w1); break;
+    }
 }
 
 // ---- K6 ---------------------------------------------------------------------------------------------------
@@ -227,7 +249,7 @@ extern "C" int bflow_corr_lookup(const bflow_plane_t* planes, int P, const float
     if (rc) return rc;
     BFLOW_REQUIRE(coords && out && B > 0 && h1 > 0 && w1 > 0, BFLOW_E_ARG, "corr_lookup: bad arguments");
     dim3 grid(bflow::ceil_div((long long)h1 * w1, TILE), P, B);
-    hipLaunchKernelGGL(corr_lookup_kernel<false>, grid, dim3(LTHREADS), 0, (hipStream_t)stream, a, coords, out, B, h1, w1);
+    launch_lookup<false>(grid, (hipStream_t)stream, a, coords, out, B, h1, w1);
     return bflow::launch_status("corr_lookup");
 }
 
@@ -241,6 +263,6 @@ extern "C" int bflow_corr_lookup_bezier(const bflow_plane_t* planes, int P, cons
     a.deg = deg;
     for (int i = 0; i < T * deg; ++i) a.coef[i] = coef[i];
     dim3 grid(bflow::ceil_div((long long)h1 * w1, TILE), P, B);
-    hipLaunchKernelGGL(corr_lookup_kernel<true>, grid, dim3(LTHREADS), 0, (hipStream_t)stream, a, params, out, B, h1, w1);
+    launch_lookup<true>(grid, (hipStream_t)stream, a, params, out, B, h1, w1);
     return bflow::launch_status("corr_lookup_bezier");
 }
