@@ -11,12 +11,17 @@ Everything is allocated with torch (caller-owned memory); the kernels only see p
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
 
 from . import hip
+
+# Correlation-build arithmetic: "split" = split-fp16 MFMA engine (fp32-class accuracy, ~2^-22 per product; default),
+# "f32" = exact fp32 MFMA.  Both are parity-tested against the oracle; override with BFLOW_CORR_PRECISION.
+PRECISION = os.environ.get("BFLOW_CORR_PRECISION", "split")
 
 _LIST_TYPES: Tuple[type, ...] = (list, tuple)
 try:  # omegaconf is optional (the reference passes ListConfig objects when driven by Hydra, corr.py:8,147)
@@ -89,10 +94,16 @@ class CorrComputation:
         N = h * w
         T = self.num_targets_overall
         vol = torch.empty((T, B, N, N), dtype=torch.float32, device=self._fmap1[0].device)
+        split = (PRECISION == "split") and D % 32 == 0
         t0 = 0
         for f1, f2 in zip(self._fmap1, self._fmap2):
             tg = f2.shape[0]
-            hip.corr_build_f32(f1.float().contiguous().view(B, D, N), f2.float().contiguous().view(tg, B, D, N), vol[t0:t0 + tg])
+            f1 = f1.float().contiguous().view(B, D, N)
+            f2 = f2.float().contiguous().view(tg * B, D, N)
+            if split:   # split-fp16 MFMA engine: HBM-write-bound
+                hip.corr_build_split(hip.split_pack(f1), hip.split_pack(f2), vol[t0:t0 + tg], tg, B, N, shared_f1=True)
+            else:       # exact-fp32 MFMA
+                hip.corr_build_f32(f1, f2.view(tg, B, D, N), vol[t0:t0 + tg])
             t0 += tg
         return vol.view(T, B * N, 1, h, w)
 

@@ -23,7 +23,7 @@ MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -63,6 +63,8 @@ def lib() -> ctypes.CDLL:
     L.bflow_last_error_string.argtypes = []
     sig = {
         "bflow_corr_build_f32": [vp, vp, vp, i, i, i, i, ll, vp],
+        "bflow_split_pack": [vp, vp, vp, i, i, i, i, vp],
+        "bflow_corr_build_split": [vp, vp, vp, vp, vp, i, i, i, i, i, ll, vp],
         "bflow_corr_pool2x2": [vp, vp, ll, i, i, vp],
         "bflow_corr_lookup": [ctypes.POINTER(PlaneDesc), i, vp, vp, i, i, i, i, vp],
         "bflow_corr_lookup_bezier": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, i, i, i, vp],
@@ -138,6 +140,28 @@ def corr_build_f32(f1: torch.Tensor, f2: torch.Tensor, out: torch.Tensor):
     assert out.shape == (T, B, N, N)
     _check(lib().bflow_corr_build_f32(_dev(f1, name="f1"), _dev(f2, name="f2"), _dev(out, name="out"), T, B, D, N, tstride, _stream()),
            "bflow_corr_build_f32")
+
+
+def padded_rows(n: int, tile: int = 128) -> int:
+    return (n + tile - 1) // tile * tile
+
+
+def split_pack(src: torch.Tensor) -> torch.Tensor:
+    """src (R, D, N) fp32 -> (2, R, Np, D) fp16: [0] = hi, [1] = lo (x ~= hi + lo * 2^-11), rows N..Np zero."""
+    R, D, N = src.shape
+    Np = padded_rows(N)
+    out = torch.empty((2, R, Np, D), dtype=torch.float16, device=src.device)
+    _check(lib().bflow_split_pack(_dev(src, name="src"), out[0].data_ptr(), out[1].data_ptr(), R, D, N, Np, _stream()), "bflow_split_pack")
+    return out
+
+
+def corr_build_split(p1: torch.Tensor, p2: torch.Tensor, out: torch.Tensor, T: int, B: int, N: int, shared_f1: bool):
+    """p1 = split_pack(f1 viewed (B or T*B, D, N)), p2 = split_pack(f2 viewed (T*B, D, N)); out (T, B, N, N)."""
+    _, R2, Np, D = p2.shape
+    assert R2 == T * B and p1.shape[1] == (B if shared_f1 else T * B) and out.shape == (T, B, N, N)
+    assert p1.dtype == torch.float16 and p2.dtype == torch.float16 and p1.is_cuda and p2.is_cuda
+    _check(lib().bflow_corr_build_split(p1[0].data_ptr(), p1[1].data_ptr(), p2[0].data_ptr(), p2[1].data_ptr(), _dev(out, name="out"),
+                                        T, B, D, N, Np, 0 if shared_f1 else B * Np * D, _stream()), "bflow_corr_build_split")
 
 
 def corr_pool2x2(src: torch.Tensor, dst: torch.Tensor):

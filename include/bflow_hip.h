@@ -50,6 +50,17 @@ const char* bflow_last_error_string(void);
 int bflow_corr_build_f32(const float* f1, const float* f2, float* out,
                          int T, int B, int D, int N, long long f1_target_stride, bflow_stream_t stream);
 
+/* K5 (fast path)  the same volume on the split-fp16 MFMA engine (csrc/split_gemm.hip): every fp32 operand is carried
+ * as hi + lo*2^-11 (two fp16), the dot product as 3 fp16 MFMA chains with fp32 accumulation -> ~2^-22 relative error
+ * per product (fp32: 2^-24) at 5.3x the fp32 matrix peak, which makes K5 HBM-write-bound instead of MFMA-bound.
+ *   bflow_split_pack      : src (R, D, N) fp32 -> hi, lo (R, Np, D) fp16 (feature-contiguous), rows N..Np zeroed;
+ *                           Np = N rounded up to a multiple of 128, D % 8 == 0
+ *   bflow_corr_build_split: f1_* (B, Np, D) [f1_target_stride == 0] or per-target blocks f1_target_stride elements
+ *                           apart; f2_* (T, B, Np, D); out (T, B, N, N) fp32; D % 32 == 0                        */
+int bflow_split_pack(const float* src, void* hi, void* lo, int R, int D, int N, int Np, bflow_stream_t stream);
+int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out,
+                           int T, int B, int D, int N, int Np, long long f1_target_stride, bflow_stream_t stream);
+
 /* K6  one pyramid level: 2x2 average pooling, stride 2, floor on odd sizes, over the target plane.
  * Replaces CorrData.get_downsampled (F.avg_pool2d), models/raft_utils/corr.py:108-125.
  *   in : (planes, h, w)   out : (planes, h/2, w/2)                                                    */

@@ -79,6 +79,39 @@ def test_corr_build_vs_oracle_shapes(B, D, h, w, T):
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=3e-5 * np.sqrt(D / 16))
 
 
+@pytest.mark.parametrize("B,D,h,w,T", [(1, 256, 60, 80, 2), (2, 64, 9, 11, 3), (1, 32, 33, 40, 1)])
+def test_corr_build_split_engine_vs_oracle(B, D, h, w, T):
+    """Split-fp16 MFMA engine (hi + lo*2^-11, 3 MFMA chains): fp32-class accuracy.  Error budget: ~2^-22 per product vs
+    fp32's 2^-24 -> a few 1e-6 absolute on dot products of O(1) unit-variance terms divided by sqrt(D)."""
+    rs = np.random.RandomState(0)
+    f1 = rs.standard_normal((B, D, h, w)).astype(np.float32)
+    f2 = rs.standard_normal((T, B, D, h, w)).astype(np.float32)
+    f2[0, 0, :, 0, 0] *= 3e-3      # small and large magnitudes in the same contraction (fp16 normal range: >= 6.1e-5)
+    f2[0, 0, :, 1, 1] *= 300.0
+    N = h * w
+    ref64 = (torch.from_numpy(f1).double().view(B, D, N).transpose(1, 2).unsqueeze(0) @ torch.from_numpy(f2).double().view(T, B, D, N)) / np.sqrt(D)
+    out = torch.empty((T, B, N, N), device=DEV)
+    p1, p2 = hip.split_pack(cu(f1).view(B, D, N)), hip.split_pack(cu(f2).view(T * B, D, N))
+    hip.corr_build_split(p1, p2, out, T, B, N, shared_f1=True)
+    exact = torch.empty((T, B, N, N), device=DEV)
+    hip.corr_build_f32(cu(f1).view(B, D, N), cu(f2).view(T, B, D, N), exact)
+    # error relative to the magnitude of the summed terms (what fp32 accumulation itself is judged by): sum |a||b| / sqrt(D)
+    mag = (torch.from_numpy(np.abs(f1)).double().view(B, D, N).transpose(1, 2).unsqueeze(0) @ torch.from_numpy(np.abs(f2)).double().view(T, B, D, N)) / np.sqrt(D)
+    err_split = float(((out.cpu().double() - ref64).abs() / mag).max())
+    err_f32 = float(((exact.cpu().double() - ref64).abs() / mag).max())
+    print(f"split-fp16 max err / sum|a||b| = {err_split:.2e}   exact-fp32-MFMA = {err_f32:.2e}")
+    assert err_split < 5e-7      # 2^-22 = 2.4e-7 per product, partially averaging out; fp32 measures ~1e-7 here
+    assert err_f32 < 5e-7
+    # per-target (M-to-N) addressing
+    f1t = rs.standard_normal((T, B, D, h, w)).astype(np.float32)
+    pt = hip.split_pack(cu(f1t).view(T * B, D, N))
+    hip.corr_build_split(pt, p2, out, T, B, N, shared_f1=False)
+    ref = O.corr_volume(torch.from_numpy(f1t), torch.from_numpy(f2)).view(T, B, N, N)
+    assert float(((out.cpu() - ref).abs() / mag.float().clamp(min=1e-3)).max()) < 1e-3   # addressing check (different f1)
+    mag2 = (torch.from_numpy(np.abs(f1t)).double().view(T, B, D, N).transpose(2, 3) @ torch.from_numpy(np.abs(f2)).double().view(T, B, D, N)) / np.sqrt(D)
+    assert float(((out.cpu().double() - ref.double()).abs() / mag2).max()) < 6e-7
+
+
 def test_corr_build_full_size_properties():
     """BASELINE config C2 size (T=4, D=256, N=4800): size-independent properties instead of a CPU recomputation.
     (1) swapping the operands transposes the volume; (2) linearity in f2; (3) rows against an fp64 spot check."""

@@ -47,6 +47,11 @@ def main():
     fl = 2.0 * T * B * D * N * N
     by = 4.0 * ((1 + T) * B * D * N + T * B * N * N)
     print(f"corr_build_f32   B={B}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  ({by/ms/1e6:7.1f} GB/s algorithmic)")
+    f1v, f2v = f1.view(B, D, N), f2.view(T * B, D, N)
+    ms_p = timeit(lambda: (hip.split_pack(f1v), hip.split_pack(f2v)))
+    p1, p2 = hip.split_pack(f1v), hip.split_pack(f2v)
+    ms = timeit(lambda: hip.corr_build_split(p1, p2, vol, T, B, N, shared_f1=True))
+    print(f"corr_build_split B={B}: {ms*1e3:8.1f} us  {by/ms/1e6:7.1f} GB/s algorithmic  ({fl/ms/1e9:7.1f} TFLOP/s-equivalent), pack {ms_p*1e3:.1f} us")
     ms = timeit(lambda: blk.lookup_bezier(params, coef, out=out))
     by = 4.0 * B * N * blk.num_planes * 181
     print(f"corr_lookup_bez  B={B}: {ms*1e3:8.1f} us  {by/ms/1e6:7.1f} GB/s algorithmic")
