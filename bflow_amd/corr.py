@@ -31,6 +31,13 @@ except Exception:  # pragma: no cover
     pass
 
 
+class _PackedShape:
+    """Stand-in for an fmap2 tensor of a packed reference group: only its target count is ever asked for."""
+
+    def __init__(self, targets: int):
+        self.shape = (targets,)
+
+
 class CorrComputation:
     def __init__(self,
                  fmap1: Union[torch.Tensor, List[torch.Tensor]],
@@ -63,6 +70,22 @@ class CorrComputation:
         self._has_single_reference = single
         self._fmap1, self._fmap2, self._levels = fmap1, fmap2, levels
         self._bdhw = tuple(fmap1[0].shape)
+        self._packed = [None] * len(fmap1)   # per reference group: (p1, p2) split operands when they already exist
+
+    @classmethod
+    def from_packed(cls, p1: torch.Tensor, p2: torch.Tensor, batch: int, dim: int, height: int, width: int,
+                    num_levels_per_target: Union[int, Sequence[int]]) -> "CorrComputation":
+        """Feature maps that already live in the engine's operand format (the encoder's last convolution writes them):
+        p1 (2, B, D/32, Np, 32), p2 (2, T*B, D/32, Np, 32) fp16 hi/lo planes (k-blocked), rows >= h*w zero."""
+        levels = [int(num_levels_per_target)] if isinstance(num_levels_per_target, int) else [int(v) for v in num_levels_per_target]
+        T = p2.shape[1] // batch
+        assert p1.shape[1] == batch and p2.shape[1] == T * batch and len(levels) == T and p1.shape[2] * 32 == p2.shape[2] * 32 == dim
+        self = cls.__new__(cls)
+        self._has_single_reference = True
+        self._fmap1, self._fmap2, self._levels = [None], [_PackedShape(T)], [levels]
+        self._bdhw = (batch, dim, height, width)
+        self._packed = [(p1, p2)]
+        return self
 
     batch = property(lambda self: self._bdhw[0])
     dim = property(lambda self: self._bdhw[1])
@@ -84,6 +107,13 @@ class CorrComputation:
         return sum(self._levels, [])
 
     def __add__(self, other: "CorrComputation") -> "CorrComputation":
+        if any(p is not None for p in self._packed + other._packed):
+            assert self._bdhw == other._bdhw
+            out = CorrComputation.__new__(CorrComputation)
+            out._has_single_reference = False
+            out._fmap1, out._fmap2 = self._fmap1 + other._fmap1, self._fmap2 + other._fmap2
+            out._levels, out._bdhw, out._packed = self._levels + other._levels, self._bdhw, self._packed + other._packed
+            return out
         return CorrComputation(fmap1=self._fmap1 + other._fmap1, fmap2=self._fmap2 + other._fmap2,
                                num_levels_per_target=[torch.tensor(lv) for lv in self._levels + other._levels])
 
@@ -93,11 +123,16 @@ class CorrComputation:
         B, D, h, w = self._bdhw
         N = h * w
         T = self.num_targets_overall
-        vol = torch.empty((T, B, N, N), dtype=torch.float32, device=self._fmap1[0].device)
-        split = (PRECISION == "split") and D % 32 == 0
+        device = self._packed[0][0].device if self._packed[0] is not None else self._fmap1[0].device
+        vol = torch.empty((T, B, N, N), dtype=torch.float32, device=device)
+        split = (PRECISION == "split") and D % 64 == 0
         t0 = 0
-        for f1, f2 in zip(self._fmap1, self._fmap2):
+        for f1, f2, packed in zip(self._fmap1, self._fmap2, self._packed):
             tg = f2.shape[0]
+            if packed is not None:
+                hip.corr_build_split(packed[0], packed[1], vol[t0:t0 + tg], tg, B, N, shared_f1=True)
+                t0 += tg
+                continue
             f1 = f1.float().contiguous().view(B, D, N)
             f2 = f2.float().contiguous().view(tg * B, D, N)
             if split:   # split-fp16 MFMA engine: HBM-write-bound

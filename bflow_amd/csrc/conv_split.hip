@@ -1,0 +1,472 @@
+// Implicit-GEMM convolution on the split-fp16 MFMA engine (see split_gemm.hip for the number format).
+//
+// Activations are "blocked channels-last split" tensors: two fp16 planes (hi, lo), each laid out (B, C/32, P, 32) --
+// 32-channel blocks, P >= H*W pixel rows per image, value = hi + lo * 2^-11.  One (filter tap, channel block) pair is one
+// 32-deep k-tile whose rows (pixels) are 64-B contiguous runs, i.e. exactly the k-contiguous operand order the fp16 MFMA
+// wants AND full-line, channel-spread global reads -- no im2col buffer, no transposes:
+//       out[pix, co] = sum_{tap, c} x[pix + tap, c] * w[co, tap, c].
+// Weights are pre-split once into (KH*KW*C/32, Cout_pad, 32) planes (same k-tile-major order).
+//
+//   block  : 128 output pixels (of ONE image) x BN = 32*NT output channels, 4 waves, wave tile 32 x BN
+//   loads  : global_load_lds_dwordx4 (LDS-DMA, no staging registers) into a 3-stage ring of k-tiles; rows outside the
+//            image / beyond the last pixel read a zero page (= zero padding); XOR-swizzled 64-B LDS rows (swizzle on the
+//            per-lane source address and on the fragment read); counted vmcnt + ONE raw s_barrier per k-tile
+//   MFMA   : per 16-deep step NT x { hi*hi, hi*lo, lo*hi } v_mfma_f32_32x32x16_f16, fp32 accumulation; the fragments of
+//            both 16-deep steps are fetched before the first MFMA so LDS latency hides behind the matrix pipe
+//   epilogue (fused): per-channel affine (conv bias / folded BatchNorm), ReLU, optional per-(image, channel) sum / sum-of-
+//            squares for InstanceNorm (fp64 atomics, one per channel per block), blocked fp32 and/or blocked split stores
+//            at a channel-block offset (writes straight into concatenated buffers; a 32x32 MFMA tile is one contiguous
+//            2-KB / 4-KB run).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
+constexpr int CBM = 128, CT = 256, CSTAGES = 3;
+
+__device__ __attribute__((aligned(128))) _Float16 g_zero_page[64];   // source of every zero-padded row (static, zero-initialised)
+
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+    const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;   // matrix cores flush fp16 subnormal inputs
+    hi = (_Float16)h;
+    lo = (_Float16)((x - h) * LO_SCALE);
+}
+
+struct ConvArgs {
+    const _Float16 *xh, *xl;   // (B, CB, P_in, 32)
+    const _Float16 *wh, *wl;   // (ntaps*CB, Cout_pad, 32)
+    int H, W, CB, P_in, Ho, Wo, Cout, cout_pad;
+    int KH, KW, stride, pad_h, pad_w;
+    float* out_f32;            // blocked (B, CBo, P_out, 32) fp32 or null
+    _Float16 *oh, *ol;         // blocked split or null
+    int CBo, cb_off, P_out;    // channel blocks / first channel block / rows per image of the output buffers
+    const float *scale, *shift;   // per output channel or null
+    int act;
+    double* stats;             // (B, Cout, 2) or null
+};
+
+template <int NT>
+__global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
+    constexpr int BN = 32 * NT;
+    constexpr int BU = (NT <= 2) ? 1 : 2;                 // B units (16 rows x 64 B) per wave per plane
+    constexpr int B_ARR = BU * 4 * 1024;                  // LDS bytes of one B plane (64 or 128 rows)
+    constexpr int A_ARR = CBM * 64;
+    constexpr int O_AH = 0, O_AL = A_ARR, O_BH = 2 * A_ARR, O_BL = 2 * A_ARR + B_ARR;
+    constexpr int STAGE = 2 * A_ARR + 2 * B_ARR;          // 24 KB (NT <= 2) or 32 KB
+    constexpr int NLOADS = 4 + 2 * BU;                    // LDS-DMA instructions per wave per k-tile
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // the only shared object: ring of CSTAGES stages
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.x * CBM, n0 = blockIdx.y * BN;
+    const int HoWo = a.Ho * a.Wo;
+    const int ntaps = a.KH * a.KW;
+    const int nk = ntaps * a.CB;
+
+    // ---- LDS-DMA source coordinates: unit = 16 rows x 64 B; lane -> row lane/4, logical 16-B chunk (lane&3) ^ ((lane>>4)&3)
+    const int urow = lane >> 2;
+    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;   // in halves
+    int hb[2], wb[2];
+    bool rok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + (wave * 2 + j) * 16 + urow;
+        rok[j] = m < HoWo;
+        const int ho = m / a.Wo, wo = m - ho * a.Wo;
+        hb[j] = ho * a.stride - a.pad_h;
+        wb[j] = wo * a.stride - a.pad_w;
+    }
+    long long wsrc[BU];
+#pragma unroll
+    for (int j = 0; j < BU; ++j) {
+        int r = n0 + (wave * BU + j) * 16 + urow;
+        r = r < a.cout_pad ? r : a.cout_pad - 1;          // NT = 3 stages 128 rows of a 96-wide tile: clamp (never consumed)
+        wsrc[j] = (long long)r * 32 + uchunk;
+    }
+    const long long xb = (long long)b * a.CB * a.P_in * 32;
+    const long long wkstep = (long long)a.cout_pad * 32;
+    const _Float16* zp = g_zero_page + uchunk;
+
+#define CONV_ISSUE(SLOT, TAP, CBI)                                                                                       \
+    {                                                                                                                    \
+        char* sb = lds + (SLOT) * STAGE;                                                                                 \
+        const int r_ = (TAP) / a.KW, q_ = (TAP) - r_ * a.KW;                                                             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+            const int hi_ = hb[j] + r_, wi_ = wb[j] + q_;                                                                \
+            const bool ok = rok[j] && hi_ >= 0 && hi_ < a.H && wi_ >= 0 && wi_ < a.W;                                    \
+            const long long off = xb + ((long long)(CBI) * a.P_in + hi_ * a.W + wi_) * 32 + uchunk;                      \
+            const _Float16* ph = ok ? a.xh + off : zp;                                                                   \
+            const _Float16* pl = ok ? a.xl + off : zp;                                                                   \
+            __builtin_amdgcn_global_load_lds((gptr_t)ph, (lptr_t)(sb + O_AH + (wave * 2 + j) * 1024), 16, 0, 0);         \
+            __builtin_amdgcn_global_load_lds((gptr_t)pl, (lptr_t)(sb + O_AL + (wave * 2 + j) * 1024), 16, 0, 0);         \
+        }                                                                                                                \
+        const long long wk = (long long)((TAP) * a.CB + (CBI)) * wkstep;                                                 \
+        _Pragma("unroll") for (int j = 0; j < BU; ++j) {                                                                 \
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.wh + wk + wsrc[j]), (lptr_t)(sb + O_BH + (wave * BU + j) * 1024), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.wl + wk + wsrc[j]), (lptr_t)(sb + O_BL + (wave * BU + j) * 1024), 16, 0, 0); \
+        }                                                                                                                \
+    }
+
+    f32x16 hh[NT], xx[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            hh[n][r] = 0.f;
+            xx[n][r] = 0.f;
+        }
+
+    // (tap, channel block) of the k-tile to be issued next; the ring always runs two k-tiles ahead of the compute
+    int itap = 0, icb = 0;
+    auto advance = [&]() {
+        if (++icb == a.CB) { icb = 0; if (++itap == ntaps) itap = 0; }   // wraps at the end: tail prefetches are never consumed
+    };
+    CONV_ISSUE(0, itap, icb)
+    advance();
+    CONV_ISSUE(1, itap, icb)
+    advance();
+
+    const int sw = (l31 >> 2) & 3;
+    const int aro = (wave * 32 + l31) * 64;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (NLOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // k-tile kt has landed for every wave; slot (kt+2)%3 is free again
+        __builtin_amdgcn_sched_barrier(0);
+        CONV_ISSUE((kt + 2) % CSTAGES, itap, icb)
+        advance();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* cur = lds + (kt % CSTAGES) * STAGE;
+        half8 ah[2], al[2], bh[2][NT], bl[2][NT];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {       // fragments of BOTH 16-deep steps first ...
+            const int co = ((ks * 2 + kh) ^ sw) * 16;
+            ah[ks] = *reinterpret_cast<const half8*>(cur + O_AH + aro + co);
+            al[ks] = *reinterpret_cast<const half8*>(cur + O_AL + aro + co);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int bo = (n * 32 + l31) * 64 + co;
+                bh[ks][n] = *reinterpret_cast<const half8*>(cur + O_BH + bo);
+                bl[ks][n] = *reinterpret_cast<const half8*>(cur + O_BL + bo);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {       // ... then the MFMAs (three sweeps: no back-to-back dependent accumulators)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks][n], hh[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ks][n], xx[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ks][n], xx[n], 0, 0, 0);
+        }
+    }
+#undef CONV_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // all LDS-DMA traffic has landed: the ring can be reused for the reduction
+
+    // ---- epilogue -----------------------------------------------------------------------------------------------------
+    float* red = reinterpret_cast<float*>(lds);   // [2][4 waves][BN] partial sums
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = n0 + n * 32 + l31;
+        const bool cok = col < a.Cout;
+        const float sc = (a.scale && cok) ? a.scale[col] : 1.f;
+        const float sh = (a.shift && cok) ? a.shift[col] : 0.f;
+        const long long ob = ((long long)b * a.CBo + a.cb_off + (n0 >> 5) + n) * a.P_out * 32 + l31;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float v = (hh[n][r] + xx[n][r] * LO_INV) * sc + sh;
+            if (a.act == 1) v = fmaxf(v, 0.f);
+            if (m < HoWo && cok) {
+                const long long o = ob + (long long)m * 32;
+                if (a.out_f32) a.out_f32[o] = v;
+                if (a.oh) {
+                    _Float16 vh, vl;
+                    split1(v, vh, vl);
+                    a.oh[o] = vh;
+                    a.ol[o] = vl;
+                }
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+        if (a.stats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (kh == 0) {
+                red[(0 * 4 + wave) * BN + n * 32 + l31] = s1;
+                red[(1 * 4 + wave) * BN + n * 32 + l31] = s2;
+            }
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid - which * BN;
+            const int col = n0 + c;
+            if (col < a.Cout) {
+                const float* p = red + which * 4 * BN + c;
+                const double s = (double)p[0] + (double)p[BN] + (double)p[2 * BN] + (double)p[3 * BN];
+                atomicAdd(a.stats + ((long long)b * a.Cout + col) * 2 + which, s);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weights (Cout, Cin, KH, KW) fp32 -> split (KH*KW*CB, Cout_pad, 32), zero padded (k-tile-major)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ wh, _Float16* __restrict__ wl,
+                                                           int Cout, int Cin, int ntaps, int Cout_pad, int CB) {
+    const long long total = (long long)ntaps * CB * Cout_pad * 32;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c32 = (int)(i & 31);
+        const long long t1 = i >> 5;
+        const int co = (int)(t1 % Cout_pad);
+        const int kt = (int)(t1 / Cout_pad);
+        const int tap = kt / CB, c = (kt - tap * CB) * 32 + c32;
+        float v = 0.f;
+        if (co < Cout && c < Cin) v = w[((long long)co * Cin + c) * ntaps + tap];
+        _Float16 h, l;
+        split1(v, h, l);
+        wh[i] = h;
+        wl[i] = l;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-plane sum / sum of squares of an NCHW fp32 tensor (InstanceNorm statistics of a MIOpen conv output)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW) {
+    __shared__ double sh[2][4];
+    const float* p = x + (long long)blockIdx.x * HW;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x * 4; i + 3 < HW; i += 256 * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (int i = (HW & ~3) + threadIdx.x; i < HW; i += 256) {
+        s1 += p[i];
+        s2 += (double)p[i] * p[i];
+    }
+    s1 = bflow::wave_sum(s1);
+    s2 = bflow::wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = s1;
+        sh[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) stats[(long long)blockIdx.x * 2 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// normalise / affine + activation + residual -> blocked split.  One kernel for every "between two convolutions" step of
+// the encoder:   out = act_out( res + act_a( norm_a(a) ) ),   res in { nothing, split tensor, norm_b(b) }
+//   a, b   : fp32 blocked (B, CB, P, 32), or (a only) plain NCHW (B, C, HW) which is transposed on the fly
+//   norm_* : InstanceNorm from (sum, sumsq) statistics [stats != null]  or per-channel affine [scale/shift]  or identity
+// Thread = 8 consecutive channels of one pixel (32-B fp32 reads, 16-B fp16 writes).
+// ---------------------------------------------------------------------------------------------------------------------
+struct NormArgs {
+    const float* a; const double* stats_a; const float *scale_a, *shift_a; int a_nchw; int act_a;
+    const float* b; const double* stats_b;
+    const _Float16 *rh, *rl;
+    int act_out;
+    _Float16 *oh, *ol; float* out_f32;
+    int B, HW, C, CB, P; float eps;
+};
+
+__device__ __forceinline__ void norm_coeffs(const double* stats, const float* scale, const float* shift, int b, int c, int C, int HW,
+                                            float eps, float& mul, float& add) {
+    if (c >= C) { mul = 0.f; add = 0.f; return; }   // padded channels of the last block stay zero
+    if (stats) {   // F.instance_norm: biased variance, eps inside the sqrt
+        const double s1 = stats[((long long)b * C + c) * 2], s2 = stats[((long long)b * C + c) * 2 + 1];
+        const double mean = s1 / HW;
+        double var = s2 / HW - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        mul = rstd;
+        add = (float)(-mean) * rstd;
+    } else {
+        mul = scale ? scale[c] : 1.f;
+        add = shift ? shift[c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_act_split_kernel(NormArgs p) {
+    __shared__ float tile[32][65];                    // NCHW input only: 32 channels x 64 pixels
+    const int b = blockIdx.z, cb = blockIdx.y, p0 = blockIdx.x * 64;
+    const int pl = threadIdx.x >> 2, c8 = (threadIdx.x & 3) * 8;
+    const int pix = p0 + pl;
+    if (p.a_nchw) {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cb * 32 + ty + 4 * i, px = p0 + tx;
+            tile[ty + 4 * i][tx] = (c < p.C && px < p.HW) ? p.a[((long long)b * p.C + c) * p.HW + px] : 0.f;
+        }
+        __syncthreads();
+    }
+    if (pix >= p.HW) return;
+    const long long o = (((long long)b * p.CB + cb) * p.P + pix) * 32 + c8;
+    float v[8];
+    if (p.a_nchw) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = tile[c8 + k][pl];
+    } else {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.a + o), v1 = *reinterpret_cast<const float4*>(p.a + o + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    }
+    float bv[8];
+    if (p.b) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.b + o), v1 = *reinterpret_cast<const float4*>(p.b + o + 4);
+        bv[0] = v0.x; bv[1] = v0.y; bv[2] = v0.z; bv[3] = v0.w; bv[4] = v1.x; bv[5] = v1.y; bv[6] = v1.z; bv[7] = v1.w;
+    }
+    half8 rh8, rl8;
+    if (p.rh) {
+        rh8 = *reinterpret_cast<const half8*>(p.rh + o);
+        rl8 = *reinterpret_cast<const half8*>(p.rl + o);
+    }
+    half8 oh8, ol8;
+    float of[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = cb * 32 + c8 + k;
+        float ma, aa;
+        norm_coeffs(p.stats_a, p.scale_a, p.shift_a, b, c, p.C, p.HW, p.eps, ma, aa);
+        float x = v[k] * ma + aa;
+        if (p.act_a == 1) x = fmaxf(x, 0.f);
+        if (p.b) {
+            float mb, ab;
+            norm_coeffs(p.stats_b, nullptr, nullptr, b, c, p.C, p.HW, p.eps, mb, ab);
+            x += bv[k] * mb + ab;
+        }
+        if (p.rh) x += (float)rh8[k] + (float)rl8[k] * LO_INV;
+        if (p.act_out == 1) x = fmaxf(x, 0.f);
+        if (c >= p.C) x = 0.f;
+        _Float16 h, l;
+        split1(x, h, l);
+        oh8[k] = h;
+        ol8[k] = l;
+        of[k] = x;
+    }
+    if (p.oh) {
+        *reinterpret_cast<half8*>(p.oh + o) = oh8;
+        *reinterpret_cast<half8*>(p.ol + o) = ol8;
+    }
+    if (p.out_f32) {
+        *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(of[0], of[1], of[2], of[3]);
+        *reinterpret_cast<float4*>(p.out_f32 + o + 4) = make_float4(of[4], of[5], of[6], of[7]);
+    }
+}
+
+// blocked split -> fp32 NCHW (leaving the engine, e.g. towards the MIOpen-based update block)
+__global__ __launch_bounds__(256) void split_to_nchw_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                                            float* __restrict__ out, int HW, int CB, int P, int c_first, int c_count,
+                                                            long long out_bs) {
+    __shared__ float tile[64][33];                    // 64 pixels x 32 channels
+    const int b = blockIdx.z, cb = blockIdx.y, p0 = blockIdx.x * 64;   // cb counts blocks from c_first/32
+    {
+        const int pl = threadIdx.x >> 2, c8 = (threadIdx.x & 3) * 8;
+        const int pix = p0 + pl;
+        if (pix < HW) {
+            const long long o = (((long long)b * CB + (c_first >> 5) + cb) * P + pix) * 32 + c8;
+            const half8 h = *reinterpret_cast<const half8*>(xh + o), l = *reinterpret_cast<const half8*>(xl + o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tile[pl][c8 + k] = (float)h[k] + (float)l[k] * LO_INV;
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cb * 32 + ty + 4 * i, pix = p0 + tx;
+        if (c < c_count && pix < HW) out[b * out_bs + (long long)c * HW + pix] = tile[tx][ty + 4 * i];
+    }
+}
+
+}  // namespace
+
+extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t stream) {
+    BFLOW_REQUIRE(d && d->x_hi && d->x_lo && d->w_hi && d->w_lo, BFLOW_E_ARG, "conv_split: null operand");
+    BFLOW_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % 32 == 0, BFLOW_E_ARG, "conv_split: C=%d must be a multiple of 32", d->C);
+    BFLOW_REQUIRE(d->KH > 0 && d->KW > 0 && (d->stride == 1 || d->stride == 2) && d->Cout > 0, BFLOW_E_ARG, "conv_split: bad filter");
+    BFLOW_REQUIRE(d->out_f32 || (d->out_hi && d->out_lo), BFLOW_E_ARG, "conv_split: no output");
+    const int Ho = (d->H + 2 * d->pad_h - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad_w - d->KW) / d->stride + 1;
+    BFLOW_REQUIRE(Ho > 0 && Wo > 0, BFLOW_E_ARG, "conv_split: empty output");
+    BFLOW_REQUIRE(d->B <= 65535, BFLOW_E_LIMIT, "conv_split: batch too large");
+    const int NT = d->tile_n / 32;
+    BFLOW_REQUIRE(NT >= 2 && NT <= 4 && d->tile_n % 32 == 0, BFLOW_E_ARG, "conv_split: tile_n must be 64, 96 or 128");
+    BFLOW_REQUIRE(d->cout_pad % d->tile_n == 0 && d->cout_pad >= d->Cout, BFLOW_E_ARG, "conv_split: weights must be padded to the channel tile");
+    BFLOW_REQUIRE(d->out_channel_offset % 32 == 0, BFLOW_E_ARG, "conv_split: channel offset must be a multiple of 32");
+    ConvArgs a;
+    a.xh = (const _Float16*)d->x_hi; a.xl = (const _Float16*)d->x_lo; a.wh = (const _Float16*)d->w_hi; a.wl = (const _Float16*)d->w_lo;
+    a.H = d->H; a.W = d->W; a.CB = d->C / 32; a.P_in = d->in_rows_per_image > 0 ? d->in_rows_per_image : d->H * d->W;
+    a.Ho = Ho; a.Wo = Wo; a.Cout = d->Cout; a.cout_pad = d->cout_pad;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
+    a.out_f32 = d->out_f32; a.oh = (_Float16*)d->out_hi; a.ol = (_Float16*)d->out_lo;
+    const int out_c = d->out_channel_stride > 0 ? d->out_channel_stride : (d->Cout + 31) / 32 * 32;
+    BFLOW_REQUIRE(out_c % 32 == 0 && d->out_channel_offset + d->Cout <= out_c, BFLOW_E_ARG, "conv_split: bad output channel layout");
+    a.CBo = out_c / 32; a.cb_off = d->out_channel_offset / 32; a.P_out = d->out_rows_per_image > 0 ? d->out_rows_per_image : Ho * Wo;
+    a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
+    dim3 grid(bflow::ceil_div((long long)Ho * Wo, CBM), d->cout_pad / d->tile_n, d->B);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(N)                                                                                                      \
+    {                                                                                                                  \
+        const int lds = CSTAGES * (2 * CBM * 64 + 2 * ((N) <= 2 ? 1 : 2) * 4 * 1024);                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL(conv_split_kernel<N>, grid, dim3(CT), lds, s, a);                                           \
+    }
+    if (NT == 2) LAUNCH(2) else if (NT == 3) LAUNCH(3) else LAUNCH(4)
+#undef LAUNCH
+    return bflow::launch_status("conv_split");
+}
+
+extern "C" int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW, int cout_pad, int cin_pad,
+                                       bflow_stream_t stream) {
+    BFLOW_REQUIRE(w && w_hi && w_lo && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && cout_pad >= Cout && cin_pad >= Cin && cin_pad % 32 == 0,
+                  BFLOW_E_ARG, "conv_pack_weights: bad arguments");
+    const long long total = (long long)cout_pad * KH * KW * cin_pad;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)w_hi,
+                       (_Float16*)w_lo, Cout, Cin, KH * KW, cout_pad, cin_pad / 32);
+    return bflow::launch_status("conv_pack_weights");
+}
+
+extern "C" int bflow_plane_stats(const float* x, double* stats, long long planes, int HW, bflow_stream_t stream) {
+    BFLOW_REQUIRE(x && stats && planes > 0 && HW > 0 && planes < (1LL << 31), BFLOW_E_ARG, "plane_stats: bad arguments");
+    BFLOW_REQUIRE(((uintptr_t)x & 15) == 0 && HW % 4 == 0, BFLOW_E_ARG, "plane_stats: needs 16-B aligned planes (HW %% 4 == 0)");
+    hipLaunchKernelGGL(plane_stats_kernel, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, stats, HW);
+    return bflow::launch_status("plane_stats");
+}
+
+extern "C" int bflow_norm_act_split(const bflow_norm_desc_t* d, bflow_stream_t stream) {
+    BFLOW_REQUIRE(d && d->a && d->B > 0 && d->HW > 0 && d->C > 0, BFLOW_E_ARG, "norm_act_split: bad arguments");
+    BFLOW_REQUIRE((d->out_hi && d->out_lo) || d->out_f32, BFLOW_E_ARG, "norm_act_split: no output");
+    BFLOW_REQUIRE(!(d->b && d->a_is_nchw), BFLOW_E_ARG, "norm_act_split: second branch requires blocked inputs");
+    NormArgs p;
+    p.a = d->a; p.stats_a = d->stats_a; p.scale_a = d->scale_a; p.shift_a = d->shift_a; p.a_nchw = d->a_is_nchw; p.act_a = d->act_a;
+    p.b = d->b; p.stats_b = d->stats_b; p.rh = (const _Float16*)d->res_hi; p.rl = (const _Float16*)d->res_lo; p.act_out = d->act_out;
+    p.oh = (_Float16*)d->out_hi; p.ol = (_Float16*)d->out_lo; p.out_f32 = d->out_f32; p.B = d->B; p.HW = d->HW; p.C = d->C;
+    p.CB = (d->C + 31) / 32; p.P = d->rows_per_image > 0 ? d->rows_per_image : d->HW; p.eps = d->eps;
+    dim3 grid(bflow::ceil_div(d->HW, 64), p.CB, d->B);
+    hipLaunchKernelGGL(norm_act_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return bflow::launch_status("norm_act_split");
+}
+
+extern "C" int bflow_split_to_nchw(const void* x_hi, const void* x_lo, float* out, int B, int HW, int C, int c_first, int c_count,
+                                   long long out_batch_stride, bflow_stream_t stream) {
+    BFLOW_REQUIRE(x_hi && x_lo && out && B > 0 && HW > 0 && C > 0 && C % 32 == 0 && c_first >= 0 && c_first % 32 == 0 && c_count > 0 &&
+                      c_first + c_count <= C, BFLOW_E_ARG, "split_to_nchw: bad arguments");
+    dim3 grid(bflow::ceil_div(HW, 64), bflow::ceil_div(c_count, 32), B);
+    hipLaunchKernelGGL(split_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_hi, (const _Float16*)x_lo, out, HW,
+                       C / 32, HW, c_first, c_count, out_batch_stride);
+    return bflow::launch_status("split_to_nchw");
+}

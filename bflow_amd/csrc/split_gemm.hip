@@ -64,77 +64,83 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
                 h[k] = a;
                 l[k] = b;
             }
-            const long long o = ((long long)r * Np + n) * D + d0 + dc;
+            // k-blocked layout (R, D/32, Np, 32): a 32-deep k-tile of consecutive rows is one contiguous run of 64-B rows
+            const long long o = (((long long)r * (D / 32) + (d0 + dc) / 32) * Np + n) * 32 + ((d0 + dc) & 31);
             *reinterpret_cast<half8*>(hi + o) = h;
             *reinterpret_cast<half8*>(lo + o) = l;
         }
     }
 }
 
+constexpr int BK = 32;
+
 // ---------------------------------------------------------------------------------------------------------------
-// NT GEMM on split operands
+// v2: 256x128 block tile, 8 waves (4x2, wave tile 64x64), direct-to-LDS loads (global_load_lds_dwordx4) into a 3-stage
+// ring, XOR-swizzled 64-B LDS rows (no padding is possible with LDS-DMA: the image is lane-linear, so the swizzle is
+// applied to the per-lane SOURCE address and again on the fragment read), counted vmcnt + one raw s_barrier per k-tile.
+// Two k-tiles of loads stay in flight across every barrier; no VGPRs are spent on staging.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int ROWB = 80;                      // LDS row pitch in bytes (64 B of data + 16 B pad)
-constexpr int ARR = BM * ROWB;                // bytes of one 128 x 32 half tile
-constexpr int STAGE = 4 * ARR;                // A_hi, A_lo, B_hi, B_lo
-constexpr int GT = 256;
+constexpr int V2_BM = 256, V2_BN = 128, V2_T = 512, V2_STAGES = 3;
+constexpr int V2_AH = 0, V2_AL = V2_BM * 64, V2_BH = 2 * V2_BM * 64, V2_BL = 2 * V2_BM * 64 + V2_BN * 64;
+constexpr int V2_STAGE = 2 * V2_BM * 64 + 2 * V2_BN * 64;   // 48 KB
 
-// Register staging of one k-tile (4 arrays x 128 rows x 32 halves = 4 x 512 chunks of 16 B; thread -> chunks tid, tid+256).
-// Named scalars (token pasting), not arrays: hipcc keeps indexed staging arrays in scratch.
-#define BFLOW_G2R(P, K0)                                                                          \
-    {                                                                                             \
-        const long long off0 = (long long)(tid >> 2) * D + (K0) + (tid & 3) * 8;                  \
-        const long long off1 = off0 + 64LL * D;                                                   \
-        P##0 = *reinterpret_cast<const uint4*>(Ah + off0);                                        \
-        P##1 = *reinterpret_cast<const uint4*>(Al + off0);                                        \
-        P##2 = *reinterpret_cast<const uint4*>(Bh + off0);                                        \
-        P##3 = *reinterpret_cast<const uint4*>(Bl + off0);                                        \
-        P##4 = *reinterpret_cast<const uint4*>(Ah + off1);                                        \
-        P##5 = *reinterpret_cast<const uint4*>(Al + off1);                                        \
-        P##6 = *reinterpret_cast<const uint4*>(Bh + off1);                                        \
-        P##7 = *reinterpret_cast<const uint4*>(Bl + off1);                                        \
-    }
-#define BFLOW_R2S(P, LDSBASE)                                                                     \
-    {                                                                                             \
-        char* w0 = (LDSBASE) + (tid >> 2) * ROWB + (tid & 3) * 16;                                \
-        char* w1 = w0 + 64 * ROWB;                                                                \
-        *reinterpret_cast<uint4*>(w0 + 0 * ARR) = P##0;                                           \
-        *reinterpret_cast<uint4*>(w0 + 1 * ARR) = P##1;                                           \
-        *reinterpret_cast<uint4*>(w0 + 2 * ARR) = P##2;                                           \
-        *reinterpret_cast<uint4*>(w0 + 3 * ARR) = P##3;                                           \
-        *reinterpret_cast<uint4*>(w1 + 0 * ARR) = P##4;                                           \
-        *reinterpret_cast<uint4*>(w1 + 1 * ARR) = P##5;                                           \
-        *reinterpret_cast<uint4*>(w1 + 2 * ARR) = P##6;                                           \
-        *reinterpret_cast<uint4*>(w1 + 3 * ARR) = P##7;                                           \
-    }
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-__global__ __launch_bounds__(GT, 2) void corr_build_split_kernel(const _Float16* __restrict__ f1h, const _Float16* __restrict__ f1l,
-                                                              const _Float16* __restrict__ f2h, const _Float16* __restrict__ f2l,
-                                                              float* __restrict__ out, int B, int D, int N, int Np,
-                                                              long long f1_tstride, float sqrt_d) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];   // 2 stages x 40 KB
+__global__ __launch_bounds__(V2_T, 2) void corr_build_split_v2_kernel(const _Float16* __restrict__ f1h, const _Float16* __restrict__ f1l,
+                                                                      const _Float16* __restrict__ f2h, const _Float16* __restrict__ f2l,
+                                                                      float* __restrict__ out, int B, int D, int N, int Np,
+                                                                      long long f1_tstride, float sqrt_d) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // 3 x 48 KB ring (the ONLY shared object in this kernel)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tb = blockIdx.y, t = tb / B, b = tb - t * B;
-    // XCD-aware tile order (blocks are dealt round-robin to the 8 XCDs, each with a private 4 MB L2): give every XCD one
-    // contiguous chunk of the tile sequence, and order the sequence in panels of 8 j-tiles so that a chunk keeps its
-    // B panel (8 x 128 KB) L2-resident while the A tiles stream through once.
     int i0, j0;
     {
-        const int nwg = gridDim.x, tj = (N + BN - 1) / BN, ti = (N + BM - 1) / BM;
+        const int nwg = gridDim.x, tj = (N + V2_BN - 1) / V2_BN, ti = (N + V2_BM - 1) / V2_BM;
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = nwg >> 3, r = nwg & 7;
         const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         const int panel = wg / (8 * ti), rem = wg - panel * 8 * ti;
-        const int pw = min(8, tj - panel * 8);            // width of this panel in j-tiles
-        i0 = (rem / pw) * BM;
-        j0 = (panel * 8 + rem % pw) * BN;
+        const int pw = min(8, tj - panel * 8);
+        i0 = (rem / pw) * V2_BM;
+        j0 = (panel * 8 + rem % pw) * V2_BN;
     }
+    // rows of A beyond Np do not exist (Np is a multiple of 128, the A tile is 256 rows): clamp the source row, the
+    // corresponding outputs are never stored
+    const int a_rows = Np - i0;   // >= 128
 
-    const long long aoff = t * f1_tstride + ((long long)b * Np + i0) * D;
-    const long long boff = ((long long)tb * Np + j0) * D;
+    // operands are k-blocked: (R, D/32, Np, 32) -> element (row, k) of matrix R lives at ((R*D/32 + k/32)*Np + row)*32 + k%32
+    const long long aoff = t * f1_tstride + (long long)b * Np * D;
+    const long long boff = (long long)tb * Np * D + (long long)j0 * 32;
     const _Float16 *Ah = f1h + aoff, *Al = f1l + aoff, *Bh = f2h + boff, *Bl = f2l + boff;
+    const long long kstep = (long long)Np * 32;   // elements between consecutive 32-deep k-tiles
+
+    // per-lane source coordinates inside a 16-row x 64-B unit: row = lane/4, logical chunk = slot ^ ((row>>2)&3)
+    const int urow = lane >> 2;
+    const int uchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    // A units of this wave: rows (wave*2 + j)*16 + urow, j = 0,1 ; B unit: rows wave*16 + urow
+    int arow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 16 + urow;
+        arow[j] = i0 + (r < a_rows ? r : a_rows - 1);
+    }
+    const int brow = wave * 16 + urow;
+    const long long asrc0 = (long long)arow[0] * 32 + uchunk * 8, asrc1 = (long long)arow[1] * 32 + uchunk * 8;
+    const long long bsrc = (long long)brow * 32 + uchunk * 8;
+
+#define V2_ISSUE(SLOT, K0)                                                                                       \
+    {                                                                                                            \
+        char* sb = lds + (SLOT) * V2_STAGE;                                                                      \
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ah + asrc0 + (K0)), (lptr_t)(sb + V2_AH + (wave * 2 + 0) * 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)(Ah + asrc1 + (K0)), (lptr_t)(sb + V2_AH + (wave * 2 + 1) * 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)(Al + asrc0 + (K0)), (lptr_t)(sb + V2_AL + (wave * 2 + 0) * 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)(Al + asrc1 + (K0)), (lptr_t)(sb + V2_AL + (wave * 2 + 1) * 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)(Bh + bsrc + (K0)), (lptr_t)(sb + V2_BH + wave * 1024), 16, 0, 0);            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(Bl + bsrc + (K0)), (lptr_t)(sb + V2_BL + wave * 1024), 16, 0, 0);            \
+    }
 
     f32x16 hh[2][2], xx[2][2];
 #pragma unroll
@@ -147,82 +153,85 @@ __global__ __launch_bounds__(GT, 2) void corr_build_split_kernel(const _Float16*
                 xx[m][n][r] = 0.f;
             }
 
-    // Software pipeline: LDS holds k-tile kt (double buffered), register set st0/st1 hold tiles kt+1 / kt+2 in flight, so a
-    // global load has two k-tiles of MFMA work (~1500 cycles) plus the co-resident block to hide behind.
-    const int nk = D / BK;                     // even (D % 64 == 0 is checked on the host)
+    const int nk = D / BK;
     const int l31 = lane & 31, kh = lane >> 5;
-    uint4 sa0, sa1, sa2, sa3, sa4, sa5, sa6, sa7, sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;
-    BFLOW_G2R(sa, 0)
-    BFLOW_R2S(sa, lds)
-    BFLOW_G2R(sa, BK)
-    BFLOW_G2R(sb, (2 < nk ? 2 : 0) * BK)
-    __syncthreads();
+    // fragment read offsets: row R, logical chunk c -> R*64 + ((c ^ ((R>>2)&3)) * 16); (R>>2)&3 == (l31>>2)&3 (tile bases are x32)
+    const int sw = (l31 >> 2) & 3;
+    int aro[2], bro[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) aro[m] = (wm * 64 + m * 32 + l31) * 64;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) bro[n] = (wn * 64 + n * 32 + l31) * 64;
 
-#define BFLOW_COMPUTE(CUR)                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                   \
-        half8 ah[2], al[2], bh[2], bl[2];                                                                \
-        const int ko = ks * 32 + kh * 16;                                                                \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                  \
-            const int o = (wm * 64 + m * 32 + l31) * ROWB + ko;                                          \
-            ah[m] = *reinterpret_cast<const half8*>((CUR) + 0 * ARR + o);                                \
-            al[m] = *reinterpret_cast<const half8*>((CUR) + 1 * ARR + o);                                \
-        }                                                                                                \
-        _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                  \
-            const int o = (wn * 64 + n * 32 + l31) * ROWB + ko;                                          \
-            bh[n] = *reinterpret_cast<const half8*>((CUR) + 2 * ARR + o);                                \
-            bl[n] = *reinterpret_cast<const half8*>((CUR) + 3 * ARR + o);                                \
-        }                                                                                                \
-        /* three sweeps over the 4 accumulator tiles: consecutive MFMAs never touch the same accumulator (a dependent   \
-           32x32x16 MFMA would stall its 16-pass latency) */                                                           \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                    \
-            _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                \
-                hh[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], hh[m][n], 0, 0, 0);     \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                    \
-            _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                \
-                xx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], xx[m][n], 0, 0, 0);     \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                    \
-            _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                \
-                xx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], xx[m][n], 0, 0, 0);     \
-    }
+    V2_ISSUE(0, 0)
+    V2_ISSUE(1, (1 < nk ? 1 : 0) * kstep)
 
-    for (int kt = 0; kt < nk; kt += 2) {
-        // even step: compute tile kt from buffer 0; st0 (tile kt+1) -> buffer 1; refill st0 with tile kt+3
-        BFLOW_COMPUTE(lds)
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // this wave's loads of k-tile kt have landed (kt+1 may be in flight)
+        __builtin_amdgcn_s_barrier();                      // ... and everybody else's; everybody is also done reading slot (kt+2)%3
         __builtin_amdgcn_sched_barrier(0);
-        BFLOW_R2S(sa, lds + STAGE)
         {
-            const int k3 = (kt + 3 < nk) ? (kt + 3) * BK : 0;   // out-of-range prefetches re-read tile 0 (never consumed)
-            BFLOW_G2R(sa, k3)
+            const int kn = (kt + 2 < nk) ? (kt + 2) : 0;   // tail: keep the instruction count per iteration constant
+            const int slot = (kt + 2) % V2_STAGES;
+            V2_ISSUE(slot, kn * kstep)
         }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        // odd step: compute tile kt+1 from buffer 1; st1 (tile kt+2) -> buffer 0; refill st1 with tile kt+4
-        BFLOW_COMPUTE(lds + STAGE)
-        __builtin_amdgcn_sched_barrier(0);
-        BFLOW_R2S(sb, lds)
-        {
-            const int k4 = (kt + 4 < nk) ? (kt + 4) * BK : 0;
-            BFLOW_G2R(sb, k4)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    }
-#undef BFLOW_COMPUTE
-
-    float* O = out + (long long)tb * N * N;
-    const bool interior = (i0 + BM <= N) && (j0 + BN <= N);   // block-uniform: no per-store predication for inner tiles
+        const char* cur = lds + (kt % V2_STAGES) * V2_STAGE;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 ah[2], al[2], bh[2], bl[2];
+            const int co = ((ks * 2 + kh) ^ sw) * 16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = i0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = *reinterpret_cast<const half8*>(cur + V2_AH + aro[m] + co);
+                al[m] = *reinterpret_cast<const half8*>(cur + V2_AL + aro[m] + co);
+            }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const int col = j0 + wn * 64 + n * 32 + l31;
-                const float v = (hh[m][n][r] + xx[m][n][r] * LO_INV) / sqrt_d;
-                if (interior || (row < N && col < N)) O[(long long)row * N + col] = v;
+                bh[n] = *reinterpret_cast<const half8*>(cur + V2_BH + bro[n] + co);
+                bl[n] = *reinterpret_cast<const half8*>(cur + V2_BL + bro[n] + co);
             }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) hh[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], hh[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) xx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], xx[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) xx[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], xx[m][n], 0, 0, 0);
         }
+    }
+#undef V2_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail prefetches before the block may exit
+
+    float* O = out + (long long)tb * N * N;
+    const bool interior = (i0 + V2_BM <= N) && (j0 + V2_BN <= N);   // block-uniform
+    if (interior) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    O[(long long)row * N + j0 + wn * 64 + n * 32 + l31] = (hh[m][n][r] + xx[m][n][r] * LO_INV) / sqrt_d;
+            }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int col = j0 + wn * 64 + n * 32 + l31;
+                    if (row < N && col < N) O[(long long)row * N + col] = (hh[m][n][r] + xx[m][n][r] * LO_INV) / sqrt_d;
+                }
+            }
     }
 }
 
@@ -239,13 +248,13 @@ extern "C" int bflow_split_pack(const float* src, void* hi, void* lo, int R, int
 extern "C" int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out, int T, int B,
                                       int D, int N, int Np, long long f1_target_stride, bflow_stream_t stream) {
     BFLOW_REQUIRE(f1_hi && f1_lo && f2_hi && f2_lo && out, BFLOW_E_ARG, "corr_build_split: null pointer");
-    BFLOW_REQUIRE(T > 0 && B > 0 && N > 0 && D > 0 && D % (2 * BK) == 0 && Np >= N && Np % BM == 0, BFLOW_E_ARG,
+    BFLOW_REQUIRE(T > 0 && B > 0 && N > 0 && D > 0 && D % BK == 0 && Np >= N && Np % 128 == 0, BFLOW_E_ARG,
                   "corr_build_split: bad sizes T=%d B=%d D=%d N=%d Np=%d", T, B, D, N, Np);
     BFLOW_REQUIRE((long long)T * B <= 65535, BFLOW_E_LIMIT, "corr_build_split: T*B too large");
-    // 80 KB of dynamic LDS (> the 64 KB default limit); idempotent, per device
-    hipFuncSetAttribute(reinterpret_cast<const void*>(corr_build_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-    dim3 grid(bflow::ceil_div(N, BN) * bflow::ceil_div(N, BM), T * B);
-    hipLaunchKernelGGL(corr_build_split_kernel, grid, dim3(GT), 2 * STAGE, (hipStream_t)stream, (const _Float16*)f1_hi,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_build_split_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              V2_STAGES * V2_STAGE);   // 144 KB of dynamic LDS; idempotent, per device
+    dim3 grid2(bflow::ceil_div(N, V2_BN) * bflow::ceil_div(N, V2_BM), T * B);
+    hipLaunchKernelGGL(corr_build_split_v2_kernel, grid2, dim3(V2_T), V2_STAGES * V2_STAGE, (hipStream_t)stream, (const _Float16*)f1_hi,
                        (const _Float16*)f1_lo, (const _Float16*)f2_hi, (const _Float16*)f2_lo, out, B, D, N, Np, f1_target_stride,
                        sqrtf((float)D));
     return bflow::launch_status("corr_build_split");

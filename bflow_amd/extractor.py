@@ -6,11 +6,13 @@ hand-written kernels of the north star); what runs between them is arranged for 
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Union
+from typing import Dict, List, Optional, Sequence, Union
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import split as S
 
 
 def _make_norm(kind: str, channels: int) -> nn.Module:
@@ -74,6 +76,108 @@ class BasicEncoder(nn.Module):
                     nn.init.constant_(m.weight, 1)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
+
+    # ------------------------------------------------------------------------------------------------ split-fp16 engine
+    def _packed(self, name: str, conv: nn.Conv2d):
+        cache: Dict[str, S.PackedConvWeight] = self.__dict__.setdefault("_pack_cache", {})
+        if name not in cache:
+            cache[name] = S.PackedConvWeight()
+        return cache[name].get(conv.weight)
+
+    def _bn_affine(self, norm: nn.BatchNorm2d, conv_bias: Optional[torch.Tensor]):
+        """Eval-mode BatchNorm folded with the conv bias: y = conv * scale + shift.  Cached per (norm, bias) until a source
+        tensor changes (load_state_dict, .to(device)), so the steady-state forward launches nothing for it."""
+        cache = self.__dict__.setdefault("_affine_cache", {})
+        srcs = [norm.weight, norm.bias, norm.running_mean, norm.running_var] + ([conv_bias] if conv_bias is not None else [])
+        key = tuple((t.data_ptr(), t._version) for t in srcs)
+        hit = cache.get(id(norm))
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                scale = norm.weight / torch.sqrt(norm.running_var + norm.eps)
+                shift = norm.bias - norm.running_mean * scale
+                if conv_bias is not None:
+                    shift = shift + conv_bias * scale
+                hit = (key, scale.float().contiguous(), shift.float().contiguous())
+            cache[id(norm)] = hit
+        return hit[1], hit[2]
+
+    def forward_split(self, x: torch.Tensor, out_rows: Optional[int] = None):
+        """The same network on the split-fp16 MFMA engine (csrc/conv_split.hip): channels-last split activations, implicit-GEMM
+        convolutions with bias / folded BatchNorm / ReLU / InstanceNorm statistics fused into their epilogues, and one
+        normalise+activate+residual kernel between convolutions.  Only the 7x7 stem stays on MIOpen (its tiny input-channel
+        count makes it ~5 % of the FLOPs).  x: (n, c_in, H, W) fp32 -> SplitTensor (n, H/8, W/8, out_dim); `out_rows` pads the
+        pixel rows of the result with zeros (K5 wants a multiple of 128)."""
+        kind = self.norm_fn
+        assert kind in ("instance", "batch"), kind
+        n = x.shape[0]
+        dev = x.device
+        # InstanceNorm statistics of all 15 normalised convolutions: ONE zero-filled arena per forward
+        arena = torch.zeros((15 * n * 128 * 2,), dtype=torch.float64, device=dev) if kind == "instance" else None
+        used = [0]
+
+        def new_stats(c):
+            st = arena[used[0]:used[0] + n * c * 2].view(n, c, 2)
+            used[0] += n * c * 2
+            return st
+
+        # ---- stem: 7x7/2 on MIOpen (NCHW fp32) -> norm + relu -> split NHWC
+        y = F.conv2d(x, self.conv1.weight, None, stride=2, padding=3)
+        _, c0, h0, w0 = y.shape
+        if kind == "instance":     # the conv bias cancels under InstanceNorm
+            cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, stats_a=S.plane_stats(y), act_a=S.ACT_RELU)
+        else:
+            sc, sh = self._bn_affine(self.norm1, self.conv1.bias)
+            cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, scale_a=sc, shift_a=sh, act_a=S.ACT_RELU)
+
+        def conv_norm(name, conv, norm, src, stride, relu):
+            """conv (+ bias) -> norm -> optional relu.  instance: returns (fp32 NHWC, stats) for the fused norm kernel;
+            batch: affine + relu folded into the conv epilogue, returns (fp32 NHWC, None)."""
+            pad = conv.padding
+            pk = self._packed(name, conv)
+            if kind == "instance":
+                st = new_stats(conv.out_channels)
+                _, f = S.conv(src, pk, stride=stride, padding=pad, want_split=False, want_f32=True, stats=st)
+                return f, st
+            sc, sh = self._bn_affine(norm, conv.bias)
+            _, f = S.conv(src, pk, stride=stride, padding=pad, scale=sc, shift=sh, act=S.ACT_RELU if relu else S.ACT_NONE,
+                          want_split=False, want_f32=True)
+            return f, None
+
+        def out_hw(src, conv, stride):
+            _, H_, W_, _ = src.shape
+            return ((H_ + 2 * conv.padding[0] - conv.kernel_size[0]) // stride + 1, (W_ + 2 * conv.padding[1] - conv.kernel_size[1]) // stride + 1)
+
+        def conv_norm_relu_split(name, conv, norm, src, stride):
+            pk = self._packed(name, conv)
+            ho_wo = out_hw(src, conv, stride)
+            if kind == "instance":
+                f, st = conv_norm(name, conv, norm, src, stride, True)
+                out, _ = S.norm_act(f, (n, ho_wo[0], ho_wo[1], conv.out_channels), stats_a=st, act_a=S.ACT_RELU)
+                return out
+            sc, sh = self._bn_affine(norm, conv.bias)
+            out, _ = S.conv(src, pk, stride=stride, padding=conv.padding, scale=sc, shift=sh, act=S.ACT_RELU)
+            return out
+
+        for li in (1, 2, 3):
+            layer = getattr(self, f"layer{li}")
+            for bi, blk in enumerate(layer):
+                stride = blk.conv1.stride[0]
+                pre = f"layer{li}.{bi}"
+                a1 = conv_norm_relu_split(pre + ".conv1", blk.conv1, blk.norm1, cur, stride)
+                c2, st2 = conv_norm(pre + ".conv2", blk.conv2, blk.norm2, a1, 1, True)
+                shape = (n, a1.H, a1.W, blk.conv2.out_channels)
+                if blk.downsample is None:
+                    # relu(x + relu(norm2(conv2)))          (extractor.py:50-55)
+                    cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU if kind == "instance" else S.ACT_NONE, res=cur,
+                                        act_out=S.ACT_RELU)
+                else:
+                    d, std = conv_norm(pre + ".downsample.0", blk.downsample[0], blk.norm3, cur, stride, False)
+                    cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU if kind == "instance" else S.ACT_NONE, b=d, stats_b=std,
+                                        act_out=S.ACT_RELU)
+        pk = self._packed("conv2", self.conv2)
+        bias = self.conv2.bias
+        out, _ = S.conv(cur, pk, shift=bias, out_rows=out_rows)
+        return out
 
     def forward(self, x: Union[torch.Tensor, Sequence[torch.Tensor]], project: bool = True):
         """A list input is stacked along the batch axis and split again (extractor.py:106-110,122-123).

@@ -23,7 +23,7 @@ MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -38,6 +38,27 @@ class PlaneDesc(ctypes.Structure):
     """struct bflow_plane (include/bflow_hip.h)."""
     _fields_ = [("base", ctypes.c_void_p), ("h", ctypes.c_int), ("w", ctypes.c_int),
                 ("level", ctypes.c_int), ("target", ctypes.c_int)]
+
+
+class ConvDesc(ctypes.Structure):
+    """struct bflow_conv_desc (include/bflow_hip.h)."""
+    _fields_ = [("x_hi", ctypes.c_void_p), ("x_lo", ctypes.c_void_p), ("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p),
+                ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int), ("Cout", ctypes.c_int),
+                ("cout_pad", ctypes.c_int), ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("stride", ctypes.c_int),
+                ("pad_h", ctypes.c_int), ("pad_w", ctypes.c_int), ("tile_n", ctypes.c_int),
+                ("out_f32", ctypes.c_void_p), ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p),
+                ("out_channel_stride", ctypes.c_int), ("out_channel_offset", ctypes.c_int), ("out_rows_per_image", ctypes.c_int),
+                ("in_rows_per_image", ctypes.c_int),
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("act", ctypes.c_int), ("stats", ctypes.c_void_p)]
+
+
+class NormDesc(ctypes.Structure):
+    """struct bflow_norm_desc (include/bflow_hip.h)."""
+    _fields_ = [("a", ctypes.c_void_p), ("stats_a", ctypes.c_void_p), ("scale_a", ctypes.c_void_p), ("shift_a", ctypes.c_void_p),
+                ("a_is_nchw", ctypes.c_int), ("act_a", ctypes.c_int), ("b", ctypes.c_void_p), ("stats_b", ctypes.c_void_p),
+                ("res_hi", ctypes.c_void_p), ("res_lo", ctypes.c_void_p), ("act_out", ctypes.c_int),
+                ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p), ("out_f32", ctypes.c_void_p),
+                ("B", ctypes.c_int), ("HW", ctypes.c_int), ("C", ctypes.c_int), ("eps", ctypes.c_float), ("rows_per_image", ctypes.c_int)]
 
 
 _lib = None
@@ -65,6 +86,11 @@ def lib() -> ctypes.CDLL:
         "bflow_corr_build_f32": [vp, vp, vp, i, i, i, i, ll, vp],
         "bflow_split_pack": [vp, vp, vp, i, i, i, i, vp],
         "bflow_corr_build_split": [vp, vp, vp, vp, vp, i, i, i, i, i, ll, vp],
+        "bflow_conv_pack_weights": [vp, vp, vp, i, i, i, i, i, i, vp],
+        "bflow_conv_split": [ctypes.POINTER(ConvDesc), vp],
+        "bflow_plane_stats": [vp, vp, ll, i, vp],
+        "bflow_norm_act_split": [ctypes.POINTER(NormDesc), vp],
+        "bflow_split_to_nchw": [vp, vp, vp, i, i, i, i, i, ll, vp],
         "bflow_corr_pool2x2": [vp, vp, ll, i, i, vp],
         "bflow_corr_lookup": [ctypes.POINTER(PlaneDesc), i, vp, vp, i, i, i, i, vp],
         "bflow_corr_lookup_bezier": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, i, i, i, vp],
@@ -147,19 +173,22 @@ def padded_rows(n: int, tile: int = 128) -> int:
 
 
 def split_pack(src: torch.Tensor) -> torch.Tensor:
-    """src (R, D, N) fp32 -> (2, R, Np, D) fp16: [0] = hi, [1] = lo (x ~= hi + lo * 2^-11), rows N..Np zero."""
+    """src (R, D, N) fp32 -> (2, R, D/32, Np, 32) fp16 k-blocked operands: [0] = hi, [1] = lo (x ~= hi + lo * 2^-11),
+    rows N..Np zero."""
     R, D, N = src.shape
     Np = padded_rows(N)
-    out = torch.empty((2, R, Np, D), dtype=torch.float16, device=src.device)
+    out = torch.empty((2, R, D // 32, Np, 32), dtype=torch.float16, device=src.device)
     _check(lib().bflow_split_pack(_dev(src, name="src"), out[0].data_ptr(), out[1].data_ptr(), R, D, N, Np, _stream()), "bflow_split_pack")
     return out
 
 
 def corr_build_split(p1: torch.Tensor, p2: torch.Tensor, out: torch.Tensor, T: int, B: int, N: int, shared_f1: bool):
     """p1 = split_pack(f1 viewed (B or T*B, D, N)), p2 = split_pack(f2 viewed (T*B, D, N)); out (T, B, N, N)."""
-    _, R2, Np, D = p2.shape
+    _, R2, KB, Np, _32 = p2.shape
+    D = KB * 32
     assert R2 == T * B and p1.shape[1] == (B if shared_f1 else T * B) and out.shape == (T, B, N, N)
     assert p1.dtype == torch.float16 and p2.dtype == torch.float16 and p1.is_cuda and p2.is_cuda
+    assert p1[0].is_contiguous() and p1[1].is_contiguous() and p2[0].is_contiguous() and p2[1].is_contiguous()
     _check(lib().bflow_corr_build_split(p1[0].data_ptr(), p1[1].data_ptr(), p2[0].data_ptr(), p2[1].data_ptr(), _dev(out, name="out"),
                                         T, B, D, N, Np, 0 if shared_f1 else B * Np * D, _stream()), "bflow_corr_build_split")
 

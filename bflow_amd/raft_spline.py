@@ -17,6 +17,7 @@ Inputs must live on the GPU: there is no CPU fallback (the CPU restatement lives
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -29,6 +30,11 @@ from .corr import CorrBlockParallelMultiTarget, CorrComputation
 from .extractor import BasicEncoder
 from .timers import StageTimer
 from .update import BasicUpdateBlock
+
+
+# Encoder arithmetic: "split" = split-fp16 MFMA engine (csrc/conv_split.hip; fp32-class accuracy), "miopen" = fp32 MIOpen
+# convolutions through torch.  Both are parity-tested; override with BFLOW_CONV_ENGINE.
+CONV_ENGINE = os.environ.get("BFLOW_CONV_ENGINE", "split")
 
 
 class RAFTSpline(nn.Module):
@@ -160,17 +166,29 @@ class RAFTSpline(nn.Module):
         corr_ev = corr_img = None
         context_input = None
 
+        engine = CONV_ENGINE == "split" and self.fnet_ev is not None and self.fnet_ev.norm_fn in ("instance", "batch") \
+            and self.cnet.norm_fn in ("instance", "batch")
+
+        def encode_pair(net, x, n_ref, levels):
+            """Feature encoder on a stacked batch [reference | targets] -> CorrComputation."""
+            nb, _, Hh, Ww = x.shape
+            h8, w8 = Hh // 8, Ww // 8
+            D = net.conv2.out_channels
+            T = nb // n_ref - 1
+            if engine and D % 64 == 0:
+                # the last convolution writes K5's operand format directly: (2, nb, D/32, Np, 32), tail rows zero
+                planes = net.forward_split(x, out_rows=hip.padded_rows(h8 * w8)).planes
+                return CorrComputation.from_packed(planes[:, :n_ref], planes[:, n_ref:], n_ref, D, h8, w8, levels)
+            fm = net(x).float()
+            return CorrComputation(fm[:n_ref], fm[n_ref:].view(T, n_ref, *fm.shape[1:]), num_levels_per_target=levels)
+
         if self.fnet_ev is not None:
             assert voxel_grid is not None
             if tm: tm.start("fnet_ev")
             voxel_grid = voxel_grid.contiguous().float()
             grids, context_input = self.gen_voxel_grids(voxel_grid)
             B = voxel_grid.shape[0]
-            fm = self.fnet_ev(torch.cat(grids, dim=0)).float()             # ((T+1)*B, D, h, w): [reference | targets]
-            T = len(grids) - 1
-            fmap1 = fm[:B]
-            fmap2 = fm[B:].view(T, B, *fm.shape[1:])
-            corr_ev = CorrComputation(fmap1, fmap2, num_levels_per_target=self.ev_corr_levels)
+            corr_ev = encode_pair(self.fnet_ev, torch.cat(grids, dim=0), B, self.ev_corr_levels)   # [reference | targets]
             if tm: tm.stop("fnet_ev")
 
         if self.fnet_img is not None:
@@ -178,8 +196,7 @@ class RAFTSpline(nn.Module):
             if tm: tm.start("fnet_img")
             images = [2 * (x.float().contiguous() / 255) - 1 for x in images]   # raft.py:134
             B = images[0].shape[0]
-            fi = self.fnet_img(torch.cat(images, dim=0)).float()
-            corr_img = CorrComputation(fi[:B], fi[B:], num_levels_per_target=self.img_corr_params["levels"])
+            corr_img = encode_pair(self.fnet_img, torch.cat(images, dim=0), B, self.img_corr_params["levels"])
             context_input = images[0] if context_input is None else torch.cat((context_input, images[0]), dim=-3)
             if tm: tm.stop("fnet_img")
         assert context_input is not None
@@ -189,10 +206,13 @@ class RAFTSpline(nn.Module):
         device = context_input.device
 
         if tm: tm.start("cnet")
-        trunk = self.cnet(context_input.contiguous(), project=False)
-        cnet = torch.nn.functional.conv2d(trunk, self.cnet.conv2.weight)     # bias folded into the split kernel
         ws = self.update_block.new_workspace(B, h, w, device)
-        ws.set_context(cnet, self.cnet.conv2.bias)
+        if engine:
+            ws.set_context_split(self.cnet.forward_split(context_input.contiguous()))
+        else:
+            trunk = self.cnet(context_input.contiguous(), project=False)
+            cnet = torch.nn.functional.conv2d(trunk, self.cnet.conv2.weight)     # bias folded into the split kernel
+            ws.set_context(cnet, self.cnet.conv2.bias)
         if tm: tm.stop("cnet")
 
         bezier = torch.zeros((B, 2 * self.bezier_degree, h, w), dtype=torch.float32, device=device)   # raft.py:150

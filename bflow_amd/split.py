@@ -1,0 +1,197 @@
+"""Split-fp16 tensors and the convolution engine's host side (csrc/conv_split.hip, include/bflow_hip.h).
+
+A `SplitTensor` is a channels-last activation held as two fp16 planes: `planes[0]` = hi, `planes[1]` = lo, each
+(B, H, W, C); value = hi + lo * 2^-11 (fp32-class accuracy on the fp16 matrix cores).  This module wraps the C-ABI calls
+that produce and consume them: weight packing, the implicit-GEMM convolution with its fused epilogues, InstanceNorm
+statistics / normalisation + activation + residual, and conversion from / to ordinary NCHW fp32 tensors."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+
+ACT_NONE, ACT_RELU = 0, 1
+LO_INV = 1.0 / 2048.0
+
+
+def _tile_for(cout: int) -> int:
+    """Output-channel tile of the conv kernel (32*NT, NT in 2..4) with the least padding."""
+    best = None
+    for t in (128, 96, 64):
+        pad = (cout + t - 1) // t * t
+        key = (pad - cout, -t)
+        if best is None or key < best[0]:
+            best = (key, t, pad)
+    return best[1]
+
+
+class SplitTensor:
+    """planes: (2, B, C/32, P, 32) fp16 (hi, lo); H x W image of P >= H*W pixel rows; C = logical channel count."""
+
+    def __init__(self, planes: torch.Tensor, H: int, W: int, C: Optional[int] = None):
+        assert planes.dtype == torch.float16 and planes.dim() == 5 and planes.shape[0] == 2 and planes.shape[4] == 32
+        assert planes.is_contiguous() and planes.shape[3] >= H * W
+        self.planes, self.H, self.W = planes, H, W
+        self.C = planes.shape[2] * 32 if C is None else C
+
+    @classmethod
+    def empty(cls, B: int, H: int, W: int, C: int, device, rows: Optional[int] = None, zero: bool = False) -> "SplitTensor":
+        rows = H * W if rows is None else rows
+        alloc = torch.zeros if zero else torch.empty
+        return cls(alloc((2, B, (C + 31) // 32, rows, 32), dtype=torch.float16, device=device), H, W, C)
+
+    @property
+    def shape(self) -> Tuple[int, int, int, int]:
+        return (self.planes.shape[1], self.H, self.W, self.C)   # logical (B, H, W, C)
+
+    @property
+    def rows(self) -> int:
+        return self.planes.shape[3]
+
+    @property
+    def channels_padded(self) -> int:
+        return self.planes.shape[2] * 32
+
+    @property
+    def hi(self) -> torch.Tensor:
+        return self.planes[0]
+
+    @property
+    def lo(self) -> torch.Tensor:
+        return self.planes[1]
+
+    def to_nchw(self, c_first: int = 0, c_count: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, H, W, C = self.shape
+        assert self.rows == H * W
+        c_count = C - c_first if c_count is None else c_count
+        if out is None:
+            out = torch.empty((B, c_count, H, W), dtype=torch.float32, device=self.planes.device)
+        assert out.shape[0] == B and out.shape[1] == c_count and out[0].is_contiguous()
+        bs = out.stride(0) if B > 1 else c_count * H * W
+        hip._check(hip.lib().bflow_split_to_nchw(self.hi.data_ptr(), self.lo.data_ptr(), out.data_ptr(), B, H * W, self.channels_padded,
+                                                 c_first, c_count, bs, hip._stream()), "bflow_split_to_nchw")
+        return out
+
+    def float_nhwc(self) -> torch.Tensor:
+        """(B, H, W, C) fp32 value (debug / tests)."""
+        v = self.hi.float() + self.lo.float() * LO_INV            # (B, CB, P, 32)
+        B, CB, P, _ = v.shape
+        return v[:, :, :self.H * self.W].permute(0, 2, 1, 3).reshape(B, self.H, self.W, CB * 32)[..., :self.C]
+
+
+def blocked_f32_to_nhwc(t: torch.Tensor, H: int, W: int, C: int) -> torch.Tensor:
+    """(B, C/32, P, 32) blocked fp32 -> (B, H, W, C) (debug / tests)."""
+    B, CB, P, _ = t.shape
+    return t[:, :, :H * W].permute(0, 2, 1, 3).reshape(B, H, W, CB * 32)[..., :C]
+
+
+class PackedConvWeight:
+    """Conv weights pre-split for the engine: (cout_pad, KH*KW, cin_pad) fp16 hi/lo planes; rebuilt when the source changes."""
+
+    def __init__(self):
+        self._key = None
+        self.planes = None
+
+    def get(self, weight: torch.Tensor, cin_pad: Optional[int] = None):
+        cout, cin, kh, kw = weight.shape
+        cin_pad = (cin + 31) // 32 * 32 if cin_pad is None else cin_pad
+        tile = _tile_for(cout)
+        cout_pad = (cout + tile - 1) // tile * tile
+        key = (weight.data_ptr(), weight._version, cin_pad, str(weight.device))
+        if self._key != key:
+            w = weight.detach().float().contiguous()
+            planes = torch.empty((2, kh * kw * (cin_pad // 32), cout_pad, 32), dtype=torch.float16, device=w.device)
+            hip._check(hip.lib().bflow_conv_pack_weights(hip._dev(w, name="weight"), planes[0].data_ptr(), planes[1].data_ptr(), cout, cin,
+                                                         kh, kw, cout_pad, cin_pad, hip._stream()), "bflow_conv_pack_weights")
+            self._key, self.planes, self.meta = key, planes, (cout, cin_pad, kh, kw, tile, cout_pad)
+        return self.planes, self.meta
+
+
+def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optional[torch.Tensor] = None,
+         shift: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_split: Optional[SplitTensor] = None,
+         out_f32: Optional[torch.Tensor] = None, channel_offset: int = 0, stats: Optional[torch.Tensor] = None,
+         want_split: bool = True, want_f32: bool = False, out_rows: Optional[int] = None, zero_rows: bool = False):
+    """Implicit-GEMM convolution.  `packed` = PackedConvWeight.get(weight).  Returns (split_out or None, f32_out or None);
+    f32_out is blocked fp32 (B, Cs/32, P_out, 32).  When out_* buffers are given the result is written at channel
+    `channel_offset` (a multiple of 32) of their channel dimension (free concatenation).  out_rows > Ho*Wo allocates
+    zero-filled tail rows (K5's 128-row operand padding)."""
+    planes, (cout, cin_pad, kh, kw, tile, cout_pad) = packed
+    B, H, W, _ = x.shape
+    assert x.channels_padded == cin_pad, f"input has {x.channels_padded} (padded) channels, packed weight expects {cin_pad}"
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    Ho, Wo = (H + 2 * ph - kh) // stride + 1, (W + 2 * pw - kw) // stride + 1
+    dev = x.planes.device
+    rows = Ho * Wo if out_rows is None else out_rows
+    if out_split is None and want_split:
+        out_split = SplitTensor.empty(B, Ho, Wo, cout, dev, rows=rows, zero=zero_rows or rows != Ho * Wo)
+    if out_f32 is None and want_f32:
+        out_f32 = torch.empty((B, (cout + 31) // 32, rows, 32), dtype=torch.float32, device=dev)
+    cs = None
+    for o in (out_split.planes[0] if out_split is not None else None, out_f32):
+        if o is not None:
+            assert o.shape[0] == B and o.shape[2] == rows and o.shape[3] == 32 and o.is_contiguous()
+            assert cs is None or cs == o.shape[1] * 32
+            cs = o.shape[1] * 32
+    assert cs is not None and channel_offset % 32 == 0 and channel_offset + cout <= cs
+    d = hip.ConvDesc()
+    d.x_hi, d.x_lo, d.w_hi, d.w_lo = x.hi.data_ptr(), x.lo.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr()
+    d.B, d.H, d.W, d.C, d.Cout, d.cout_pad = B, H, W, cin_pad, cout, cout_pad
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.tile_n = kh, kw, stride, ph, pw, tile
+    d.out_f32 = None if out_f32 is None else out_f32.data_ptr()
+    d.out_hi = None if out_split is None else out_split.hi.data_ptr()
+    d.out_lo = None if out_split is None else out_split.lo.data_ptr()
+    d.out_channel_stride, d.out_channel_offset, d.out_rows_per_image, d.in_rows_per_image = cs, channel_offset, rows, x.rows
+    d.scale = None if scale is None else hip._dev(scale, name="scale")
+    d.shift = None if shift is None else hip._dev(shift, name="shift")
+    d.act = act
+    d.stats = None if stats is None else hip._dev(stats, torch.float64, "stats")
+    hip._check(hip.lib().bflow_conv_split(ctypes.byref(d), hip._stream()), "bflow_conv_split")
+    return out_split, out_f32
+
+
+def plane_stats(x_nchw: torch.Tensor) -> torch.Tensor:
+    """(B, C, 2) fp64 (sum, sum of squares) per plane of an NCHW fp32 tensor."""
+    B, C, H, W = x_nchw.shape
+    stats = torch.empty((B, C, 2), dtype=torch.float64, device=x_nchw.device)
+    hip._check(hip.lib().bflow_plane_stats(hip._dev(x_nchw, name="x"), stats.data_ptr(), B * C, H * W, hip._stream()), "bflow_plane_stats")
+    return stats
+
+
+def norm_act(a: torch.Tensor, shape_bhwc, a_is_nchw: bool = False, stats_a: Optional[torch.Tensor] = None,
+             scale_a: Optional[torch.Tensor] = None, shift_a: Optional[torch.Tensor] = None, act_a: int = ACT_NONE,
+             b: Optional[torch.Tensor] = None, stats_b: Optional[torch.Tensor] = None, res: Optional[SplitTensor] = None,
+             act_out: int = ACT_NONE, eps: float = 1e-5, out: Optional[SplitTensor] = None, out_f32: Optional[torch.Tensor] = None,
+             want_split: bool = True) -> Tuple[Optional[SplitTensor], Optional[torch.Tensor]]:
+    """out = act_out(res + act_a(norm_a(a)))  (see bflow_norm_act_split).  a / b: blocked fp32 (B, C/32, H*W, 32), or a: NCHW."""
+    B, H, W, C = shape_bhwc
+    if out is None and want_split:
+        out = SplitTensor.empty(B, H, W, C, a.device)
+    d = hip.NormDesc()
+    d.a = hip._dev(a, name="a")
+    d.stats_a = None if stats_a is None else hip._dev(stats_a, torch.float64, "stats_a")
+    d.scale_a = None if scale_a is None else hip._dev(scale_a, name="scale_a")
+    d.shift_a = None if shift_a is None else hip._dev(shift_a, name="shift_a")
+    d.a_is_nchw, d.act_a = int(a_is_nchw), act_a
+    d.b = None if b is None else hip._dev(b, name="b")
+    d.stats_b = None if stats_b is None else hip._dev(stats_b, torch.float64, "stats_b")
+    d.res_hi = None if res is None else res.hi.data_ptr()
+    d.res_lo = None if res is None else res.lo.data_ptr()
+    assert res is None or res.rows == H * W
+    d.act_out = act_out
+    d.out_hi = None if out is None else out.hi.data_ptr()
+    d.out_lo = None if out is None else out.lo.data_ptr()
+    assert out is None or out.rows == H * W
+    d.out_f32 = None if out_f32 is None else hip._dev(out_f32, name="out_f32")
+    d.B, d.HW, d.C, d.eps, d.rows_per_image = B, H * W, C, eps, H * W
+    hip._check(hip.lib().bflow_norm_act_split(ctypes.byref(d), hip._stream()), "bflow_norm_act_split")
+    return out, out_f32
+
+
+def from_nchw(x: torch.Tensor) -> SplitTensor:
+    """NCHW fp32 -> blocked split (identity transform); channels are zero-padded to the next multiple of 32."""
+    B, C, H, W = x.shape
+    out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True)
+    return out

@@ -80,6 +80,20 @@ class UpdateWorkspace:
         self.net.copy_(self.hx[:, :h0])
 
 
+def _set_context_split(self, cnet_split):
+    """Context features straight from the split-fp16 encoder: (B, h, w, hdim+cdim) split NHWC -> NCHW slices of hx."""
+    h0, c0 = self.hdim, self.cdim
+    cnet_split.to_nchw(0, h0, out=self.hx[:, :h0])
+    cnet_split.to_nchw(h0, c0, out=self.hx[:, h0:h0 + c0])
+    self.hx[:, :h0].tanh_()
+    self.hx[:, h0:h0 + c0].relu_()
+    self.rhx[:, h0:h0 + c0].copy_(self.hx[:, h0:h0 + c0])
+    self.net.copy_(self.hx[:, :h0])
+
+
+UpdateWorkspace.set_context_split = _set_context_split
+
+
 class BasicUpdateBlock(nn.Module):
     def __init__(self, model_params: Dict[str, Any], hidden_dim: int = 128):
         super().__init__()

@@ -61,6 +61,64 @@ int bflow_split_pack(const float* src, void* hi, void* lo, int R, int D, int N, 
 int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out,
                            int T, int B, int D, int N, int Np, long long f1_target_stride, bflow_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * K4 / K9-K11  convolutions on the split-fp16 MFMA engine (csrc/conv_split.hip).
+ * Replaces F.conv2d + norm + ReLU + residual of BasicEncoder / ResidualBlock (models/raft_utils/extractor.py:47-55,
+ * 103-125) with an implicit GEMM over channels-last split tensors: two fp16 planes (hi, lo) of shape (B, H, W, C),
+ * value = hi + lo * 2^-11 (fp32-class accuracy, ~2^-22 relative per product).
+ *
+ * bflow_conv_pack_weights : w (Cout, Cin, KH, KW) fp32 -> w_hi/w_lo (KH*KW*cin_pad/32, cout_pad, 32) fp16, zero padded;
+ *                           cout_pad = multiple of the channel tile, cin_pad = multiple of 32.
+ * bflow_conv_split        : out[b, ho, wo, co] = act( scale[co] * conv(x, w)[b, ho, wo, co] + shift[co] ), zero padding,
+ *                           stride 1 or 2.  Outputs (any subset): fp32 NHWC `out_f32`, split NHWC `out_hi/out_lo`, both
+ *                           addressed as (B, Ho*Wo, out_channel_stride) + out_channel_offset (concatenation for free);
+ *                           `stats` (B, Cout, 2) fp64 receives += (sum, sum of squares) over Ho*Wo of the written
+ *                           values (the InstanceNorm statistics; zero it first).                               */
+typedef struct bflow_conv_desc {
+    const void *x_hi, *x_lo;          /* blocked (B, C/32, P_in, 32) fp16 planes, C % 32 == 0                    */
+    const void *w_hi, *w_lo;          /* packed weights (KH*KW*C/32, cout_pad, 32)                               */
+    int B, H, W, C, Cout, cout_pad;
+    int KH, KW, stride, pad_h, pad_w;
+    int tile_n;                       /* output-channel tile: 64, 96 or 128 (cout_pad % tile_n == 0)             */
+    float* out_f32;                   /* or NULL                                                                 */
+    void *out_hi, *out_lo;            /* or NULL                                                                 */
+    int out_channel_stride;           /* 0 = Cout                                                                */
+    int out_channel_offset;
+    int out_rows_per_image;           /* pixel rows per image in the output buffers; 0 = Ho*Wo (larger values leave
+                                         zero tail rows, e.g. the 128-row tile padding K5 wants)                 */
+    int in_rows_per_image;            /* pixel rows per image of x; 0 = H*W                                      */
+    const float *scale, *shift;       /* per output channel, or NULL (= 1 / 0)                                   */
+    int act;                          /* 0 = identity, 1 = relu                                                  */
+    double* stats;                    /* or NULL                                                                 */
+} bflow_conv_desc_t;
+int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
+                            int cout_pad, int cin_pad, bflow_stream_t stream);
+int bflow_conv_split(const bflow_conv_desc_t* desc, bflow_stream_t stream);
+
+/* bflow_plane_stats: stats[p] = (sum, sum of squares) of plane p of an NCHW fp32 tensor (planes = B*C, HW % 4 == 0).
+ * bflow_norm_act_split: out = act_out( res + act_a( norm_a(a) ) ) -> split NHWC (and/or fp32 NHWC), where
+ *     a     : fp32 NHWC (B, HW, C), or NCHW (B, C, HW) when a_is_nchw (transposed on the fly);
+ *     norm_a: InstanceNorm from stats_a (B, C, 2) [biased variance, eps inside the sqrt: F.instance_norm] if stats_a,
+ *             else the per-channel affine scale_a/shift_a (folded BatchNorm), else identity;
+ *     res   : nothing | split tensor res_hi/res_lo | InstanceNorm(b; stats_b) of a second fp32 NHWC tensor
+ *             (the 1x1 down-sampling branch, extractor.py:43-44,52-53).                                         */
+typedef struct bflow_norm_desc {
+    const float* a; const double* stats_a; const float *scale_a, *shift_a; int a_is_nchw; int act_a;
+    const float* b; const double* stats_b;
+    const void *res_hi, *res_lo;
+    int act_out;
+    void *out_hi, *out_lo; float* out_f32;
+    int B, HW, C; float eps;
+    int rows_per_image;               /* pixel rows per image of the blocked tensors; 0 = HW                     */
+} bflow_norm_desc_t;
+int bflow_plane_stats(const float* x, double* stats, long long planes, int HW, bflow_stream_t stream);
+int bflow_norm_act_split(const bflow_norm_desc_t* desc, bflow_stream_t stream);
+
+/* bflow_split_to_nchw: channels [c_first, c_first+c_count) of a split NHWC tensor -> fp32 (B, c_count, HW) planes with
+ * an element batch stride (leaving the engine towards NCHW consumers).                                          */
+int bflow_split_to_nchw(const void* x_hi, const void* x_lo, float* out, int B, int HW, int C, int c_first, int c_count,
+                        long long out_batch_stride, bflow_stream_t stream);
+
 /* K6  one pyramid level: 2x2 average pooling, stride 2, floor on odd sizes, over the target plane.
  * Replaces CorrData.get_downsampled (F.avg_pool2d), models/raft_utils/corr.py:108-125.
  *   in : (planes, h, w)   out : (planes, h/2, w/2)                                                    */
