@@ -38,9 +38,11 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
 }
 
 struct ConvArgs {
-    const _Float16 *xh, *xl;   // (B, CB, P_in, 32)
+    const _Float16 *xh, *xl;   // (B, CB1, P_in, 32): channel blocks [0, CB1)
+    const _Float16 *x2h, *x2l; // (B, CB - CB1, P_in, 32): channel blocks [CB1, CB)  (virtual concatenation) or null
     const _Float16 *wh, *wl;   // (ntaps*CB, Cout_pad, 32)
-    int H, W, CB, P_in, Ho, Wo, Cout, cout_pad;
+    int H, W, CB, CB1, P_in, Ho, Wo, Cout, cout_pad;
+    const float* addend;       // blocked fp32 (B, ceil(Cout/32), P_out, 32) added before the activation, or null
     int KH, KW, stride, pad_h, pad_w;
     float* out_f32;            // blocked (B, CBo, P_out, 32) fp32 or null
     _Float16 *oh, *ol;         // blocked split or null
@@ -90,7 +92,8 @@ __global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
         r = r < a.cout_pad ? r : a.cout_pad - 1;          // NT = 3 stages 128 rows of a 96-wide tile: clamp (never consumed)
         wsrc[j] = (long long)r * 32 + uchunk;
     }
-    const long long xb = (long long)b * a.CB * a.P_in * 32;
+    const int CB2 = a.CB - a.CB1;
+    const long long xb1 = (long long)b * a.CB1 * a.P_in * 32, xb2 = (long long)b * CB2 * a.P_in * 32;
     const long long wkstep = (long long)a.cout_pad * 32;
     const _Float16* zp = g_zero_page + uchunk;
 
@@ -98,12 +101,16 @@ __global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
     {                                                                                                                    \
         char* sb = lds + (SLOT) * STAGE;                                                                                 \
         const int r_ = (TAP) / a.KW, q_ = (TAP) - r_ * a.KW;                                                             \
+        const bool first_ = (CBI) < a.CB1;                       /* which of the two concatenated sources (uniform) */  \
+        const _Float16* srch = first_ ? a.xh + xb1 : a.x2h + xb2;                                                        \
+        const _Float16* srcl = first_ ? a.xl + xb1 : a.x2l + xb2;                                                        \
+        const int cbl_ = first_ ? (CBI) : (CBI) - a.CB1;                                                                 \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
             const int hi_ = hb[j] + r_, wi_ = wb[j] + q_;                                                                \
             const bool ok = rok[j] && hi_ >= 0 && hi_ < a.H && wi_ >= 0 && wi_ < a.W;                                    \
-            const long long off = xb + ((long long)(CBI) * a.P_in + hi_ * a.W + wi_) * 32 + uchunk;                      \
-            const _Float16* ph = ok ? a.xh + off : zp;                                                                   \
-            const _Float16* pl = ok ? a.xl + off : zp;                                                                   \
+            const long long off = ((long long)cbl_ * a.P_in + hi_ * a.W + wi_) * 32 + uchunk;                            \
+            const _Float16* ph = ok ? srch + off : zp;                                                                   \
+            const _Float16* pl = ok ? srcl + off : zp;                                                                   \
             __builtin_amdgcn_global_load_lds((gptr_t)ph, (lptr_t)(sb + O_AH + (wave * 2 + j) * 1024), 16, 0, 0);         \
             __builtin_amdgcn_global_load_lds((gptr_t)pl, (lptr_t)(sb + O_AL + (wave * 2 + j) * 1024), 16, 0, 0);         \
         }                                                                                                                \
@@ -179,12 +186,15 @@ __global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
         const float sc = (a.scale && cok) ? a.scale[col] : 1.f;
         const float sh = (a.shift && cok) ? a.shift[col] : 0.f;
         const long long ob = ((long long)b * a.CBo + a.cb_off + (n0 >> 5) + n) * a.P_out * 32 + l31;
+        const long long ab = ((long long)b * ((a.Cout + 31) >> 5) + (n0 >> 5) + n) * a.P_out * 32 + l31;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             float v = (hh[n][r] + xx[n][r] * LO_INV) * sc + sh;
+            if (a.addend && m < HoWo && cok) v += a.addend[ab + (long long)m * 32];
             if (a.act == 1) v = fmaxf(v, 0.f);
+            else if (a.act == 2) v = tanhf(v);
             if (m < HoWo && cok) {
                 const long long o = ob + (long long)m * 32;
                 if (a.out_f32) a.out_f32[o] = v;
@@ -351,6 +361,7 @@ __global__ __launch_bounds__(256) void norm_act_split_kernel(NormArgs p) {
         }
         if (p.rh) x += (float)rh8[k] + (float)rl8[k] * LO_INV;
         if (p.act_out == 1) x = fmaxf(x, 0.f);
+        else if (p.act_out == 2) x = tanhf(x);
         if (c >= p.C) x = 0.f;
         _Float16 h, l;
         split1(x, h, l);
@@ -405,10 +416,13 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     BFLOW_REQUIRE(d->B <= 65535, BFLOW_E_LIMIT, "conv_split: batch too large");
     const int NT = d->tile_n / 32;
     BFLOW_REQUIRE(NT >= 2 && NT <= 4 && d->tile_n % 32 == 0, BFLOW_E_ARG, "conv_split: tile_n must be 64, 96 or 128");
-    BFLOW_REQUIRE(d->cout_pad % d->tile_n == 0 && d->cout_pad >= d->Cout, BFLOW_E_ARG, "conv_split: weights must be padded to the channel tile");
+    BFLOW_REQUIRE(d->cout_pad >= d->Cout, BFLOW_E_ARG, "conv_split: cout_pad < Cout");
     BFLOW_REQUIRE(d->out_channel_offset % 32 == 0, BFLOW_E_ARG, "conv_split: channel offset must be a multiple of 32");
     ConvArgs a;
     a.xh = (const _Float16*)d->x_hi; a.xl = (const _Float16*)d->x_lo; a.wh = (const _Float16*)d->w_hi; a.wl = (const _Float16*)d->w_lo;
+    a.x2h = (const _Float16*)d->x2_hi; a.x2l = (const _Float16*)d->x2_lo; a.addend = d->addend;
+    a.CB1 = (d->x2_hi && d->x2_lo) ? d->x_split_channels / 32 : d->C / 32;
+    BFLOW_REQUIRE(a.CB1 > 0 && a.CB1 <= d->C / 32 && d->x_split_channels % 32 == 0, BFLOW_E_ARG, "conv_split: bad two-source split");
     a.H = d->H; a.W = d->W; a.CB = d->C / 32; a.P_in = d->in_rows_per_image > 0 ? d->in_rows_per_image : d->H * d->W;
     a.Ho = Ho; a.Wo = Wo; a.Cout = d->Cout; a.cout_pad = d->cout_pad;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
@@ -417,7 +431,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     BFLOW_REQUIRE(out_c % 32 == 0 && d->out_channel_offset + d->Cout <= out_c, BFLOW_E_ARG, "conv_split: bad output channel layout");
     a.CBo = out_c / 32; a.cb_off = d->out_channel_offset / 32; a.P_out = d->out_rows_per_image > 0 ? d->out_rows_per_image : Ho * Wo;
     a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
-    dim3 grid(bflow::ceil_div((long long)Ho * Wo, CBM), d->cout_pad / d->tile_n, d->B);
+    dim3 grid(bflow::ceil_div((long long)Ho * Wo, CBM), bflow::ceil_div(d->Cout, d->tile_n), d->B);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(N)                                                                                                      \
     {                                                                                                                  \

@@ -101,7 +101,7 @@ class BasicEncoder(nn.Module):
             cache[id(norm)] = hit
         return hit[1], hit[2]
 
-    def forward_split(self, x: torch.Tensor, out_rows: Optional[int] = None):
+    def forward_split(self, x: torch.Tensor, out_rows: Optional[int] = None, trunk_only: bool = False):
         """The same network on the split-fp16 MFMA engine (csrc/conv_split.hip): channels-last split activations, implicit-GEMM
         convolutions with bias / folded BatchNorm / ReLU / InstanceNorm statistics fused into their epilogues, and one
         normalise+activate+residual kernel between convolutions.  Only the 7x7 stem stays on MIOpen (its tiny input-channel
@@ -174,6 +174,8 @@ class BasicEncoder(nn.Module):
                     d, std = conv_norm(pre + ".downsample.0", blk.downsample[0], blk.norm3, cur, stride, False)
                     cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU if kind == "instance" else S.ACT_NONE, b=d, stats_b=std,
                                         act_out=S.ACT_RELU)
+        if trunk_only:      # the caller applies the 1x1 projection itself (e.g. split into tanh / relu halves, raft.py:145-147)
+            return cur
         pk = self._packed("conv2", self.conv2)
         bias = self.conv2.bias
         out, _ = S.conv(cur, pk, shift=bias, out_rows=out_rows)

@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
+from . import split as S
 from .bezier import BezierCurves, polynomial_coefficients
 from .corr import CorrBlockParallelMultiTarget, CorrComputation
 from .extractor import BasicEncoder
@@ -35,6 +36,7 @@ from .update import BasicUpdateBlock
 # Encoder arithmetic: "split" = split-fp16 MFMA engine (csrc/conv_split.hip; fp32-class accuracy), "miopen" = fp32 MIOpen
 # convolutions through torch.  Both are parity-tested; override with BFLOW_CONV_ENGINE.
 CONV_ENGINE = os.environ.get("BFLOW_CONV_ENGINE", "split")
+UPDATE_ENGINE = os.environ.get("BFLOW_UPDATE_ENGINE", "split")   # GRU / motion-encoder / head convolutions: "split" | "miopen"
 
 
 class RAFTSpline(nn.Module):
@@ -205,11 +207,18 @@ class RAFTSpline(nn.Module):
         h, w = H // 8, W // 8
         device = context_input.device
 
+        ub = self.update_block
+        engine_update = engine and UPDATE_ENGINE == "split" and ub.hidden_dim % 32 == 0 and ub.motion_dim % 32 == 0 \
+            and ub.context_dim % 32 == 0 and ub.bezier_planes <= 32
         if tm: tm.start("cnet")
-        ws = self.update_block.new_workspace(B, h, w, device)
-        if engine:
+        if engine_update:
+            ws = ub.new_split_workspace(B, h, w, device)
+            ub.set_context_split(ws, self.cnet.forward_split(context_input.contiguous(), trunk_only=True), self.cnet.conv2)
+        elif engine:
+            ws = ub.new_workspace(B, h, w, device)
             ws.set_context_split(self.cnet.forward_split(context_input.contiguous()))
         else:
+            ws = ub.new_workspace(B, h, w, device)
             trunk = self.cnet(context_input.contiguous(), project=False)
             cnet = torch.nn.functional.conv2d(trunk, self.cnet.conv2.weight)     # bias folded into the split kernel
             ws.set_context(cnet, self.cnet.conv2.bias)
@@ -226,6 +235,8 @@ class RAFTSpline(nn.Module):
 
         coef = self._coefficients()
         corr_feat = corr_block.new_output()
+        if engine_update:
+            S.bezier_update(bezier, None, ws.BZ, 0, ws.M, ub.motion_dim // 32)     # emit the initial Bezier channel block
         ups: List[torch.Tensor] = []
         if tm: tm.start("all iters")
         for itr in range(iters):
@@ -235,9 +246,14 @@ class RAFTSpline(nn.Module):
             if tm: tm.stop("corr lookup (per iter)")
             need_mask = (not test_mode) or itr == iters - 1
             if tm: tm.start("update (per iter)")
-            raw_mask = self.update_block.step(ws, corr_feat, bezier, need_mask)
-            if need_mask:
-                ups.append(hip.cvx_upsample(bezier, raw_mask, self.update_block.mask[2].bias, 0.25))
+            if engine_update:
+                mask = ub.step_split(ws, corr_feat, bezier, need_mask)
+                if need_mask:
+                    ups.append(hip.cvx_upsample(bezier, mask, None, 0.25))
+            else:
+                raw_mask = ub.step(ws, corr_feat, bezier, need_mask)
+                if need_mask:
+                    ups.append(hip.cvx_upsample(bezier, raw_mask, ub.mask[2].bias, 0.25))
             if tm: tm.stop("update (per iter)")
             if tm: tm.stop("1 iter")
         if tm: tm.stop("all iters")

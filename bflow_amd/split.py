@@ -13,19 +13,21 @@ import torch
 
 from . import hip
 
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 LO_INV = 1.0 / 2048.0
 
 
-def _tile_for(cout: int) -> int:
-    """Output-channel tile of the conv kernel (32*NT, NT in 2..4) with the least padding."""
-    best = None
+def pick_tile(cout: int, m_tiles: int) -> int:
+    """Output-channel tile (64 / 96 / 128).  Large problems take the widest tile with the least padding; small ones (too few
+    128-pixel tiles to fill 256 CUs, e.g. the batch-1 update block) take 64 to get more workgroups."""
+    cands = []
     for t in (128, 96, 64):
-        pad = (cout + t - 1) // t * t
-        key = (pad - cout, -t)
-        if best is None or key < best[0]:
-            best = (key, t, pad)
-    return best[1]
+        ny = (cout + t - 1) // t
+        cands.append((ny * t - cout, -t, t, ny * m_tiles))
+    if max(c[3] for c in cands) >= 512:
+        ok = [c for c in cands if c[3] >= 512]
+        return min(ok)[2]
+    return 64
 
 
 class SplitTensor:
@@ -98,33 +100,37 @@ class PackedConvWeight:
     def get(self, weight: torch.Tensor, cin_pad: Optional[int] = None):
         cout, cin, kh, kw = weight.shape
         cin_pad = (cin + 31) // 32 * 32 if cin_pad is None else cin_pad
-        tile = _tile_for(cout)
-        cout_pad = (cout + tile - 1) // tile * tile
+        cout_pad = (cout + 127) // 128 * 128   # any channel tile (64/96/128) may read up to 128 rows from its first row
         key = (weight.data_ptr(), weight._version, cin_pad, str(weight.device))
         if self._key != key:
             w = weight.detach().float().contiguous()
             planes = torch.empty((2, kh * kw * (cin_pad // 32), cout_pad, 32), dtype=torch.float16, device=w.device)
             hip._check(hip.lib().bflow_conv_pack_weights(hip._dev(w, name="weight"), planes[0].data_ptr(), planes[1].data_ptr(), cout, cin,
                                                          kh, kw, cout_pad, cin_pad, hip._stream()), "bflow_conv_pack_weights")
-            self._key, self.planes, self.meta = key, planes, (cout, cin_pad, kh, kw, tile, cout_pad)
+            self._key, self.planes, self.meta = key, planes, (cout, cin_pad, kh, kw, cout_pad)
         return self.planes, self.meta
 
 
 def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optional[torch.Tensor] = None,
          shift: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_split: Optional[SplitTensor] = None,
          out_f32: Optional[torch.Tensor] = None, channel_offset: int = 0, stats: Optional[torch.Tensor] = None,
-         want_split: bool = True, want_f32: bool = False, out_rows: Optional[int] = None, zero_rows: bool = False):
+         want_split: bool = True, want_f32: bool = False, out_rows: Optional[int] = None, zero_rows: bool = False,
+         x2: Optional[SplitTensor] = None, addend: Optional[torch.Tensor] = None, tile: Optional[int] = None):
     """Implicit-GEMM convolution.  `packed` = PackedConvWeight.get(weight).  Returns (split_out or None, f32_out or None);
     f32_out is blocked fp32 (B, Cs/32, P_out, 32).  When out_* buffers are given the result is written at channel
     `channel_offset` (a multiple of 32) of their channel dimension (free concatenation).  out_rows > Ho*Wo allocates
     zero-filled tail rows (K5's 128-row operand padding)."""
-    planes, (cout, cin_pad, kh, kw, tile, cout_pad) = packed
+    planes, (cout, cin_pad, kh, kw, cout_pad) = packed
     B, H, W, _ = x.shape
-    assert x.channels_padded == cin_pad, f"input has {x.channels_padded} (padded) channels, packed weight expects {cin_pad}"
+    c_in = x.channels_padded + (0 if x2 is None else x2.channels_padded)
+    assert c_in == cin_pad, f"input has {c_in} (padded) channels, packed weight expects {cin_pad}"
+    assert x2 is None or (x2.rows == x.rows and x2.H == H and x2.W == W)
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
     Ho, Wo = (H + 2 * ph - kh) // stride + 1, (W + 2 * pw - kw) // stride + 1
     dev = x.planes.device
     rows = Ho * Wo if out_rows is None else out_rows
+    if tile is None:
+        tile = pick_tile(cout, B * ((Ho * Wo + 127) // 128))
     if out_split is None and want_split:
         out_split = SplitTensor.empty(B, Ho, Wo, cout, dev, rows=rows, zero=zero_rows or rows != Ho * Wo)
     if out_f32 is None and want_f32:
@@ -144,6 +150,11 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
     d.out_hi = None if out_split is None else out_split.hi.data_ptr()
     d.out_lo = None if out_split is None else out_split.lo.data_ptr()
     d.out_channel_stride, d.out_channel_offset, d.out_rows_per_image, d.in_rows_per_image = cs, channel_offset, rows, x.rows
+    if x2 is not None:
+        d.x2_hi, d.x2_lo, d.x_split_channels = x2.hi.data_ptr(), x2.lo.data_ptr(), x.channels_padded
+    if addend is not None:
+        assert addend.dtype == torch.float32 and addend.is_contiguous() and tuple(addend.shape) == (B, (cout + 31) // 32, rows, 32)
+        d.addend = addend.data_ptr()
     d.scale = None if scale is None else hip._dev(scale, name="scale")
     d.shift = None if shift is None else hip._dev(shift, name="shift")
     d.act = act
@@ -195,3 +206,29 @@ def from_nchw(x: torch.Tensor) -> SplitTensor:
     B, C, H, W = x.shape
     out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True)
     return out
+
+
+def gru_rh(zr: torch.Tensor, h: SplitTensor, rh: SplitTensor):
+    """rh = sigmoid(zr[:, C:2C]) * h   (zr: blocked fp32 (B, 2C/32, P, 32))."""
+    B, _, _, C = h.shape
+    hip._check(hip.lib().bflow_gru_rh_blocked(hip._dev(zr, name="zr"), h.hi.data_ptr(), h.lo.data_ptr(), rh.hi.data_ptr(), rh.lo.data_ptr(),
+                                              B, C, h.rows, hip._stream()), "bflow_gru_rh_blocked")
+
+
+def gru_blend(zr: torch.Tensor, q: torch.Tensor, h: SplitTensor):
+    """h = (1 - sigmoid(z)) * h + sigmoid(z) * tanh(q), in place."""
+    B, _, _, C = h.shape
+    hip._check(hip.lib().bflow_gru_blend_blocked(hip._dev(zr, name="zr"), hip._dev(q, name="q"), h.hi.data_ptr(), h.lo.data_ptr(), B, C,
+                                                 h.rows, hip._stream()), "bflow_gru_blend_blocked")
+
+
+def bezier_update(params: torch.Tensor, delta: Optional[torch.Tensor], dst: SplitTensor, dst_block: int,
+                  dst2: Optional[SplitTensor] = None, dst2_block: int = 0):
+    """params (B, 2deg, h, w) fp32 += delta (blocked fp32, first 2deg channels); re-emit as split channel block(s)."""
+    B, C2 = params.shape[:2]
+    P = params.shape[2] * params.shape[3]
+    assert dst.rows == P and (dst2 is None or dst2.rows == P)
+    hip._check(hip.lib().bflow_bezier_update(hip._dev(params, name="params"), None if delta is None else hip._dev(delta, name="delta"), C2,
+                                             dst.hi.data_ptr(), dst.lo.data_ptr(), dst.planes.shape[2], dst_block,
+                                             None if dst2 is None else dst2.hi.data_ptr(), None if dst2 is None else dst2.lo.data_ptr(),
+                                             0 if dst2 is None else dst2.planes.shape[2], dst2_block, B, P, hip._stream()), "bflow_bezier_update")

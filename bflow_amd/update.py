@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import hip
+from . import split as S
 
 
 class BezierHead(nn.Module):
@@ -94,6 +95,20 @@ def _set_context_split(self, cnet_split):
 UpdateWorkspace.set_context_split = _set_context_split
 
 
+class SplitWorkspace:
+    """Buffers of one forward when the update block runs on the split-fp16 engine (blocked channels-last split tensors)."""
+
+    def __init__(self, blk: "BasicUpdateBlock", batch: int, h: int, w: int, device):
+        hd, md = blk.hidden_dim, blk.motion_dim
+        self.H = S.SplitTensor.empty(batch, h, w, hd, device)                    # hidden state
+        self.RH = S.SplitTensor.empty(batch, h, w, hd, device)                   # r * h
+        self.M = S.SplitTensor.empty(batch, h, w, md + 32, device, zero=True)    # [motion conv (md-2deg, zero padded to md) | Bezier block]
+        self.BZ = S.SplitTensor.empty(batch, h, w, 32, device)                   # Bezier parameters alone (input of convf1)
+        self.INP = None                                                          # relu(context) split, set by set_context
+        self.corbez = S.SplitTensor.empty(batch, h, w, 256, device)
+        self.inp_terms = None
+
+
 class BasicUpdateBlock(nn.Module):
     def __init__(self, model_params: Dict[str, Any], hidden_dim: int = 128):
         super().__init__()
@@ -157,6 +172,99 @@ class BasicUpdateBlock(nn.Module):
         m1 = F.conv2d(ws.net, self.mask[0].weight, padding=1)
         hip.bias_act_inplace(m1, self.mask[0].bias, hip.ACT_RELU)
         return F.conv2d(m1, self.mask[2].weight)
+
+    # ------------------------------------------------------------------------------------------------ split-fp16 engine
+    def _pk(self, name: str, weight_fn, cin_pad=None):
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        if name not in cache:
+            cache[name] = [S.PackedConvWeight(), None, None]
+        entry = cache[name]
+        srcs = weight_fn.__defaults__            # the source parameters the derived weight is built from
+        key = tuple((t.data_ptr(), t._version) for t in srcs)
+        if entry[1] != key:
+            with torch.no_grad():
+                entry[2] = weight_fn().contiguous()
+            entry[1] = key
+        return entry[0].get(entry[2], cin_pad)
+
+    def _gate_weights(self, sfx: str):
+        """Gate convolutions re-indexed for the engine's inputs.  The reference convolves cat([h, inp, motion]) (update.py:34-37);
+        here the loop-invariant `inp` part is split off (it is convolved ONCE per frame and enters as an addend), and the
+        remaining input is the virtual concatenation [h | motion conv (zero padded) | Bezier block (zero padded to 32)]."""
+        g = self.gru
+        hd, cd, md, bz = self.hidden_dim, self.context_dim, self.motion_dim, self.bezier_planes
+        cz, cr, cq = getattr(g, "convz" + sfx), getattr(g, "convr" + sfx), getattr(g, "convq" + sfx)
+
+        def hm(w):   # (Cout, hd+cd+md, kh, kw) -> (Cout, hd + md + 32, kh, kw)
+            co, _, kh, kw = w.shape
+            z = w.new_zeros
+            mconv = w[:, hd + cd:hd + cd + md - bz]
+            return torch.cat([w[:, :hd], mconv, z((co, bz, kh, kw)), w[:, hd + cd + md - bz:], z((co, 32 - bz, kh, kw))], dim=1)
+
+        def zr_hm(a=cz.weight, b=cr.weight): return hm(torch.cat([a, b], dim=0))
+        def q_hm(a=cq.weight): return hm(a)
+        def zr_inp(a=cz.weight, b=cr.weight): return torch.cat([a, b], dim=0)[:, hd:hd + cd]
+        def q_inp(a=cq.weight): return a[:, hd:hd + cd]
+        def zr_bias(a=cz.bias, b=cr.bias): return torch.cat([a, b], dim=0)
+        return (self._pk("zr_hm" + sfx, zr_hm), self._pk("q_hm" + sfx, q_hm), self._pk("zr_inp" + sfx, zr_inp),
+                self._pk("q_inp" + sfx, q_inp), zr_bias, cq.bias, cz.padding)
+
+    def new_split_workspace(self, batch: int, h: int, w: int, device) -> SplitWorkspace:
+        return SplitWorkspace(self, batch, h, w, device)
+
+    def set_context_split(self, ws: SplitWorkspace, trunk: "S.SplitTensor", conv2: nn.Conv2d):
+        """net = tanh(cnet[:, :hdim]) -> ws.H, inp = relu(cnet[:, hdim:]) -> ws.INP (raft.py:144-147): the encoder's 1x1 projection
+        is applied as two convolutions with the activation in their epilogues.  Then the loop-invariant `inp` parts of the six
+        gate convolutions are evaluated once (with the gate biases folded in)."""
+        hd = self.hidden_dim
+
+        def w_net(a=conv2.weight): return a[:hd]
+        def w_inp(a=conv2.weight): return a[hd:]
+        S.conv(trunk, self._pk("cnet_net", w_net), shift=conv2.bias[:hd].contiguous(), act=S.ACT_TANH, out_split=ws.H)
+        ws.INP, _ = S.conv(trunk, self._pk("cnet_inp", w_inp), shift=conv2.bias[hd:].contiguous(), act=S.ACT_RELU)
+        terms = []
+        for sfx in ("1", "2"):
+            _, _, zr_inp, q_inp, zr_bias, q_bias, pad = self._gate_weights(sfx)
+            bz = self.__dict__.setdefault("_bias_cache", {})
+            if ("zr" + sfx) not in bz or bz["zr" + sfx][0] != tuple(t._version for t in zr_bias.__defaults__):
+                with torch.no_grad():
+                    bz["zr" + sfx] = (tuple(t._version for t in zr_bias.__defaults__), zr_bias().contiguous())
+            _, t_zr = S.conv(ws.INP, zr_inp, padding=pad, shift=bz["zr" + sfx][1], want_split=False, want_f32=True)
+            _, t_q = S.conv(ws.INP, q_inp, padding=pad, shift=q_bias, want_split=False, want_f32=True)
+            terms.append((t_zr, t_q))
+        ws.inp_terms = terms
+
+    def step_split(self, ws: SplitWorkspace, corr: torch.Tensor, bezier: torch.Tensor, need_mask: bool):
+        """One iteration of update.py:116-126 on the split-fp16 engine.  corr: (B, P*81, h, w) fp32 (look-up output), bezier:
+        (B, 2*deg, h, w) fp32 updated IN PLACE.  Returns the mask logits incl. bias (B, 576, h, w) fp32 or None."""
+        enc = self.encoder
+        # ---- motion encoder (update.py:88-97); every bias + relu lives in a conv epilogue, every cat is a channel offset
+        cs = S.from_nchw(corr)
+        c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
+        S.conv(c1, self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
+               out_split=ws.corbez, channel_offset=0)
+        f1, _ = S.conv(ws.BZ, self._pk("convf1", lambda a=enc.convf1.weight: a, 32), padding=3, shift=enc.convf1.bias, act=S.ACT_RELU)
+        S.conv(f1, self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
+               out_split=ws.corbez, channel_offset=192)
+        S.conv(ws.corbez, self._pk("conv", lambda a=enc.conv.weight: a), padding=1, shift=enc.conv.bias, act=S.ACT_RELU,
+               out_split=ws.M, channel_offset=0)
+        # ---- separable conv-GRU (update.py:33-48)
+        for sfx, (t_zr, t_q) in zip(("1", "2"), ws.inp_terms):
+            zr_hm, q_hm, _, _, _, _, pad = self._gate_weights(sfx)
+            _, zr = S.conv(ws.H, zr_hm, x2=ws.M, padding=pad, addend=t_zr, want_split=False, want_f32=True)
+            S.gru_rh(zr, ws.H, ws.RH)
+            _, q = S.conv(ws.RH, q_hm, x2=ws.M, padding=pad, addend=t_q, want_split=False, want_f32=True)
+            S.gru_blend(zr, q, ws.H)
+        # ---- heads (update.py:17-18,111-114,120-125)
+        bh = self.bezier_head
+        d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
+        _, d2 = S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, want_split=False, want_f32=True)
+        S.bezier_update(bezier, d2, ws.BZ, 0, ws.M, self.motion_dim // 32)
+        if not need_mask:
+            return None
+        m1, _ = S.conv(ws.H, self._pk("mask0", lambda a=self.mask[0].weight: a), padding=1, shift=self.mask[0].bias, act=S.ACT_RELU)
+        m2, _ = S.conv(m1, self._pk("mask2", lambda a=self.mask[2].weight: a), shift=self.mask[2].bias)
+        return m2.to_nchw()
 
     def forward(self, net, inp, corr, bezier):
         """Reference-shaped call (update.py:116-126): returns (net, mask, delta_bezier) without mutating the inputs."""

@@ -87,8 +87,13 @@ typedef struct bflow_conv_desc {
     int out_rows_per_image;           /* pixel rows per image in the output buffers; 0 = Ho*Wo (larger values leave
                                          zero tail rows, e.g. the 128-row tile padding K5 wants)                 */
     int in_rows_per_image;            /* pixel rows per image of x; 0 = H*W                                      */
+    const void *x2_hi, *x2_lo;        /* optional second input: channels [x_split_channels, C) come from x2 (its own
+                                         (B, (C - x_split_channels)/32, P_in, 32) planes): torch.cat for free        */
+    int x_split_channels;             /* multiple of 32; ignored when x2 is NULL                                  */
+    const float* addend;              /* optional blocked fp32 (B, ceil(Cout/32), P_out, 32) added before `act`
+                                         (loop-invariant partial convolutions, update.py:35-37)                    */
     const float *scale, *shift;       /* per output channel, or NULL (= 1 / 0)                                   */
-    int act;                          /* 0 = identity, 1 = relu                                                  */
+    int act;                          /* 0 = identity, 1 = relu, 2 = tanh                                        */
     double* stats;                    /* or NULL                                                                 */
 } bflow_conv_desc_t;
 int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
@@ -118,6 +123,20 @@ int bflow_norm_act_split(const bflow_norm_desc_t* desc, bflow_stream_t stream);
  * an element batch stride (leaving the engine towards NCHW consumers).                                          */
 int bflow_split_to_nchw(const void* x_hi, const void* x_lo, float* out, int B, int HW, int C, int c_first, int c_count,
                         long long out_batch_stride, bflow_stream_t stream);
+
+/* GRU gates / Bezier update on blocked tensors (P pixel rows per image, C hidden channels, C % 32 == 0):
+ *   bflow_gru_rh_blocked   : rh = sigmoid(zr[:, C:2C]) * h                       zr blocked fp32 (B, 2C/32, P, 32)
+ *   bflow_gru_blend_blocked: h = (1 - sigmoid(zr[:, :C])) * h + sigmoid(zr[:, :C]) * tanh(q), in place on the split state
+ *   bflow_bezier_update    : params[b, c, pix] += delta[b, c, pix] (delta blocked fp32, first 2*deg channels) and the
+ *                            updated parameters are re-emitted as one split channel block at block `cb_off` of a
+ *                            (B, CB_total, P, 32) split buffer (the GRU input of the next iteration) and, if blk2 is
+ *                            not NULL, of a second buffer.  delta may be NULL (only re-emit).  params: plain (B, C2, P) fp32 (the layout the look-up kernel reads).     */
+int bflow_gru_rh_blocked(const float* zr, const void* h_hi, const void* h_lo, void* rh_hi, void* rh_lo,
+                         int B, int C, int P, bflow_stream_t stream);
+int bflow_gru_blend_blocked(const float* zr, const float* q, void* h_hi, void* h_lo, int B, int C, int P,
+                            bflow_stream_t stream);
+int bflow_bezier_update(float* params, const float* delta, int C2, void* blk_hi, void* blk_lo, int CB_total, int cb_off,
+                        void* blk2_hi, void* blk2_lo, int CB_total2, int cb_off2, int B, int P, bflow_stream_t stream);
 
 /* K6  one pyramid level: 2x2 average pooling, stride 2, floor on odd sizes, over the target plane.
  * Replaces CorrData.get_downsampled (F.avg_pool2d), models/raft_utils/corr.py:108-125.
