@@ -25,11 +25,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
-constexpr int CBM = 128, CT = 256, CSTAGES = 3;
-
-__device__ __attribute__((aligned(128))) _Float16 g_zero_page[64];   // source of every zero-padded row (static, zero-initialised)
+constexpr int CBM = 128, CT = 256;
 
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;   // matrix cores flush fp16 subnormal inputs
@@ -52,8 +51,16 @@ struct ConvArgs {
     double* stats;             // (B, Cout, 2) or null
 };
 
-template <int NT>
-__global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
+// NT = output-channel tile / 32;  S = depth of the LDS ring (k-tiles in flight = S - 1): 3 for grids that fill the chip
+// (2 workgroups per CU hide each other's latency), deeper for small grids (batch-1 update block: <= 1 workgroup per CU, so
+// the whole 160 KB of LDS can go into prefetch depth).
+//   KG = k-groups per workgroup: with KG = 2 the workgroup has 8 waves; waves 0-3 and 4-7 own the same output tile but alternate
+//        k-tiles (each group with its own LDS ring) and are summed through LDS at the end.  A small grid then runs 2 waves per
+//        SIMD, so one group's LDS/issue latency hides behind the other's MFMAs (intra-workgroup split-K).
+template <int NT, int S, int KG>
+__global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only builtins (buffer resources); the host pass only needs the stub
+    constexpr int CSTAGES = S;
     constexpr int BN = 32 * NT;
     constexpr int BU = (NT <= 2) ? 1 : 2;                 // B units (16 rows x 64 B) per wave per plane
     constexpr int B_ARR = BU * 4 * 1024;                  // LDS bytes of one B plane (64 or 128 rows)
@@ -64,60 +71,88 @@ __global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // the only shared object: ring of CSTAGES stages
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3, grp = wave_all >> 2;      // wave inside its k-group, k-group
     const int l31 = lane & 31, kh = lane >> 5;
     const int b = blockIdx.z;
     const int m0 = blockIdx.x * CBM, n0 = blockIdx.y * BN;
     const int HoWo = a.Ho * a.Wo;
     const int ntaps = a.KH * a.KW;
     const int nk = ntaps * a.CB;
+    char* const ring = lds + grp * (CSTAGES * STAGE);        // this k-group's LDS ring
 
-    // ---- LDS-DMA source coordinates: unit = 16 rows x 64 B; lane -> row lane/4, logical 16-B chunk (lane&3) ^ ((lane>>4)&3)
+    // ---- LDS-DMA sources.  Everything per-iteration is kept to a handful of instructions (the loop is otherwise bound by
+    // address arithmetic, not by the matrix cores): the planes are addressed through BUFFER descriptors, so a padded / invalid
+    // row is simply an out-of-range offset (the hardware returns zeros); per lane there is ONE constant byte offset per staged
+    // row plus a bit mask of the filter taps that fall inside the image; the (tap, channel-block) part of the address is a
+    // running scalar.  unit = 16 rows x 64 B; lane -> row lane/4, logical 16-B chunk (lane&3) ^ ((lane>>4)&3).
     const int urow = lane >> 2;
     const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;   // in halves
-    int hb[2], wb[2];
-    bool rok[2];
+    int aoffb[2];                 // byte offset of (row's centre pixel - padding origin), may be negative
+    unsigned long long vmask[2];  // bit t: filter tap t of this row lies inside the image
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + (wave * 2 + j) * 16 + urow;
-        rok[j] = m < HoWo;
+        const bool rok = m < HoWo;
         const int ho = m / a.Wo, wo = m - ho * a.Wo;
-        hb[j] = ho * a.stride - a.pad_h;
-        wb[j] = wo * a.stride - a.pad_w;
+        const int hb = ho * a.stride - a.pad_h, wb = wo * a.stride - a.pad_w;
+        aoffb[j] = ((hb * a.W + wb) * 32 + uchunk) * 2;
+        unsigned long long mk = 0;
+        for (int t = 0; t < ntaps; ++t) {
+            const int r = t / a.KW, q = t - r * a.KW;
+            const int hi_ = hb + r, wi_ = wb + q;
+            if (rok && hi_ >= 0 && hi_ < a.H && wi_ >= 0 && wi_ < a.W) mk |= 1ull << t;
+        }
+        vmask[j] = mk;
     }
-    long long wsrc[BU];
+    unsigned wvo[BU];             // byte offset of this lane's weight row inside a k-tile
 #pragma unroll
     for (int j = 0; j < BU; ++j) {
         int r = n0 + (wave * BU + j) * 16 + urow;
         r = r < a.cout_pad ? r : a.cout_pad - 1;          // NT = 3 stages 128 rows of a 96-wide tile: clamp (never consumed)
-        wsrc[j] = (long long)r * 32 + uchunk;
+        wvo[j] = (unsigned)((r * 32 + uchunk) * 2);
     }
     const int CB2 = a.CB - a.CB1;
-    const long long xb1 = (long long)b * a.CB1 * a.P_in * 32, xb2 = (long long)b * CB2 * a.P_in * 32;
-    const long long wkstep = (long long)a.cout_pad * 32;
-    const _Float16* zp = g_zero_page + uchunk;
+    const int plane_b = a.P_in * 64;                       // bytes of one channel block of one image
+    const rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xh + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_l1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xl + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_h2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2h + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const rsrc_t r_l2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2l + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const int wtile_b = a.cout_pad * 64;                   // bytes of one weight k-tile
+    const rsrc_t r_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, nk * wtile_b, 0x00020000);
+    const rsrc_t r_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.wl, 0, nk * wtile_b, 0x00020000);
 
-#define CONV_ISSUE(SLOT, TAP, CBI)                                                                                       \
+    // running (uniform) position of the k-tile to be issued next: tap it, column iq inside the filter row, channel block icb,
+    // byte offset of the tap itoff = (r*W + q)*64, flat k-tile index ik.  k-group g takes k-tiles g, g+KG, ...
+    int it = 0, iq = 0, icb = grp, itoff = 0, ik = grp;
+    bool ivalid = true;
+    auto settle = [&]() {
+        while (icb >= a.CB) {
+            icb -= a.CB; ++it; ++iq; itoff += 64;
+            if (iq == a.KW) { iq = 0; itoff += (a.W - a.KW) * 64; }
+        }
+        if (it >= ntaps) { ivalid = false; it = 0; iq = 0; icb = 0; itoff = 0; ik = 0; }   // tail: zero rows, any weights
+    };
+    settle();
+    auto advance = [&]() { icb += KG; ik += KG; if (ivalid) settle(); else { icb = 0; ik = 0; } };
+
+#define CONV_ISSUE(SB)                                                                                                   \
     {                                                                                                                    \
-        char* sb = lds + (SLOT) * STAGE;                                                                                 \
-        const int r_ = (TAP) / a.KW, q_ = (TAP) - r_ * a.KW;                                                             \
-        const bool first_ = (CBI) < a.CB1;                       /* which of the two concatenated sources (uniform) */  \
-        const _Float16* srch = first_ ? a.xh + xb1 : a.x2h + xb2;                                                        \
-        const _Float16* srcl = first_ ? a.xl + xb1 : a.x2l + xb2;                                                        \
-        const int cbl_ = first_ ? (CBI) : (CBI) - a.CB1;                                                                 \
+        char* sb = (SB);                                                                                                 \
+        const bool first_ = icb < a.CB1;                         /* which of the two concatenated sources (uniform) */   \
+        const rsrc_t rh_ = first_ ? r_h1 : r_h2;                                                                         \
+        const rsrc_t rl_ = first_ ? r_l1 : r_l2;                                                                         \
+        const int ub_ = (first_ ? icb : icb - a.CB1) * plane_b + itoff;                                                  \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
-            const int hi_ = hb[j] + r_, wi_ = wb[j] + q_;                                                                \
-            const bool ok = rok[j] && hi_ >= 0 && hi_ < a.H && wi_ >= 0 && wi_ < a.W;                                    \
-            const long long off = ((long long)cbl_ * a.P_in + hi_ * a.W + wi_) * 32 + uchunk;                            \
-            const _Float16* ph = ok ? srch + off : zp;                                                                   \
-            const _Float16* pl = ok ? srcl + off : zp;                                                                   \
-            __builtin_amdgcn_global_load_lds((gptr_t)ph, (lptr_t)(sb + O_AH + (wave * 2 + j) * 1024), 16, 0, 0);         \
-            __builtin_amdgcn_global_load_lds((gptr_t)pl, (lptr_t)(sb + O_AL + (wave * 2 + j) * 1024), 16, 0, 0);         \
+            const bool ok = ivalid && ((vmask[j] >> it) & 1ull);                                                         \
+            const unsigned vo = ok ? (unsigned)(aoffb[j] + ub_) : 0x80000000u;      /* out of range -> zeros */          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rh_, (lptr_t)(sb + O_AH + (wave * 2 + j) * 1024), 16, vo, 0, 0, 0);  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl_, (lptr_t)(sb + O_AL + (wave * 2 + j) * 1024), 16, vo, 0, 0, 0);  \
         }                                                                                                                \
-        const long long wk = (long long)((TAP) * a.CB + (CBI)) * wkstep;                                                 \
+        const int wso_ = ik * wtile_b;                                                                                   \
         _Pragma("unroll") for (int j = 0; j < BU; ++j) {                                                                 \
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.wh + wk + wsrc[j]), (lptr_t)(sb + O_BH + (wave * BU + j) * 1024), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.wl + wk + wsrc[j]), (lptr_t)(sb + O_BL + (wave * BU + j) * 1024), 16, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wh, (lptr_t)(sb + O_BH + (wave * BU + j) * 1024), 16, wvo[j], wso_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wl, (lptr_t)(sb + O_BL + (wave * BU + j) * 1024), 16, wvo[j], wso_, 0, 0); \
         }                                                                                                                \
     }
 
@@ -131,25 +166,26 @@ __global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
         }
 
     // (tap, channel block) of the k-tile to be issued next; the ring always runs two k-tiles ahead of the compute
-    int itap = 0, icb = 0;
-    auto advance = [&]() {
-        if (++icb == a.CB) { icb = 0; if (++itap == ntaps) itap = 0; }   // wraps at the end: tail prefetches are never consumed
-    };
-    CONV_ISSUE(0, itap, icb)
-    advance();
-    CONV_ISSUE(1, itap, icb)
-    advance();
+#pragma unroll
+    for (int st = 0; st < CSTAGES - 1; ++st) {
+        CONV_ISSUE(ring + st * STAGE)
+        advance();
+    }
 
     const int sw = (l31 >> 2) & 3;
     const int aro = (wave * 32 + l31) * 64;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (NLOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // k-tile kt has landed for every wave; slot (kt+2)%3 is free again
+    const int nsteps = (nk + KG - 1) / KG;
+    int islot = CSTAGES - 1, cslot = 0;        // ring slot to fill / to consume
+    for (int kt = 0; kt < nsteps; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((CSTAGES - 2) * NLOADS) : "memory");   // k-tile kt landed; S-2 newer tiles may fly
+        __builtin_amdgcn_s_barrier();          // ... for every wave; the slot of k-tile kt-1 is free again
         __builtin_amdgcn_sched_barrier(0);
-        CONV_ISSUE((kt + 2) % CSTAGES, itap, icb)
+        CONV_ISSUE(ring + islot * STAGE)
         advance();
+        if (++islot == CSTAGES) islot = 0;
         __builtin_amdgcn_sched_barrier(0);
-        const char* cur = lds + (kt % CSTAGES) * STAGE;
+        const char* cur = ring + cslot * STAGE;
+        if (++cslot == CSTAGES) cslot = 0;
         half8 ah[2], al[2], bh[2][NT], bl[2][NT];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {       // fragments of BOTH 16-deep steps first ...
@@ -177,6 +213,25 @@ __global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();              // all LDS-DMA traffic has landed: the ring can be reused for the reduction
 
+    // ---- combine the k-groups through LDS (group 1 publishes acc = hh + xx/2048, group 0 adds it) ---------------------------
+    if (KG == 2) {
+        float* xch = reinterpret_cast<float*>(lds) + 2 * 4 * BN;   // behind the statistics scratch; [wave][n][r][lane]
+        if (grp == 1) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[((wave * NT + n) * 16 + r) * 64 + lane] = hh[n][r] + xx[n][r] * LO_INV;
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hh[n][r] += xch[((wave * NT + n) * 16 + r) * 64 + lane];
+        }
+    }
+    const bool writer = (grp == 0);
+
     // ---- epilogue -----------------------------------------------------------------------------------------------------
     float* red = reinterpret_cast<float*>(lds);   // [2][4 waves][BN] partial sums
 #pragma unroll
@@ -195,7 +250,7 @@ __global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
             if (a.addend && m < HoWo && cok) v += a.addend[ab + (long long)m * 32];
             if (a.act == 1) v = fmaxf(v, 0.f);
             else if (a.act == 2) v = tanhf(v);
-            if (m < HoWo && cok) {
+            if (writer && m < HoWo && cok) {
                 const long long o = ob + (long long)m * 32;
                 if (a.out_f32) a.out_f32[o] = v;
                 if (a.oh) {
@@ -211,7 +266,7 @@ __global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
         if (a.stats) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            if (kh == 0) {
+            if (kh == 0 && writer) {
                 red[(0 * 4 + wave) * BN + n * 32 + l31] = s1;
                 red[(1 * 4 + wave) * BN + n * 32 + l31] = s2;
             }
@@ -229,6 +284,7 @@ __global__ __launch_bounds__(CT, 2) void conv_split_kernel(ConvArgs a) {
             }
         }
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -414,6 +470,12 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     const int Ho = (d->H + 2 * d->pad_h - d->KH) / d->stride + 1, Wo = (d->W + 2 * d->pad_w - d->KW) / d->stride + 1;
     BFLOW_REQUIRE(Ho > 0 && Wo > 0, BFLOW_E_ARG, "conv_split: empty output");
     BFLOW_REQUIRE(d->B <= 65535, BFLOW_E_LIMIT, "conv_split: batch too large");
+    BFLOW_REQUIRE(d->KH * d->KW <= 64, BFLOW_E_LIMIT, "conv_split: more than 64 filter taps");
+    {
+        const long long P_in = d->in_rows_per_image > 0 ? d->in_rows_per_image : (long long)d->H * d->W;
+        BFLOW_REQUIRE((long long)(d->C / 32) * P_in * 64 < (1LL << 31) && (long long)d->KH * d->KW * (d->C / 32) * d->cout_pad * 64 < (1LL << 31),
+                      BFLOW_E_LIMIT, "conv_split: an image / the weights exceed the 2 GB buffer-addressing window");
+    }
     const int NT = d->tile_n / 32;
     BFLOW_REQUIRE(NT >= 2 && NT <= 4 && d->tile_n % 32 == 0, BFLOW_E_ARG, "conv_split: tile_n must be 64, 96 or 128");
     BFLOW_REQUIRE(d->cout_pad >= d->Cout, BFLOW_E_ARG, "conv_split: cout_pad < Cout");
@@ -433,13 +495,17 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
     dim3 grid(bflow::ceil_div((long long)Ho * Wo, CBM), bflow::ceil_div(d->Cout, d->tile_n), d->B);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(N)                                                                                                      \
+    const long long nblocks = (long long)grid.x * grid.y * grid.z;
+    const bool deep = nblocks <= 320;   // at most ~1 workgroup per CU: spend the LDS on prefetch depth instead of co-residency
+#define LAUNCH(N, SS, KGG)                                                                                             \
     {                                                                                                                  \
-        const int lds = CSTAGES * (2 * CBM * 64 + 2 * ((N) <= 2 ? 1 : 2) * 4 * 1024);                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL(conv_split_kernel<N>, grid, dim3(CT), lds, s, a);                                           \
+        const int lds = (KGG) * (SS) * (2 * CBM * 64 + 2 * ((N) <= 2 ? 1 : 2) * 4 * 1024);                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<N, SS, KGG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((conv_split_kernel<N, SS, KGG>), grid, dim3(CT * (KGG)), lds, s, a);                        \
     }
-    if (NT == 2) LAUNCH(2) else if (NT == 3) LAUNCH(3) else LAUNCH(4)
+    if (NT == 2) { if (deep) LAUNCH(2, 3, 2) else LAUNCH(2, 3, 1) }
+    else if (NT == 3) { if (deep) LAUNCH(3, 5, 1) else LAUNCH(3, 3, 1) }
+    else { if (deep) LAUNCH(4, 5, 1) else LAUNCH(4, 3, 1) }
 #undef LAUNCH
     return bflow::launch_status("conv_split");
 }
