@@ -33,6 +33,7 @@ from bflow_amd.weights import deterministic_state_dict  # noqa: E402
 
 H, W, ITERS, CFG = 480, 640, 12, "E_LU4_BD2"
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_SPLIT_TFLOPS = round(2500.0 / 3, 1)   # fp16 dense MFMA peak (~2.5 PFLOP/s) / 3 MFMA passes per fp32-class product
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
@@ -157,7 +158,8 @@ def main():
             "metric": "frames/sec (whole node), raft-spline DSEC 640x480 12-iter",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "arithmetic": "fp32 values carried as split fp16 pairs (hi + lo*2^-11) on the fp16 matrix cores, fp32 accumulation; parity 1e-5 px EPE vs the fp32 CPU reference",
+            "data": "synthetic",
             "config": {"workload": f"raft-spline {CFG} events-only, DSEC-shaped voxel grid (9x{H}x{W}), batch {B}/GPU, "
                                    f"{ITERS} GRU iters (BASELINE configs[1]), random-init deterministic weights",
                        "batch_per_gpu": B, "global_batch": world * B, "iters": ITERS, "hipgraph": not args.no_graph},
@@ -176,42 +178,78 @@ def main():
         out["ms_per_gru_iter"] = round((t12 - t6) / (ITERS // 2) * 1e3, 4)
         out["ms_fixed_part"] = round((t12 - ITERS * (t12 - t6) / (ITERS // 2)) * 1e3, 4)
 
-        # dominant hand-written kernel: K5 correlation build (fp32 MFMA), on the operands of this very workload
-        with torch.no_grad():
-            grids, _ = model.gen_voxel_grids(vox)
-            fm = model.fnet_ev(torch.cat(grids, dim=0)).float()
-        T, D, N = 4, fm.shape[1], fm.shape[2] * fm.shape[3]
-        f1 = fm[:B].reshape(B, D, N).contiguous()
-        f2 = fm[B:].reshape(T, B, D, N).contiguous()
-        vol = torch.empty((T, B, N, N), device=dev)
-        for _ in range(3):
-            hip.corr_build_f32(f1, f2, vol)
-        ms = kernel_event_ms(lambda: hip.corr_build_f32(f1, f2, vol), max(args.steps, 10))
-        flops = 2.0 * T * B * D * N * N                       # 2*T*B*D*N^2 = 47.19 GFLOP per sample at C2
-        bytes_alg = 4.0 * ((1 + T) * B * D * N + T * B * N * N)  # 393.2 MB per sample at C2
-        tflops = flops / (ms * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "corr_build_f32_kernel", "bound": "mfma", "achieved": round(tflops, 2),
-                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4),
-                           "traffic": None, "avg_launch_ms": round(ms, 4), "flop_per_launch": flops,
-                           "algorithmic_bytes_per_launch": bytes_alg,
-                           "hbm_GBs_at_this_rate": round(bytes_alg / (ms * 1e-3) / 1e9, 1)}
-        # secondary: the look-up gather (HBM-bound), 24.33 MB algorithmic per sample-iteration at C2
+        # ---- rooflines of the hand-written kernels, each timed with hipEvents on the launch stream on the operands of this
+        # very workload (the timed region above is graph replays, inside which events cannot be recorded)
+        from bflow_amd import split as S
         from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
         with torch.no_grad():
-            blk = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(fm[:B], fm[B:].view(T, B, D, *fm.shape[2:]),
-                                                                                    cfg["correlation"]["ev"]["levels"]))
+            grids, _ = model.gen_voxel_grids(vox)
+            x5 = torch.cat(grids, dim=0)
+            # (1) dominant kernel by time: the split-fp16 implicit-GEMM convolution (73 % of the frame).  Largest single launch:
+            #     encoder layer1 conv, 64->64 3x3 on the 5 stacked half-resolution maps (5B x 240 x 320).
+            y = torch.nn.functional.conv2d(x5, model.fnet_ev.conv1.weight, None, stride=2, padding=3)
+            n5, c0, h0, w0 = y.shape
+            cur, _ = S.norm_act(y, (n5, h0, w0, c0), a_is_nchw=True, stats_a=S.plane_stats(y), act_a=S.ACT_RELU)
+            blk = model.fnet_ev.layer1[0]
+            pk = S.PackedConvWeight().get(blk.conv1.weight)
+            st = torch.zeros((n5, 64, 2), dtype=torch.float64, device=dev)
+            launch_conv = lambda: S.conv(cur, pk, stride=1, padding=1, want_split=False, want_f32=True, stats=st)
+            for _ in range(3):
+                launch_conv()
+            ms_c = kernel_event_ms(launch_conv, max(args.steps, 10))
+            flops_c = 2.0 * n5 * h0 * w0 * 64 * 64 * 9
+            # bytes: split input (4 B/elem) + fp32 output (4 B/elem) + packed weights
+            bytes_c = 4.0 * n5 * h0 * w0 * 64 * 2 + 4.0 * 64 * 64 * 9
+            tf_c = flops_c / (ms_c * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "conv_split_kernel<2,3,1> (encoder layer1 3x3 64->64, 5x240x320)", "bound": "mfma",
+                               "achieved": round(tf_c, 2), "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": round(tf_c / PEAK_SPLIT_TFLOPS, 4),
+                               "traffic": None, "avg_launch_ms": round(ms_c, 4), "flop_per_launch": flops_c,
+                               "algorithmic_bytes_per_launch": bytes_c,
+                               "note": "algorithmic (fp32-equivalent) FLOPs; the split scheme executes 3 fp16 MFMAs per product, so "
+                                       "peak = 2500 TFLOP/s fp16 dense / 3"}
+            # (2) K5 correlation build on the same engine (HBM-write-bound by design): 393.2 MB algorithmic per sample
+            D = model.fnet_ev.conv2.out_channels
+            hh8, ww8 = H // 8, W // 8
+            N = hh8 * ww8
+            T = len(grids) - 1
+            planes = model.fnet_ev.forward_split(x5, out_rows=hip.padded_rows(N)).planes
+            vol = torch.empty((T, B, N, N), device=dev)
+            launch_k5 = lambda: hip.corr_build_split(planes[:, :B], planes[:, B:], vol, T, B, N, shared_f1=True)
+            for _ in range(3):
+                launch_k5()
+            ms = kernel_event_ms(launch_k5, max(args.steps, 10))
+            flops = 2.0 * T * B * D * N * N
+            bytes_alg = 4.0 * ((1 + T) * B * D * N + T * B * N * N)
+            out["roofline_corr_build"] = {"kernel": "corr_build_split_v2_kernel", "bound": "hbm", "achieved": round(bytes_alg / (ms * 1e-3) / 1e9, 1),
+                                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bytes_alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                          "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_alg,
+                                          "flop_per_launch": flops, "tflops_equivalent": round(flops / (ms * 1e-3) / 1e12, 1)}
+            # (3) the look-up gather (HBM-bound), 24.33 MB algorithmic per sample-iteration at C2
+            cc = CorrComputation.from_packed(planes[:, :B], planes[:, B:], B, D, hh8, ww8, cfg["correlation"]["ev"]["levels"])
+            cblk = CorrBlockParallelMultiTarget(corr_computation_events=cc)
             params = low.get_params().clone()
-            feat = blk.new_output()
+            feat = cblk.new_output()
             coef = model._coefficients()
             for _ in range(3):
-                blk.lookup_bezier(params, coef, out=feat)
-            ms_l = kernel_event_ms(lambda: blk.lookup_bezier(params, coef, out=feat), max(args.steps, 10))
-        lbytes = 4.0 * B * N * blk.num_planes * (100 + 81)
+                cblk.lookup_bezier(params, coef, out=feat)
+            ms_l = kernel_event_ms(lambda: cblk.lookup_bezier(params, coef, out=feat), max(args.steps, 10))
+        lbytes = 4.0 * B * N * cblk.num_planes * (100 + 81)
         out["roofline_lookup"] = {"kernel": "corr_lookup_kernel<fused bezier>", "bound": "hbm",
                                   "achieved": round(lbytes / (ms_l * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": round(lbytes / (ms_l * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
                                   "avg_launch_ms": round(ms_l, 4), "algorithmic_bytes_per_launch": lbytes}
-        del blk, vol
+        del cblk, vol, planes
+        # HBM traffic per launch: cannot be read from inside this process; taken from the committed rocprofv3 --pmc passes of the
+        # same kernels on the same shapes (profiles/r01_pmc.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["kernels"]
+            for key, name in (("roofline", "conv_split_kernel<2,3,1> (encoder layer1 3x3 64->64, 5x240x320)"),
+                              ("roofline_corr_build", "corr_build_split_v2_kernel"), ("roofline_lookup", "corr_lookup_kernel<fused bezier>")):
+                if name in pmc and B == 1:
+                    out[key]["traffic"] = pmc[name]["traffic"]
+                    out[key]["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
+        except Exception:
+            pass
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, torch.from_numpy(vox_np[:1]))
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
