@@ -17,6 +17,7 @@
 //            squares for InstanceNorm (fp64 atomics, one per channel per block), blocked fp32 and/or blocked split stores
 //            at a channel-block offset (writes straight into concatenated buffers; a 32x32 MFMA tile is one contiguous
 //            2-KB / 4-KB run).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -42,14 +43,130 @@ struct ConvArgs {
     const _Float16 *wh, *wl;   // (ntaps*CB, Cout_pad, 32)
     int H, W, CB, CB1, P_in, Ho, Wo, Cout, cout_pad;
     const float* addend;       // blocked fp32 (B, ceil(Cout/32), P_out, 32) added before the activation, or null
-    int KH, KW, stride, pad_h, pad_w;
+    int KH, KW, stride, pad_h, pad_w, n_tiles;
     float* out_f32;            // blocked (B, CBo, P_out, 32) fp32 or null
     _Float16 *oh, *ol;         // blocked split or null
     int CBo, cb_off, P_out;    // channel blocks / first channel block / rows per image of the output buffers
     const float *scale, *shift;   // per output channel or null
     int act;
     double* stats;             // (B, Cout, 2) or null
+    int ablate;                // debug
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue shared by both kernels.  The MFMAs are issued with the WEIGHT fragment as the A operand and the activation
+// fragment as B, so an accumulator tile is D[channel][pixel]: lane = pixel, and registers 4j..4j+3 of a lane are 4 CONSECUTIVE
+// channels (8j + 4*(lane>>5) + 0..3) of that pixel.
+// A lane-per-pixel store (every lane a different 64/128-B row) is issue-bound in the memory pipeline (~600 cycles per wave
+// instruction, measured: the epilogue was 5 of the 10 us of an empty-loop launch), so each wave first transposes its 32x32
+// tile through a private LDS slab (float4 writes, row stride 36 floats = conflict-free) and then walks it in MEMORY order:
+// lane -> (row lane/8 + 8*it, channels 4*(lane&7)..+3).  Everything after the accumulation (scale/shift, addend, activation,
+// hi/lo split, statistics) happens on that side, so the addend loads and all stores are fully coalesced (1 KB fp32 / 512 B
+// fp16 contiguous per wave instruction).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+#define CONV_STG_STRIDE 36                       // floats per staged pixel row (32 + 4 pad)
+#define CONV_STG_BYTES (4 * 32 * CONV_STG_STRIDE * 4)
+
+template <int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, int mw, int n0, int rows_valid,
+                                              int lane, int wave, int tid, bool writer, float* red) {
+    constexpr int BN = 32 * NT;
+    constexpr int RS = CONV_STG_STRIDE;
+    float* stg = red + 2 * 4 * BN + wave * (32 * RS);     // this wave's slab, behind the statistics scratch
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int rr = lane >> 3, ch = (lane & 7) * 4;        // read side: rows rr + 8*it, channels ch .. ch+3 of the block
+    if (writer) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int cbase = n0 + n * 32;
+            if (cbase >= a.Cout) break;                   // channel blocks past the padded output are never written
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r0 = 4 * j;
+                *reinterpret_cast<float4*>(stg + l31 * RS + 8 * j + 4 * kh) =
+                    make_float4(hh[n][r0] + xx[n][r0] * LO_INV, hh[n][r0 + 1] + xx[n][r0 + 1] * LO_INV, hh[n][r0 + 2] + xx[n][r0 + 2] * LO_INV,
+                                hh[n][r0 + 3] + xx[n][r0 + 3] * LO_INV);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            float sc[4], sh[4];
+            bool cok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cc = cbase + ch + k;
+                cok[k] = cc < a.Cout;
+                sc[k] = (a.scale && cok[k]) ? a.scale[cc] : 1.f;
+                sh[k] = (a.shift && cok[k]) ? a.shift[cc] : 0.f;
+            }
+            const long long ob = (((long long)b * a.CBo + a.cb_off + (n0 >> 5) + n) * a.P_out) * 32 + ch;
+            const long long ab = (((long long)b * ((a.Cout + 31) >> 5) + (n0 >> 5) + n) * a.P_out) * 32 + ch;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + rr;
+                const int m = mw + row;
+                const bool mok = m < rows_valid;
+                const float4 raw = *reinterpret_cast<const float4*>(stg + row * RS + ch);
+                float v[4] = {raw.x * sc[0] + sh[0], raw.y * sc[1] + sh[1], raw.z * sc[2] + sh[2], raw.w * sc[3] + sh[3]};
+                if (a.addend && mok) {
+                    const float4 ad = *reinterpret_cast<const float4*>(a.addend + ab + (long long)m * 32);
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (a.act == 1) v[k] = fmaxf(v[k], 0.f);
+                    else if (a.act == 2) v[k] = tanhf(v[k]);
+                    if (!cok[k]) v[k] = 0.f;                // padded channels of the last block are written as zeros
+                    if (mok) { s1[k] += v[k]; s2[k] += v[k] * v[k]; }
+                }
+                if (mok) {
+                    if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + ob + (long long)m * 32) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (a.oh) {
+                        half4v h4, l4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            _Float16 x1, x2;
+                            split1(v[k], x1, x2);
+                            h4[k] = x1;
+                            l4[k] = x2;
+                        }
+                        *reinterpret_cast<half4v*>(a.oh + ob + (long long)m * 32) = h4;
+                        *reinterpret_cast<half4v*>(a.ol + ob + (long long)m * 32) = l4;
+                    }
+                }
+            }
+            if (a.stats) {                                  // per-channel sums over this wave's 32 pixels: lanes with equal lane&7
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int off = 8; off < 64; off <<= 1) {
+                        s1[k] += __shfl_xor(s1[k], off, 64);
+                        s2[k] += __shfl_xor(s2[k], off, 64);
+                    }
+                    if (lane < 8) {
+                        red[(0 * 4 + wave) * BN + n * 32 + ch + k] = s1[k];
+                        red[(1 * 4 + wave) * BN + n * 32 + ch + k] = s2[k];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();                // the slab is rewritten by the next channel block
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid - which * BN;
+            const int col = n0 + c;
+            if (col < a.Cout) {
+                const float* p = red + which * 4 * BN + c;
+                const double sum = (double)p[0] + (double)p[BN] + (double)p[2 * BN] + (double)p[3 * BN];
+                atomicAdd(a.stats + ((long long)b * a.Cout + col) * 2 + which, sum);
+            }
+        }
+    }
+}
 
 // NT = output-channel tile / 32;  S = depth of the LDS ring (k-tiles in flight = S - 1): 3 for grids that fill the chip
 // (2 workgroups per CU hide each other's latency), deeper for small grids (batch-1 update block: <= 1 workgroup per CU, so
@@ -75,8 +192,19 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
     const int wave = wave_all & 3, grp = wave_all >> 2;      // wave inside its k-group, k-group
     const int l31 = lane & 31, kh = lane >> 5;
     const int b = blockIdx.z;
-    const int m0 = blockIdx.x * CBM, n0 = blockIdx.y * BN;
     const int HoWo = a.Ho * a.Wo;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (private 4 MB L2 each); the 1-D grid is decoded so
+    // that ALL channel tiles of one pixel tile run on the SAME XCD, back to back: the pixel tile's activation rows are then
+    // fetched from the Infinity Cache once per XCD instead of once per channel tile, and re-read from L2 (4x lower latency).
+    int m0, n0;
+    {
+        const int ntn = a.n_tiles;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int mt = (slot / ntn) * 8 + xcd;
+        m0 = mt * CBM;
+        n0 = (slot - (slot / ntn) * ntn) * BN;
+        if (m0 >= HoWo) return;      // padding workgroups of the last group of 8 pixel tiles (uniform per workgroup)
+    }
     const int ntaps = a.KH * a.KW;
     const int nk = ntaps * a.CB;
     char* const ring = lds + grp * (CSTAGES * STAGE);        // this k-group's LDS ring
@@ -202,11 +330,11 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {       // ... then the MFMAs (three sweeps: no back-to-back dependent accumulators)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks][n], hh[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][n], ah[ks], hh[n], 0, 0, 0);   // D[channel][pixel]
 #pragma unroll
-            for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ks][n], xx[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks][n], ah[ks], xx[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ks][n], xx[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][n], al[ks], xx[n], 0, 0, 0);
         }
     }
 #undef CONV_ISSUE
@@ -229,61 +357,182 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hh[n][r] += xch[((wave * NT + n) * 16 + r) * 64 + lane];
         }
+        __syncthreads();                           // the exchange area is reused by the epilogue's staging slabs
     }
     const bool writer = (grp == 0);
 
-    // ---- epilogue -----------------------------------------------------------------------------------------------------
-    float* red = reinterpret_cast<float*>(lds);   // [2][4 waves][BN] partial sums
+    // ---- epilogue (lane = pixel wave*32 + l31 of this tile) --------------------------------------------------------------
+    conv_epilogue<NT>(a, hh, xx, b, m0 + wave * 32, n0, HoWo, lane, wave, tid, writer, reinterpret_cast<float*>(lds));
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-reuse variant for stride-1 "same" convolutions with KW = 3 or 5 taps per filter row.
+// The per-CU global->LDS fill rate (~25-40 GB/s per CU, measured) bounds the generic kernel, which re-loads the activation
+// tile for every tap.  Here one k-step is a whole FILTER ROW of one channel block: the 128 + KW - 1 input pixels the row
+// touches are staged ONCE and the KW horizontal taps read them at row offsets 0..KW-1, so the activation bytes per MFMA drop
+// by KW and every barrier / issue round is amortised over KW x more matrix work (KW*12 MFMAs per wave at NT = 2).
+//   * flattened pixels: tap q of output pixel m reads staged row (m - m0) + q; a tap that would leave the image ROW is masked
+//     in registers (per-lane KW-bit mask of x + q - pad in [0, W)), a filter row that leaves the image is an out-of-range
+//     buffer offset (zeros), exactly like the padding of the generic kernel;
+//   * 2-stage LDS ring (stage = 144 activation rows + KW weight tiles, hi and lo), loads of step k+1 fly under the MFMAs of k.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, int KW>
+__global__ __launch_bounds__(CT, 1) void conv_row_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BN = 32 * NT;
+    constexpr int BU = (NT <= 2) ? 1 : 2;
+    constexpr int AROWS = 144;                            // 128 + KW - 1 rounded up to 16-row units (9 units)
+    constexpr int A_ARR = AROWS * 64, B_TAP = BU * 4 * 1024, B_ARR = KW * B_TAP;
+    constexpr int O_AH = 0, O_AL = A_ARR, O_BH = 2 * A_ARR, O_BL = 2 * A_ARR + B_ARR;
+    constexpr int STAGE = 2 * A_ARR + 2 * B_ARR;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.z;
+    const int HW = a.H * a.W;                              // stride 1, same padding: Ho*Wo == H*W
+    int m0, n0;
+    {
+        const int ntn = a.n_tiles;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int mt = (slot / ntn) * 8 + xcd;
+        m0 = mt * CBM;
+        n0 = (slot - (slot / ntn) * ntn) * BN;
+        if (m0 >= HW) return;
+    }
+    const int nsteps = a.KH * a.CB;                        // (filter row, channel block)
+
+    const int urow = lane >> 2;
+    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    // staged activation row j holds input pixel  m0 + j - pad_w + (r - pad_h) * W ; this wave loads units wave, wave+4 (+8: wave 0)
+    int prow[3];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = n0 + n * 32 + l31;
-        const bool cok = col < a.Cout;
-        const float sc = (a.scale && cok) ? a.scale[col] : 1.f;
-        const float sh = (a.shift && cok) ? a.shift[col] : 0.f;
-        const long long ob = ((long long)b * a.CBo + a.cb_off + (n0 >> 5) + n) * a.P_out * 32 + l31;
-        const long long ab = ((long long)b * ((a.Cout + 31) >> 5) + (n0 >> 5) + n) * a.P_out * 32 + l31;
-        float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < 3; ++j) prow[j] = m0 + (wave + 4 * j) * 16 + urow - a.pad_w;
+    unsigned wvo[BU];
+#pragma unroll
+    for (int j = 0; j < BU; ++j) {
+        int r = n0 + (wave * BU + j) * 16 + urow;
+        r = r < a.cout_pad ? r : a.cout_pad - 1;
+        wvo[j] = (unsigned)((r * 32 + uchunk) * 2);
+    }
+    const int CB2 = a.CB - a.CB1;
+    const int plane_b = a.P_in * 64;
+    const rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xh + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_l1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xl + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_h2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2h + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const rsrc_t r_l2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2l + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const int wtile_b = a.cout_pad * 64;
+    const rsrc_t r_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, a.KH * KW * a.CB * wtile_b, 0x00020000);
+    const rsrc_t r_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.wl, 0, a.KH * KW * a.CB * wtile_b, 0x00020000);
+
+    int ir = 0, icb = 0;                                   // next step to issue
+    bool ivalid = true;
+    auto advance = [&]() { if (++icb == a.CB) { icb = 0; if (++ir == a.KH) { ir = 0; ivalid = false; } } };
+
+#define ROW_ISSUE(SB)                                                                                                    \
+    {                                                                                                                    \
+        char* sb = (SB);                                                                                                 \
+        const bool first_ = icb < a.CB1;                                                                                 \
+        const rsrc_t rh_ = first_ ? r_h1 : r_h2;                                                                         \
+        const rsrc_t rl_ = first_ ? r_l1 : r_l2;                                                                         \
+        const int cbb_ = (first_ ? icb : icb - a.CB1) * plane_b;                                                         \
+        const int dy_ = (ir - a.pad_h) * a.W;                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+            const int p_ = prow[j] + dy_;                                                                                \
+            const unsigned vo = (ivalid && p_ >= 0 && p_ < HW) ? (unsigned)(cbb_ + p_ * 64 + uchunk * 2) : 0x80000000u;  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rh_, (lptr_t)(sb + O_AH + (wave + 4 * j) * 1024), 16, vo, 0, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl_, (lptr_t)(sb + O_AL + (wave + 4 * j) * 1024), 16, vo, 0, 0, 0); \
+        }                                                                                                                \
+        if (wave == 0) {                                   /* ninth unit: rows 128..143 */                              \
+            const int p_ = prow[2] + dy_;                                                                                \
+            const unsigned vo = (ivalid && p_ >= 0 && p_ < HW) ? (unsigned)(cbb_ + p_ * 64 + uchunk * 2) : 0x80000000u;  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rh_, (lptr_t)(sb + O_AH + 8 * 1024), 16, vo, 0, 0, 0);              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl_, (lptr_t)(sb + O_AL + 8 * 1024), 16, vo, 0, 0, 0);              \
+        }                                                                                                                \
+        _Pragma("unroll") for (int q = 0; q < KW; ++q) {                                                                 \
+            const int wso_ = ((ir * KW + q) * a.CB + icb) * wtile_b;                                                     \
+            _Pragma("unroll") for (int j = 0; j < BU; ++j) {                                                             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wh, (lptr_t)(sb + O_BH + q * B_TAP + (wave * BU + j) * 1024), 16, wvo[j], wso_, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wl, (lptr_t)(sb + O_BL + q * B_TAP + (wave * BU + j) * 1024), 16, wvo[j], wso_, 0, 0); \
+            }                                                                                                            \
+        }                                                                                                                \
+    }
+
+    f32x16 hh[NT], xx[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            float v = (hh[n][r] + xx[n][r] * LO_INV) * sc + sh;
-            if (a.addend && m < HoWo && cok) v += a.addend[ab + (long long)m * 32];
-            if (a.act == 1) v = fmaxf(v, 0.f);
-            else if (a.act == 2) v = tanhf(v);
-            if (writer && m < HoWo && cok) {
-                const long long o = ob + (long long)m * 32;
-                if (a.out_f32) a.out_f32[o] = v;
-                if (a.oh) {
-                    _Float16 vh, vl;
-                    split1(v, vh, vl);
-                    a.oh[o] = vh;
-                    a.ol[o] = vl;
+            hh[n][r] = 0.f;
+            xx[n][r] = 0.f;
+        }
+
+    // per-lane horizontal validity of the KW taps for this lane's output pixel (MFMA A row = wave*32 + l31)
+    unsigned qmask = 0;
+    {
+        const int m = m0 + wave * 32 + l31;
+        const int x = m % a.W;
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+            const int xi = x + q - a.pad_w;
+            if (m < HW && xi >= 0 && xi < a.W) qmask |= 1u << q;
+        }
+    }
+
+    if (!(a.ablate & 4)) ROW_ISSUE(lds)
+    advance();
+    int cur_slot = 0;
+    for (int kt = 0; kt < nsteps; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step kt landed (nothing else is in flight at this point)
+        __builtin_amdgcn_s_barrier();                      // for every wave; the other slot is free again
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(a.ablate & 1)) ROW_ISSUE(lds + (cur_slot ^ 1) * STAGE)            // step kt+1 flies under this step's KW*NT*6 MFMAs
+        advance();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* cur = lds + cur_slot * STAGE;
+        cur_slot ^= 1;
+        if (a.ablate & 2) continue;
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+            const int R = wave * 32 + l31 + q;
+            const int sw = (R >> 2) & 3;
+            const bool keep = (qmask >> q) & 1u;
+            half8 ah[2], al[2], bh[2][NT], bl[2][NT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int co = ((ks * 2 + kh) ^ sw) * 16;
+                const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                const half8 th = *reinterpret_cast<const half8*>(cur + O_AH + R * 64 + co);
+                const half8 tl = *reinterpret_cast<const half8*>(cur + O_AL + R * 64 + co);
+                ah[ks] = keep ? th : z8;
+                al[ks] = keep ? tl : z8;
+                const int cob = ((ks * 2 + kh) ^ ((l31 >> 2) & 3)) * 16;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int bo = q * B_TAP + (n * 32 + l31) * 64 + cob;
+                    bh[ks][n] = *reinterpret_cast<const half8*>(cur + O_BH + bo);
+                    bl[ks][n] = *reinterpret_cast<const half8*>(cur + O_BL + bo);
                 }
-                s1 += v;
-                s2 += v * v;
             }
-        }
-        if (a.stats) {
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (kh == 0 && writer) {
-                red[(0 * 4 + wave) * BN + n * 32 + l31] = s1;
-                red[(1 * 4 + wave) * BN + n * 32 + l31] = s2;
-            }
-        }
-    }
-    if (a.stats) {
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid - which * BN;
-            const int col = n0 + c;
-            if (col < a.Cout) {
-                const float* p = red + which * 4 * BN + c;
-                const double s = (double)p[0] + (double)p[BN] + (double)p[2 * BN] + (double)p[3 * BN];
-                atomicAdd(a.stats + ((long long)b * a.Cout + col) * 2 + which, s);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][n], ah[ks], hh[n], 0, 0, 0);   // D[channel][pixel]
+#pragma unroll
+                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks][n], ah[ks], xx[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][n], al[ks], xx[n], 0, 0, 0);
             }
         }
     }
+#undef ROW_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (a.ablate & 8) return;
+    conv_epilogue<NT>(a, hh, xx, b, m0 + wave * 32, n0, HW, lane, wave, tid, true, reinterpret_cast<float*>(lds));
 #endif
 }
 
@@ -341,6 +590,8 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restric
 //   norm_* : InstanceNorm from (sum, sumsq) statistics [stats != null]  or per-channel affine [scale/shift]  or identity
 // Thread = 8 consecutive channels of one pixel (32-B fp32 reads, 16-B fp16 writes).
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int NORM_TILES_PER_BLOCK = 4;
+
 struct NormArgs {
     const float* a; const double* stats_a; const float *scale_a, *shift_a; int a_nchw; int act_a;
     const float* b; const double* stats_b;
@@ -369,69 +620,83 @@ __device__ __forceinline__ void norm_coeffs(const double* stats, const float* sc
 
 __global__ __launch_bounds__(256) void norm_act_split_kernel(NormArgs p) {
     __shared__ float tile[32][65];                    // NCHW input only: 32 channels x 64 pixels
-    const int b = blockIdx.z, cb = blockIdx.y, p0 = blockIdx.x * 64;
-    const int pl = threadIdx.x >> 2, c8 = (threadIdx.x & 3) * 8;
-    const int pix = p0 + pl;
-    if (p.a_nchw) {
-        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = cb * 32 + ty + 4 * i, px = p0 + tx;
-            tile[ty + 4 * i][tx] = (c < p.C && px < p.HW) ? p.a[((long long)b * p.C + c) * p.HW + px] : 0.f;
-        }
-        __syncthreads();
-    }
-    if (pix >= p.HW) return;
-    const long long o = (((long long)b * p.CB + cb) * p.P + pix) * 32 + c8;
-    float v[8];
-    if (p.a_nchw) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = tile[c8 + k][pl];
-    } else {
-        const float4 v0 = *reinterpret_cast<const float4*>(p.a + o), v1 = *reinterpret_cast<const float4*>(p.a + o + 4);
-        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-    }
-    float bv[8];
-    if (p.b) {
-        const float4 v0 = *reinterpret_cast<const float4*>(p.b + o), v1 = *reinterpret_cast<const float4*>(p.b + o + 4);
-        bv[0] = v0.x; bv[1] = v0.y; bv[2] = v0.z; bv[3] = v0.w; bv[4] = v1.x; bv[5] = v1.y; bv[6] = v1.z; bv[7] = v1.w;
-    }
-    half8 rh8, rl8;
-    if (p.rh) {
-        rh8 = *reinterpret_cast<const half8*>(p.rh + o);
-        rl8 = *reinterpret_cast<const half8*>(p.rl + o);
-    }
-    half8 oh8, ol8;
-    float of[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = cb * 32 + c8 + k;
-        float ma, aa;
-        norm_coeffs(p.stats_a, p.scale_a, p.shift_a, b, c, p.C, p.HW, p.eps, ma, aa);
-        float x = v[k] * ma + aa;
-        if (p.act_a == 1) x = fmaxf(x, 0.f);
+    __shared__ float coef[4][32];                     // (mul_a, add_a, mul_b, add_b) of this block's 32 channels: computed ONCE
+    const int b = blockIdx.z, cb = blockIdx.y;        // (the fp64 mean / variance / rsqrt per element dominated this kernel)
+    if (threadIdx.x < 32) {
+        const int c = cb * 32 + threadIdx.x;
+        float m, a2;
+        norm_coeffs(p.stats_a, p.scale_a, p.shift_a, b, c, p.C, p.HW, p.eps, m, a2);
+        coef[0][threadIdx.x] = m;
+        coef[1][threadIdx.x] = a2;
         if (p.b) {
-            float mb, ab;
-            norm_coeffs(p.stats_b, nullptr, nullptr, b, c, p.C, p.HW, p.eps, mb, ab);
-            x += bv[k] * mb + ab;
+            norm_coeffs(p.stats_b, nullptr, nullptr, b, c, p.C, p.HW, p.eps, m, a2);
+            coef[2][threadIdx.x] = m;
+            coef[3][threadIdx.x] = a2;
         }
-        if (p.rh) x += (float)rh8[k] + (float)rl8[k] * LO_INV;
-        if (p.act_out == 1) x = fmaxf(x, 0.f);
-        else if (p.act_out == 2) x = tanhf(x);
-        if (c >= p.C) x = 0.f;
-        _Float16 h, l;
-        split1(x, h, l);
-        oh8[k] = h;
-        ol8[k] = l;
-        of[k] = x;
     }
-    if (p.oh) {
-        *reinterpret_cast<half8*>(p.oh + o) = oh8;
-        *reinterpret_cast<half8*>(p.ol + o) = ol8;
-    }
-    if (p.out_f32) {
-        *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(of[0], of[1], of[2], of[3]);
-        *reinterpret_cast<float4*>(p.out_f32 + o + 4) = make_float4(of[4], of[5], of[6], of[7]);
+    __syncthreads();
+    const int pl = threadIdx.x >> 2, c8 = (threadIdx.x & 3) * 8;
+    // each block walks NORM_TILES_PER_BLOCK consecutive 64-pixel tiles
+    for (int tix = 0; tix < NORM_TILES_PER_BLOCK; ++tix) {
+        const int p0 = (blockIdx.x * NORM_TILES_PER_BLOCK + tix) * 64;
+        if (p0 >= p.HW) break;
+        const int pix = p0 + pl;
+        if (p.a_nchw) {
+            __syncthreads();
+            const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = cb * 32 + ty + 4 * i, px = p0 + tx;
+                tile[ty + 4 * i][tx] = (c < p.C && px < p.HW) ? p.a[((long long)b * p.C + c) * p.HW + px] : 0.f;
+            }
+            __syncthreads();
+        }
+        if (pix >= p.HW) continue;
+        const long long o = (((long long)b * p.CB + cb) * p.P + pix) * 32 + c8;
+        float v[8];
+        if (p.a_nchw) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tile[c8 + k][pl];
+        } else {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.a + o), v1 = *reinterpret_cast<const float4*>(p.a + o + 4);
+            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        }
+        float bv[8];
+        if (p.b) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.b + o), v1 = *reinterpret_cast<const float4*>(p.b + o + 4);
+            bv[0] = v0.x; bv[1] = v0.y; bv[2] = v0.z; bv[3] = v0.w; bv[4] = v1.x; bv[5] = v1.y; bv[6] = v1.z; bv[7] = v1.w;
+        }
+        half8 rh8, rl8;
+        if (p.rh) {
+            rh8 = *reinterpret_cast<const half8*>(p.rh + o);
+            rl8 = *reinterpret_cast<const half8*>(p.rl + o);
+        }
+        half8 oh8, ol8;
+        float of[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = cb * 32 + c8 + k;
+            float x = v[k] * coef[0][c8 + k] + coef[1][c8 + k];
+            if (p.act_a == 1) x = fmaxf(x, 0.f);
+            if (p.b) x += bv[k] * coef[2][c8 + k] + coef[3][c8 + k];
+            if (p.rh) x += (float)rh8[k] + (float)rl8[k] * LO_INV;
+            if (p.act_out == 1) x = fmaxf(x, 0.f);
+            else if (p.act_out == 2) x = tanhf(x);
+            if (c >= p.C) x = 0.f;
+            _Float16 h, l;
+            split1(x, h, l);
+            oh8[k] = h;
+            ol8[k] = l;
+            of[k] = x;
+        }
+        if (p.oh) {
+            *reinterpret_cast<half8*>(p.oh + o) = oh8;
+            *reinterpret_cast<half8*>(p.ol + o) = ol8;
+        }
+        if (p.out_f32) {
+            *reinterpret_cast<float4*>(p.out_f32 + o) = make_float4(of[0], of[1], of[2], of[3]);
+            *reinterpret_cast<float4*>(p.out_f32 + o + 4) = make_float4(of[4], of[5], of[6], of[7]);
+        }
     }
 }
 
@@ -493,9 +758,27 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     BFLOW_REQUIRE(out_c % 32 == 0 && d->out_channel_offset + d->Cout <= out_c, BFLOW_E_ARG, "conv_split: bad output channel layout");
     a.CBo = out_c / 32; a.cb_off = d->out_channel_offset / 32; a.P_out = d->out_rows_per_image > 0 ? d->out_rows_per_image : Ho * Wo;
     a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
-    dim3 grid(bflow::ceil_div((long long)Ho * Wo, CBM), bflow::ceil_div(d->Cout, d->tile_n), d->B);
+    a.ablate = getenv("BFLOW_ABLATE") ? atoi(getenv("BFLOW_ABLATE")) : 0;
+    a.n_tiles = bflow::ceil_div(d->Cout, d->tile_n);
+    const int m_tiles8 = (bflow::ceil_div((long long)Ho * Wo, CBM) + 7) / 8 * 8;   // pixel tiles, padded to the 8 XCDs
+    dim3 grid(m_tiles8 * a.n_tiles, 1, d->B);
     hipStream_t s = (hipStream_t)stream;
-    const long long nblocks = (long long)grid.x * grid.y * grid.z;
+    const long long nblocks = (long long)bflow::ceil_div((long long)Ho * Wo, CBM) * a.n_tiles * d->B;
+    // row-reuse kernel: stride 1, "same" padding, 3 or 5 taps per filter row
+    const bool row_ok = d->stride == 1 && (d->KW == 3 || d->KW == 5) && d->pad_w == (d->KW - 1) / 2 && d->pad_h == (d->KH - 1) / 2 &&
+                        !(d->KW == 5 && NT > 2) && !getenv("BFLOW_NO_ROW_KERNEL");
+    if (row_ok) {
+#define LAUNCH_ROW(N, K)                                                                                               \
+    {                                                                                                                  \
+        const int lds = 2 * (2 * 144 * 64 + 2 * (K) * ((N) <= 2 ? 1 : 2) * 4 * 1024);                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_row_kernel<N, K>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((conv_row_kernel<N, K>), grid, dim3(CT), lds, s, a);                                        \
+    }
+        if (d->KW == 3) { if (NT == 2) LAUNCH_ROW(2, 3) else if (NT == 3) LAUNCH_ROW(3, 3) else LAUNCH_ROW(4, 3) }
+        else LAUNCH_ROW(2, 5)
+#undef LAUNCH_ROW
+        return bflow::launch_status("conv_split(row)");
+    }
     const bool deep = nblocks <= 320;   // at most ~1 workgroup per CU: spend the LDS on prefetch depth instead of co-residency
 #define LAUNCH(N, SS, KGG)                                                                                             \
     {                                                                                                                  \
@@ -536,7 +819,7 @@ extern "C" int bflow_norm_act_split(const bflow_norm_desc_t* d, bflow_stream_t s
     p.b = d->b; p.stats_b = d->stats_b; p.rh = (const _Float16*)d->res_hi; p.rl = (const _Float16*)d->res_lo; p.act_out = d->act_out;
     p.oh = (_Float16*)d->out_hi; p.ol = (_Float16*)d->out_lo; p.out_f32 = d->out_f32; p.B = d->B; p.HW = d->HW; p.C = d->C;
     p.CB = (d->C + 31) / 32; p.P = d->rows_per_image > 0 ? d->rows_per_image : d->HW; p.eps = d->eps;
-    dim3 grid(bflow::ceil_div(d->HW, 64), p.CB, d->B);
+    dim3 grid(bflow::ceil_div(d->HW, 64 * NORM_TILES_PER_BLOCK), p.CB, d->B);
     hipLaunchKernelGGL(norm_act_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return bflow::launch_status("norm_act_split");
 }

@@ -236,7 +236,7 @@ class RAFTSpline(nn.Module):
         coef = self._coefficients()
         corr_feat = corr_block.new_output()
         if engine_update:
-            S.bezier_update(bezier, None, ws.BZ, 0, ws.M, ub.motion_dim // 32)     # emit the initial Bezier channel block
+            S.bezier_update(bezier, None, ws.M, ub.motion_dim // 32)     # emit the initial Bezier channel block
         ups: List[torch.Tensor] = []
         if tm: tm.start("all iters")
         for itr in range(iters):

@@ -103,7 +103,6 @@ class SplitWorkspace:
         self.H = S.SplitTensor.empty(batch, h, w, hd, device)                    # hidden state
         self.RH = S.SplitTensor.empty(batch, h, w, hd, device)                   # r * h
         self.M = S.SplitTensor.empty(batch, h, w, md + 32, device, zero=True)    # [motion conv (md-2deg, zero padded to md) | Bezier block]
-        self.BZ = S.SplitTensor.empty(batch, h, w, 32, device)                   # Bezier parameters alone (input of convf1)
         self.INP = None                                                          # relu(context) split, set by set_context
         self.corbez = S.SplitTensor.empty(batch, h, w, 256, device)
         self.inp_terms = None
@@ -243,7 +242,11 @@ class BasicUpdateBlock(nn.Module):
         c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
         S.conv(c1, self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
                out_split=ws.corbez, channel_offset=0)
-        f1, _ = S.conv(ws.BZ, self._pk("convf1", lambda a=enc.convf1.weight: a, 32), padding=3, shift=enc.convf1.bias, act=S.ACT_RELU)
+        # 7x7 over the 2*deg Bezier channels as a dense 1x1 GEMM over an im2col'ed split tensor (K = 49*2deg instead of 49 k-tiles)
+        kh, kw = enc.convf1.kernel_size
+        col = S.im2col_small(bezier, kh, kw, enc.convf1.padding)
+        f1, _ = S.conv(col, self._pk("convf1_cols", lambda a=enc.convf1.weight: a.permute(0, 2, 3, 1).reshape(a.shape[0], -1, 1, 1)),
+                       shift=enc.convf1.bias, act=S.ACT_RELU)
         S.conv(f1, self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
                out_split=ws.corbez, channel_offset=192)
         S.conv(ws.corbez, self._pk("conv", lambda a=enc.conv.weight: a), padding=1, shift=enc.conv.bias, act=S.ACT_RELU,
@@ -258,8 +261,11 @@ class BasicUpdateBlock(nn.Module):
         # ---- heads (update.py:17-18,111-114,120-125)
         bh = self.bezier_head
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
-        _, d2 = S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, want_split=False, want_f32=True)
-        S.bezier_update(bezier, d2, ws.BZ, 0, ws.M, self.motion_dim // 32)
+        if bh.conv2.out_channels <= 8:    # 4 output channels: exact fp32 on the vector ALU instead of a 94 %-padded MFMA tile
+            d2 = S.conv_small_cout(d1, bh.conv2.weight, bh.conv2.bias, padding=1)
+        else:
+            _, d2 = S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, want_split=False, want_f32=True)
+        S.bezier_update(bezier, d2, ws.M, self.motion_dim // 32)
         if not need_mask:
             return None
         m1, _ = S.conv(ws.H, self._pk("mask0", lambda a=self.mask[0].weight: a), padding=1, shift=self.mask[0].bias, act=S.ACT_RELU)
