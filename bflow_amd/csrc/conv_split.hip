@@ -18,6 +18,8 @@
 //            at a channel-block offset (writes straight into concatenated buffers; a 32x32 MFMA tile is one contiguous
 //            2-KB / 4-KB run).
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -50,7 +52,6 @@ struct ConvArgs {
     const float *scale, *shift;   // per output channel or null
     int act;
     double* stats;             // (B, Cout, 2) or null
-    int ablate;                // debug
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -68,8 +69,9 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 #define CONV_STG_STRIDE 36                       // floats per staged pixel row (32 + 4 pad)
 #define CONV_STG_BYTES (4 * 32 * CONV_STG_STRIDE * 4)
 
-template <int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, int mw, int n0, int rows_valid,
+// `pixel_of(row)` maps row 0..31 of the wave's slab to the pixel row of the output image (or -1: outside, not written).
+template <int NT, typename PixelOf>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, PixelOf pixel_of, int n0,
                                               int lane, int wave, int tid, bool writer, float* red) {
     constexpr int BN = 32 * NT;
     constexpr int RS = CONV_STG_STRIDE;
@@ -105,8 +107,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 8 + rr;
-                const int m = mw + row;
-                const bool mok = m < rows_valid;
+                const int m = pixel_of(row);
+                const bool mok = m >= 0;
                 const float4 raw = *reinterpret_cast<const float4*>(stg + row * RS + ch);
                 float v[4] = {raw.x * sc[0] + sh[0], raw.y * sc[1] + sh[1], raw.z * sc[2] + sh[2], raw.w * sc[3] + sh[3]};
                 if (a.addend && mok) {
@@ -362,102 +364,109 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
     const bool writer = (grp == 0);
 
     // ---- epilogue (lane = pixel wave*32 + l31 of this tile) --------------------------------------------------------------
-    conv_epilogue<NT>(a, hh, xx, b, m0 + wave * 32, n0, HoWo, lane, wave, tid, writer, reinterpret_cast<float*>(lds));
+    const int mw = m0 + wave * 32;
+    conv_epilogue<NT>(a, hh, xx, b, [=](int row) { return mw + row < HoWo ? mw + row : -1; }, n0, lane, wave, tid, writer,
+                      reinterpret_cast<float*>(lds));
 #endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Row-reuse variant for stride-1 "same" convolutions with KW = 3 or 5 taps per filter row.
-// The per-CU global->LDS fill rate (~25-40 GB/s per CU, measured) bounds the generic kernel, which re-loads the activation
-// tile for every tap.  Here one k-step is a whole FILTER ROW of one channel block: the 128 + KW - 1 input pixels the row
-// touches are staged ONCE and the KW horizontal taps read them at row offsets 0..KW-1, so the activation bytes per MFMA drop
-// by KW and every barrier / issue round is amortised over KW x more matrix work (KW*12 MFMAs per wave at NT = 2).
-//   * flattened pixels: tap q of output pixel m reads staged row (m - m0) + q; a tap that would leave the image ROW is masked
-//     in registers (per-lane KW-bit mask of x + q - pad in [0, W)), a filter row that leaves the image is an out-of-range
-//     buffer offset (zeros), exactly like the padding of the generic kernel;
-//   * 2-stage LDS ring (stage = 144 activation rows + KW weight tiles, hi and lo), loads of step k+1 fly under the MFMAs of k.
+// Halo variant for stride-1 "same" convolutions (3x3, 1x5, 5x1): the kernels above are bound by the global->LDS fill rate of
+// a CU (~25 B/clk measured, L2-resident data), not by the matrix cores, and the generic kernel re-stages the activation tile
+// for EVERY tap.  Here a workgroup owns an 8 x 16 pixel patch; per 32-channel block its (8+KH-1) x (16+KW-1) halo patch is
+// staged ONCE (out-of-image pixels are out-of-range buffer offsets = zeros, so there are no tap masks at all) and every tap
+// reads it at a constant row offset r*(16+KW-1) + q.  Only the weight tile is streamed per tap (4-slot ring), so the bytes
+// staged per MFMA drop ~2.3x (3x3, 64-channel tile) and 32-channel tiles (2x the workgroups for the small batch-1 grids of
+// the update block) become affordable.
+//   k-step = (channel block, tap), taps unrolled: the s_waitcnt immediates are compile-time functions of the tap.
+//   LDS: 2 halo buffers (12 units x 1 KB x 2 planes each) + 4 weight slots (NT x 4 KB) = 64 / 80 KB -> 2 workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, int KW>
-__global__ __launch_bounds__(CT, 1) void conv_row_kernel(ConvArgs a) {
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NT, int KH, int KW>
+__global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BN = 32 * NT;
-    constexpr int BU = (NT <= 2) ? 1 : 2;
-    constexpr int AROWS = 144;                            // 128 + KW - 1 rounded up to 16-row units (9 units)
-    constexpr int A_ARR = AROWS * 64, B_TAP = BU * 4 * 1024, B_ARR = KW * B_TAP;
-    constexpr int O_AH = 0, O_AL = A_ARR, O_BH = 2 * A_ARR, O_BL = 2 * A_ARR + B_ARR;
-    constexpr int STAGE = 2 * A_ARR + 2 * B_ARR;
+    constexpr int TH = 8, TW = 16;
+    constexpr int HWD = TW + KW - 1, HR = HWD * (TH + KH - 1);     // halo patch: rows of 64 B per plane
+    constexpr int A_UNITS = (HR + 15) / 16;                         // 16-row LDS-DMA units per plane (12 / 10 / 12)
+    static_assert(A_UNITS % 2 == 0 && A_UNITS <= 12, "halo patch must split evenly over the waves");
+    constexpr int AP = A_UNITS / 2;                                 // pieces per wave per channel block
+    constexpr int A_PLANE = A_UNITS * 1024, A_BUF = 2 * A_PLANE;
+    constexpr int NTAPS = KH * KW;
+    constexpr int B_PLANE = NT * 2048, B_SLOT = 2 * B_PLANE;        // NT*32 weight rows x 64 B per plane
+    constexpr int SB = 4, LA = 2;                                   // weight ring slots, look-ahead in taps
+    static_assert(NTAPS >= 4, "the halo of the next block must land within a block");
+    constexpr int O_B = 2 * A_BUF;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int b = blockIdx.z;
-    const int HW = a.H * a.W;                              // stride 1, same padding: Ho*Wo == H*W
-    int m0, n0;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    int y0, x0, n0;
     {
         const int ntn = a.n_tiles;
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int mt = (slot / ntn) * 8 + xcd;
-        m0 = mt * CBM;
-        n0 = (slot - (slot / ntn) * ntn) * BN;
-        if (m0 >= HW) return;
+        const int mt = (slot / ntn) * 8 + xcd;                      // all channel tiles of a patch on one XCD, back to back
+        if (mt >= tiles_x * tiles_y) return;
+        n0 = (slot - (slot / ntn) * ntn) * 32 * NT;
+        const int ty = mt / tiles_x;
+        y0 = ty * TH;
+        x0 = (mt - ty * tiles_x) * TW;
     }
-    const int nsteps = a.KH * a.CB;                        // (filter row, channel block)
 
+    // ---- LDS-DMA sources ------------------------------------------------------------------------------------------
     const int urow = lane >> 2;
-    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
-    // staged activation row j holds input pixel  m0 + j - pad_w + (r - pad_h) * W ; this wave loads units wave, wave+4 (+8: wave 0)
-    int prow[3];
+    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;        // halves; LDS chunk = logical chunk ^ ((row >> 2) & 3)
+    // halo: wave w stages plane (w & 1), units (w >> 1) + 2 i
+    unsigned aoff[AP];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) prow[j] = m0 + (wave + 4 * j) * 16 + urow - a.pad_w;
-    unsigned wvo[BU];
+    for (int i = 0; i < AP; ++i) {
+        const int row = ((wave >> 1) + 2 * i) * 16 + urow;
+        const int hy = row / HWD, hx = row - hy * HWD;
+        const int py = y0 - a.pad_h + hy, px = x0 - a.pad_w + hx;
+        const bool ok = row < HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
+        aoff[i] = ok ? (unsigned)(((py * a.W + px) * 32 + uchunk) * 2) : 0x80000000u;
+    }
+    // weights: wave w stages plane (w >> 1), units (w*NT + j) % (2 NT)
+    unsigned wvo[NT];
 #pragma unroll
-    for (int j = 0; j < BU; ++j) {
-        int r = n0 + (wave * BU + j) * 16 + urow;
-        r = r < a.cout_pad ? r : a.cout_pad - 1;
+    for (int j = 0; j < NT; ++j) {
+        const int r = n0 + ((wave * NT + j) % (2 * NT)) * 16 + urow;     // < cout_pad (a multiple of 128)
         wvo[j] = (unsigned)((r * 32 + uchunk) * 2);
     }
     const int CB2 = a.CB - a.CB1;
     const int plane_b = a.P_in * 64;
-    const rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xh + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
-    const rsrc_t r_l1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xl + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
-    const rsrc_t r_h2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2h + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
-    const rsrc_t r_l2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2l + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const bool lo_a = wave & 1, lo_w = wave >> 1;
+    const rsrc_t r_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_a ? a.xl : a.xh) + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_a ? a.x2l : a.x2h) + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
     const int wtile_b = a.cout_pad * 64;
-    const rsrc_t r_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, a.KH * KW * a.CB * wtile_b, 0x00020000);
-    const rsrc_t r_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.wl, 0, a.KH * KW * a.CB * wtile_b, 0x00020000);
+    const rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(lo_w ? a.wl : a.wh), 0, NTAPS * a.CB * wtile_b, 0x00020000);
+    char* const a_dst = lds + (lo_a ? A_PLANE : 0) + (wave >> 1) * 1024;
+    char* const w_dst = lds + O_B + (lo_w ? B_PLANE : 0);
 
-    int ir = 0, icb = 0;                                   // next step to issue
-    bool ivalid = true;
-    auto advance = [&]() { if (++icb == a.CB) { icb = 0; if (++ir == a.KH) { ir = 0; ivalid = false; } } };
-
-#define ROW_ISSUE(SB)                                                                                                    \
+#define HALO_ISSUE_A(CBI, BUF)                                                                                           \
     {                                                                                                                    \
-        char* sb = (SB);                                                                                                 \
-        const bool first_ = icb < a.CB1;                                                                                 \
-        const rsrc_t rh_ = first_ ? r_h1 : r_h2;                                                                         \
-        const rsrc_t rl_ = first_ ? r_l1 : r_l2;                                                                         \
-        const int cbb_ = (first_ ? icb : icb - a.CB1) * plane_b;                                                         \
-        const int dy_ = (ir - a.pad_h) * a.W;                                                                            \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
-            const int p_ = prow[j] + dy_;                                                                                \
-            const unsigned vo = (ivalid && p_ >= 0 && p_ < HW) ? (unsigned)(cbb_ + p_ * 64 + uchunk * 2) : 0x80000000u;  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rh_, (lptr_t)(sb + O_AH + (wave + 4 * j) * 1024), 16, vo, 0, 0, 0); \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl_, (lptr_t)(sb + O_AL + (wave + 4 * j) * 1024), 16, vo, 0, 0, 0); \
-        }                                                                                                                \
-        if (wave == 0) {                                   /* ninth unit: rows 128..143 */                              \
-            const int p_ = prow[2] + dy_;                                                                                \
-            const unsigned vo = (ivalid && p_ >= 0 && p_ < HW) ? (unsigned)(cbb_ + p_ * 64 + uchunk * 2) : 0x80000000u;  \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rh_, (lptr_t)(sb + O_AH + 8 * 1024), 16, vo, 0, 0, 0);              \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl_, (lptr_t)(sb + O_AL + 8 * 1024), 16, vo, 0, 0, 0);              \
-        }                                                                                                                \
-        _Pragma("unroll") for (int q = 0; q < KW; ++q) {                                                                 \
-            const int wso_ = ((ir * KW + q) * a.CB + icb) * wtile_b;                                                     \
-            _Pragma("unroll") for (int j = 0; j < BU; ++j) {                                                             \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wh, (lptr_t)(sb + O_BH + q * B_TAP + (wave * BU + j) * 1024), 16, wvo[j], wso_, 0, 0); \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wl, (lptr_t)(sb + O_BL + q * B_TAP + (wave * BU + j) * 1024), 16, wvo[j], wso_, 0, 0); \
-            }                                                                                                            \
-        }                                                                                                                \
+        const int cbi_ = (CBI) < a.CB ? (CBI) : a.CB - 1;             /* past the last block: a harmless re-load */      \
+        const bool first_ = cbi_ < a.CB1;                                                                                \
+        const rsrc_t ra_ = first_ ? r_a1 : r_a2;                                                                         \
+        const int so_ = (first_ ? cbi_ : cbi_ - a.CB1) * plane_b;                                                        \
+        _Pragma("unroll") for (int i = 0; i < AP; ++i)                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lptr_t)(a_dst + (BUF) * A_BUF + i * 2048), 16, aoff[i], so_, 0, 0); \
+    }
+#define HALO_ISSUE_B(CBI, TAP, SLOT)                                                                                     \
+    {                                                                                                                    \
+        const int so_ = ((TAP) * a.CB + (CBI)) * wtile_b;             /* past the last block: in range, unused */        \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (SLOT) * B_SLOT + ((wave * NT + j) % (2 * NT)) * 1024), 16, \
+                                                     wvo[j], so_, 0, 0);                                                 \
     }
 
     f32x16 hh[NT], xx[NT];
@@ -469,70 +478,74 @@ __global__ __launch_bounds__(CT, 1) void conv_row_kernel(ConvArgs a) {
             xx[n][r] = 0.f;
         }
 
-    // per-lane horizontal validity of the KW taps for this lane's output pixel (MFMA A row = wave*32 + l31)
-    unsigned qmask = 0;
-    {
-        const int m = m0 + wave * 32 + l31;
-        const int x = m % a.W;
+    HALO_ISSUE_A(0, 0)
 #pragma unroll
-        for (int q = 0; q < KW; ++q) {
-            const int xi = x + q - a.pad_w;
-            if (m < HW && xi >= 0 && xi < a.W) qmask |= 1u << q;
-        }
-    }
+    for (int t = 0; t < LA; ++t) HALO_ISSUE_B(0, t, t)
 
-    if (!(a.ablate & 4)) ROW_ISSUE(lds)
-    advance();
-    int cur_slot = 0;
-    for (int kt = 0; kt < nsteps; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step kt landed (nothing else is in flight at this point)
-        __builtin_amdgcn_s_barrier();                      // for every wave; the other slot is free again
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(a.ablate & 1)) ROW_ISSUE(lds + (cur_slot ^ 1) * STAGE)            // step kt+1 flies under this step's KW*NT*6 MFMAs
-        advance();
-        __builtin_amdgcn_sched_barrier(0);
-        const char* cur = lds + cur_slot * STAGE;
-        cur_slot ^= 1;
-        if (a.ablate & 2) continue;
-#pragma unroll
-        for (int q = 0; q < KW; ++q) {
-            const int R = wave * 32 + l31 + q;
+    // this lane's pixel inside the patch (MFMA B-operand row = pixel) and its halo row for tap (0, 0)
+    const int R0 = (wave * 2 + (l31 >> 4)) * HWD + (l31 & 15);
+    const int wsw = (l31 >> 2) & 3;
+    int islot = LA, cslot = 0;
+    for (int cb = 0; cb < a.CB; ++cb) {
+        const char* abuf = lds + (cb & 1) * A_BUF;
+        static_for<0, NTAPS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            // Loads issued after this tap's weight tile (itself issued LA = 2 steps ago, after that step's halo issue if any):
+            // LA-1 newer weight tiles, plus the next block's halo when it was issued one step ago (halo issue is at tap 1).
+            // The taps are unrolled and hipcc lets the fragment reads of step s complete AFTER the barrier of step s+1, so a
+            // slot may only be refilled two barriers after its last reader: the weight slot filled at step s was consumed at
+            // step s-2 (ring of 4, look-ahead 2), the halo buffer filled at tap 1 was last read at the previous block's last tap.
+            constexpr int NEWER_B = (LA - 1) * NT;
+            if (t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER_B + AP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER_B) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 1) HALO_ISSUE_A(cb + 1, (cb + 1) & 1)
+            {
+                constexpr int tn = (t + LA) % NTAPS;
+                const int cbn = cb + (t + LA) / NTAPS;
+                HALO_ISSUE_B(cbn, tn, islot)
+            }
+            if (++islot == SB) islot = 0;
+            __builtin_amdgcn_sched_barrier(0);
+            const char* wcur = lds + O_B + cslot * B_SLOT;
+            if (++cslot == SB) cslot = 0;
+            const int R = R0 + (t / KW) * HWD + (t % KW);
             const int sw = (R >> 2) & 3;
-            const bool keep = (qmask >> q) & 1u;
-            half8 ah[2], al[2], bh[2][NT], bl[2][NT];
+            half8 xh[2], xl[2], wh[2][NT], wl[2][NT];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int co = ((ks * 2 + kh) ^ sw) * 16;
-                const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                const half8 th = *reinterpret_cast<const half8*>(cur + O_AH + R * 64 + co);
-                const half8 tl = *reinterpret_cast<const half8*>(cur + O_AL + R * 64 + co);
-                ah[ks] = keep ? th : z8;
-                al[ks] = keep ? tl : z8;
-                const int cob = ((ks * 2 + kh) ^ ((l31 >> 2) & 3)) * 16;
+                const int ao = R * 64 + (((ks * 2 + kh) ^ sw) * 16);
+                xh[ks] = *reinterpret_cast<const half8*>(abuf + ao);
+                xl[ks] = *reinterpret_cast<const half8*>(abuf + A_PLANE + ao);
+                const int co = ((ks * 2 + kh) ^ wsw) * 16;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const int bo = q * B_TAP + (n * 32 + l31) * 64 + cob;
-                    bh[ks][n] = *reinterpret_cast<const half8*>(cur + O_BH + bo);
-                    bl[ks][n] = *reinterpret_cast<const half8*>(cur + O_BL + bo);
+                    const int wo = (n * 32 + l31) * 64 + co;
+                    wh[ks][n] = *reinterpret_cast<const half8*>(wcur + wo);
+                    wl[ks][n] = *reinterpret_cast<const half8*>(wcur + B_PLANE + wo);
                 }
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][n], ah[ks], hh[n], 0, 0, 0);   // D[channel][pixel]
+                for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][n], xh[ks], hh[n], 0, 0, 0);   // D[channel][pixel]
 #pragma unroll
-                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks][n], ah[ks], xx[n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks][n], xh[ks], xx[n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][n], al[ks], xx[n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][n], xl[ks], xx[n], 0, 0, 0);
             }
-        }
+        });
     }
-#undef ROW_ISSUE
+#undef HALO_ISSUE_A
+#undef HALO_ISSUE_B
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    if (a.ablate & 8) return;
-    conv_epilogue<NT>(a, hh, xx, b, m0 + wave * 32, n0, HW, lane, wave, tid, true, reinterpret_cast<float*>(lds));
+    const int W = a.W, H = a.H, yw = y0 + wave * 2;
+    conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
+        const int y = yw + (row >> 4), x = x0 + (row & 15);
+        return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, true, reinterpret_cast<float*>(lds));
 #endif
 }
 
@@ -758,26 +771,33 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     BFLOW_REQUIRE(out_c % 32 == 0 && d->out_channel_offset + d->Cout <= out_c, BFLOW_E_ARG, "conv_split: bad output channel layout");
     a.CBo = out_c / 32; a.cb_off = d->out_channel_offset / 32; a.P_out = d->out_rows_per_image > 0 ? d->out_rows_per_image : Ho * Wo;
     a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
-    a.ablate = getenv("BFLOW_ABLATE") ? atoi(getenv("BFLOW_ABLATE")) : 0;
     a.n_tiles = bflow::ceil_div(d->Cout, d->tile_n);
     const int m_tiles8 = (bflow::ceil_div((long long)Ho * Wo, CBM) + 7) / 8 * 8;   // pixel tiles, padded to the 8 XCDs
     dim3 grid(m_tiles8 * a.n_tiles, 1, d->B);
     hipStream_t s = (hipStream_t)stream;
     const long long nblocks = (long long)bflow::ceil_div((long long)Ho * Wo, CBM) * a.n_tiles * d->B;
-    // row-reuse kernel: stride 1, "same" padding, 3 or 5 taps per filter row
-    const bool row_ok = d->stride == 1 && (d->KW == 3 || d->KW == 5) && d->pad_w == (d->KW - 1) / 2 && d->pad_h == (d->KH - 1) / 2 &&
-                        !(d->KW == 5 && NT > 2) && !getenv("BFLOW_NO_ROW_KERNEL");
-    if (row_ok) {
-#define LAUNCH_ROW(N, K)                                                                                               \
+    // halo kernel: stride 1, "same" padding, 3x3 / 1x5 / 5x1
+    const char* force = getenv("BFLOW_CONV_KERNEL");           // tests: "generic" forces the generic kernel for every shape
+    const bool same = d->stride == 1 && d->pad_w == (d->KW - 1) / 2 && d->pad_h == (d->KH - 1) / 2;
+    const int shape = (d->KH == 3 && d->KW == 3) ? 1 : (d->KH == 1 && d->KW == 5) ? 2 : (d->KH == 5 && d->KW == 1) ? 3 : 0;
+    if (same && shape && !(force && strcmp(force, "halo") != 0)) {
+        const int patches = bflow::ceil_div(d->H, 8) * bflow::ceil_div(d->W, 16);
+        const int patches8 = (patches + 7) / 8 * 8;
+        // 64-channel tiles unless that leaves most CUs without a workgroup (batch-1 update block: 40 patches)
+        const int nt = ((long long)patches * d->B * bflow::ceil_div(d->Cout, 64) >= 200) ? 2 : 1;
+        a.n_tiles = bflow::ceil_div(d->Cout, 32 * nt);
+        dim3 hgrid(patches8 * a.n_tiles, 1, d->B);
+#define LAUNCH_HALO(N, KHH, KWW)                                                                                       \
     {                                                                                                                  \
-        const int lds = 2 * (2 * 144 * 64 + 2 * (K) * ((N) <= 2 ? 1 : 2) * 4 * 1024);                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_row_kernel<N, K>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((conv_row_kernel<N, K>), grid, dim3(CT), lds, s, a);                                        \
+        const int lds = 2 * 2 * (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16) * 1024 + 4 * (N) * 4096;              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<N, KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((conv_halo_kernel<N, KHH, KWW>), hgrid, dim3(CT), lds, s, a);                               \
     }
-        if (d->KW == 3) { if (NT == 2) LAUNCH_ROW(2, 3) else if (NT == 3) LAUNCH_ROW(3, 3) else LAUNCH_ROW(4, 3) }
-        else LAUNCH_ROW(2, 5)
-#undef LAUNCH_ROW
-        return bflow::launch_status("conv_split(row)");
+        if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else LAUNCH_HALO(1, 3, 3) }
+        else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else LAUNCH_HALO(1, 1, 5) }
+        else { if (nt == 2) LAUNCH_HALO(2, 5, 1) else LAUNCH_HALO(1, 5, 1) }
+#undef LAUNCH_HALO
+        return bflow::launch_status("conv_split(halo)");
     }
     const bool deep = nblocks <= 320;   // at most ~1 workgroup per CU: spend the LDS on prefetch depth instead of co-residency
 #define LAUNCH(N, SS, KGG)                                                                                             \

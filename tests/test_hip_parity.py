@@ -361,6 +361,9 @@ def test_cpu_inputs_fail_loudly():
     (384, 128, (1, 5), 1, (0, 2), 15, 20, 1),    # GRU horizontal
     (384, 128, (5, 1), 1, (2, 0), 15, 20, 1),    # GRU vertical
     (96, 126, (3, 3), 1, (1, 1), 12, 16, 1),     # Cout not a multiple of 32 (motion-encoder output)
+    (64, 96, (3, 3), 1, (1, 1), 100, 150, 2),    # enough patches for the 64-channel tile of the halo kernel, ragged patches
+    (32, 64, (1, 5), 1, (0, 2), 90, 120, 2),
+    (32, 64, (5, 1), 1, (2, 0), 90, 120, 2),
 ])
 def test_conv_split_engine_vs_fp64(cin, cout, k, stride, pad, H, W, B):
     from bflow_amd import split as S
