@@ -603,7 +603,6 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restric
 //   norm_* : InstanceNorm from (sum, sumsq) statistics [stats != null]  or per-channel affine [scale/shift]  or identity
 // Thread = 8 consecutive channels of one pixel (32-B fp32 reads, 16-B fp16 writes).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int NORM_TILES_PER_BLOCK = 4;
 
 struct NormArgs {
     const float* a; const double* stats_a; const float *scale_a, *shift_a; int a_nchw; int act_a;
@@ -612,6 +611,7 @@ struct NormArgs {
     int act_out;
     _Float16 *oh, *ol; float* out_f32;
     int B, HW, C, CB, P; float eps;
+    int tiles_per_block;   // consecutive 64-pixel tiles walked by one block (amortises the coefficient set-up on big grids)
 };
 
 __device__ __forceinline__ void norm_coeffs(const double* stats, const float* scale, const float* shift, int b, int c, int C, int HW,
@@ -649,9 +649,8 @@ __global__ __launch_bounds__(256) void norm_act_split_kernel(NormArgs p) {
     }
     __syncthreads();
     const int pl = threadIdx.x >> 2, c8 = (threadIdx.x & 3) * 8;
-    // each block walks NORM_TILES_PER_BLOCK consecutive 64-pixel tiles
-    for (int tix = 0; tix < NORM_TILES_PER_BLOCK; ++tix) {
-        const int p0 = (blockIdx.x * NORM_TILES_PER_BLOCK + tix) * 64;
+    for (int tix = 0; tix < p.tiles_per_block; ++tix) {
+        const int p0 = (blockIdx.x * p.tiles_per_block + tix) * 64;
         if (p0 >= p.HW) break;
         const int pix = p0 + pl;
         if (p.a_nchw) {
@@ -839,7 +838,9 @@ extern "C" int bflow_norm_act_split(const bflow_norm_desc_t* d, bflow_stream_t s
     p.b = d->b; p.stats_b = d->stats_b; p.rh = (const _Float16*)d->res_hi; p.rl = (const _Float16*)d->res_lo; p.act_out = d->act_out;
     p.oh = (_Float16*)d->out_hi; p.ol = (_Float16*)d->out_lo; p.out_f32 = d->out_f32; p.B = d->B; p.HW = d->HW; p.C = d->C;
     p.CB = (d->C + 31) / 32; p.P = d->rows_per_image > 0 ? d->rows_per_image : d->HW; p.eps = d->eps;
-    dim3 grid(bflow::ceil_div(d->HW, 64 * NORM_TILES_PER_BLOCK), p.CB, d->B);
+    const long long tiles = (long long)bflow::ceil_div(d->HW, 64) * p.CB * d->B;
+    p.tiles_per_block = tiles >= 8192 ? 4 : tiles >= 4096 ? 2 : 1;       // keep >= ~2000 blocks in flight
+    dim3 grid(bflow::ceil_div(d->HW, 64 * p.tiles_per_block), p.CB, d->B);
     hipLaunchKernelGGL(norm_act_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return bflow::launch_status("norm_act_split");
 }

@@ -151,63 +151,7 @@ extern "C" int bflow_bezier_update(float* params, const float* delta, int C2, vo
     return bflow::launch_status("bezier_update");
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Small-Cout convolution on the vector ALU (exact fp32): the Bezier head's last conv has 2*deg <= 8 output channels, for which a
-// 64-wide MFMA tile would be 94 % padding and 72 sequential k-tiles of latency.  8 lanes share one output pixel (one 32-channel
-// block each), the weights sit in LDS as [tap][channel][8] so one ds_read_b128 x2 feeds 8 FMAs, lanes are reduced with shuffles.
-//   x: blocked split (B, CB, P, 32); w: (Cout, CB*32, KH, KW) fp32; out: blocked fp32 (B, 1, P, 32), channels [0, Cout)
-// Reference: BezierHead.conv2, models/raft_spline/update.py:15,18.
-// ---------------------------------------------------------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(256) void conv_small_cout_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
-                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ out, int H, int W, int CB, int P, int Cout, int KH, int KW,
-                                                              int pad_h, int pad_w) {
-    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [ntaps][C][8]
-    const int C = CB * 32, ntaps = KH * KW;
-    for (int i = threadIdx.x; i < ntaps * C * 8; i += 256) {
-        const int co = i & 7, c = (i >> 3) % C, t = (i >> 3) / C;
-        wsm[i] = (co < Cout) ? w[((long long)co * C + c) * ntaps + t] : 0.f;
-    }
-    __syncthreads();
-    const int b = blockIdx.y;
-    const int lanes_per_pix = CB;                       // host guarantees CB in {1,2,4,8}
-    const int pix = blockIdx.x * (256 / lanes_per_pix) + threadIdx.x / lanes_per_pix;
-    const int cb = threadIdx.x % lanes_per_pix;
-    const bool live = pix < H * W;
-    const int y = live ? pix / W : 0, x = live ? pix - y * W : 0;
-    float acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    for (int t = 0; t < ntaps; ++t) {
-        const int r = t / KW, q = t - r * KW;
-        const int yy = y + r - pad_h, xx = x + q - pad_w;
-        if (!live || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-        const long long o = (((long long)b * CB + cb) * P + yy * W + xx) * 32;
-        const float* wt = wsm + ((long long)t * C + cb * 32) * 8;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const half8 h = *reinterpret_cast<const half8*>(xh + o + g * 8), l = *reinterpret_cast<const half8*>(xl + o + g * 8);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = (float)h[k] + (float)l[k] * LO_INV;
-                const float4 w0 = *reinterpret_cast<const float4*>(wt + (g * 8 + k) * 8), w1 = *reinterpret_cast<const float4*>(wt + (g * 8 + k) * 8 + 4);
-                acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]); acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
-                acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]); acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
-            }
-        }
-    }
-    for (int off = 1; off < lanes_per_pix; off <<= 1)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
-    if (live && cb == 0) {
-        float* op = out + ((long long)b * P + pix) * 32;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < Cout) op[k] = acc[k] + (bias ? bias[k] : 0.f);
-    }
-}
-
 // 2-D neighbourhood gather of a few-channel fp32 NCHW tensor into a blocked split tensor: out[b, pix, tap*C + c] =
 // x[b, c, y + r - pad, x + q - pad] (zero outside), K = KH*KW*C padded to a multiple of 32 with zeros.  Turns the 7x7
 // convolution over the 2*deg Bezier channels (update.py:62,91) into a dense 1x1 GEMM instead of 49 mostly-empty k-tiles.
@@ -243,22 +187,6 @@ __global__ __launch_bounds__(256) void im2col_small_kernel(const float* __restri
     }
 }
 }  // namespace
-
-extern "C" int bflow_conv_small_cout(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* out, int B, int H, int W,
-                                     int C, int rows_per_image, int Cout, int KH, int KW, int pad_h, int pad_w, bflow_stream_t stream) {
-    BFLOW_REQUIRE(x_hi && x_lo && w && out && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0, BFLOW_E_ARG, "conv_small_cout: bad arguments");
-    const int CB = C / 32;
-    BFLOW_REQUIRE(C % 32 == 0 && (CB == 1 || CB == 2 || CB == 4 || CB == 8) && Cout >= 1 && Cout <= 8, BFLOW_E_LIMIT,
-                  "conv_small_cout: needs C in {32,64,128,256} and Cout <= 8 (C=%d Cout=%d)", C, Cout);
-    const int P = rows_per_image > 0 ? rows_per_image : H * W;
-    const size_t lds = (size_t)KH * KW * C * 8 * sizeof(float);
-    BFLOW_REQUIRE(lds <= 150 * 1024, BFLOW_E_LIMIT, "conv_small_cout: weights do not fit in LDS");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_cout_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(bflow::ceil_div(H * W, 256 / CB), B);
-    hipLaunchKernelGGL(conv_small_cout_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const _Float16*)x_hi, (const _Float16*)x_lo, w, bias,
-                       out, H, W, CB, P, Cout, KH, KW, pad_h, pad_w);
-    return bflow::launch_status("conv_small_cout");
-}
 
 extern "C" int bflow_im2col_small(const float* x, void* out_hi, void* out_lo, int B, int C, int H, int W, int KH, int KW, int pad_h, int pad_w,
                                   int rows_per_image, bflow_stream_t stream) {

@@ -234,19 +234,6 @@ def bezier_update(params: torch.Tensor, delta: Optional[torch.Tensor], dst: Spli
                                              0 if dst2 is None else dst2.planes.shape[2], dst2_block, B, P, hip._stream()), "bflow_bezier_update")
 
 
-def conv_small_cout(x: SplitTensor, weight: torch.Tensor, bias: Optional[torch.Tensor], padding=(0, 0)) -> torch.Tensor:
-    """Exact-fp32 VALU convolution for Cout <= 8 -> blocked fp32 (B, 1, P, 32) (first Cout channels valid)."""
-    B, H, W, _ = x.shape
-    cout, cin, kh, kw = weight.shape
-    assert cin == x.channels_padded and cout <= 8
-    ph, pw = (padding, padding) if isinstance(padding, int) else padding
-    out = torch.empty((B, 1, x.rows, 32), dtype=torch.float32, device=x.planes.device)
-    hip._check(hip.lib().bflow_conv_small_cout(x.hi.data_ptr(), x.lo.data_ptr(), hip._dev(weight, name="weight"),
-                                               None if bias is None else hip._dev(bias, name="bias"), out.data_ptr(), B, H, W, cin, x.rows,
-                                               cout, kh, kw, ph, pw, hip._stream()), "bflow_conv_small_cout")
-    return out
-
-
 def im2col_small(x: torch.Tensor, kh: int, kw: int, padding, out: Optional[SplitTensor] = None) -> SplitTensor:
     """x (B, C, H, W) fp32 -> blocked split (B, H, W, kh*kw*C) with K index = tap*C + c."""
     B, C, H, W = x.shape

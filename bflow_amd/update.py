@@ -261,10 +261,7 @@ class BasicUpdateBlock(nn.Module):
         # ---- heads (update.py:17-18,111-114,120-125)
         bh = self.bezier_head
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
-        if bh.conv2.out_channels <= 8:    # 4 output channels: exact fp32 on the vector ALU instead of a 94 %-padded MFMA tile
-            d2 = S.conv_small_cout(d1, bh.conv2.weight, bh.conv2.bias, padding=1)
-        else:
-            _, d2 = S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, want_split=False, want_f32=True)
+        _, d2 = S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, want_split=False, want_f32=True)
         S.bezier_update(bezier, d2, ws.M, self.motion_dim // 32)
         if not need_mask:
             return None

@@ -138,12 +138,8 @@ int bflow_gru_blend_blocked(const float* zr, const float* q, void* h_hi, void* h
 int bflow_bezier_update(float* params, const float* delta, int C2, void* blk_hi, void* blk_lo, int CB_total, int cb_off,
                         void* blk2_hi, void* blk2_lo, int CB_total2, int cb_off2, int B, int P, bflow_stream_t stream);
 
-/* bflow_conv_small_cout: exact-fp32 convolution for Cout <= 8 on the vector ALU (the Bezier head's last conv, update.py:15,18):
- *   x blocked split (B, C/32, P, 32), C in {32,64,128,256}; w (Cout, C, KH, KW) fp32; out blocked fp32 (B, 1, P, 32), channels < Cout.
- * bflow_im2col_small: out[b, pix, tap*C + c] = x[b, c, y+r-pad_h, x+q-pad_w] (zeros outside) as a blocked split tensor with
+/* bflow_im2col_small: out[b, pix, tap*C + c] = x[b, c, y+r-pad_h, x+q-pad_w] (zeros outside) as a blocked split tensor with
  *   ceil(KH*KW*C/32) channel blocks: turns the 7x7 convolution over the 2*deg Bezier channels (update.py:62,91) into a 1x1 GEMM. */
-int bflow_conv_small_cout(const void* x_hi, const void* x_lo, const float* w, const float* bias, float* out, int B, int H, int W,
-                          int C, int rows_per_image, int Cout, int KH, int KW, int pad_h, int pad_w, bflow_stream_t stream);
 int bflow_im2col_small(const float* x, void* out_hi, void* out_lo, int B, int C, int H, int W, int KH, int KW, int pad_h, int pad_w,
                        int rows_per_image, bflow_stream_t stream);
 
