@@ -52,6 +52,9 @@ struct ConvArgs {
     const float *scale, *shift;   // per output channel or null
     int act;
     double* stats;             // (B, Cout, 2) or null
+    int gate;                  // 0 | 1 (zr) | 2 (blend): fused GRU gates, see bflow_conv_desc_t
+    const _Float16 *gh, *gl;   // h planes (B, CBo, P_out, 32)
+    const float* gz;           // z (B, CBo, P_out, 32)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -122,7 +125,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                     if (!cok[k]) v[k] = 0.f;                // padded channels of the last block are written as zeros
                     if (mok) { s1[k] += v[k]; s2[k] += v[k] * v[k]; }
                 }
-                if (mok) {
+                if (mok && a.gate) {
+                    // SepConvGRU gates (update.py:38-47).  Block index inside the (B, CBo, P, 32) gate buffers: the z half of a
+                    // "zr" convolution and a "blend" convolution map 1:1, the r half is shifted down by CBo blocks.
+                    const int cbk = (n0 >> 5) + n;
+                    const bool r_half = a.gate == 1 && cbk >= a.CBo;
+                    const long long gb = (((long long)b * a.CBo + (r_half ? cbk - a.CBo : cbk)) * a.P_out + m) * 32 + ch;
+                    if (a.gate == 1 && !r_half) {
+                        *reinterpret_cast<float4*>(a.out_f32 + gb) = make_float4(bflow::sigmoidf_(v[0]), bflow::sigmoidf_(v[1]),
+                                                                                 bflow::sigmoidf_(v[2]), bflow::sigmoidf_(v[3]));
+                    } else {
+                        const half4v hh4 = *reinterpret_cast<const half4v*>(a.gh + gb), hl4 = *reinterpret_cast<const half4v*>(a.gl + gb);
+                        float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (a.gate == 2) z4 = *reinterpret_cast<const float4*>(a.gz + gb);
+                        const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+                        half4v h4, l4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float h = (float)hh4[k] + (float)hl4[k] * LO_INV;
+                            const float o = (a.gate == 1) ? bflow::sigmoidf_(v[k]) * h : (1.f - zz[k]) * h + zz[k] * tanhf(v[k]);
+                            _Float16 x1, x2;
+                            split1(o, x1, x2);
+                            h4[k] = x1;
+                            l4[k] = x2;
+                        }
+                        *reinterpret_cast<half4v*>(a.oh + gb) = h4;
+                        *reinterpret_cast<half4v*>(a.ol + gb) = l4;
+                    }
+                } else if (mok) {
                     if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + ob + (long long)m * 32) = make_float4(v[0], v[1], v[2], v[3]);
                     if (a.oh) {
                         half4v h4, l4;
@@ -488,7 +518,7 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
     int islot = LA, cslot = 0;
     for (int cb = 0; cb < a.CB; ++cb) {
         const char* abuf = lds + (cb & 1) * A_BUF;
-        static_for<0, NTAPS>([&](auto tc) {
+        static_for<0, NTAPS>([&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
             // Loads issued after this tap's weight tile (itself issued LA = 2 steps ago, after that step's halo issue if any):
             // LA-1 newer weight tiles, plus the next block's halo when it was issued one step ago (halo issue is at tap 1).
@@ -546,6 +576,187 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
     conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
         const int y = yw + (row >> 4), x = x0 + (row & 15);
         return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, true, reinterpret_cast<float*>(lds));
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small-grid halo variant (batch-1 update block: 40 patches x Cout/32 workgroups <= one per CU).  With one 4-wave workgroup
+// per CU every SIMD holds a single wave and each (wait, barrier, fragment reads, 6 MFMAs) step is a serial latency chain
+// (~400 cycles for 192 cycles of matrix work, measured).  Here
+//   * 8 waves: wave (s, g) owns pixel slab s like above but only k-half g of every 32-channel block (the two 16-deep MFMA
+//     sub-steps are split across the groups, which share the staged halo AND the weight tiles); two waves per SIMD
+//     interleave, the partial sums are combined through LDS at the end;
+//   * a step is a whole filter row (3x3: 3 taps) or the whole filter (1x5 / 5x1: 5 taps): 3-5x fewer barriers;
+//   * 32-channel tile only (NT = 1), 2 weight slots; the fragment reads of a step are pinned before the next barrier
+//     (sched_barrier), so a slot / halo buffer may be refilled one barrier after its last reader;
+//   * the 8 waves split every stage into whole 1-KB pieces plus, when the count is not a multiple of 8, one half piece
+//     (lanes 0-31 or 32-63 active).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KH, int KW>
+__global__ __launch_bounds__(2 * CT, 1) void conv_halo8_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TH = 8, TW = 16;
+    constexpr int HWD = TW + KW - 1, HR = HWD * (TH + KH - 1);
+    constexpr int A_UNITS = (HR + 15) / 16;
+    constexpr int A_PLANE = A_UNITS * 1024, A_BUF = 2 * A_PLANE;
+    constexpr int NTAPS = KH * KW;
+    constexpr int TPS = (NTAPS == 9) ? 3 : NTAPS;                   // taps per step
+    constexpr int NST = NTAPS / TPS;                                // steps per channel block (3 or 1)
+    constexpr int B_TAP = 4096, B_SLOT = TPS * B_TAP;               // per tap: 32 weight rows x 64 B x 2 planes
+    constexpr int O_B = 2 * A_BUF;
+    // wave (q, plane): plane = wave_all & 1 (hi / lo), q = wave_all >> 1.  Per plane a halo buffer is A_UNITS 1-KB pieces and a
+    // weight slot 2*TPS (tap-major, 2 units per tap); wave q takes pieces q + 4 i, and when the count is 4 k + 2 the last two
+    // pieces are split into half pieces (q >> 1), half (q & 1): lanes 0-31 or 32-63 active.
+    constexpr int NFA = A_UNITS / 4, NFB = (2 * TPS) / 4;           // whole pieces per wave
+    constexpr bool HALF_A = (A_UNITS % 4) != 0, HALF_B = ((2 * TPS) % 4) != 0;
+    static_assert(A_UNITS % 2 == 0, "stages must split into whole + half pieces over 4 waves per plane");
+    constexpr int NIA = NFA + (HALF_A ? 1 : 0), NIB = NFB + (HALF_B ? 1 : 0);   // load instructions per wave per stage
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3, grp = wave_all >> 2;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.z;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    int y0, x0, n0;
+    {
+        const int ntn = a.n_tiles;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int mt = (slot / ntn) * 8 + xcd;
+        if (mt >= tiles_x * tiles_y) return;
+        n0 = (slot - (slot / ntn) * ntn) * 32;
+        const int ty = mt / tiles_x;
+        y0 = ty * TH;
+        x0 = (mt - ty * tiles_x) * TW;
+    }
+
+    // ---- LDS-DMA sources ------------------------------------------------------------------------------------------
+    const int urow = lane >> 2;
+    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    const int q = wave_all >> 1;
+    const bool lo_p = wave_all & 1;
+    const bool half_on = (lane >> 5) == (q & 1);                    // lanes of this wave's half piece
+    unsigned aoff[NIA];
+    int a_unit[NIA];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int unit = (i < NFA) ? q + 4 * i : 4 * NFA + (q >> 1);
+        a_unit[i] = unit;
+        const int row = unit * 16 + urow;
+        const int hy = row / HWD, hx = row - hy * HWD;
+        const int py = y0 - a.pad_h + hy, px = x0 - a.pad_w + hx;
+        const bool ok = row < HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
+        aoff[i] = ok ? (unsigned)(((py * a.W + px) * 32 + uchunk) * 2) : 0x80000000u;
+    }
+    const unsigned wvo0 = (unsigned)(((n0 + urow) * 32 + uchunk) * 2), wvo1 = wvo0 + 16 * 64;   // weight rows of unit 0 / 1
+    const int CB2 = a.CB - a.CB1;
+    const int plane_b = a.P_in * 64;
+    const rsrc_t r_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_p ? a.xl : a.xh) + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_p ? a.x2l : a.x2h) + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const int wtile_b = a.cout_pad * 64;
+    const rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(lo_p ? a.wl : a.wh), 0, NTAPS * a.CB * wtile_b, 0x00020000);
+    char* const a_dst = lds + (lo_p ? A_PLANE : 0);
+    char* const w_dst = lds + O_B + (lo_p ? 2048 : 0);
+
+#define H8_ISSUE_A(CBI, BUF)                                                                                             \
+    {                                                                                                                    \
+        const int cbi_ = (CBI) < a.CB ? (CBI) : a.CB - 1;                                                                \
+        const bool first_ = cbi_ < a.CB1;                                                                                \
+        const rsrc_t ra_ = first_ ? r_a1 : r_a2;                                                                         \
+        const int so_ = (first_ ? cbi_ : cbi_ - a.CB1) * plane_b;                                                        \
+        _Pragma("unroll") for (int i = 0; i < NIA; ++i)                                                                  \
+            if (i < NFA || half_on)                                                                                      \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lptr_t)(a_dst + (BUF) * A_BUF + a_unit[i] * 1024), 16, aoff[i], so_, 0, 0); \
+    }
+    // weight slot for step (CBI, ST): taps ST*TPS .. ST*TPS + TPS - 1; piece idx -> tap idx / 2, unit idx & 1
+#define H8_ISSUE_B(CBI, ST, SLOT)                                                                                        \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NIB; ++i) {                                                                \
+            const int idx_ = (i < NFB) ? q + 4 * i : 4 * NFB + (q >> 1);                                                 \
+            const int so_ = (((ST) * TPS + (idx_ >> 1)) * a.CB + (CBI)) * wtile_b;   /* past the end: out of range, never consumed */ \
+            if (i < NFB || half_on)                                                                                      \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (SLOT) * B_SLOT + (idx_ >> 1) * B_TAP + (idx_ & 1) * 1024), 16, \
+                                                         (idx_ & 1) ? wvo1 : wvo0, so_, 0, 0);                           \
+        }                                                                                                                \
+    }
+
+    f32x16 hh[1], x1, x2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        hh[0][r] = 0.f;
+        x1[r] = 0.f;
+        x2[r] = 0.f;
+    }
+
+    H8_ISSUE_A(0, 0)
+    H8_ISSUE_B(0, 0, 0)
+
+    const int R0 = (wave * 2 + (l31 >> 4)) * HWD + (l31 & 15);
+    const int kq = grp * 2 + kh;                                    // this lane's 16-B k-chunk of the 64-B row
+    const int wro = l31 * 64 + ((kq ^ ((l31 >> 2) & 3)) * 16);      // weight fragment offset inside a (tap, plane) tile
+    int cur = 0;
+    for (int cb = 0; cb < a.CB; ++cb) {
+        const char* abuf = lds + (cb & 1) * A_BUF;
+        static_for<0, NTAPS>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int st = t / TPS, j = t % TPS;
+            if (j == 0) {                          // ---- step boundary
+                // in flight, oldest first: [halo of block cb+1 (issued at st 0, AFTER that step's weights)], weights of this step
+                if (NST > 1 && st == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    constexpr int stn = (st + 1) % NST;
+                    const int cbn = cb + (st + 1) / NST;
+                    H8_ISSUE_B(cbn, stn, cur ^ 1)
+                }
+                if (st == 0) H8_ISSUE_A(cb + 1, (cb + 1) & 1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const char* wcur = lds + O_B + cur * B_SLOT;
+            const int R = R0 + (t / KW) * HWD + (t % KW);
+            const int ao = R * 64 + ((kq ^ ((R >> 2) & 3)) * 16);
+            const half8 xh = *reinterpret_cast<const half8*>(abuf + ao);
+            const half8 xl = *reinterpret_cast<const half8*>(abuf + A_PLANE + ao);
+            const half8 wh = *reinterpret_cast<const half8*>(wcur + j * B_TAP + wro);
+            const half8 wl = *reinterpret_cast<const half8*>(wcur + j * B_TAP + 2048 + wro);
+            hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh[0], 0, 0, 0);   // D[channel][pixel]
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, x1, 0, 0, 0);
+            x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, x2, 0, 0, 0);
+            if (j == TPS - 1) {
+                __builtin_amdgcn_sched_barrier(0);   // fragment reads complete before the next barrier releases the refill
+                cur ^= 1;
+            }
+        });
+    }
+#undef H8_ISSUE_A
+#undef H8_ISSUE_B
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- combine the two k-halves through LDS, then group 0 runs the shared epilogue -------------------------------------
+    {
+        float* xch = reinterpret_cast<float*>(lds) + 2 * 4 * 32;
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64 + lane] = hh[0][r] + (x1[r] + x2[r]) * LO_INV;
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hh[0][r] += xch[(wave * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    f32x16 xx[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xx[0][r] = x1[r] + x2[r];
+    const int W = a.W, H = a.H, yw = y0 + wave * 2;
+    conv_epilogue<1>(a, hh, xx, b, [=](int row) {
+        const int y = yw + (row >> 4), x = x0 + (row & 15);
+        return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, grp == 0, reinterpret_cast<float*>(lds));
 #endif
 }
 
@@ -767,9 +978,17 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
     a.out_f32 = d->out_f32; a.oh = (_Float16*)d->out_hi; a.ol = (_Float16*)d->out_lo;
     const int out_c = d->out_channel_stride > 0 ? d->out_channel_stride : (d->Cout + 31) / 32 * 32;
-    BFLOW_REQUIRE(out_c % 32 == 0 && d->out_channel_offset + d->Cout <= out_c, BFLOW_E_ARG, "conv_split: bad output channel layout");
+    BFLOW_REQUIRE(out_c % 32 == 0 && (d->gate == 1 ? d->Cout == 2 * out_c : d->out_channel_offset + d->Cout <= out_c), BFLOW_E_ARG,
+                  "conv_split: bad output channel layout");
     a.CBo = out_c / 32; a.cb_off = d->out_channel_offset / 32; a.P_out = d->out_rows_per_image > 0 ? d->out_rows_per_image : Ho * Wo;
     a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
+    a.gate = d->gate; a.gh = (const _Float16*)d->gate_h_hi; a.gl = (const _Float16*)d->gate_h_lo; a.gz = d->gate_z;
+    if (d->gate) {
+        BFLOW_REQUIRE((d->gate == 1 || d->gate == 2) && d->gate_h_hi && d->gate_h_lo && d->out_hi && d->out_lo && !d->stats && d->act == 0 &&
+                          d->out_channel_offset == 0 && d->Cout % 32 == 0, BFLOW_E_ARG, "conv_split: bad gate arguments");
+        BFLOW_REQUIRE(d->gate == 1 ? (d->out_f32 && d->Cout == 2 * out_c) : (d->gate_z && d->Cout == out_c), BFLOW_E_ARG,
+                      "conv_split: gate buffers must hold Cout/2 (zr) or Cout (blend) channels");
+    }
     a.n_tiles = bflow::ceil_div(d->Cout, d->tile_n);
     const int m_tiles8 = (bflow::ceil_div((long long)Ho * Wo, CBM) + 7) / 8 * 8;   // pixel tiles, padded to the 8 XCDs
     dim3 grid(m_tiles8 * a.n_tiles, 1, d->B);
@@ -779,7 +998,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     const char* force = getenv("BFLOW_CONV_KERNEL");           // tests: "generic" forces the generic kernel for every shape
     const bool same = d->stride == 1 && d->pad_w == (d->KW - 1) / 2 && d->pad_h == (d->KH - 1) / 2;
     const int shape = (d->KH == 3 && d->KW == 3) ? 1 : (d->KH == 1 && d->KW == 5) ? 2 : (d->KH == 5 && d->KW == 1) ? 3 : 0;
-    if (same && shape && !(force && strcmp(force, "halo") != 0)) {
+    if (same && shape && !(force && strncmp(force, "halo", 4) != 0)) {
         const int patches = bflow::ceil_div(d->H, 8) * bflow::ceil_div(d->W, 16);
         const int patches8 = (patches + 7) / 8 * 8;
         // 64-channel tiles unless that leaves most CUs without a workgroup (batch-1 update block: 40 patches)
@@ -792,10 +1011,18 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<N, KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((conv_halo_kernel<N, KHH, KWW>), hgrid, dim3(CT), lds, s, a);                               \
     }
-        if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else LAUNCH_HALO(1, 3, 3) }
-        else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else LAUNCH_HALO(1, 1, 5) }
-        else { if (nt == 2) LAUNCH_HALO(2, 5, 1) else LAUNCH_HALO(1, 5, 1) }
+#define LAUNCH_HALO8(KHH, KWW)                                                                                         \
+    {                                                                                                                  \
+        const int lds = 2 * 2 * (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16) * 1024 + 2 * ((KHH) * (KWW) == 9 ? 3 : (KHH) * (KWW)) * 4096; \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo8_kernel<KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((conv_halo8_kernel<KHH, KWW>), hgrid, dim3(2 * CT), lds, s, a);                             \
+    }
+        const bool small8 = nt == 1 && !(force && strcmp(force, "halo4") == 0);   // small grids: the 8-wave split-k variant
+        if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }
+        else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else if (small8) LAUNCH_HALO8(1, 5) else LAUNCH_HALO(1, 1, 5) }
+        else { if (nt == 2) LAUNCH_HALO(2, 5, 1) else if (small8) LAUNCH_HALO8(5, 1) else LAUNCH_HALO(1, 5, 1) }
 #undef LAUNCH_HALO
+#undef LAUNCH_HALO8
         return bflow::launch_status("conv_split(halo)");
     }
     const bool deep = nblocks <= 320;   // at most ~1 workgroup per CU: spend the LDS on prefetch depth instead of co-residency

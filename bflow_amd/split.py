@@ -14,6 +14,7 @@ import torch
 from . import hip
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+GATE_NONE, GATE_ZR, GATE_BLEND = 0, 1, 2
 LO_INV = 1.0 / 2048.0
 
 
@@ -115,11 +116,13 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
          shift: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_split: Optional[SplitTensor] = None,
          out_f32: Optional[torch.Tensor] = None, channel_offset: int = 0, stats: Optional[torch.Tensor] = None,
          want_split: bool = True, want_f32: bool = False, out_rows: Optional[int] = None, zero_rows: bool = False,
-         x2: Optional[SplitTensor] = None, addend: Optional[torch.Tensor] = None, tile: Optional[int] = None):
+         x2: Optional[SplitTensor] = None, addend: Optional[torch.Tensor] = None, tile: Optional[int] = None,
+         gate: int = GATE_NONE, gate_h: Optional[SplitTensor] = None, gate_z: Optional[torch.Tensor] = None):
     """Implicit-GEMM convolution.  `packed` = PackedConvWeight.get(weight).  Returns (split_out or None, f32_out or None);
     f32_out is blocked fp32 (B, Cs/32, P_out, 32).  When out_* buffers are given the result is written at channel
     `channel_offset` (a multiple of 32) of their channel dimension (free concatenation).  out_rows > Ho*Wo allocates
-    zero-filled tail rows (K5's 128-row operand padding)."""
+    zero-filled tail rows (K5's 128-row operand padding).
+    gate = GATE_ZR / GATE_BLEND fuses the SepConvGRU element-wise stage (update.py:38-47) into the epilogue: see bflow_conv_desc_t."""
     planes, (cout, cin_pad, kh, kw, cout_pad) = packed
     B, H, W, _ = x.shape
     c_in = x.channels_padded + (0 if x2 is None else x2.channels_padded)
@@ -141,7 +144,14 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
             assert o.shape[0] == B and o.shape[2] == rows and o.shape[3] == 32 and o.is_contiguous()
             assert cs is None or cs == o.shape[1] * 32
             cs = o.shape[1] * 32
-    assert cs is not None and channel_offset % 32 == 0 and channel_offset + cout <= cs
+    assert cs is not None and channel_offset % 32 == 0
+    if gate == GATE_NONE:
+        assert channel_offset + cout <= cs
+    else:
+        ch = cout // 2 if gate == GATE_ZR else cout
+        assert cs == ch and channel_offset == 0 and out_split is not None and gate_h is not None and gate_h.planes.shape == out_split.planes.shape
+        assert gate != GATE_ZR or (out_f32 is not None and tuple(out_f32.shape) == (B, ch // 32, rows, 32))
+        assert gate != GATE_BLEND or (gate_z is not None and tuple(gate_z.shape) == (B, ch // 32, rows, 32) and gate_z.dtype == torch.float32)
     d = hip.ConvDesc()
     d.x_hi, d.x_lo, d.w_hi, d.w_lo = x.hi.data_ptr(), x.lo.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr()
     d.B, d.H, d.W, d.C, d.Cout, d.cout_pad = B, H, W, cin_pad, cout, cout_pad
@@ -159,6 +169,9 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
     d.shift = None if shift is None else hip._dev(shift, name="shift")
     d.act = act
     d.stats = None if stats is None else hip._dev(stats, torch.float64, "stats")
+    if gate != GATE_NONE:
+        d.gate, d.gate_h_hi, d.gate_h_lo = gate, gate_h.hi.data_ptr(), gate_h.lo.data_ptr()
+        d.gate_z = None if gate_z is None else gate_z.data_ptr()
     hip._check(hip.lib().bflow_conv_split(ctypes.byref(d), hip._stream()), "bflow_conv_split")
     return out_split, out_f32
 

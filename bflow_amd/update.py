@@ -12,6 +12,7 @@ from __future__ import annotations
 
 from typing import Any, Dict, Optional
 
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -102,6 +103,7 @@ class SplitWorkspace:
         hd, md = blk.hidden_dim, blk.motion_dim
         self.H = S.SplitTensor.empty(batch, h, w, hd, device)                    # hidden state
         self.RH = S.SplitTensor.empty(batch, h, w, hd, device)                   # r * h
+        self.Z = torch.empty((batch, hd // 32, h * w, 32), dtype=torch.float32, device=device)   # update gate z (blocked fp32)
         self.M = S.SplitTensor.empty(batch, h, w, md + 32, device, zero=True)    # [motion conv (md-2deg, zero padded to md) | Bezier block]
         self.INP = None                                                          # relu(context) split, set by set_context
         self.corbez = S.SplitTensor.empty(batch, h, w, 256, device)
@@ -254,10 +256,9 @@ class BasicUpdateBlock(nn.Module):
         # ---- separable conv-GRU (update.py:33-48)
         for sfx, (t_zr, t_q) in zip(("1", "2"), ws.inp_terms):
             zr_hm, q_hm, _, _, _, _, pad = self._gate_weights(sfx)
-            _, zr = S.conv(ws.H, zr_hm, x2=ws.M, padding=pad, addend=t_zr, want_split=False, want_f32=True)
-            S.gru_rh(zr, ws.H, ws.RH)
-            _, q = S.conv(ws.RH, q_hm, x2=ws.M, padding=pad, addend=t_q, want_split=False, want_f32=True)
-            S.gru_blend(zr, q, ws.H)
+            # z | r in one convolution; sigmoid, r * h (-> RH) and the final blend (-> H, in place) live in the conv epilogues
+            S.conv(ws.H, zr_hm, x2=ws.M, padding=pad, addend=t_zr, gate=S.GATE_ZR, gate_h=ws.H, out_split=ws.RH, out_f32=ws.Z)
+            S.conv(ws.RH, q_hm, x2=ws.M, padding=pad, addend=t_q, gate=S.GATE_BLEND, gate_h=ws.H, gate_z=ws.Z, out_split=ws.H)
         # ---- heads (update.py:17-18,111-114,120-125)
         bh = self.bezier_head
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)

@@ -95,6 +95,15 @@ typedef struct bflow_conv_desc {
     const float *scale, *shift;       /* per output channel, or NULL (= 1 / 0)                                   */
     int act;                          /* 0 = identity, 1 = relu, 2 = tanh                                        */
     double* stats;                    /* or NULL                                                                 */
+    int gate;                         /* fused SepConvGRU gates (update.py:38-47), evaluated in the epilogue on v = conv + addend:
+                                         0 = none;
+                                         1 = "zr": Cout = 2*Ch.  channels [0, Ch): out_f32[c] = sigmoid(v) (the update gate z);
+                                             channels [Ch, 2Ch): out_hi/lo[c - Ch] = split(sigmoid(v) * h[c - Ch])  (r * h);
+                                         2 = "blend": Cout = Ch.  out_hi/lo[c] = split((1 - z[c]) * h[c] + z[c] * tanh(v));
+                                         h = gate_h_hi/lo, z = gate_z; every gate buffer is blocked (B, Ch/32, P_out, 32) like the
+                                         outputs (out_channel_stride = Ch, offset 0); out may alias h (blend, in place).       */
+    const void *gate_h_hi, *gate_h_lo;
+    const float* gate_z;
 } bflow_conv_desc_t;
 int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
                             int cout_pad, int cin_pad, bflow_stream_t stream);
