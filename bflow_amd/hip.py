@@ -357,3 +357,43 @@ def epe_accumulate(pred: torch.Tensor, gt: torch.Tensor, valid: Optional[torch.T
         pv = _dev(valid.view(torch.uint8) if valid.dtype == torch.bool else valid, torch.uint8, "valid")
     _check(lib().bflow_epe_accumulate(_dev(pred, name="pred"), _dev(gt, name="gt"), pv, B, C, HW, _dev(acc, torch.float64, "acc"), _stream()),
            "bflow_epe_accumulate")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Two-branch concurrency.  The batch-1 kernels of the update block launch <= 240 workgroups for 256 CUs and independent
+# branches (correlation features vs. Bezier features in the motion encoder, context encoder vs. feature encoder) exist,
+# so a branch is issued on a side stream between fork() and join().  Under hipGraph capture the stream dependencies become
+# graph edges; in eager mode they are stream waits.  Buffers that cross the branches are owned by the caller's workspace
+# (alive until after the join), branch-local temporaries are stream-ordered on the side stream.
+# ----------------------------------------------------------------------------------------------------------------------
+_side_streams = {}
+
+
+class Branch:
+    """`with Branch(enabled) as br:` runs the block on the side stream; `br.join()` makes the current stream wait for it."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled and torch.cuda.is_available()
+        self._ctx = None
+        if self.enabled:
+            self.main = torch.cuda.current_stream()
+            key = self.main.device_index
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device=self.main.device)
+            self.side = _side_streams[key]
+
+    def __enter__(self):
+        if self.enabled:
+            self.side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.enabled:
+            self.main.wait_stream(self.side)

@@ -184,45 +184,51 @@ class RAFTSpline(nn.Module):
             fm = net(x).float()
             return CorrComputation(fm[:n_ref], fm[n_ref:].view(T, n_ref, *fm.shape[1:]), num_levels_per_target=levels)
 
+        # ---- inputs of the three encoders (raft.py:118-141)
+        grids = None
         if self.fnet_ev is not None:
             assert voxel_grid is not None
-            if tm: tm.start("fnet_ev")
             voxel_grid = voxel_grid.contiguous().float()
             grids, context_input = self.gen_voxel_grids(voxel_grid)
-            B = voxel_grid.shape[0]
-            corr_ev = encode_pair(self.fnet_ev, torch.cat(grids, dim=0), B, self.ev_corr_levels)   # [reference | targets]
-            if tm: tm.stop("fnet_ev")
-
         if self.fnet_img is not None:
             assert images is not None and len(images) == 2
-            if tm: tm.start("fnet_img")
             images = [2 * (x.float().contiguous() / 255) - 1 for x in images]   # raft.py:134
-            B = images[0].shape[0]
-            corr_img = encode_pair(self.fnet_img, torch.cat(images, dim=0), B, self.img_corr_params["levels"])
             context_input = images[0] if context_input is None else torch.cat((context_input, images[0]), dim=-3)
-            if tm: tm.stop("fnet_img")
         assert context_input is not None
         B, _, H, W = context_input.shape
         assert H % 8 == 0 and W % 8 == 0                                       # bezier.py:67-68
         h, w = H // 8, W // 8
         device = context_input.device
 
+        # ---- context encoder on a side stream: a batch-1 chain of small launches that hides under the 5-image feature encoder
         ub = self.update_block
         engine_update = engine and UPDATE_ENGINE == "split" and ub.hidden_dim % 32 == 0 and ub.motion_dim % 32 == 0 \
             and ub.context_dim % 32 == 0 and ub.bezier_planes <= 32
         if tm: tm.start("cnet")
-        if engine_update:
-            ws = ub.new_split_workspace(B, h, w, device)
-            ub.set_context_split(ws, self.cnet.forward_split(context_input.contiguous(), trunk_only=True), self.cnet.conv2)
-        elif engine:
-            ws = ub.new_workspace(B, h, w, device)
-            ws.set_context_split(self.cnet.forward_split(context_input.contiguous()))
-        else:
-            ws = ub.new_workspace(B, h, w, device)
-            trunk = self.cnet(context_input.contiguous(), project=False)
-            cnet = torch.nn.functional.conv2d(trunk, self.cnet.conv2.weight)     # bias folded into the split kernel
-            ws.set_context(cnet, self.cnet.conv2.bias)
+        with hip.Branch(tm is None) as cnet_branch:
+            if engine_update:
+                ws = ub.new_split_workspace(B, h, w, device)
+                ws.overlap = tm is None
+                ub.set_context_split(ws, self.cnet.forward_split(context_input.contiguous(), trunk_only=True), self.cnet.conv2)
+            elif engine:
+                ws = ub.new_workspace(B, h, w, device)
+                ws.set_context_split(self.cnet.forward_split(context_input.contiguous()))
+            else:
+                ws = ub.new_workspace(B, h, w, device)
+                trunk = self.cnet(context_input.contiguous(), project=False)
+                cnet = torch.nn.functional.conv2d(trunk, self.cnet.conv2.weight)     # bias folded into the split kernel
+                ws.set_context(cnet, self.cnet.conv2.bias)
         if tm: tm.stop("cnet")
+
+        # ---- feature encoders + correlation volumes
+        if self.fnet_ev is not None:
+            if tm: tm.start("fnet_ev")
+            corr_ev = encode_pair(self.fnet_ev, torch.cat(grids, dim=0), B, self.ev_corr_levels)   # [reference | targets]
+            if tm: tm.stop("fnet_ev")
+        if self.fnet_img is not None:
+            if tm: tm.start("fnet_img")
+            corr_img = encode_pair(self.fnet_img, torch.cat(images, dim=0), B, self.img_corr_params["levels"])
+            if tm: tm.stop("fnet_img")
 
         bezier = torch.zeros((B, 2 * self.bezier_degree, h, w), dtype=torch.float32, device=device)   # raft.py:150
         if flow_init is not None:
@@ -232,6 +238,7 @@ class RAFTSpline(nn.Module):
         if tm: tm.start("corr computation")
         corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img)
         if tm: tm.stop("corr computation")
+        cnet_branch.join()
 
         coef = self._coefficients()
         corr_feat = corr_block.new_output()
@@ -241,10 +248,16 @@ class RAFTSpline(nn.Module):
         if tm: tm.start("all iters")
         for itr in range(iters):
             if tm: tm.start("1 iter")
+            need_mask = (not test_mode) or itr == iters - 1
+            if engine_update and tm is None:
+                # the look-up runs inside the step, next to the (independent) Bezier branch of the motion encoder
+                mask = ub.step_split(ws, lambda: corr_block.lookup_bezier(bezier, coef, out=corr_feat), bezier, need_mask)
+                if need_mask:
+                    ups.append(hip.cvx_upsample(bezier, mask, None, 0.25))
+                continue
             if tm: tm.start("corr lookup (per iter)")          # includes 'get_flow (per iter)': fused into the gather
             corr_block.lookup_bezier(bezier, coef, out=corr_feat)
             if tm: tm.stop("corr lookup (per iter)")
-            need_mask = (not test_mode) or itr == iters - 1
             if tm: tm.start("update (per iter)")
             if engine_update:
                 mask = ub.step_split(ws, corr_feat, bezier, need_mask)

@@ -108,6 +108,7 @@ class SplitWorkspace:
         self.INP = None                                                          # relu(context) split, set by set_context
         self.corbez = S.SplitTensor.empty(batch, h, w, 256, device)
         self.inp_terms = None
+        self.overlap = True                                                      # independent branches on a side stream
 
 
 class BasicUpdateBlock(nn.Module):
@@ -235,22 +236,25 @@ class BasicUpdateBlock(nn.Module):
             terms.append((t_zr, t_q))
         ws.inp_terms = terms
 
-    def step_split(self, ws: SplitWorkspace, corr: torch.Tensor, bezier: torch.Tensor, need_mask: bool):
-        """One iteration of update.py:116-126 on the split-fp16 engine.  corr: (B, P*81, h, w) fp32 (look-up output), bezier:
-        (B, 2*deg, h, w) fp32 updated IN PLACE.  Returns the mask logits incl. bias (B, 576, h, w) fp32 or None."""
+    def step_split(self, ws: SplitWorkspace, corr, bezier: torch.Tensor, need_mask: bool):
+        """One iteration of update.py:116-126 on the split-fp16 engine.  corr: (B, P*81, h, w) fp32 (look-up output) or a callable
+        producing it (then the look-up itself overlaps with the Bezier branch), bezier: (B, 2*deg, h, w) fp32 updated IN PLACE.
+        Returns the mask logits incl. bias (B, 576, h, w) fp32 or None."""
         enc = self.encoder
         # ---- motion encoder (update.py:88-97); every bias + relu lives in a conv epilogue, every cat is a channel offset
-        cs = S.from_nchw(corr)
+        # the Bezier branch (7x7 as im2col + 1x1 GEMM, then 3x3) is independent of the correlation branch: side stream
+        with hip.Branch(ws.overlap) as flow_branch:
+            kh, kw = enc.convf1.kernel_size
+            col = S.im2col_small(bezier, kh, kw, enc.convf1.padding)
+            f1, _ = S.conv(col, self._pk("convf1_cols", lambda a=enc.convf1.weight: a.permute(0, 2, 3, 1).reshape(a.shape[0], -1, 1, 1)),
+                           shift=enc.convf1.bias, act=S.ACT_RELU)
+            S.conv(f1, self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
+                   out_split=ws.corbez, channel_offset=192)
+        cs = S.from_nchw(corr() if callable(corr) else corr)
         c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
         S.conv(c1, self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
                out_split=ws.corbez, channel_offset=0)
-        # 7x7 over the 2*deg Bezier channels as a dense 1x1 GEMM over an im2col'ed split tensor (K = 49*2deg instead of 49 k-tiles)
-        kh, kw = enc.convf1.kernel_size
-        col = S.im2col_small(bezier, kh, kw, enc.convf1.padding)
-        f1, _ = S.conv(col, self._pk("convf1_cols", lambda a=enc.convf1.weight: a.permute(0, 2, 3, 1).reshape(a.shape[0], -1, 1, 1)),
-                       shift=enc.convf1.bias, act=S.ACT_RELU)
-        S.conv(f1, self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
-               out_split=ws.corbez, channel_offset=192)
+        flow_branch.join()
         S.conv(ws.corbez, self._pk("conv", lambda a=enc.conv.weight: a), padding=1, shift=enc.conv.bias, act=S.ACT_RELU,
                out_split=ws.M, channel_offset=0)
         # ---- separable conv-GRU (update.py:33-48)
