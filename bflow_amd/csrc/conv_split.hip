@@ -55,6 +55,7 @@ struct ConvArgs {
     int gate;                  // 0 | 1 (zr) | 2 (blend): fused GRU gates, see bflow_conv_desc_t
     const _Float16 *gh, *gl;   // h planes (B, CBo, P_out, 32)
     const float* gz;           // z (B, CBo, P_out, 32)
+    float* acc;                // fp32 (B, Cout, Ho*Wo) accumulated in place, or null
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -124,6 +125,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                     else if (a.act == 2) v[k] = tanhf(v[k]);
                     if (!cok[k]) v[k] = 0.f;                // padded channels of the last block are written as zeros
                     if (mok) { s1[k] += v[k]; s2[k] += v[k] * v[k]; }
+                }
+                if (mok && a.acc) {                             // acc[b, c, m] += v; continue with the updated value
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (cok[k]) {
+                            float* pa = a.acc + ((long long)b * a.Cout + cbase + ch + k) * (a.Ho * a.Wo) + m;
+                            v[k] += *pa;
+                            *pa = v[k];
+                        }
                 }
                 if (mok && a.gate) {
                     // SepConvGRU gates (update.py:38-47).  Block index inside the (B, CBo, P, 32) gate buffers: the z half of a
@@ -586,31 +596,32 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 //   * 8 waves: wave (s, g) owns pixel slab s like above but only k-half g of every 32-channel block (the two 16-deep MFMA
 //     sub-steps are split across the groups, which share the staged halo AND the weight tiles); two waves per SIMD
 //     interleave, the partial sums are combined through LDS at the end;
-//   * a step is a whole filter row (3x3: 3 taps) or the whole filter (1x5 / 5x1: 5 taps): 3-5x fewer barriers;
+//   * a step is 3 taps (a filter row of a 3x3; 3 + 2 taps of a 1x5 / 5x1): ~3x fewer barriers, LDS 64-72 KB so that two
+//     workgroups fit a CU (the 320 workgroups of the 256-channel z|r convolution then run in one round);
 //   * 32-channel tile only (NT = 1), 2 weight slots; the fragment reads of a step are pinned before the next barrier
 //     (sched_barrier), so a slot / halo buffer may be refilled one barrier after its last reader;
 //   * the 8 waves split every stage into whole 1-KB pieces plus, when the count is not a multiple of 8, one half piece
 //     (lanes 0-31 or 32-63 active).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KH, int KW>
-__global__ __launch_bounds__(2 * CT, 1) void conv_halo8_kernel(ConvArgs a) {
+__global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 8, TW = 16;
     constexpr int HWD = TW + KW - 1, HR = HWD * (TH + KH - 1);
     constexpr int A_UNITS = (HR + 15) / 16;
     constexpr int A_PLANE = A_UNITS * 1024, A_BUF = 2 * A_PLANE;
     constexpr int NTAPS = KH * KW;
-    constexpr int TPS = (NTAPS == 9) ? 3 : NTAPS;                   // taps per step
-    constexpr int NST = NTAPS / TPS;                                // steps per channel block (3 or 1)
+    constexpr int TPS = 3;                                          // taps per step (the last step of a 5-tap filter has 2)
+    constexpr int NST = (NTAPS + TPS - 1) / TPS;                    // steps per channel block (3 or 2)
     constexpr int B_TAP = 4096, B_SLOT = TPS * B_TAP;               // per tap: 32 weight rows x 64 B x 2 planes
     constexpr int O_B = 2 * A_BUF;
     // wave (q, plane): plane = wave_all & 1 (hi / lo), q = wave_all >> 1.  Per plane a halo buffer is A_UNITS 1-KB pieces and a
     // weight slot 2*TPS (tap-major, 2 units per tap); wave q takes pieces q + 4 i, and when the count is 4 k + 2 the last two
     // pieces are split into half pieces (q >> 1), half (q & 1): lanes 0-31 or 32-63 active.
-    constexpr int NFA = A_UNITS / 4, NFB = (2 * TPS) / 4;           // whole pieces per wave
-    constexpr bool HALF_A = (A_UNITS % 4) != 0, HALF_B = ((2 * TPS) % 4) != 0;
+    constexpr int NFA = A_UNITS / 4;                                // whole pieces per wave
+    constexpr bool HALF_A = (A_UNITS % 4) != 0;
     static_assert(A_UNITS % 2 == 0, "stages must split into whole + half pieces over 4 waves per plane");
-    constexpr int NIA = NFA + (HALF_A ? 1 : 0), NIB = NFB + (HALF_B ? 1 : 0);   // load instructions per wave per stage
+    constexpr int NIA = NFA + (HALF_A ? 1 : 0);                     // halo load instructions per wave per channel block
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -669,13 +680,16 @@ __global__ __launch_bounds__(2 * CT, 1) void conv_halo8_kernel(ConvArgs a) {
             if (i < NFA || half_on)                                                                                      \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lptr_t)(a_dst + (BUF) * A_BUF + a_unit[i] * 1024), 16, aoff[i], so_, 0, 0); \
     }
-    // weight slot for step (CBI, ST): taps ST*TPS .. ST*TPS + TPS - 1; piece idx -> tap idx / 2, unit idx & 1
+    // weight slot for step (CBI, ST): taps ST*TPS .. ; piece idx -> tap idx / 2, unit idx & 1.  ST is a compile-time constant.
 #define H8_ISSUE_B(CBI, ST, SLOT)                                                                                        \
     {                                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < NIB; ++i) {                                                                \
-            const int idx_ = (i < NFB) ? q + 4 * i : 4 * NFB + (q >> 1);                                                 \
+        constexpr int ntp_ = (NTAPS - (ST) * TPS) < TPS ? (NTAPS - (ST) * TPS) : TPS;      /* taps of this step */       \
+        constexpr int nfb_ = (2 * ntp_) / 4;                                                                             \
+        constexpr bool halfb_ = ((2 * ntp_) % 4) != 0;                                                                   \
+        _Pragma("unroll") for (int i = 0; i < nfb_ + (halfb_ ? 1 : 0); ++i) {                                            \
+            const int idx_ = (i < nfb_) ? q + 4 * i : 4 * nfb_ + (q >> 1);                                               \
             const int so_ = (((ST) * TPS + (idx_ >> 1)) * a.CB + (CBI)) * wtile_b;   /* past the end: out of range, never consumed */ \
-            if (i < NFB || half_on)                                                                                      \
+            if (i < nfb_ || half_on)                                                                                     \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (SLOT) * B_SLOT + (idx_ >> 1) * B_TAP + (idx_ & 1) * 1024), 16, \
                                                          (idx_ & 1) ? wvo1 : wvo0, so_, 0, 0);                           \
         }                                                                                                                \
@@ -725,7 +739,7 @@ __global__ __launch_bounds__(2 * CT, 1) void conv_halo8_kernel(ConvArgs a) {
             hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh[0], 0, 0, 0);   // D[channel][pixel]
             x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, x1, 0, 0, 0);
             x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, x2, 0, 0, 0);
-            if (j == TPS - 1) {
+            if (j == TPS - 1 || t == NTAPS - 1) {
                 __builtin_amdgcn_sched_barrier(0);   // fragment reads complete before the next barrier releases the refill
                 cur ^= 1;
             }
@@ -982,6 +996,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
                   "conv_split: bad output channel layout");
     a.CBo = out_c / 32; a.cb_off = d->out_channel_offset / 32; a.P_out = d->out_rows_per_image > 0 ? d->out_rows_per_image : Ho * Wo;
     a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
+    a.acc = d->acc_nchw;
     a.gate = d->gate; a.gh = (const _Float16*)d->gate_h_hi; a.gl = (const _Float16*)d->gate_h_lo; a.gz = d->gate_z;
     if (d->gate) {
         BFLOW_REQUIRE((d->gate == 1 || d->gate == 2) && d->gate_h_hi && d->gate_h_lo && d->out_hi && d->out_lo && !d->stats && d->act == 0 &&
@@ -1013,7 +1028,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     }
 #define LAUNCH_HALO8(KHH, KWW)                                                                                         \
     {                                                                                                                  \
-        const int lds = 2 * 2 * (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16) * 1024 + 2 * ((KHH) * (KWW) == 9 ? 3 : (KHH) * (KWW)) * 4096; \
+        const int lds = 2 * 2 * (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16) * 1024 + 2 * 3 * 4096;                   \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo8_kernel<KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((conv_halo8_kernel<KHH, KWW>), hgrid, dim3(2 * CT), lds, s, a);                             \
     }

@@ -51,7 +51,8 @@ class ConvDesc(ctypes.Structure):
                 ("in_rows_per_image", ctypes.c_int), ("x2_hi", ctypes.c_void_p), ("x2_lo", ctypes.c_void_p),
                 ("x_split_channels", ctypes.c_int), ("addend", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("act", ctypes.c_int), ("stats", ctypes.c_void_p),
-                ("gate", ctypes.c_int), ("gate_h_hi", ctypes.c_void_p), ("gate_h_lo", ctypes.c_void_p), ("gate_z", ctypes.c_void_p)]
+                ("gate", ctypes.c_int), ("gate_h_hi", ctypes.c_void_p), ("gate_h_lo", ctypes.c_void_p), ("gate_z", ctypes.c_void_p),
+                ("acc_nchw", ctypes.c_void_p)]
 
 
 class NormDesc(ctypes.Structure):

@@ -117,11 +117,13 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
          out_f32: Optional[torch.Tensor] = None, channel_offset: int = 0, stats: Optional[torch.Tensor] = None,
          want_split: bool = True, want_f32: bool = False, out_rows: Optional[int] = None, zero_rows: bool = False,
          x2: Optional[SplitTensor] = None, addend: Optional[torch.Tensor] = None, tile: Optional[int] = None,
-         gate: int = GATE_NONE, gate_h: Optional[SplitTensor] = None, gate_z: Optional[torch.Tensor] = None):
+         gate: int = GATE_NONE, gate_h: Optional[SplitTensor] = None, gate_z: Optional[torch.Tensor] = None,
+         acc_nchw: Optional[torch.Tensor] = None):
     """Implicit-GEMM convolution.  `packed` = PackedConvWeight.get(weight).  Returns (split_out or None, f32_out or None);
     f32_out is blocked fp32 (B, Cs/32, P_out, 32).  When out_* buffers are given the result is written at channel
     `channel_offset` (a multiple of 32) of their channel dimension (free concatenation).  out_rows > Ho*Wo allocates
     zero-filled tail rows (K5's 128-row operand padding).
+    acc_nchw (B, cout, Ho, Wo) fp32: accumulated in place (+= result), outputs receive the updated value.
     gate = GATE_ZR / GATE_BLEND fuses the SepConvGRU element-wise stage (update.py:38-47) into the epilogue: see bflow_conv_desc_t."""
     planes, (cout, cin_pad, kh, kw, cout_pad) = packed
     B, H, W, _ = x.shape
@@ -169,6 +171,9 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
     d.shift = None if shift is None else hip._dev(shift, name="shift")
     d.act = act
     d.stats = None if stats is None else hip._dev(stats, torch.float64, "stats")
+    if acc_nchw is not None:
+        assert acc_nchw.dtype == torch.float32 and acc_nchw.is_contiguous() and tuple(acc_nchw.shape) == (B, cout, Ho, Wo) and stats is None
+        d.acc_nchw = acc_nchw.data_ptr()
     if gate != GATE_NONE:
         d.gate, d.gate_h_hi, d.gate_h_lo = gate, gate_h.hi.data_ptr(), gate_h.lo.data_ptr()
         d.gate_z = None if gate_z is None else gate_z.data_ptr()

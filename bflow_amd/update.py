@@ -242,19 +242,21 @@ class BasicUpdateBlock(nn.Module):
         Returns the mask logits incl. bias (B, 576, h, w) fp32 or None."""
         enc = self.encoder
         # ---- motion encoder (update.py:88-97); every bias + relu lives in a conv epilogue, every cat is a channel offset
-        # the Bezier branch (7x7 as im2col + 1x1 GEMM, then 3x3) is independent of the correlation branch: side stream
-        with hip.Branch(ws.overlap) as flow_branch:
-            kh, kw = enc.convf1.kernel_size
-            col = S.im2col_small(bezier, kh, kw, enc.convf1.padding)
-            f1, _ = S.conv(col, self._pk("convf1_cols", lambda a=enc.convf1.weight: a.permute(0, 2, 3, 1).reshape(a.shape[0], -1, 1, 1)),
-                           shift=enc.convf1.bias, act=S.ACT_RELU)
-            S.conv(f1, self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
-                   out_split=ws.corbez, channel_offset=192)
-        cs = S.from_nchw(corr() if callable(corr) else corr)
-        c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
-        S.conv(c1, self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
-               out_split=ws.corbez, channel_offset=0)
-        flow_branch.join()
+        # The correlation branch (look-up -> 1x1 -> 3x3) and the Bezier branch (7x7 as im2col + 1x1 GEMM -> 3x3) are independent.
+        # The LONGER one is issued on the side stream: the graph keeps the captured stream's nodes on one hardware queue, and a
+        # cross-queue join costs ~10 us unless the other side finished long before (measured both ways).
+        with hip.Branch(ws.overlap) as corr_branch:
+            cs = S.from_nchw(corr() if callable(corr) else corr)
+            c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
+            S.conv(c1, self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
+                   out_split=ws.corbez, channel_offset=0)
+        kh, kw = enc.convf1.kernel_size
+        col = S.im2col_small(bezier, kh, kw, enc.convf1.padding)
+        f1, _ = S.conv(col, self._pk("convf1_cols", lambda a=enc.convf1.weight: a.permute(0, 2, 3, 1).reshape(a.shape[0], -1, 1, 1)),
+                       shift=enc.convf1.bias, act=S.ACT_RELU)
+        S.conv(f1, self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
+               out_split=ws.corbez, channel_offset=192)
+        corr_branch.join()
         S.conv(ws.corbez, self._pk("conv", lambda a=enc.conv.weight: a), padding=1, shift=enc.conv.bias, act=S.ACT_RELU,
                out_split=ws.M, channel_offset=0)
         # ---- separable conv-GRU (update.py:33-48)
@@ -266,8 +268,9 @@ class BasicUpdateBlock(nn.Module):
         # ---- heads (update.py:17-18,111-114,120-125)
         bh = self.bezier_head
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
-        _, d2 = S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, want_split=False, want_f32=True)
-        S.bezier_update(bezier, d2, ws.M, self.motion_dim // 32)
+        # bezier += delta (bezier.py:137-139) and the new Bezier channel block of M are produced by the epilogue
+        S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, acc_nchw=bezier, out_split=ws.M,
+               channel_offset=self.motion_dim)
         if not need_mask:
             return None
         m1, _ = S.conv(ws.H, self._pk("mask0", lambda a=self.mask[0].weight: a), padding=1, shift=self.mask[0].bias, act=S.ACT_RELU)

@@ -104,6 +104,10 @@ typedef struct bflow_conv_desc {
                                          outputs (out_channel_stride = Ch, offset 0); out may alias h (blend, in place).       */
     const void *gate_h_hi, *gate_h_lo;
     const float* gate_z;
+    float* acc_nchw;                  /* optional fp32 (B, Cout, Ho*Wo): acc += result (after scale/shift/addend/act); the UPDATED
+                                         value is what out_f32 / out_hi/lo receive.  Fuses BezierCurves.delta_update_params
+                                         (bezier.py:137-139) and the re-emission of the Bezier channel block into the head's last
+                                         convolution.                                                                          */
 } bflow_conv_desc_t;
 int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
                             int cout_pad, int cin_pad, bflow_stream_t stream);

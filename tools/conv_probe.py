@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 B = args.batch
 shapes = [("convc1 1x1 576->256", 576, 256, (1, 1), 1, (0, 0), 60, 80, B), ("convc2 3x3 256->192", 256, 192, (3, 3), 1, (1, 1), 60, 80, B),
           ("gru zr 1x5 288->256", 288, 256, (1, 5), 1, (0, 2), 60, 80, B), ("gru q 5x1 288->128", 288, 128, (5, 1), 1, (2, 0), 60, 80, B),
+          ("gru zr 5x1 288->256", 288, 256, (5, 1), 1, (2, 0), 60, 80, B),
           ("head2 3x3 256->4", 256, 4, (3, 3), 1, (1, 1), 60, 80, B), ("enc l1 3x3 64->64 @240x320", 64, 64, (3, 3), 1, (1, 1), 240, 320, 5 * B),
           ("enc l3 3x3 128->128 @60x80", 128, 128, (3, 3), 1, (1, 1), 60, 80, 5 * B)]
 for name, cin, cout, k, st, pad, H, W, n in shapes:
