@@ -210,3 +210,15 @@ class CorrBlockParallelMultiTarget:
         out = self.new_output() if out is None else out
         hip.corr_lookup_bezier(self._table, params, coef, out)
         return out
+
+    def new_output_split(self):
+        """Zero-initialised blocked split tensor for lookup_bezier_split (pad channels of the last block stay zero)."""
+        from .split import SplitTensor
+        h, w = self._hw
+        return SplitTensor.empty(self._batch, h, w, self.num_planes * 81, self._pyramid[0][0].device, zero=True)
+
+    def lookup_bezier_split(self, params: torch.Tensor, coef: np.ndarray, out):
+        """lookup_bezier writing the conv engine's blocked split layout directly (no NCHW intermediate)."""
+        assert coef.shape[0] == self._num_targets_base
+        hip.corr_lookup_bezier_split(self._table, params, coef, out.planes)
+        return out

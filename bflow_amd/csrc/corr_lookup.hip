@@ -22,7 +22,8 @@ constexpr int R = BFLOW_LOOKUP_RADIUS;   // 4
 constexpr int WIN = 2 * R + 1;           // 9
 constexpr int PATCH = 12;                // floor(c)-5 .. floor(c)+6 covers every bilinear corner incl. round-off flips
 constexpr int PSTRIDE = PATCH * PATCH + 1;  // 145 floats (odd -> bank-conflict free for lane == pixel)
-constexpr int TILE = 64;                 // query pixels per block
+constexpr int TILE = 64;                 // query pixels per block (fp32 NCHW output)
+constexpr int TILE_SPLIT = 16;           // ... of the split-output variant: 2x the workgroups (the gather is latency-bound)
 constexpr int LTHREADS = 192;           // 3 waves: each produces 3 of the 9 window rows in phase 2
 
 struct PlaneDev {
@@ -47,21 +48,28 @@ __device__ __forceinline__ float roundtrip(float x, int size) {
     return (g + 1.0f) * (sm1 / 2.0f);
 }
 
-template <bool FUSED, int BATCH>
+// SPLIT = true: the features are written as the blocked split-fp16 tensor (2 planes (B, CBk, Prow, 32), value = hi + lo/2048) the
+// conv engine consumes (conv_split.hip), instead of fp32 NCHW: the 81 values of a pixel are staged in LDS and written in
+// memory order (lane = 8 consecutive channels of a pixel), which removes the NCHW -> blocked conversion launch per iteration.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+template <bool FUSED, int BATCH, bool SPLIT, int TL>
 __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, const float* __restrict__ src,
-                                                              float* __restrict__ out, int B, int h1, int w1) {
-    __shared__ float patch[TILE * PSTRIDE];
-    __shared__ float s_cx[TILE], s_cy[TILE];
-    __shared__ int s_ox[TILE], s_oy[TILE];
+                                                              float* __restrict__ out, _Float16* __restrict__ oh,
+                                                              _Float16* __restrict__ ol, int CBk, int Prow, int B, int h1, int w1) {
+    __shared__ float patch[TL * PSTRIDE];
+    __shared__ float stage[SPLIT ? TL * (WIN * WIN) : 1];
+    __shared__ float s_cx[TL], s_cy[TL];
+    __shared__ int s_ox[TL], s_oy[TL];
 
     const int tid = threadIdx.x;
     const int N = h1 * w1;
     const int p = blockIdx.y;
     const int b = blockIdx.z;
-    const int n0 = blockIdx.x * TILE;
+    const int n0 = blockIdx.x * TL;
     const PlaneDev pl = args.planes[p];
 
-    if (tid < TILE) {
+    if (tid < TL) {
         const int n = n0 + tid;
         float cx = 0.f, cy = 0.f;
         if (n < N) {
@@ -105,10 +113,10 @@ __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, 
         const int plane_sz = pl.h * pl.w;                       // < 2^24 (checked on the host): 32-bit offsets inside the slab
         const float* slab = pl.base + ((long long)b * N + n0) * plane_sz;
         constexpr int ROWS_PER_PASS = LTHREADS / 16;            // 12
-        static_assert(ROWS_PER_PASS == PATCH && TILE % BATCH == 0, "one pass gathers one 12x12 patch");
-        const int npix = min(TILE, N - n0);
+        static_assert(ROWS_PER_PASS == PATCH && TL % BATCH == 0, "one pass gathers one 12x12 patch");
+        const int npix = min(TL, N - n0);
 #pragma unroll
-        for (int p0 = 0; p0 < TILE; p0 += BATCH) {
+        for (int p0 = 0; p0 < TL; p0 += BATCH) {
             float v[BATCH];
 #pragma unroll
             for (int j = 0; j < BATCH; ++j) {
@@ -129,9 +137,10 @@ __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, 
     }
     __syncthreads();
 
-    // ---- phase 2: lane == pixel, wave w produces window rows dy = 3w .. 3w+2 (27 of the 81 taps) ---------------
+    // ---- phase 2: thread = (pixel, group g of LTHREADS/TL): window rows dy = g, g + G, ... (9 taps each) ----------------
     {
-        const int pix = tid & 63, wv = tid >> 6;
+        constexpr int G = LTHREADS / TL;
+        const int pix = tid % TL, wv = tid / TL;
         const int n = n0 + pix;
         const float cx = s_cx[pix], cy = s_cy[pix];
         const int ox = s_ox[pix], oy = s_oy[pix];
@@ -151,8 +160,9 @@ __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, 
         float* o = out + ((long long)b * args.P * (WIN * WIN) + (long long)p * (WIN * WIN)) * N + n;
         if (n < N) {
 #pragma unroll
-        for (int jr = 0; jr < 3; ++jr) {
-            const int ky = wv * 3 + jr;
+        for (int jr = 0; jr < (WIN + G - 1) / G; ++jr) {
+            const int ky = wv + jr * G;
+            if (ky >= WIN) break;
             float iy = roundtrip(cy + (float)(ky - R), pl.h);
             iy = fminf(fmaxf(iy, -1.0e4f), 1.0e4f);
             const float fy0 = floorf(iy);
@@ -170,9 +180,45 @@ __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, 
                 v += q[PATCH] * (ww * ws);
                 v += q[PATCH + 1] * (we * ws);
                 v = ok ? v : 0.f;
-                o[(long long)(ky * WIN + kx) * N] = v;
+                if (SPLIT) stage[pix * (WIN * WIN) + ky * WIN + kx] = v;
+                else o[(long long)(ky * WIN + kx) * N] = v;
             }
         }
+        }
+    }
+    if (SPLIT) {
+        __syncthreads();
+        // channels [81 p, 81 p + 81) of the pixel tile: items = (channel block, pixel, 8-channel chunk), chunk fastest
+        constexpr int NCH = WIN * WIN;
+        const int c_first = p * NCH, cb_first = c_first >> 5, cb_last = (c_first + NCH - 1) >> 5;
+        const int items = (cb_last - cb_first + 1) * TL * 4;
+        for (int it = tid; it < items; it += LTHREADS) {
+            const int chunk = it & 3, pix = (it >> 2) % TL, cb = cb_first + it / (4 * TL);
+            const int n = n0 + pix;
+            const int k0 = cb * 32 + chunk * 8 - c_first;          // window index of the chunk's first channel
+            if (n >= N || k0 <= -8 || k0 >= NCH) continue;
+            const long long o = (((long long)b * CBk + cb) * Prow + n) * 32 + chunk * 8;
+            const float* sp = stage + pix * NCH;
+            if (k0 >= 0 && k0 + 8 <= NCH) {
+                half8 h8, l8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float x = sp[k0 + k];
+                    const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;   // fp16 subnormals are flushed by the MFMA
+                    h8[k] = (_Float16)h;
+                    l8[k] = (_Float16)((x - h) * 2048.0f);
+                }
+                *reinterpret_cast<half8*>(oh + o) = h8;
+                *reinterpret_cast<half8*>(ol + o) = l8;
+            } else {
+                for (int k = 0; k < 8; ++k) {                   // ragged chunk shared with the neighbouring plane's workgroup
+                    if (k0 + k < 0 || k0 + k >= NCH) continue;
+                    const float x = sp[k0 + k];
+                    const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;
+                    oh[o + k] = (_Float16)h;
+                    ol[o + k] = (_Float16)((x - h) * 2048.0f);
+                }
+            }
         }
     }
 }
@@ -211,9 +257,9 @@ int lookup_batch() {
 template <bool FUSED>
 void launch_lookup(dim3 grid, hipStream_t s, const LookupArgs& a, const float* src, float* out, int B, int h1, int w1) {
     switch (lookup_batch()) {
-        case 16: hipLaunchKernelGGL((corr_lookup_kernel<FUSED, 16>), grid, dim3(LTHREADS), 0, s, a, src, out, B, h1, w1); break;
-        case 64: hipLaunchKernelGGL((corr_lookup_kernel<FUSED, 64>), grid, dim3(LTHREADS), 0, s, a, src, out, B, h1, w1); break;
-        default: hipLaunchKernelGGL((corr_lookup_kernel<FUSED, 32>), grid, dim3(LTHREADS), 0, s, a, src, out, B, h1, w1); break;
+        case 16: hipLaunchKernelGGL((corr_lookup_kernel<FUSED, 16, false, TILE>), grid, dim3(LTHREADS), 0, s, a, src, out, nullptr, nullptr, 0, 0, B, h1, w1); break;
+        case 64: hipLaunchKernelGGL((corr_lookup_kernel<FUSED, 64, false, TILE>), grid, dim3(LTHREADS), 0, s, a, src, out, nullptr, nullptr, 0, 0, B, h1, w1); break;
+        default: hipLaunchKernelGGL((corr_lookup_kernel<FUSED, 32, false, TILE>), grid, dim3(LTHREADS), 0, s, a, src, out, nullptr, nullptr, 0, 0, B, h1, w1); break;
     }
 }
 
@@ -265,4 +311,22 @@ extern "C" int bflow_corr_lookup_bezier(const bflow_plane_t* planes, int P, cons
     dim3 grid(bflow::ceil_div((long long)h1 * w1, TILE), P, B);
     launch_lookup<true>(grid, (hipStream_t)stream, a, params, out, B, h1, w1);
     return bflow::launch_status("corr_lookup_bezier");
+}
+
+extern "C" int bflow_corr_lookup_bezier_split(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
+                                              void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
+                                              bflow_stream_t stream) {
+    LookupArgs a;
+    int rc = fill_args(a, planes, P, T);
+    if (rc) return rc;
+    BFLOW_REQUIRE(params && coef && out_hi && out_lo && B > 0 && h1 > 0 && w1 > 0, BFLOW_E_ARG, "corr_lookup_bezier_split: bad arguments");
+    BFLOW_REQUIRE(deg >= 1 && deg <= BFLOW_MAX_DEGREE, BFLOW_E_LIMIT, "corr_lookup_bezier_split: degree %d", deg);
+    BFLOW_REQUIRE(channel_blocks * 32 >= P * (2 * BFLOW_LOOKUP_RADIUS + 1) * (2 * BFLOW_LOOKUP_RADIUS + 1) && rows_per_image >= h1 * w1,
+                  BFLOW_E_ARG, "corr_lookup_bezier_split: output too small");
+    a.deg = deg;
+    for (int i = 0; i < T * deg; ++i) a.coef[i] = coef[i];
+    dim3 grid(bflow::ceil_div((long long)h1 * w1, TILE_SPLIT), P, B);
+    hipLaunchKernelGGL((corr_lookup_kernel<true, TILE_SPLIT, true, TILE_SPLIT>), grid, dim3(LTHREADS), 0, (hipStream_t)stream, a, params, nullptr, (_Float16*)out_hi,
+                       (_Float16*)out_lo, channel_blocks, rows_per_image, B, h1, w1);
+    return bflow::launch_status("corr_lookup_bezier_split");
 }

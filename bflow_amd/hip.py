@@ -24,7 +24,7 @@ ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
     "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_gru_rh_blocked", "bflow_gru_blend_blocked", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
-    "bflow_corr_lookup_bezier", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
+    "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
 )
@@ -101,6 +101,7 @@ def lib() -> ctypes.CDLL:
         "bflow_corr_pool2x2": [vp, vp, ll, i, i, vp],
         "bflow_corr_lookup": [ctypes.POINTER(PlaneDesc), i, vp, vp, i, i, i, i, vp],
         "bflow_corr_lookup_bezier": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, i, i, i, vp],
+        "bflow_corr_lookup_bezier_split": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_bezier_coeffs": [ctypes.POINTER(ctypes.c_double), i, i, ctypes.POINTER(ctypes.c_float)],
         "bflow_bezier_eval": [vp, ctypes.POINTER(ctypes.c_float), i, i, i, i, i, i, vp, vp],
         "bflow_concat2_act": [vp, ll, i, vp, i, vp, ll, i, vp, i, vp, ll, vp, ll, i, i, vp],
@@ -236,6 +237,19 @@ def corr_lookup_bezier(table, params: torch.Tensor, coef: np.ndarray, out: torch
     assert out.shape == (B, P * 81, h1, w1)
     _check(lib().bflow_corr_lookup_bezier(table, P, _dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                           T, deg, _dev(out, name="out"), B, h1, w1, _stream()), "bflow_corr_lookup_bezier")
+
+
+def corr_lookup_bezier_split(table, params: torch.Tensor, coef: np.ndarray, out_planes: torch.Tensor):
+    """out_planes: (2, B, CBk, rows, 32) fp16 (hi, lo), zero-initialised once by the caller (pad channels are never written)."""
+    B, C2, h1, w1 = params.shape
+    T, deg = coef.shape
+    assert C2 == 2 * deg and coef.dtype == np.float32 and coef.flags["C_CONTIGUOUS"]
+    P = len(table)
+    assert out_planes.dtype == torch.float16 and out_planes.is_contiguous() and out_planes.shape[0] == 2 and out_planes.shape[1] == B \
+        and out_planes.shape[4] == 32 and out_planes.shape[2] * 32 >= P * 81 and out_planes.shape[3] >= h1 * w1
+    _check(lib().bflow_corr_lookup_bezier_split(table, P, _dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                                T, deg, out_planes[0].data_ptr(), out_planes[1].data_ptr(), out_planes.shape[2],
+                                                out_planes.shape[3], B, h1, w1, _stream()), "bflow_corr_lookup_bezier_split")
 
 
 # ------------------------------------------------------------------------------------------------ K8

@@ -241,7 +241,7 @@ class RAFTSpline(nn.Module):
         cnet_branch.join()
 
         coef = self._coefficients()
-        corr_feat = corr_block.new_output()
+        corr_feat = corr_block.new_output_split() if (engine_update and tm is None) else corr_block.new_output()
         if engine_update:
             S.bezier_update(bezier, None, ws.M, ub.motion_dim // 32)     # emit the initial Bezier channel block
         ups: List[torch.Tensor] = []
@@ -251,7 +251,7 @@ class RAFTSpline(nn.Module):
             need_mask = (not test_mode) or itr == iters - 1
             if engine_update and tm is None:
                 # the look-up runs inside the step, next to the (independent) Bezier branch of the motion encoder
-                mask = ub.step_split(ws, lambda: corr_block.lookup_bezier(bezier, coef, out=corr_feat), bezier, need_mask)
+                mask = ub.step_split(ws, lambda: corr_block.lookup_bezier_split(bezier, coef, out=corr_feat), bezier, need_mask)
                 if need_mask:
                     ups.append(hip.cvx_upsample(bezier, mask, None, 0.25))
                 continue

@@ -237,8 +237,8 @@ class BasicUpdateBlock(nn.Module):
         ws.inp_terms = terms
 
     def step_split(self, ws: SplitWorkspace, corr, bezier: torch.Tensor, need_mask: bool):
-        """One iteration of update.py:116-126 on the split-fp16 engine.  corr: (B, P*81, h, w) fp32 (look-up output) or a callable
-        producing it (then the look-up itself overlaps with the Bezier branch), bezier: (B, 2*deg, h, w) fp32 updated IN PLACE.
+        """One iteration of update.py:116-126 on the split-fp16 engine.  corr: (B, P*81, h, w) fp32 (look-up output), the same as a blocked SplitTensor, or a
+        callable producing either (then the look-up itself overlaps with the Bezier branch), bezier: (B, 2*deg, h, w) fp32 updated IN PLACE.
         Returns the mask logits incl. bias (B, 576, h, w) fp32 or None."""
         enc = self.encoder
         # ---- motion encoder (update.py:88-97); every bias + relu lives in a conv epilogue, every cat is a channel offset
@@ -246,7 +246,9 @@ class BasicUpdateBlock(nn.Module):
         # The LONGER one is issued on the side stream: the graph keeps the captured stream's nodes on one hardware queue, and a
         # cross-queue join costs ~10 us unless the other side finished long before (measured both ways).
         with hip.Branch(ws.overlap) as corr_branch:
-            cs = S.from_nchw(corr() if callable(corr) else corr)
+            cs = corr() if callable(corr) else corr
+            if not isinstance(cs, S.SplitTensor):
+                cs = S.from_nchw(cs)
             c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
             S.conv(c1, self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
                    out_split=ws.corbez, channel_offset=0)

@@ -184,6 +184,12 @@ int bflow_corr_lookup(const bflow_plane_t* planes, int P, const float* coords, f
  *   params : (B, 2*deg, h1, w1)            coef : HOST (T, deg) fp32 row-major (bflow_bezier_coeffs)    */
 int bflow_corr_lookup_bezier(const bflow_plane_t* planes, int P, const float* params, const float* coef,
                              int T, int deg, float* out, int B, int h1, int w1, bflow_stream_t stream);
+/* The same fused look-up writing the blocked split-fp16 tensor the conv engine consumes: planes (B, channel_blocks, rows_per_image, 32)
+ * fp16, value = hi + lo * 2^-11, channel = plane * 81 + window index; channels >= P*81 of the last block are NOT written (keep the
+ * buffer zero-initialised).  Removes the NCHW -> blocked conversion in front of BasicMotionEncoder.convc1 (update.py:88).            */
+int bflow_corr_lookup_bezier_split(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
+                                   void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
+                                   bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K8  Bezier polynomial coefficients C(deg,i) (1-t)^(deg-i) t^i, i = 1..deg, computed in fp64 on the HOST

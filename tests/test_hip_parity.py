@@ -171,6 +171,13 @@ def test_lookup_fused_bezier_matches_unfused(deg):
     pyr = O.corr_pyramid(O.corr_volume(f1.cpu(), f2.cpu()), [1, 2, 4])
     ref = O.corr_lookup(pyr, coords)
     np.testing.assert_allclose(unfused.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=5e-5)
+    # the blocked split-fp16 output (what the conv engine consumes) carries the same values to ~2^-22 relative, pads stay zero
+    sp = blk.lookup_bezier_split(cu(params), coef, blk.new_output_split())
+    C = fused.shape[1]
+    nhwc = sp.float_nhwc()
+    back = nhwc[..., :C].permute(0, 3, 1, 2)
+    assert (back - fused).abs().max().item() <= 4e-7 * float(fused.abs().max()) + 1e-9
+    assert sp.planes.shape[2] == (C + 31) // 32 and float(sp.planes[:, :, -1, :, C % 32:].abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------------------------- K8 / K13
