@@ -178,78 +178,39 @@ def main():
         out["ms_per_gru_iter"] = round((t12 - t6) / (ITERS // 2) * 1e3, 4)
         out["ms_fixed_part"] = round((t12 - ITERS * (t12 - t6) / (ITERS // 2)) * 1e3, 4)
 
-        # ---- rooflines of the hand-written kernels, each timed with hipEvents on the launch stream on the operands of this
-        # very workload (the timed region above is graph replays, inside which events cannot be recorded)
-        from bflow_amd import split as S
-        from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
-        with torch.no_grad():
-            grids, _ = model.gen_voxel_grids(vox)
-            x5 = torch.cat(grids, dim=0)
-            # (1) dominant kernel by time: the split-fp16 implicit-GEMM convolution (73 % of the frame).  Largest single launch:
-            #     encoder layer1 conv, 64->64 3x3 on the 5 stacked half-resolution maps (5B x 240 x 320).
-            y = torch.nn.functional.conv2d(x5, model.fnet_ev.conv1.weight, None, stride=2, padding=3)
-            n5, c0, h0, w0 = y.shape
-            cur, _ = S.norm_act(y, (n5, h0, w0, c0), a_is_nchw=True, stats_a=S.plane_stats(y), act_a=S.ACT_RELU)
-            blk = model.fnet_ev.layer1[0]
-            pk = S.PackedConvWeight().get(blk.conv1.weight)
-            st = torch.zeros((n5, 64, 2), dtype=torch.float64, device=dev)
-            launch_conv = lambda: S.conv(cur, pk, stride=1, padding=1, want_split=False, want_f32=True, stats=st)
-            for _ in range(3):
-                launch_conv()
-            ms_c = kernel_event_ms(launch_conv, max(args.steps, 10))
-            flops_c = 2.0 * n5 * h0 * w0 * 64 * 64 * 9
-            # bytes: split input (4 B/elem) + fp32 output (4 B/elem) + packed weights
-            bytes_c = 4.0 * n5 * h0 * w0 * 64 * 2 + 4.0 * 64 * 64 * 9
-            tf_c = flops_c / (ms_c * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "conv_split_kernel<2,3,1> (encoder layer1 3x3 64->64, 5x240x320)", "bound": "mfma",
-                               "achieved": round(tf_c, 2), "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": round(tf_c / PEAK_SPLIT_TFLOPS, 4),
-                               "traffic": None, "avg_launch_ms": round(ms_c, 4), "flop_per_launch": flops_c,
-                               "algorithmic_bytes_per_launch": bytes_c,
-                               "note": "algorithmic (fp32-equivalent) FLOPs; the split scheme executes 3 fp16 MFMAs per product, so "
-                                       "peak = 2500 TFLOP/s fp16 dense / 3"}
-            # (2) K5 correlation build on the same engine (HBM-write-bound by design): 393.2 MB algorithmic per sample
-            D = model.fnet_ev.conv2.out_channels
-            hh8, ww8 = H // 8, W // 8
-            N = hh8 * ww8
-            T = len(grids) - 1
-            planes = model.fnet_ev.forward_split(x5, out_rows=hip.padded_rows(N)).planes
-            vol = torch.empty((T, B, N, N), device=dev)
-            launch_k5 = lambda: hip.corr_build_split(planes[:, :B], planes[:, B:], vol, T, B, N, shared_f1=True)
-            for _ in range(3):
-                launch_k5()
-            ms = kernel_event_ms(launch_k5, max(args.steps, 10))
-            flops = 2.0 * T * B * D * N * N
-            bytes_alg = 4.0 * ((1 + T) * B * D * N + T * B * N * N)
-            out["roofline_corr_build"] = {"kernel": "corr_build_split_v2_kernel", "bound": "hbm", "achieved": round(bytes_alg / (ms * 1e-3) / 1e9, 1),
-                                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bytes_alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                          "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_alg,
-                                          "flop_per_launch": flops, "tflops_equivalent": round(flops / (ms * 1e-3) / 1e12, 1)}
-            # (3) the look-up gather (HBM-bound), 24.33 MB algorithmic per sample-iteration at C2
-            cc = CorrComputation.from_packed(planes[:, :B], planes[:, B:], B, D, hh8, ww8, cfg["correlation"]["ev"]["levels"])
-            cblk = CorrBlockParallelMultiTarget(corr_computation_events=cc)
-            params = low.get_params().clone()
-            feat = cblk.new_output()
-            coef = model._coefficients()
-            for _ in range(3):
-                cblk.lookup_bezier(params, coef, out=feat)
-            ms_l = kernel_event_ms(lambda: cblk.lookup_bezier(params, coef, out=feat), max(args.steps, 10))
-        lbytes = 4.0 * B * N * cblk.num_planes * (100 + 81)
-        out["roofline_lookup"] = {"kernel": "corr_lookup_kernel<fused bezier>", "bound": "hbm",
-                                  "achieved": round(lbytes / (ms_l * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": round(lbytes / (ms_l * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-                                  "avg_launch_ms": round(ms_l, 4), "algorithmic_bytes_per_launch": lbytes}
-        del cblk, vol, planes
-        # HBM traffic per launch: cannot be read from inside this process; taken from the committed rocprofv3 --pmc passes of the
-        # same kernels on the same shapes (profiles/r01_pmc.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE)
+        # ---- rooflines of the hand-written kernels (tools/roofline_kernels.py), each timed with hipEvents on the launch stream on
+        # the operands of this very workload (the timed region above is graph replays, inside which events cannot be recorded)
+        from tools.roofline_kernels import build as roofline_kernels
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["kernels"]
-            for key, name in (("roofline", "conv_split_kernel<2,3,1> (encoder layer1 3x3 64->64, 5x240x320)"),
-                              ("roofline_corr_build", "corr_build_split_v2_kernel"), ("roofline_lookup", "corr_lookup_kernel<fused bezier>")):
-                if name in pmc and B == 1:
-                    out[key]["traffic"] = pmc[name]["traffic"]
-                    out[key]["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
         except Exception:
-            pass
+            pmc = {}
+        for k in roofline_kernels(model, vox, cfg, low.get_params()):
+            for _ in range(3):
+                k["launch"]()
+            ms = kernel_event_ms(k["launch"], max(args.steps, 10))
+            if k["bound"] == "mfma":
+                tf = k["flops"] / (ms * 1e-3) / 1e12
+                r = {"kernel": k["name"], "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / PEAK_SPLIT_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4), "flop_per_launch": k["flops"],
+                     "algorithmic_bytes_per_launch": k["bytes"],
+                     "note": "algorithmic (fp32-equivalent) FLOPs; the split scheme executes 3 fp16 MFMAs per product, so "
+                             "peak = 2500 TFLOP/s fp16 dense / 3"}
+            else:
+                gbs = k["bytes"] / (ms * 1e-3) / 1e9
+                r = {"kernel": k["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+                     "algorithmic_bytes_per_launch": k["bytes"]}
+                if k["flops"]:
+                    r["flop_per_launch"] = k["flops"]
+                    r["tflops_equivalent"] = round(k["flops"] / (ms * 1e-3) / 1e12, 1)
+            # HBM traffic per launch cannot be read from inside this process: it is taken from the committed rocprofv3 --pmc passes of
+            # the same launches (profiles/r01_pmc.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE)
+            if k["name"] in pmc and B == 1:
+                r["traffic"] = pmc[k["name"]]["traffic"]
+                r["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
+            out[k["key"]] = r
+            k.clear()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, torch.from_numpy(vox_np[:1]))
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

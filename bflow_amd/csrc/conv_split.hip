@@ -74,12 +74,12 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 #define CONV_STG_BYTES (4 * 32 * CONV_STG_STRIDE * 4)
 
 // `pixel_of(row)` maps row 0..31 of the wave's slab to the pixel row of the output image (or -1: outside, not written).
-template <int NT, typename PixelOf>
+template <int NT, int NW = 4, typename PixelOf>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, PixelOf pixel_of, int n0,
                                               int lane, int wave, int tid, bool writer, float* red) {
     constexpr int BN = 32 * NT;
     constexpr int RS = CONV_STG_STRIDE;
-    float* stg = red + 2 * 4 * BN + wave * (32 * RS);     // this wave's slab, behind the statistics scratch
+    float* stg = red + 2 * NW * BN + wave * (32 * RS);    // this wave's slab, behind the statistics scratch [2][NW][BN]
     const int kh = lane >> 5, l31 = lane & 31;
     const int rr = lane >> 3, ch = (lane & 7) * 4;        // read side: rows rr + 8*it, channels ch .. ch+3 of the block
     if (writer) {
@@ -187,8 +187,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                         s2[k] += __shfl_xor(s2[k], off, 64);
                     }
                     if (lane < 8) {
-                        red[(0 * 4 + wave) * BN + n * 32 + ch + k] = s1[k];
-                        red[(1 * 4 + wave) * BN + n * 32 + ch + k] = s2[k];
+                        red[(0 * NW + wave) * BN + n * 32 + ch + k] = s1[k];
+                        red[(1 * NW + wave) * BN + n * 32 + ch + k] = s2[k];
                     }
                 }
             }
@@ -202,8 +202,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
             const int which = tid / BN, c = tid - which * BN;
             const int col = n0 + c;
             if (col < a.Cout) {
-                const float* p = red + which * 4 * BN + c;
-                const double sum = (double)p[0] + (double)p[BN] + (double)p[2 * BN] + (double)p[3 * BN];
+                const float* p = red + which * NW * BN + c;
+                double sum = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += (double)p[w * BN];
                 atomicAdd(a.stats + ((long long)b * a.Cout + col) * 2 + which, sum);
             }
         }
@@ -429,17 +431,22 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// (A 16 x 16 patch / 8-wave / up-to-128-channel variant -- half the weight bytes per MFMA -- was measured 10-25 % SLOWER on
+// every encoder and batch-8 shape: eight waves that meet at one barrier per tap serialise more than two independent 4-wave
+// workgroups per CU do.  NW stays a constant so that the index arithmetic below reads generally.)
 template <int NT, int KH, int KW>
 __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int TH = 8, TW = 16;
+    constexpr int NW = 4;
+    constexpr int TH = 2 * NW, TW = 16;
     constexpr int HWD = TW + KW - 1, HR = HWD * (TH + KH - 1);     // halo patch: rows of 64 B per plane
-    constexpr int A_UNITS = (HR + 15) / 16;                         // 16-row LDS-DMA units per plane (12 / 10 / 12)
-    static_assert(A_UNITS % 2 == 0 && A_UNITS <= 12, "halo patch must split evenly over the waves");
-    constexpr int AP = A_UNITS / 2;                                 // pieces per wave per channel block
+    constexpr int A_UNITS = ((HR + 15) / 16 + NW / 2 - 1) / (NW / 2) * (NW / 2);   // 16-row LDS-DMA units per plane, a multiple of NW/2
+    constexpr int AP = A_UNITS / (NW / 2);                          // pieces per wave per channel block (plane = wave parity)
     constexpr int A_PLANE = A_UNITS * 1024, A_BUF = 2 * A_PLANE;
     constexpr int NTAPS = KH * KW;
     constexpr int B_PLANE = NT * 2048, B_SLOT = 2 * B_PLANE;        // NT*32 weight rows x 64 B per plane
+    constexpr int NBP = 4 * NT / NW;                                // weight pieces per wave per tap
+    static_assert((4 * NT) % NW == 0, "weight tile must split evenly over the waves");
     constexpr int SB = 4, LA = 2;                                   // weight ring slots, look-ahead in taps
     static_assert(NTAPS >= 4, "the halo of the next block must land within a block");
     constexpr int O_B = 2 * A_BUF;
@@ -465,26 +472,26 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
     // ---- LDS-DMA sources ------------------------------------------------------------------------------------------
     const int urow = lane >> 2;
     const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;        // halves; LDS chunk = logical chunk ^ ((row >> 2) & 3)
-    // halo: wave w stages plane (w & 1), units (w >> 1) + 2 i
+    // halo: wave w stages plane (w & 1), units (w >> 1) + (NW/2) i
     unsigned aoff[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int row = ((wave >> 1) + 2 * i) * 16 + urow;
+        const int row = ((wave >> 1) + (NW / 2) * i) * 16 + urow;
         const int hy = row / HWD, hx = row - hy * HWD;
         const int py = y0 - a.pad_h + hy, px = x0 - a.pad_w + hx;
         const bool ok = row < HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
         aoff[i] = ok ? (unsigned)(((py * a.W + px) * 32 + uchunk) * 2) : 0x80000000u;
     }
-    // weights: wave w stages plane (w >> 1), units (w*NT + j) % (2 NT)
-    unsigned wvo[NT];
+    // weights: piece p = w*NBP + j of a tap's 4 NT pieces: plane p / (2 NT) = w / (NW/2), unit p % (2 NT)
+    unsigned wvo[NBP];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int r = n0 + ((wave * NT + j) % (2 * NT)) * 16 + urow;     // < cout_pad (a multiple of 128)
+    for (int j = 0; j < NBP; ++j) {
+        const int r = n0 + ((wave * NBP + j) % (2 * NT)) * 16 + urow;    // < cout_pad (a multiple of 128)
         wvo[j] = (unsigned)((r * 32 + uchunk) * 2);
     }
     const int CB2 = a.CB - a.CB1;
     const int plane_b = a.P_in * 64;
-    const bool lo_a = wave & 1, lo_w = wave >> 1;
+    const bool lo_a = wave & 1, lo_w = wave / (NW / 2);
     const rsrc_t r_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_a ? a.xl : a.xh) + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
     const rsrc_t r_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_a ? a.x2l : a.x2h) + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
     const int wtile_b = a.cout_pad * 64;
@@ -499,13 +506,13 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
         const rsrc_t ra_ = first_ ? r_a1 : r_a2;                                                                         \
         const int so_ = (first_ ? cbi_ : cbi_ - a.CB1) * plane_b;                                                        \
         _Pragma("unroll") for (int i = 0; i < AP; ++i)                                                                   \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lptr_t)(a_dst + (BUF) * A_BUF + i * 2048), 16, aoff[i], so_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lptr_t)(a_dst + (BUF) * A_BUF + i * (NW / 2) * 1024), 16, aoff[i], so_, 0, 0); \
     }
 #define HALO_ISSUE_B(CBI, TAP, SLOT)                                                                                     \
     {                                                                                                                    \
         const int so_ = ((TAP) * a.CB + (CBI)) * wtile_b;             /* past the last block: in range, unused */        \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                   \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (SLOT) * B_SLOT + ((wave * NT + j) % (2 * NT)) * 1024), 16, \
+        _Pragma("unroll") for (int j = 0; j < NBP; ++j)                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (SLOT) * B_SLOT + ((wave * NBP + j) % (2 * NT)) * 1024), 16, \
                                                      wvo[j], so_, 0, 0);                                                 \
     }
 
@@ -520,63 +527,83 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 
     HALO_ISSUE_A(0, 0)
 #pragma unroll
-    for (int t = 0; t < LA; ++t) HALO_ISSUE_B(0, t, t)
+    for (int t = 0; t <= LA; ++t) HALO_ISSUE_B(0, t, t)
 
     // this lane's pixel inside the patch (MFMA B-operand row = pixel) and its halo row for tap (0, 0)
     const int R0 = (wave * 2 + (l31 >> 4)) * HWD + (l31 & 15);
     const int wsw = (l31 >> 2) & 3;
-    int islot = LA, cslot = 0;
+    // Register pipelining: the fragments of tap s+1 are read from LDS while the MFMAs of tap s run (one wave per SIMD and
+    // workgroup: nothing else hides the ds_read latency).  `cur` is consumed, `nxt` is in flight.
+    half8 cxh[2], cxl[2], cwh[2][NT], cwl[2][NT], nxh[2], nxl[2], nwh[2][NT], nwl[2][NT];
+#define HALO_READ(XH, XL, WH, WL, ABUF, WSLOT, TAP)                                                                      \
+    {                                                                                                                    \
+        const int R_ = R0 + ((TAP) / KW) * HWD + ((TAP) % KW);                                                           \
+        const int sw_ = (R_ >> 2) & 3;                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                               \
+            const int ao_ = R_ * 64 + (((ks * 2 + kh) ^ sw_) * 16);                                                      \
+            XH[ks] = *reinterpret_cast<const half8*>((ABUF) + ao_);                                                      \
+            XL[ks] = *reinterpret_cast<const half8*>((ABUF) + A_PLANE + ao_);                                            \
+            const int co_ = ((ks * 2 + kh) ^ wsw) * 16;                                                                  \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                             \
+                const int wo_ = (n * 32 + l31) * 64 + co_;                                                               \
+                WH[ks][n] = *reinterpret_cast<const half8*>((WSLOT) + wo_);                                              \
+                WL[ks][n] = *reinterpret_cast<const half8*>((WSLOT) + B_PLANE + wo_);                                    \
+            }                                                                                                            \
+        }                                                                                                                \
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA * NBP) : "memory");      // halo 0 and weight tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    HALO_READ(cxh, cxl, cwh, cwl, lds, lds + O_B, 0)
+    int islot = LA + 1, rslot = 1;              // ring slot to fill / to read next
     for (int cb = 0; cb < a.CB; ++cb) {
         const char* abuf = lds + (cb & 1) * A_BUF;
+        const char* abuf_next = lds + ((cb + 1) & 1) * A_BUF;
+        const bool last_cb = cb + 1 == a.CB;
         static_for<0, NTAPS>([&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
-            // Loads issued after this tap's weight tile (itself issued LA = 2 steps ago, after that step's halo issue if any):
-            // LA-1 newer weight tiles, plus the next block's halo when it was issued one step ago (halo issue is at tap 1).
-            // The taps are unrolled and hipcc lets the fragment reads of step s complete AFTER the barrier of step s+1, so a
-            // slot may only be refilled two barriers after its last reader: the weight slot filled at step s was consumed at
-            // step s-2 (ring of 4, look-ahead 2), the halo buffer filled at tap 1 was last read at the previous block's last tap.
-            constexpr int NEWER_B = (LA - 1) * NT;
-            if (t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER_B + AP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER_B) : "memory");
+            // Step s = (cb, t) consumes the fragments read one step ago and READS tap s+1, whose weight tile was issued at step
+            // s-2 (after that step's halo issue, if any).  Issued since: the tile of step s-1 and, when s-1 was tap 1, the next
+            // block's halo.  A slot / halo buffer is refilled two barriers after its last reader (hipcc lets fragment reads
+            // complete after the next barrier): ring of 4 = {being drained, being read, 2 in flight}.
+            if (t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + AP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (t == 1) HALO_ISSUE_A(cb + 1, (cb + 1) & 1)
             {
-                constexpr int tn = (t + LA) % NTAPS;
-                const int cbn = cb + (t + LA) / NTAPS;
+                constexpr int tn = (t + LA + 1) % NTAPS;
+                const int cbn = cb + (t + LA + 1) / NTAPS;
                 HALO_ISSUE_B(cbn, tn, islot)
             }
             if (++islot == SB) islot = 0;
             __builtin_amdgcn_sched_barrier(0);
-            const char* wcur = lds + O_B + cslot * B_SLOT;
-            if (++cslot == SB) cslot = 0;
-            const int R = R0 + (t / KW) * HWD + (t % KW);
-            const int sw = (R >> 2) & 3;
-            half8 xh[2], xl[2], wh[2][NT], wl[2][NT];
+            const char* wnext = lds + O_B + rslot * B_SLOT;
+            if (++rslot == SB) rslot = 0;
+            if (t + 1 < NTAPS) HALO_READ(nxh, nxl, nwh, nwl, abuf, wnext, (t + 1) % NTAPS)
+            else if (!last_cb) HALO_READ(nxh, nxl, nwh, nwl, abuf_next, wnext, 0)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int ao = R * 64 + (((ks * 2 + kh) ^ sw) * 16);
-                xh[ks] = *reinterpret_cast<const half8*>(abuf + ao);
-                xl[ks] = *reinterpret_cast<const half8*>(abuf + A_PLANE + ao);
-                const int co = ((ks * 2 + kh) ^ wsw) * 16;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int wo = (n * 32 + l31) * 64 + co;
-                    wh[ks][n] = *reinterpret_cast<const half8*>(wcur + wo);
-                    wl[ks][n] = *reinterpret_cast<const half8*>(wcur + B_PLANE + wo);
-                }
+                for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh[ks][n], cxh[ks], hh[n], 0, 0, 0);   // D[channel][pixel]
+#pragma unroll
+                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwl[ks][n], cxh[ks], xx[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh[ks][n], cxl[ks], xx[n], 0, 0, 0);
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                cxh[ks] = nxh[ks];
+                cxl[ks] = nxl[ks];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][n], xh[ks], hh[n], 0, 0, 0);   // D[channel][pixel]
-#pragma unroll
-                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks][n], xh[ks], xx[n], 0, 0, 0);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][n], xl[ks], xx[n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) {
+                    cwh[ks][n] = nwh[ks][n];
+                    cwl[ks][n] = nwl[ks][n];
+                }
             }
         });
     }
+#undef HALO_READ
 #undef HALO_ISSUE_A
 #undef HALO_ISSUE_B
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1015,14 +1042,14 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     const int shape = (d->KH == 3 && d->KW == 3) ? 1 : (d->KH == 1 && d->KW == 5) ? 2 : (d->KH == 5 && d->KW == 1) ? 3 : 0;
     if (same && shape && !(force && strncmp(force, "halo", 4) != 0)) {
         const int patches = bflow::ceil_div(d->H, 8) * bflow::ceil_div(d->W, 16);
-        const int patches8 = (patches + 7) / 8 * 8;
         // 64-channel tiles unless that leaves most CUs without a workgroup (batch-1 update block: 40 patches)
         const int nt = ((long long)patches * d->B * bflow::ceil_div(d->Cout, 64) >= 200) ? 2 : 1;
         a.n_tiles = bflow::ceil_div(d->Cout, 32 * nt);
-        dim3 hgrid(patches8 * a.n_tiles, 1, d->B);
+        dim3 hgrid((patches + 7) / 8 * 8 * a.n_tiles, 1, d->B);
 #define LAUNCH_HALO(N, KHH, KWW)                                                                                       \
     {                                                                                                                  \
-        const int lds = 2 * 2 * (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16) * 1024 + 4 * (N) * 4096;              \
+        constexpr int units_ = (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16 + 1) / 2 * 2;                           \
+        const int lds = 2 * 2 * units_ * 1024 + 4 * (N) * 4096;                                                        \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<N, KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((conv_halo_kernel<N, KHH, KWW>), hgrid, dim3(CT), lds, s, a);                               \
     }

@@ -1,5 +1,6 @@
-// GRU gates and Bezier parameter update on blocked (B, C/32, P, 32) tensors -- the element-wise glue of the update block when
-// its convolutions run on the split-fp16 engine (conv_split.hip).  Thread = 8 consecutive channels of one pixel: 32-B fp32 /
+// Bezier parameter block emission and the small im2col on blocked (B, C/32, P, 32) tensors -- what is left of the element-wise
+// glue of the update block when its convolutions run on the split-fp16 engine (conv_split.hip fuses the GRU gates and the
+// parameter update into its epilogue).  Thread = 8 consecutive channels of one pixel: 32-B fp32 /
 // 16-B fp16 accesses, fully coalesced (a 32-channel block row is one 64-B / 128-B run).
 // Reference: SepConvGRU.forward, models/raft_spline/update.py:33-48; BezierCurves.delta_update_params, bezier.py:137-139.
 #include "common.h"
@@ -7,7 +8,7 @@
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
+constexpr float LO_SCALE = 2048.0f;
 
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;
@@ -18,66 +19,6 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
 __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-
-// element index e over (B, C/32, P, 4 groups of 8 channels)
-__global__ __launch_bounds__(256) void gru_rh_blocked_kernel(const float* __restrict__ zr, const _Float16* __restrict__ hh,
-                                                             const _Float16* __restrict__ hl, _Float16* __restrict__ rh,
-                                                             _Float16* __restrict__ rl, int B, int CB, int P) {
-    const long long total = (long long)B * CB * P * 4;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const long long row = e >> 2;               // (b*CB + cb)*P + pix
-        const int g = (int)(e & 3);
-        const long long bcb = row / P;
-        const int pix = (int)(row - bcb * P);
-        const int b = (int)(bcb / CB), cb = (int)(bcb - (long long)b * CB);
-        const long long oh = row * 32 + g * 8;
-        const long long oz = (((long long)b * 2 * CB + CB + cb) * P + pix) * 32 + g * 8;   // r gate = second half of zr
-        float r[8];
-        ld8(zr + oz, r);
-        const half8 h8 = *reinterpret_cast<const half8*>(hh + oh), l8 = *reinterpret_cast<const half8*>(hl + oh);
-        half8 o1, o2;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float h = (float)h8[k] + (float)l8[k] * LO_INV;
-            _Float16 a, c;
-            split1(bflow::sigmoidf_(r[k]) * h, a, c);
-            o1[k] = a;
-            o2[k] = c;
-        }
-        *reinterpret_cast<half8*>(rh + oh) = o1;
-        *reinterpret_cast<half8*>(rl + oh) = o2;
-    }
-}
-
-__global__ __launch_bounds__(256) void gru_blend_blocked_kernel(const float* __restrict__ zr, const float* __restrict__ q,
-                                                                _Float16* __restrict__ hh, _Float16* __restrict__ hl, int B, int CB, int P) {
-    const long long total = (long long)B * CB * P * 4;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const long long row = e >> 2;
-        const int g = (int)(e & 3);
-        const long long bcb = row / P;
-        const int pix = (int)(row - bcb * P);
-        const int b = (int)(bcb / CB), cb = (int)(bcb - (long long)b * CB);
-        const long long oh = row * 32 + g * 8;
-        const long long oz = (((long long)b * 2 * CB + cb) * P + pix) * 32 + g * 8;        // z gate = first half of zr
-        float z[8], qq[8];
-        ld8(zr + oz, z);
-        ld8(q + oh, qq);
-        const half8 h8 = *reinterpret_cast<const half8*>(hh + oh), l8 = *reinterpret_cast<const half8*>(hl + oh);
-        half8 o1, o2;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float h = (float)h8[k] + (float)l8[k] * LO_INV;
-            const float zz = bflow::sigmoidf_(z[k]);
-            _Float16 a, c;
-            split1((1.f - zz) * h + zz * tanhf(qq[k]), a, c);
-            o1[k] = a;
-            o2[k] = c;
-        }
-        *reinterpret_cast<half8*>(hh + oh) = o1;
-        *reinterpret_cast<half8*>(hl + oh) = o2;
-    }
 }
 
 // thread = one pixel of one image: C2 <= 32 parameters
@@ -125,22 +66,7 @@ __global__ __launch_bounds__(256) void bezier_update_kernel(float* __restrict__ 
 
 }  // namespace
 
-extern "C" int bflow_gru_rh_blocked(const float* zr, const void* h_hi, const void* h_lo, void* rh_hi, void* rh_lo, int B, int C, int P,
-                                    bflow_stream_t stream) {
-    BFLOW_REQUIRE(zr && h_hi && h_lo && rh_hi && rh_lo && B > 0 && C > 0 && C % 32 == 0 && P > 0, BFLOW_E_ARG, "gru_rh_blocked: bad arguments");
-    const long long total = (long long)B * (C / 32) * P * 4;
-    hipLaunchKernelGGL(gru_rh_blocked_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, zr,
-                       (const _Float16*)h_hi, (const _Float16*)h_lo, (_Float16*)rh_hi, (_Float16*)rh_lo, B, C / 32, P);
-    return bflow::launch_status("gru_rh_blocked");
-}
 
-extern "C" int bflow_gru_blend_blocked(const float* zr, const float* q, void* h_hi, void* h_lo, int B, int C, int P, bflow_stream_t stream) {
-    BFLOW_REQUIRE(zr && q && h_hi && h_lo && B > 0 && C > 0 && C % 32 == 0 && P > 0, BFLOW_E_ARG, "gru_blend_blocked: bad arguments");
-    const long long total = (long long)B * (C / 32) * P * 4;
-    hipLaunchKernelGGL(gru_blend_blocked_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, zr, q,
-                       (_Float16*)h_hi, (_Float16*)h_lo, B, C / 32, P);
-    return bflow::launch_status("gru_blend_blocked");
-}
 
 extern "C" int bflow_bezier_update(float* params, const float* delta, int C2, void* blk_hi, void* blk_lo, int CB_total, int cb_off,
                                    void* blk2_hi, void* blk2_lo, int CB_total2, int cb_off2, int B, int P, bflow_stream_t stream) {

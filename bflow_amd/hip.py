@@ -17,13 +17,14 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libbflow_hip.so")
+# BFLOW_HIP_LIB points at an alternative build of the SAME ABI (A/B timing of two kernel versions inside one gpurun call)
+_LIB_PATH = os.environ.get("BFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libbflow_hip.so")
 
 MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_gru_rh_blocked", "bflow_gru_blend_blocked", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -94,8 +95,6 @@ def lib() -> ctypes.CDLL:
         "bflow_plane_stats": [vp, vp, ll, i, vp],
         "bflow_norm_act_split": [ctypes.POINTER(NormDesc), vp],
         "bflow_split_to_nchw": [vp, vp, vp, i, i, i, i, i, ll, vp],
-        "bflow_gru_rh_blocked": [vp, vp, vp, vp, vp, i, i, i, vp],
-        "bflow_gru_blend_blocked": [vp, vp, vp, vp, i, i, i, vp],
         "bflow_bezier_update": [vp, vp, i, vp, vp, i, i, vp, vp, i, i, i, i, vp],
         "bflow_im2col_small": [vp, vp, vp, i, i, i, i, i, i, i, i, i, vp],
         "bflow_corr_pool2x2": [vp, vp, ll, i, i, vp],

@@ -226,20 +226,6 @@ def from_nchw(x: torch.Tensor) -> SplitTensor:
     return out
 
 
-def gru_rh(zr: torch.Tensor, h: SplitTensor, rh: SplitTensor):
-    """rh = sigmoid(zr[:, C:2C]) * h   (zr: blocked fp32 (B, 2C/32, P, 32))."""
-    B, _, _, C = h.shape
-    hip._check(hip.lib().bflow_gru_rh_blocked(hip._dev(zr, name="zr"), h.hi.data_ptr(), h.lo.data_ptr(), rh.hi.data_ptr(), rh.lo.data_ptr(),
-                                              B, C, h.rows, hip._stream()), "bflow_gru_rh_blocked")
-
-
-def gru_blend(zr: torch.Tensor, q: torch.Tensor, h: SplitTensor):
-    """h = (1 - sigmoid(z)) * h + sigmoid(z) * tanh(q), in place."""
-    B, _, _, C = h.shape
-    hip._check(hip.lib().bflow_gru_blend_blocked(hip._dev(zr, name="zr"), hip._dev(q, name="q"), h.hi.data_ptr(), h.lo.data_ptr(), B, C,
-                                                 h.rows, hip._stream()), "bflow_gru_blend_blocked")
-
-
 def bezier_update(params: torch.Tensor, delta: Optional[torch.Tensor], dst: SplitTensor, dst_block: int,
                   dst2: Optional[SplitTensor] = None, dst2_block: int = 0):
     """params (B, 2deg, h, w) fp32 += delta (blocked fp32, first 2deg channels); re-emit as split channel block(s)."""

@@ -137,17 +137,12 @@ int bflow_norm_act_split(const bflow_norm_desc_t* desc, bflow_stream_t stream);
 int bflow_split_to_nchw(const void* x_hi, const void* x_lo, float* out, int B, int HW, int C, int c_first, int c_count,
                         long long out_batch_stride, bflow_stream_t stream);
 
-/* GRU gates / Bezier update on blocked tensors (P pixel rows per image, C hidden channels, C % 32 == 0):
- *   bflow_gru_rh_blocked   : rh = sigmoid(zr[:, C:2C]) * h                       zr blocked fp32 (B, 2C/32, P, 32)
- *   bflow_gru_blend_blocked: h = (1 - sigmoid(zr[:, :C])) * h + sigmoid(zr[:, :C]) * tanh(q), in place on the split state
+/* Bezier parameter block on blocked tensors (P pixel rows per image).  The SepConvGRU gates and the per-iteration parameter update
+ * are fused into bflow_conv_split's epilogue (`gate`, `acc_nchw`); what is left is the emission of the INITIAL parameter block:
  *   bflow_bezier_update    : params[b, c, pix] += delta[b, c, pix] (delta blocked fp32, first 2*deg channels) and the
  *                            updated parameters are re-emitted as one split channel block at block `cb_off` of a
  *                            (B, CB_total, P, 32) split buffer (the GRU input of the next iteration) and, if blk2 is
  *                            not NULL, of a second buffer.  delta may be NULL (only re-emit).  params: plain (B, C2, P) fp32 (the layout the look-up kernel reads).     */
-int bflow_gru_rh_blocked(const float* zr, const void* h_hi, const void* h_lo, void* rh_hi, void* rh_lo,
-                         int B, int C, int P, bflow_stream_t stream);
-int bflow_gru_blend_blocked(const float* zr, const float* q, void* h_hi, void* h_lo, int B, int C, int P,
-                            bflow_stream_t stream);
 int bflow_bezier_update(float* params, const float* delta, int C2, void* blk_hi, void* blk_lo, int CB_total, int cb_off,
                         void* blk2_hi, void* blk2_lo, int CB_total2, int cb_off2, int B, int P, bflow_stream_t stream);
 
