@@ -24,6 +24,15 @@ static inline int stream_grid(long long work_items, int block) {
     return (int)g;
 }
 
+// Grid for kernels that end in a few global atomics per block (reductions): every block adds to the same 2-3 addresses, and
+// 2048 blocks x fp64 atomics on one address serialise to tens of microseconds -- more than the streaming pass itself.
+static inline int reduce_grid(long long work_items, int block) {
+    long long g = (work_items + (long long)block * 8 - 1) / ((long long)block * 8);
+    if (g > 512) g = 512;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -147,9 +147,9 @@ extern "C" int bflow_voxel_norm(float* grid, long long n, double* ws, bflow_stre
         bflow::set_error("voxel_norm: memset: %s", hipGetErrorString(e));
         return (int)e;
     }
-    const int g = bflow::stream_grid(n, 256);
-    hipLaunchKernelGGL(norm_pass1, dim3(g), dim3(256), 0, s, grid, n, ws);
-    hipLaunchKernelGGL(norm_pass2, dim3(g), dim3(256), 0, s, grid, n, ws);
+    const int g = bflow::stream_grid(n, 256), gr = bflow::reduce_grid(n, 256);
+    hipLaunchKernelGGL(norm_pass1, dim3(gr), dim3(256), 0, s, grid, n, ws);
+    hipLaunchKernelGGL(norm_pass2, dim3(gr), dim3(256), 0, s, grid, n, ws);
     hipLaunchKernelGGL(norm_pass3, dim3(g), dim3(256), 0, s, grid, n, ws);
     return bflow::launch_status("voxel_norm");
 }

@@ -54,6 +54,13 @@ def reduce_epe(epe_sum: torch.Tensor, count: torch.Tensor) -> Tuple[torch.Tensor
     return tot[0] / tot[1], tot[0], tot[1]
 
 
+def reduce_metric_states(state: torch.Tensor) -> torch.Tensor:
+    """Sum an (M, 2) [value sum, batch count] metric-state table over the ranks (dist_reduce_fx="sum" for every metric of
+    utils/metrics.py) with ONE all-gather; returns the summed table.  Epoch value of row m = table[m, 0] / table[m, 1]."""
+    flat = state.double().reshape(-1)
+    return all_gather_records(flat).sum(dim=0).reshape(state.shape)
+
+
 def evaluate_sharded(forward_flow: Callable[[int, int], torch.Tensor], gt_flow: Callable[[int, int], torch.Tensor],
                      epe_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], global_batch: int,
                      micro_batch: int, rank: int, world: int, device=None):

@@ -28,6 +28,7 @@ EXPORTS = (
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
+    "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate",
 )
 
 
@@ -114,6 +115,9 @@ def lib() -> ctypes.CDLL:
         "bflow_voxel_scatter_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
         "bflow_voxel_norm": [vp, ll, vp, vp],
         "bflow_epe_accumulate": [vp, vp, vp, i, i, ll, vp, vp],
+        "bflow_flow_metrics_accumulate": [vp, vp, vp, i, i, ll, f, f, f, vp, vp],
+        "bflow_traj_len": [vp, vp, i, i, i, ll, vp],
+        "bflow_pad_replicate": [vp, vp, ll, i, i, i, i, i, i, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -371,6 +375,37 @@ def epe_accumulate(pred: torch.Tensor, gt: torch.Tensor, valid: Optional[torch.T
         pv = _dev(valid.view(torch.uint8) if valid.dtype == torch.bool else valid, torch.uint8, "valid")
     _check(lib().bflow_epe_accumulate(_dev(pred, name="pred"), _dev(gt, name="gt"), pv, B, C, HW, _dev(acc, torch.float64, "acc"), _stream()),
            "bflow_epe_accumulate")
+
+
+def flow_metrics_accumulate(pred: torch.Tensor, gt: torch.Tensor, valid: Optional[torch.Tensor], n_pixels: Sequence[float], acc: torch.Tensor):
+    """acc (6,) float64 += [sum epe, #valid, sum angular error (rad), #n-pixel errors for the 3 thresholds]."""
+    B, C = pred.shape[:2]
+    HW = int(np.prod(pred.shape[2:]))
+    assert pred.shape == gt.shape and len(n_pixels) == 3 and acc.numel() == 6
+    pv = None
+    if valid is not None:
+        assert valid.dtype in (torch.bool, torch.uint8) and valid.numel() == B * HW
+        pv = _dev(valid.view(torch.uint8) if valid.dtype == torch.bool else valid, torch.uint8, "valid")
+    _check(lib().bflow_flow_metrics_accumulate(_dev(pred, name="pred"), _dev(gt, name="gt"), pv, B, C, HW, float(n_pixels[0]), float(n_pixels[1]),
+                                               float(n_pixels[2]), _dev(acc, torch.float64, "acc"), _stream()), "bflow_flow_metrics_accumulate")
+
+
+def traj_len(targets: torch.Tensor) -> torch.Tensor:
+    """targets (M, B, C, *) -> (B, *) summed length of the per-pixel polyline."""
+    M, B, C = targets.shape[:3]
+    out = torch.empty((B,) + tuple(targets.shape[3:]), dtype=torch.float32, device=targets.device)
+    _check(lib().bflow_traj_len(_dev(targets, name="targets"), _dev(out), M, B, C, int(np.prod(targets.shape[3:])), _stream()), "bflow_traj_len")
+    return out
+
+
+def pad_replicate(x: torch.Tensor, pad: Sequence[int]) -> torch.Tensor:
+    """F.pad(x, [left, right, top, bottom], mode='replicate') on the last two dims."""
+    H, W = x.shape[-2:]
+    pl, pr, pt, pb = (int(v) for v in pad)
+    out = torch.empty(tuple(x.shape[:-2]) + (H + pt + pb, W + pl + pr), dtype=torch.float32, device=x.device)
+    _check(lib().bflow_pad_replicate(_dev(x, name="x"), _dev(out), int(np.prod(x.shape[:-2])), H, W, pl, pr, pt, pb, _stream()),
+           "bflow_pad_replicate")
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------

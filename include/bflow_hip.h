@@ -273,6 +273,20 @@ int bflow_voxel_norm(float* grid, long long n, double* workspace, bflow_stream_t
 int bflow_epe_accumulate(const float* pred, const float* gt, const unsigned char* valid,
                          int B, int C, long long HW, double* acc, bflow_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Validation harness: the per-batch sums behind AE / NPE / EPE_MULTI / AE_MULTI (utils/metrics.py:51-193,
+ * 216-296), EPE_MULTI's trajectory-length filter (:60-64) and InputPadder.pad (modules/utils.py:48-83).
+ *   bflow_flow_metrics_accumulate: one pass over (pred, gt, valid) as in bflow_epe_accumulate; acc is device double[6], zeroed
+ *       by the caller: acc[0] += sum epe, acc[1] += valid pixels, acc[2] += sum of the angular error in RADIANS between
+ *       (u, v, 1) vectors (cosine clamped to [-1, 1]), acc[3+k] += #pixels with epe > n_pixels_k and epe / max(|gt|, 1e-6) >= 0.05.
+ *   bflow_traj_len: targets (M, B, C, HW) stacked ground-truth flows -> out (B, HW) = sum_m ||t_m - t_{m-1}||_2.
+ *   bflow_pad_replicate: x (planes, H, W) -> out (planes, H + top + bottom, W + left + right), edge values replicated.       */
+int bflow_flow_metrics_accumulate(const float* pred, const float* gt, const unsigned char* valid, int B, int C, long long HW,
+                                  float n_pixels0, float n_pixels1, float n_pixels2, double* acc, bflow_stream_t stream);
+int bflow_traj_len(const float* targets, float* out, int M, int B, int C, long long HW, bflow_stream_t stream);
+int bflow_pad_replicate(const float* x, float* out, long long planes, int H, int W, int pad_left, int pad_right, int pad_top,
+                        int pad_bottom, bflow_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -513,6 +513,113 @@ def epe_masked(source: Tensor, target: Tensor, valid_mask: Optional[Tensor] = No
     return torch.mean(epe)
 
 
+def epe_masked_multi(source_lst, target_lst, valid_mask_lst=None) -> Optional[Tensor]:
+    """utils/metrics.py:216-239: mean over the predictions whose mask is non-empty of the per-prediction masked EPE."""
+    num_preds = len(source_lst)
+    assert num_preds > 0 and len(target_lst) == num_preds
+    if valid_mask_lst is not None:
+        assert len(valid_mask_lst) == num_preds
+    else:
+        valid_mask_lst = [None] * num_preds
+    epe_sum, den = 0, 0
+    for src, tgt, vm in zip(source_lst, target_lst, valid_mask_lst):
+        e = epe_masked(src, tgt, vm)
+        if e is not None:
+            epe_sum = epe_sum + e
+            den += 1
+    if den == 0:
+        return None
+    return epe_sum / den
+
+
+def ae_masked(source: Tensor, target: Tensor, valid_mask: Optional[Tensor] = None, degrees: bool = True) -> Tensor:
+    """utils/metrics.py:259-296: angle between (u, v, 1) vectors, clamped cosine, masked mean (no empty-mask guard there)."""
+    assert source.ndim > 2 and source.shape == target.shape
+    ext_shape = list(source.shape)
+    ext_shape[1] = 1
+    ext = torch.ones(ext_shape, device=source.device)
+    s_ext, t_ext = torch.cat((source, ext), dim=1), torch.cat((target, ext), dim=1)
+    nom = torch.sum(s_ext * t_ext, dim=1)
+    den = torch.linalg.norm(s_ext, dim=1) * torch.linalg.norm(t_ext, dim=1)
+    tmp = torch.div(nom, den)
+    tmp[tmp > 1.0] = 1.0
+    tmp[tmp < -1.0] = -1.0
+    ae = torch.acos(tmp)
+    if degrees:
+        ae = ae / math.pi * 180
+    if valid_mask is not None:
+        assert valid_mask.dtype == torch.bool and ae.shape == valid_mask.shape
+        return ae[valid_mask].sum() / valid_mask.sum()
+    return torch.mean(ae)
+
+
+def ae_masked_multi(source_lst, target_lst, valid_mask_lst=None, degrees: bool = True) -> Tensor:
+    """utils/metrics.py:241-256: plain mean over the predictions."""
+    num_preds = len(source_lst)
+    assert num_preds > 0 and len(target_lst) == num_preds
+    if valid_mask_lst is None:
+        valid_mask_lst = [None] * num_preds
+    total = 0
+    for src, tgt, vm in zip(source_lst, target_lst, valid_mask_lst):
+        total = total + ae_masked(src, tgt, vm, degrees)
+    return total / num_preds
+
+
+def n_pixel_error_masked(source: Tensor, target: Tensor, valid_mask: Optional[Tensor], n_pixels: float) -> Tensor:
+    """utils/metrics.py:160-193: percentage of (valid) pixels with error > n_pixels AND relative error >= 5 %."""
+    assert source.ndim > 2 and source.shape == target.shape
+    if valid_mask is not None:
+        assert valid_mask.dtype == torch.bool
+        num_valid = torch.sum(valid_mask)
+        assert num_valid > 0
+    gt_magn = torch.linalg.norm(target, dim=1)
+    err_magn = torch.linalg.norm(source - target, dim=1)
+    if valid_mask is not None:
+        rel = torch.zeros_like(err_magn)
+        rel[valid_mask] = err_magn[valid_mask] / torch.clip(gt_magn[valid_mask], min=1e-6)
+    else:
+        rel = err_magn / torch.clip(gt_magn, min=1e-6)
+    emap = (err_magn > n_pixels) & (rel >= 0.05)
+    if valid_mask is not None:
+        err = emap[valid_mask].sum() / num_valid
+    else:
+        err = torch.mean(emap.float())
+    return err * 100
+
+
+def compute_traj_len(target_lst) -> Tensor:
+    """EPE_MULTI.compute_traj_len, utils/metrics.py:60-64: summed length of the ground-truth polyline per pixel, (N, *)."""
+    st = torch.stack(list(target_lst), dim=0)
+    diff = st[1:] - st[:-1]
+    return diff.square().sum(dim=2).sqrt().sum(dim=0)
+
+
+def predictions_from_lin_assumption(source: Tensor, target_timestamps) -> list:
+    """utils/metrics.py:298-305."""
+    assert max(target_timestamps) <= 1 and 0 <= min(target_timestamps)
+    return [ts * source for ts in target_timestamps]
+
+
+def input_pad_amounts(ht: int, wd: int, min_size: int = 8, no_top_padding: bool = False):
+    """InputPadder.pad's padding list [left, right, top, bottom] (modules/utils.py:63-73)."""
+    pad_ht = (((ht // min_size) + 1) * min_size - ht) % min_size
+    pad_wd = (((wd // min_size) + 1) * min_size - wd) % min_size
+    if no_top_padding:
+        return [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+    return [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
+
+
+def input_pad(x: Tensor, pad) -> Tensor:
+    """InputPadder.pad (modules/utils.py:78): replicate padding of the last two dims."""
+    return F.pad(x, list(pad), mode="replicate")
+
+
+def input_unpad(x: Tensor, pad) -> Tensor:
+    """InputPadder.unpad (modules/utils.py:80-83)."""
+    ht, wd = x.shape[-2:]
+    return x[..., pad[2]:ht - pad[3], pad[0]:wd - pad[1]]
+
+
 # --------------------------------------------------------------------------------------
 # Configs of BASELINE.json (SURVEY.md section 8 table)
 # --------------------------------------------------------------------------------------

@@ -155,6 +155,52 @@ def main():
         np.savez_compressed(os.path.join(out_dir, "epe.npz"), a=a, b=b, mask=m,
                             epe=ns.epe_masked(torch.from_numpy(a), torch.from_numpy(b)).numpy(),
                             epe_masked=ns.epe_masked(torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(m)).numpy())
+
+        # ---------------- validation metrics (SURVEY f-3): AE, NPE, EPE_MULTI / AE_MULTI, linear-assumption predictions ----------------
+        rs = np.random.RandomState(61)
+        M = 4
+        preds = [rs.standard_normal((2, 2, 13, 17)).astype(np.float32) * 3 for _ in range(M)]
+        gts = [(p + rs.standard_normal(p.shape).astype(np.float32) * s) for p, s in zip(preds, (0.05, 0.5, 2.0, 6.0))]
+        gts[1][0, :, 0, 0] = 0.0                       # zero ground-truth vector: clip(|gt|, 1e-6) branch of NPE
+        preds[2][1, :, 3, 3] = gts[2][1, :, 3, 3]      # exact hit: cosine clamps at 1
+        masks = [rs.uniform(size=(2, 13, 17)) < q for q in (0.7, 0.5, 0.9, 0.0)]   # the last mask is EMPTY
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        mt = {"M": np.int64(M)}
+        for i in range(M):
+            mt[f"pred{i}"], mt[f"gt{i}"], mt[f"mask{i}"] = preds[i], gts[i], masks[i]
+            mt[f"ae{i}"] = ns.ae_masked(T(preds[i]), T(gts[i])).numpy()
+            mt[f"ae_rad{i}"] = ns.ae_masked(T(preds[i]), T(gts[i]), None, degrees=False).numpy()
+            for n in (1, 2, 3):
+                mt[f"npe{n}_{i}"] = ns.n_pixel_error_masked(T(preds[i]), T(gts[i]), None, n).numpy()
+            if masks[i].any():
+                mt[f"ae_m{i}"] = ns.ae_masked(T(preds[i]), T(gts[i]), T(masks[i])).numpy()
+                for n in (1, 2, 3):
+                    mt[f"npe{n}_m{i}"] = ns.n_pixel_error_masked(T(preds[i]), T(gts[i]), T(masks[i]), n).numpy()
+        mt["epe_multi"] = ns.epe_masked_multi([T(p) for p in preds], [T(g) for g in gts]).numpy()
+        mt["epe_multi_m"] = ns.epe_masked_multi([T(p) for p in preds], [T(g) for g in gts], [T(m) for m in masks]).numpy()   # skips the empty mask
+        mt["ae_multi"] = ns.ae_masked_multi([T(p) for p in preds], [T(g) for g in gts]).numpy()
+        mt["ae_multi_m3"] = ns.ae_masked_multi([T(p) for p in preds[:3]], [T(g) for g in gts[:3]], [T(m) for m in masks[:3]]).numpy()
+        mt["traj_len"] = ns.EPE_MULTI.compute_traj_len([T(g) for g in gts]).numpy()
+        em = ns.EPE_MULTI(min_traj_len=4.0, max_traj_len=30.0)
+        em.update([T(p) for p in preds[:3]], [T(g) for g in gts[:3]], [T(m) for m in masks[:3]])
+        mt["epe_multi_traj_4_30"] = em.compute().numpy()
+        ts = [0.25, 0.5, 0.75, 1.0]
+        lin = ns.predictions_from_lin_assumption(T(preds[3]), ts)
+        mt["lin_ts"] = np.array(ts, dtype=np.float64)
+        mt["epe_multi_lin"] = ns.epe_masked_multi(lin, [T(g) for g in gts]).numpy()
+        np.savez_compressed(os.path.join(out_dir, "metrics.npz"), **mt)
+
+        # ---------------- InputPadder (replicate padding to a multiple of 8) ----------------
+        pd = {}
+        rs = np.random.RandomState(71)
+        for tag, (hh, ww), no_top in (("a", (21, 30), False), ("b", (21, 30), True), ("c", (24, 32), False), ("d", (17, 9), False)):
+            x = rs.standard_normal((2, 3, hh, ww)).astype(np.float32)
+            padder = ns.InputPadder(min_size=8, no_top_padding=no_top)
+            y = padder.pad(T(x))
+            pd[f"x_{tag}"], pd[f"y_{tag}"], pd[f"pad_{tag}"] = x, y.numpy(), np.array(padder._pad, dtype=np.int64)
+            pd[f"no_top_{tag}"] = np.bool_(no_top)
+            assert np.array_equal(padder.unpad(y).numpy(), x)
+        np.savez_compressed(os.path.join(out_dir, "padder.npz"), **pd)
     print("golden fixtures written to", out_dir)
 
 

@@ -73,7 +73,9 @@ def import_reference():
     # NOTE: importing representations pins torch to 1 thread (representations.py:5-6); undo it.
     from data.utils.representations import VoxelGrid, norm_voxel_grid
     torch.set_num_threads(nthreads)
-    from utils.metrics import epe_masked
+    from utils.metrics import (epe_masked, epe_masked_multi, ae_masked, ae_masked_multi, n_pixel_error_masked, predictions_from_lin_assumption,
+                               EPE_MULTI)
+    from modules.utils import InputPadder
     ns.RAFTSpline = RAFTSpline
     ns.BezierCurves = BezierCurves
     ns.BasicUpdateBlock = BasicUpdateBlock
@@ -86,4 +88,7 @@ def import_reference():
     ns.VoxelGrid = VoxelGrid
     ns.norm_voxel_grid = norm_voxel_grid
     ns.epe_masked = epe_masked
+    ns.epe_masked_multi, ns.ae_masked, ns.ae_masked_multi = epe_masked_multi, ae_masked, ae_masked_multi
+    ns.n_pixel_error_masked, ns.predictions_from_lin_assumption = n_pixel_error_masked, predictions_from_lin_assumption
+    ns.EPE_MULTI, ns.InputPadder = EPE_MULTI, InputPadder
     return ns

@@ -415,3 +415,116 @@ def test_encoder_split_engine_vs_oracle():
         eb = (a2 - b2).abs().max().item() / float(b2.abs().max())
     print(f"split-engine encoder: max err / max|ref|  fnet(instance) {ea:.2e}  cnet(batch) {eb:.2e}")
     assert ea < 5e-5 and eb < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------- validation harness
+def test_flow_metrics_golden(golden_dir):
+    from bflow_amd import metrics as MX
+    g = dict(np.load(os.path.join(golden_dir, "metrics.npz")))
+    M = int(g["M"])
+    preds, gts, masks = [cu(g[f"pred{i}"]) for i in range(M)], [cu(g[f"gt{i}"]) for i in range(M)], [cu(g[f"mask{i}"]) for i in range(M)]
+    tol = dict(rtol=2e-6, atol=1e-6)
+    # angular error: acos is ill-conditioned near cos = 1 (d(acos)/dc = 1/sin): one fp32 ulp of the cosine moves a 1-degree angle by
+    # 2e-4 relative, so two correct fp32 evaluations agree to ~1e-4 on the mean of small angles (case 0), ~1e-6 on large ones
+    atol_ae = dict(rtol=1e-4, atol=1e-6)
+    for i in range(M):
+        np.testing.assert_allclose(MX.ae_masked(preds[i], gts[i]).cpu().numpy(), g[f"ae{i}"], **atol_ae)
+        np.testing.assert_allclose(MX.ae_masked(preds[i], gts[i], None, degrees=False).cpu().numpy(), g[f"ae_rad{i}"], **atol_ae)
+        for n in (1, 2, 3):
+            np.testing.assert_allclose(MX.n_pixel_error_masked(preds[i], gts[i], None, n).cpu().numpy(), g[f"npe{n}_{i}"], **tol)
+        if g[f"mask{i}"].any():
+            np.testing.assert_allclose(MX.ae_masked(preds[i], gts[i], masks[i]).cpu().numpy(), g[f"ae_m{i}"], **atol_ae)
+            for n in (1, 2, 3):
+                np.testing.assert_allclose(MX.n_pixel_error_masked(preds[i], gts[i], masks[i], n).cpu().numpy(), g[f"npe{n}_m{i}"], **tol)
+    np.testing.assert_allclose(MX.epe_masked_multi(preds, gts).cpu().numpy(), g["epe_multi"], **tol)
+    np.testing.assert_allclose(MX.epe_masked_multi(preds, gts, masks).cpu().numpy(), g["epe_multi_m"], **tol)
+    assert MX.epe_masked_multi(preds[3:], gts[3:], masks[3:]) is None
+    np.testing.assert_allclose(MX.ae_masked_multi(preds, gts).cpu().numpy(), g["ae_multi"], **atol_ae)
+    np.testing.assert_allclose(MX.ae_masked_multi(preds[:3], gts[:3], masks[:3]).cpu().numpy(), g["ae_multi_m3"], **atol_ae)
+    np.testing.assert_allclose(MX.EPE_MULTI.compute_traj_len(gts).cpu().numpy(), g["traj_len"], rtol=1e-6, atol=1e-6)
+    em = MX.EPE_MULTI(min_traj_len=4.0, max_traj_len=30.0)
+    em.update(preds[:3], gts[:3], masks[:3])
+    np.testing.assert_allclose(em.compute().cpu().numpy(), g["epe_multi_traj_4_30"], **tol)
+    lin = MX.predictions_from_lin_assumption(preds[3], list(g["lin_ts"]))
+    np.testing.assert_allclose(MX.epe_masked_multi(lin, gts).cpu().numpy(), g["epe_multi_lin"], **tol)
+    # the single-pass collection gives the same five numbers as the five separate metrics
+    sm = MX.SingleFlowMetrics(prefix="val/")
+    vals = sm(preds[1], gts[1], masks[1])
+    np.testing.assert_allclose(vals["val/ae"].cpu().numpy(), g["ae_m1"], **atol_ae)
+    np.testing.assert_allclose(vals["val/2pe"].cpu().numpy(), g["npe2_m1"], **tol)
+    np.testing.assert_allclose(vals["val/epe"].cpu().numpy(), O.epe_masked(torch.from_numpy(g["pred1"]), torch.from_numpy(g["gt1"]),
+                                                                             torch.from_numpy(g["mask1"])).numpy(), **tol)
+
+
+def test_input_padder_golden(golden_dir):
+    from bflow_amd.validation import InputPadder
+    g = dict(np.load(os.path.join(golden_dir, "padder.npz")))
+    for tag in "abcd":
+        p = InputPadder(8, bool(g[f"no_top_{tag}"]))
+        x = cu(g[f"x_{tag}"])
+        assert p.requires_padding(x) == (tag != "c")
+        y = p.pad(x)
+        assert p._pad == list(g[f"pad_{tag}"])
+        np.testing.assert_array_equal(y.cpu().numpy(), g[f"y_{tag}"])
+        assert torch.equal(p.unpad(y), x)
+
+
+def _small_model(cname):
+    cfg = O.model_config(cname)
+    sd = O.make_state_dict(cfg, seed=0)
+    m = bflow_amd.RAFTSpline(cfg).eval()
+    m.load_state_dict(sd)
+    return cfg, sd, m.to(DEV)
+
+
+def test_validation_step_dsec_padded_vs_oracle():
+    """DSEC branch of validation_step on a frame that is NOT a multiple of 8: pad -> forward -> unpad -> epe/ae/1-3pe."""
+    from bflow_amd.validation import DataLoading, DataSetType, Validator
+    cfg, sd, m = _small_model("E_LU4_BD2")
+    B, Hh, Ww = 1, 171, 203                                       # -> padded to 176 x 208
+    vox = synthetic.voxel_grid(B, 9, Hh, Ww, seed=5)
+    gt = synthetic.gt_flow(B, Hh, Ww, seed=6)
+    valid = np.random.RandomState(7).uniform(size=(B, Hh, Ww)) < 0.7
+    v = Validator(m, cfg)
+    out = v.validation_step({DataLoading.FLOW: cu(gt), DataLoading.FLOW_VALID: cu(valid), DataLoading.EV_REPR: cu(vox),
+                             DataLoading.DATASET_TYPE: [DataSetType.DSEC]})
+    pad = O.input_pad_amounts(Hh, Ww)
+    _, up = O.forward(sd, cfg, O.input_pad(torch.from_numpy(vox), pad), None, iters=cfg["num_iter"]["test"], test_mode=True)
+    flow = O.input_unpad(O.bezier_flow(up, [1.0])[0], pad)
+    assert out["pred"].shape == (B, 2, Hh, Ww)
+    assert float(O.epe_masked(out["pred"].cpu(), flow)) < EPE_TOL
+    res = v.compute()
+    tg, tv = torch.from_numpy(gt), torch.from_numpy(valid)
+    want = {"val/epe": O.epe_masked(flow, tg, tv), "val/ae": O.ae_masked(flow, tg, tv),
+            "val/1pe": O.n_pixel_error_masked(flow, tg, tv, 1), "val/2pe": O.n_pixel_error_masked(flow, tg, tv, 2),
+            "val/3pe": O.n_pixel_error_masked(flow, tg, tv, 3)}
+    for k, w in want.items():
+        assert abs(float(res[k]) - float(w)) <= 1e-3 * max(1.0, abs(float(w))), (k, float(res[k]), float(w))
+    assert tuple(out["ev_repr_reduced"].shape) == (B, Hh, Ww) and v.state().shape == (9, 2)   # sliced before the padding (raft_spline.py:214-215)
+
+
+def test_validation_step_multiflow_vs_oracle():
+    """MultiFlow branch: M flows at the ground-truth timestamps, multi metrics and the linear-assumption baseline."""
+    from bflow_amd.validation import DataLoading, DataSetType, Validator
+    cfg, sd, m = _small_model("E_LU5_BD10")
+    B, Hh, Ww = 1, 144, 176
+    C = cfg["num_bins"]["context"] + cfg["num_bins"]["correlation"] - 1
+    vox = synthetic.voxel_grid(B, C, Hh, Ww, seed=8)
+    ts = [0.2, 0.4, 0.6, 0.8, 1.0]
+    gts = [synthetic.gt_flow(B, Hh, Ww, seed=20 + i) * t for i, t in enumerate(ts)]
+    v = Validator(m, cfg)
+    batch = {DataLoading.FLOW: [cu(g) for g in gts], DataLoading.EV_REPR: cu(vox), DataLoading.DATASET_TYPE: [DataSetType.MULTIFLOW2D],
+             DataLoading.FLOW_TIMESTAMPS: [torch.full((B,), t) for t in ts],
+             DataLoading.BIN_META: {"nbins_context": [cfg["num_bins"]["context"]], "nbins_correlation": [cfg["num_bins"]["correlation"]],
+                                    "nbins_total": [C]}}
+    v.validation_step(batch)
+    res = v.compute()
+    _, up = O.forward(sd, cfg, torch.from_numpy(vox), None, iters=cfg["num_iter"]["test"], test_mode=True)
+    flows = O.bezier_flow(up, ts)
+    tg = [torch.from_numpy(g) for g in gts]
+    lin = O.predictions_from_lin_assumption(flows[-1], ts)
+    want = {"val/epe": O.epe_masked(flows[-1], tg[-1]), "val/ae": O.ae_masked(flows[-1], tg[-1]),
+            "val/epe_multi": O.epe_masked_multi(flows, tg), "val/ae_multi": O.ae_masked_multi(flows, tg),
+            "val/epe_multi_lin": O.epe_masked_multi(lin, tg), "val/ae_multi_lin": O.ae_masked_multi(lin, tg)}
+    for k, w in want.items():
+        assert abs(float(res[k]) - float(w)) <= 1e-3 * max(1.0, abs(float(w))), (k, float(res[k]), float(w))

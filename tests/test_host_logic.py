@@ -150,8 +150,17 @@ def fwd(first, n):
 def gt(first, n):
     return torch.from_numpy(synthetic.gt_flow(n, H, W, seed=99, first_sample=first))
 mean, s, c = bdist.evaluate_sharded(fwd, gt, O.epe_masked, G, 1, rank, world)
+# the validation harness's (M, 2) metric-state table (SURVEY 8(f-3)): every rank holds the rows of ITS samples, one all-gather sums them
+start, stop = bdist.shard_range(G, rank, world)
+table = torch.zeros(9, 2, dtype=torch.float64)
+for i in range(start, stop):
+    p, g = fwd(i, 1), gt(i, 1)
+    table[0] += torch.stack([O.epe_masked(p, g).double(), torch.tensor(1.0, dtype=torch.float64)])
+    table[1] += torch.stack([O.ae_masked(p, g).double(), torch.tensor(1.0, dtype=torch.float64)])
+    table[3] += torch.stack([O.n_pixel_error_masked(p, g, None, 2).double(), torch.tensor(1.0, dtype=torch.float64)])
+table = bdist.reduce_metric_states(table)
 if rank == 0:
-    print("RESULT " + json.dumps(dict(mean=float(mean), sum=float(s), count=float(c), world=world)))
+    print("RESULT " + json.dumps(dict(mean=float(mean), sum=float(s), count=float(c), world=world, table=table.tolist())))
 import torch.distributed as d
 if d.is_initialized():
     d.barrier(); d.destroy_process_group()
@@ -178,3 +187,6 @@ def test_two_rank_gloo_shard_equivalence():
     two = _run_world(2, 29632)
     assert one["count"] == two["count"] == 4
     assert abs(one["sum"] - two["sum"]) < 1e-9 and abs(one["mean"] - two["mean"]) < 1e-9
+    t1, t2 = np.array(one["table"]), np.array(two["table"])
+    assert t1.shape == (9, 2) and t1[0, 1] == 4 and np.allclose(t1, t2, rtol=0, atol=1e-9)
+    assert abs(t1[0, 0] - one["sum"]) < 1e-9                      # row 0 is the EPE state

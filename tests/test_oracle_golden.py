@@ -130,6 +130,47 @@ def test_epe(golden_dir):
     assert O.epe_masked(a, b, torch.zeros_like(m)) is None
 
 
+def test_validation_metrics(golden_dir):
+    """SURVEY f-3: AE / NPE / EPE_MULTI / AE_MULTI / linear-assumption predictions vs the reference's outputs."""
+    g = _load(golden_dir, "metrics")
+    M = int(g["M"])
+    T = lambda k: torch.from_numpy(g[k])
+    preds, gts, masks = [T(f"pred{i}") for i in range(M)], [T(f"gt{i}") for i in range(M)], [T(f"mask{i}") for i in range(M)]
+    for i in range(M):
+        np.testing.assert_array_equal(O.ae_masked(preds[i], gts[i]).numpy(), g[f"ae{i}"])
+        np.testing.assert_array_equal(O.ae_masked(preds[i], gts[i], None, degrees=False).numpy(), g[f"ae_rad{i}"])
+        for n in (1, 2, 3):
+            np.testing.assert_array_equal(O.n_pixel_error_masked(preds[i], gts[i], None, n).numpy(), g[f"npe{n}_{i}"])
+        if bool(masks[i].any()):
+            np.testing.assert_array_equal(O.ae_masked(preds[i], gts[i], masks[i]).numpy(), g[f"ae_m{i}"])
+            for n in (1, 2, 3):
+                np.testing.assert_array_equal(O.n_pixel_error_masked(preds[i], gts[i], masks[i], n).numpy(), g[f"npe{n}_m{i}"])
+    np.testing.assert_array_equal(O.epe_masked_multi(preds, gts).numpy(), g["epe_multi"])
+    np.testing.assert_array_equal(O.epe_masked_multi(preds, gts, masks).numpy(), g["epe_multi_m"])
+    assert O.epe_masked_multi(preds[3:], gts[3:], masks[3:]) is None          # only an empty mask
+    np.testing.assert_array_equal(O.ae_masked_multi(preds, gts).numpy(), g["ae_multi"])
+    np.testing.assert_array_equal(O.ae_masked_multi(preds[:3], gts[:3], masks[:3]).numpy(), g["ae_multi_m3"])
+    np.testing.assert_array_equal(O.compute_traj_len(gts).numpy(), g["traj_len"])
+    tl = O.compute_traj_len(gts[:3])
+    ok = (tl >= 4.0) & (tl <= 30.0)
+    e = O.epe_masked_multi(preds[:3], gts[:3], [m & ok for m in masks[:3]])
+    np.testing.assert_array_equal(e.double().float().numpy(), g["epe_multi_traj_4_30"])
+    lin = O.predictions_from_lin_assumption(preds[3], list(g["lin_ts"]))
+    np.testing.assert_array_equal(O.epe_masked_multi(lin, gts).numpy(), g["epe_multi_lin"])
+
+
+def test_input_padder(golden_dir):
+    g = _load(golden_dir, "padder")
+    for tag in "abcd":
+        x = torch.from_numpy(g[f"x_{tag}"])
+        pad = O.input_pad_amounts(x.shape[-2], x.shape[-1], 8, bool(g[f"no_top_{tag}"]))
+        assert pad == list(g[f"pad_{tag}"])
+        y = O.input_pad(x, pad)
+        np.testing.assert_array_equal(y.numpy(), g[f"y_{tag}"])
+        assert y.shape[-2] % 8 == 0 and y.shape[-1] % 8 == 0
+        assert torch.equal(O.input_unpad(y, pad), x)
+
+
 def test_param_inventory_counts():
     # SURVEY.md section 5: 5,344,832 parameters for the events-only DSEC model
     cfg = O.model_config("E_LU4_BD2")

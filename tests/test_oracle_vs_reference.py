@@ -69,3 +69,28 @@ def test_voxel_and_norm(ref):
         b = O.voxel_grid_convert(*(torch.from_numpy(v) for v in (x, y, pol, t)), 5, 48, 64, 10000, 110000)
         assert torch.equal(a, b)
         assert torch.equal(ref.norm_voxel_grid(a.clone()), O.norm_voxel_grid(b.clone()))
+
+
+def test_validation_metrics_and_padder(ref):
+    """SURVEY f-3 restatements against the live reference on fresh random data (bit-exact: same torch calls)."""
+    g = torch.Generator().manual_seed(5)
+    preds = [torch.randn(2, 2, 19, 23, generator=g) * 4 for _ in range(3)]
+    gts = [p + torch.randn(p.shape, generator=g) * s for p, s in zip(preds, (0.1, 1.0, 5.0))]
+    masks = [torch.rand(2, 19, 23, generator=g) < 0.6 for _ in range(3)]
+    for p, t, m in zip(preds, gts, masks):
+        for vm in (None, m):
+            assert torch.equal(ref.ae_masked(p, t, vm), O.ae_masked(p, t, vm))
+            assert torch.equal(ref.ae_masked(p, t, vm, degrees=False), O.ae_masked(p, t, vm, degrees=False))
+            for n in (1, 2, 3):
+                assert torch.equal(ref.n_pixel_error_masked(p, t, vm, n), O.n_pixel_error_masked(p, t, vm, n))
+    assert torch.equal(ref.epe_masked_multi(preds, gts, masks), O.epe_masked_multi(preds, gts, masks))
+    assert torch.equal(ref.ae_masked_multi(preds, gts, masks), O.ae_masked_multi(preds, gts, masks))
+    assert torch.equal(ref.EPE_MULTI.compute_traj_len(gts), O.compute_traj_len(gts))
+    for a, b in zip(ref.predictions_from_lin_assumption(preds[0], [0.2, 1.0]), O.predictions_from_lin_assumption(preds[0], [0.2, 1.0])):
+        assert torch.equal(a, b)
+    for (hh, ww), no_top in (((21, 30), False), ((37, 41), True), ((16, 24), False)):
+        x = torch.randn(1, 2, hh, ww, generator=g)
+        rp = ref.InputPadder(8, no_top)
+        y = rp.pad(x)
+        pad = O.input_pad_amounts(hh, ww, 8, no_top)
+        assert pad == rp._pad and torch.equal(y, O.input_pad(x, pad)) and torch.equal(rp.unpad(y), O.input_unpad(y, pad))
