@@ -59,6 +59,60 @@ __global__ __launch_bounds__(256) void voxel_scatter_kernel(const XY* __restrict
     }
 }
 
+// f-1: DSEC sample assembly.  Raw sensor events (uint16 x / y, 0/1 polarity) are rectified through the per-sequence
+// map (BaseSubSequence._rectify_events, data/dsec/subsequence/base.py:137-143: rectify_map[y, x] -> (x', y') float32) and
+// scattered tri-linearly in the same kernel: the rectified coordinate arrays are never materialised.  Events whose raw
+// coordinates fall outside the map (the reference asserts on them) are skipped and counted in *bad.
+__global__ __launch_bounds__(256) void voxel_scatter_rect_kernel(const unsigned short* __restrict__ xs, const unsigned short* __restrict__ ys,
+                                                                 const unsigned char* __restrict__ pol, const long long* __restrict__ ts,
+                                                                 long long n, const float* __restrict__ rect, long long t0c, long long t1c,
+                                                                 float* __restrict__ grid, int C, int H, int W, int* __restrict__ bad) {
+    const float denom = (float)(t1c - t0c);
+    const float cm1 = (float)(C - 1);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int xr = xs[e], yr = ys[e];
+        if (xr >= W || yr >= H) {
+            if (bad) atomicAdd(bad, 1);
+            continue;
+        }
+        const float2 xy = *reinterpret_cast<const float2*>(rect + ((long long)yr * W + xr) * 2);
+        const float t_norm = (float)(ts[e] - t0c) / denom * cm1;
+        const float tf = floorf(t_norm);
+        const float tcl = fminf(fmaxf(tf, -4.f), (float)C + 4.f);
+        const int t0 = (int)tcl;
+        const float value = 2.f * (float)pol[e] - 1.f;
+        const float x = xy.x, y = xy.y;
+        const float xf = floorf(x), yf = floorf(y);
+        const float xcl = fminf(fmaxf(xf, -4.f), (float)W + 4.f), ycl = fminf(fmaxf(yf, -4.f), (float)H + 4.f);
+        const bool sane = (xf == xcl) && (yf == ycl) && (tf == tcl);
+        const int x0 = (int)xcl, y0 = (int)ycl;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int xl = x0 + dx, yl = y0 + dy, tl = t0 + dt;
+                    if (sane && xl < W && xl >= 0 && yl < H && yl >= 0 && tl >= 0 && tl < C) {
+                        const float wgt = value * (1.f - fabsf((float)xl - x)) * (1.f - fabsf((float)yl - y)) * (1.f - fabsf((float)tl - t_norm));
+                        atomicAdd(grid + ((long long)tl * H + yl) * W + xl, wgt);
+                    }
+                }
+    }
+}
+
+// max |a - b| over n floats -> *out (float bits are ordered like unsigned ints for non-negative values); out zeroed by the caller.
+// TwoStepSubSequence.__getitem__ asserts that the temporal slice shared by the two grids agrees (twostep.py:83).
+__global__ __launch_bounds__(256) void maxabs_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                          unsigned int* __restrict__ out) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(a[i] - b[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
 __device__ __forceinline__ void block_accumulate(double v0, double v1, double* dst0, double* dst1) {
     __shared__ double sh[2][4];
     v0 = bflow::wave_sum(v0);
@@ -152,4 +206,23 @@ extern "C" int bflow_voxel_norm(float* grid, long long n, double* ws, bflow_stre
     hipLaunchKernelGGL(norm_pass2, dim3(gr), dim3(256), 0, s, grid, n, ws);
     hipLaunchKernelGGL(norm_pass3, dim3(g), dim3(256), 0, s, grid, n, ws);
     return bflow::launch_status("voxel_norm");
+}
+
+extern "C" int bflow_voxel_scatter_rectified(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,
+                                             long long n, const float* rectify_map, long long t0c, long long t1c, float* grid, int C, int H,
+                                             int W, int* bad_count, bflow_stream_t stream) {
+    BFLOW_REQUIRE(grid && rectify_map && C > 1 && H > 1 && W > 1, BFLOW_E_ARG, "voxel_scatter_rectified: bad grid / map");
+    BFLOW_REQUIRE(t1c > t0c, BFLOW_E_ARG, "voxel_scatter_rectified: t1_center must be > t0_center");
+    BFLOW_REQUIRE(((uintptr_t)rectify_map & 7) == 0, BFLOW_E_ARG, "voxel_scatter_rectified: the map must be 8-byte aligned");
+    if (n == 0) return 0;
+    BFLOW_REQUIRE(x && y && pol && t && n > 0, BFLOW_E_ARG, "voxel_scatter_rectified: bad event arrays");
+    hipLaunchKernelGGL(voxel_scatter_rect_kernel, dim3(bflow::stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, pol, t, n,
+                       rectify_map, t0c, t1c, grid, C, H, W, bad_count);
+    return bflow::launch_status("voxel_scatter_rectified");
+}
+
+extern "C" int bflow_maxabs_diff(const float* a, const float* b, long long n, float* out, bflow_stream_t stream) {
+    BFLOW_REQUIRE(a && b && out && n > 0, BFLOW_E_ARG, "maxabs_diff: bad arguments");
+    hipLaunchKernelGGL(maxabs_diff_kernel, dim3(bflow::reduce_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, (unsigned int*)out);
+    return bflow::launch_status("maxabs_diff");
 }

@@ -1,0 +1,132 @@
+"""DSEC two-step sample assembly on the GPU -- SURVEY 8(f-1).
+
+What `TwoStepSubSequence.__getitem__` (data/dsec/subsequence/twostep.py:44-100) and `BaseSubSequence` (base.py:121-204) do on one
+CPU DataLoader worker per sample -- pick the current / previous flow interval, cut the event stream around each (one extra bin on
+either side), rectify the raw sensor coordinates through the sequence's map, build two voxel grids, drop the temporal slice they
+share, normalise -- with the arithmetic in HIP kernels:
+
+    raw events (uint16 x / y, 0/1 polarity, int64 us)  --bflow_voxel_scatter_rectified-->  grid_prev, grid_cur   (K1 + map gather)
+    max |grid_prev[-1] - grid_cur[0]| < 0.5             --bflow_maxabs_diff-->              the reference's consistency assert
+    [grid_prev | grid_cur[1:]]                          --bflow_voxel_norm-->               (2*bins - 1, H, W) network input (K2)
+
+File I/O stays with the caller: `events` is any object with `window(t_start_us, t_end_us) -> (x, y, p, t)` tensors (GPU or host)
+covering [t_start, t_end); `EventStream` wraps an in-memory, time-sorted stream and reproduces EventSlicer's offset arithmetic
+(data/dsec/eventslicer.py:99-158).  The host-side window bookkeeping mirrors the reference line by line (asserts included).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+from .representations import VoxelGrid, norm_voxel_grid
+
+
+def event_window_indices(time_array: np.ndarray, time_start_us: int, time_end_us: int) -> Tuple[int, int]:
+    """EventSlicer.get_time_indices_offsets (eventslicer.py:99-158): [i0, i1) with time_start <= t[i0:i1] < time_end."""
+    assert time_array.ndim == 1
+    if time_array[-1] < time_start_us:
+        return time_array.size, time_array.size
+    return int(np.searchsorted(time_array, time_start_us, side="left")), int(np.searchsorted(time_array, time_end_us, side="left"))
+
+
+def twostep_windows(forward_flow_timestamps, index: int) -> List[Tuple[int, int]]:
+    """twostep.py:49-66: (ts_from, ts_to) of the current interval and of the previous one (extrapolated when index == 0)."""
+    out: List[Tuple[int, int]] = []
+    ts_from = ts_to = None
+    for idx in (index, index - 1):
+        if 0 <= idx < len(forward_flow_timestamps):
+            ts_from, ts_to = int(forward_flow_timestamps[idx][0]), int(forward_flow_timestamps[idx][1])
+        else:
+            assert idx == index - 1
+            assert ts_from is not None and ts_to is not None
+            dt = ts_to - ts_from
+            ts_to = ts_from
+            ts_from = ts_from - dt
+        out.append((ts_from, ts_to))
+    return out
+
+
+class EventStream:
+    """A time-sorted raw event stream held in memory (host numpy timestamps for the window search, payload on the GPU)."""
+
+    def __init__(self, x: np.ndarray, y: np.ndarray, p: np.ndarray, t: np.ndarray, device="cuda"):
+        assert x.shape == y.shape == p.shape == t.shape and t.ndim == 1 and t.size > 0
+        self.t_host = np.ascontiguousarray(t, dtype=np.int64)
+        self.x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint16)).to(device)
+        self.y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.uint16)).to(device)
+        self.p = torch.from_numpy(np.ascontiguousarray(p, dtype=np.uint8)).to(device)
+        self.t = torch.from_numpy(self.t_host).to(device)
+
+    def get_start_time_us(self) -> int:
+        return int(self.t_host[0])
+
+    def get_final_time_us(self) -> int:
+        return int(self.t_host[-1])
+
+    def window(self, t_start_us: int, t_end_us: int):
+        assert t_start_us < t_end_us
+        i0, i1 = event_window_indices(self.t_host, t_start_us, t_end_us)
+        return self.x[i0:i1], self.y[i0:i1], self.p[i0:i1], self.t[i0:i1]
+
+
+class TwoStepAssembler:
+    """EV_REPR of TwoStepSubSequence.__getitem__ from raw events.  num_bins / height / width / rectify_map as BaseSubSequence holds
+    them (base.py:55-84); extended_voxel_grid = version 1 (one extra bin of events on either side, base.py:196-200)."""
+
+    def __init__(self, num_bins: int, height: int, width: int, rectify_map, normalize_voxel_grid: bool = True, merge_grids: bool = True,
+                 extended_voxel_grid: bool = True, device="cuda"):
+        assert num_bins >= 1
+        self.num_bins, self.height, self.width = num_bins, height, width
+        self.voxel_grid = VoxelGrid(num_bins, height, width)
+        rm = torch.as_tensor(np.asarray(rectify_map), dtype=torch.float32) if not isinstance(rectify_map, torch.Tensor) else rectify_map.float()
+        assert tuple(rm.shape) == (height, width, 2), tuple(rm.shape)                       # base.py:140
+        self.rectify_events_map = rm.contiguous().to(device)
+        self.normalize, self.merge_grids, self.version = normalize_voxel_grid, merge_grids, 1 if extended_voxel_grid else 0
+        self.device = device
+        self._bad = torch.zeros(1, dtype=torch.int32, device=device)
+
+    # base.py:160-204 -------------------------------------------------------------------------------------------------
+    def construct_voxel_grid(self, events, ts_from: int, ts_to: int) -> torch.Tensor:
+        if self.version == 1:
+            t_start, t_end = self.voxel_grid.get_extended_time_window(ts_from, ts_to)
+            assert (ts_from - t_start) < 50000, f"ts_from: {ts_from}, t_start: {t_start}"
+            assert (t_end - ts_to) < 50000, f"t_end: {t_end}, ts_to: {ts_to}"
+            t0c, t1c = ts_from, ts_to
+        else:
+            t_start, t_end, t0c, t1c = ts_from, ts_to, None, None
+        start_us, final_us = events.get_start_time_us(), events.get_final_time_us()
+        assert t_start > start_us - 50000, "Do not request more than 50 ms before the minimum time. Otherwise, something might be wrong."
+        assert t_end < final_us + 50000, "Do not request more than 50 ms past the maximum time. Otherwise, something might be wrong."
+        t_start, t_end = max(t_start, start_us), min(t_end, final_us)
+        assert t_start < t_end
+        x, y, p, t = events.window(t_start, t_end)
+        if t0c is None:                                                                     # version 0: centres = first / last event
+            t0c, t1c = int(t[0]), int(t[-1])
+        grid = torch.zeros((self.num_bins, self.height, self.width), dtype=torch.float32, device=self.device)
+        dev = lambda a, dt: a.to(device=self.device, dtype=dt).contiguous()
+        hip.voxel_scatter_rectified(dev(x, torch.uint16), dev(y, torch.uint16), dev(p, torch.uint8), dev(t, torch.int64),
+                                    self.rectify_events_map, t0c, t1c, grid, self._bad)
+        return grid
+
+    # twostep.py:44-92 ------------------------------------------------------------------------------------------------
+    def assemble(self, events, forward_flow_timestamps, index: int, check: bool = True) -> torch.Tensor:
+        (cf, ct), (pf, pt) = twostep_windows(forward_flow_timestamps, index)
+        ev_cur = self.construct_voxel_grid(events, cf, ct)
+        ev_prev = self.construct_voxel_grid(events, pf, pt)
+        if check:
+            # base.py:141-142: raw coordinates must lie inside the map (one device->host read, like the reference's x.max())
+            assert int(self._bad) == 0, f"{int(self._bad)} events outside the {self.height}x{self.width} rectification map"
+        if self.merge_grids:
+            if check:
+                d = float(hip.maxabs_diff(ev_prev[-1], ev_cur[0]))
+                assert d < 0.5, f"{d}"                                                      # twostep.py:83
+            out = torch.empty((2 * self.num_bins - 1, self.height, self.width), dtype=torch.float32, device=self.device)
+            out[:self.num_bins].copy_(ev_prev)                                              # torch.cat((ev_repr_0, ev_repr_1[1:]))
+            out[self.num_bins:].copy_(ev_cur[1:])
+            return norm_voxel_grid(out) if self.normalize else out
+        grids = [norm_voxel_grid(g) for g in (ev_prev, ev_cur)] if self.normalize else [ev_prev, ev_cur]
+        return torch.stack(grids)

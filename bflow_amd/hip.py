@@ -28,7 +28,7 @@ EXPORTS = (
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
-    "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate",
+    "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_scatter_rectified", "bflow_maxabs_diff",
 )
 
 
@@ -114,6 +114,8 @@ def lib() -> ctypes.CDLL:
         "bflow_voxel_scatter_f32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
         "bflow_voxel_scatter_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
         "bflow_voxel_norm": [vp, ll, vp, vp],
+        "bflow_voxel_scatter_rectified": [vp, vp, vp, vp, ll, vp, ll, ll, vp, i, i, i, vp, vp],
+        "bflow_maxabs_diff": [vp, vp, ll, vp, vp],
         "bflow_epe_accumulate": [vp, vp, vp, i, i, ll, vp, vp],
         "bflow_flow_metrics_accumulate": [vp, vp, vp, i, i, ll, f, f, f, vp, vp],
         "bflow_traj_len": [vp, vp, i, i, i, ll, vp],
@@ -355,6 +357,26 @@ def voxel_scatter(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.
     else:
         raise BflowHipError(f"voxel_scatter: x/y dtype {x.dtype} unsupported (float32 or int16)")
     _check(fn(px, py, ppol, pt, n, int(t0_center), int(t1_center), _dev(grid, name="grid"), C, H, W, _stream()), "bflow_voxel_scatter")
+
+
+def voxel_scatter_rectified(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.Tensor, rectify_map: torch.Tensor,
+                            t0_center: int, t1_center: int, grid: torch.Tensor, bad_count: Optional[torch.Tensor] = None):
+    """Raw uint16 sensor coordinates -> rectify_map[y, x] -> tri-linear scatter (f-1)."""
+    C, H, W = grid.shape
+    assert tuple(rectify_map.shape) == (H, W, 2)
+    _check(lib().bflow_voxel_scatter_rectified(_dev(x, torch.uint16, "x"), _dev(y, torch.uint16, "y"), _dev(pol, torch.uint8, "pol"),
+                                               _dev(t, torch.int64, "time"), x.numel(), _dev(rectify_map, name="rectify_map"), int(t0_center),
+                                               int(t1_center), _dev(grid, name="grid"), C, H, W,
+                                               None if bad_count is None else _dev(bad_count, torch.int32, "bad_count"), _stream()),
+           "bflow_voxel_scatter_rectified")
+
+
+def maxabs_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """0-dim float32 GPU tensor max |a - b|."""
+    assert a.shape == b.shape
+    out = torch.zeros((), dtype=torch.float32, device=a.device)
+    _check(lib().bflow_maxabs_diff(_dev(a, name="a"), _dev(b, name="b"), a.numel(), _dev(out), _stream()), "bflow_maxabs_diff")
+    return out
 
 
 def voxel_norm(grid: torch.Tensor, workspace: Optional[torch.Tensor] = None):

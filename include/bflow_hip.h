@@ -264,6 +264,18 @@ int bflow_voxel_scatter_i16xy(const short* x, const short* y, const signed char*
  * Replaces norm_voxel_grid, representations.py:9-18.  workspace: device, >= 4 doubles, any contents.    */
 int bflow_voxel_norm(float* grid, long long n, double* workspace, bflow_stream_t stream);
 
+/* DSEC sample assembly: BaseSubSequence._rectify_events + _events_to_voxel_grid (data/dsec/subsequence/base.py:121-143)
+ * in one kernel.  x, y: raw sensor coordinates (uint16, as stored in events.h5), pol: 0/1, t: int64 us;
+ * rectify_map (H, W, 2) float32: rectify_map[y, x] = (x', y'), the rectified sub-pixel position, scattered tri-linearly
+ * like bflow_voxel_scatter_f32xy.  Events with x >= W or y >= H are skipped and counted in *bad_count (may be NULL;
+ * the reference asserts on them).
+ * bflow_maxabs_diff: *out = max(*out, max_i |a[i] - b[i]|) (out zeroed by the caller) -- the agreement check of the temporal
+ * slice shared by the previous and the current grid (data/dsec/subsequence/twostep.py:83).                                  */
+int bflow_voxel_scatter_rectified(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,
+                                  long long n, const float* rectify_map, long long t0_center, long long t1_center, float* grid,
+                                  int C, int H, int W, int* bad_count, bflow_stream_t stream);
+int bflow_maxabs_diff(const float* a, const float* b, long long n, float* out, bflow_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K15 end-point-error partial sums for epe_masked / the EPE metric state, utils/metrics.py:30-49,196-213:
  *   acc[0] += sum over valid pixels of sqrt(sum_c (pred-gt)^2)   (fp64)

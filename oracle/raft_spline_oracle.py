@@ -621,6 +621,80 @@ def input_unpad(x: Tensor, pad) -> Tensor:
 
 
 # --------------------------------------------------------------------------------------
+# DSEC two-step sample assembly (data/dsec/subsequence/{base,twostep}.py, data/dsec/eventslicer.py)
+# --------------------------------------------------------------------------------------
+def rectify_events(rectify_map: np.ndarray, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """BaseSubSequence._rectify_events, base.py:137-143: (n, 2) rectified (x', y') of raw integer sensor coordinates."""
+    H, W = rectify_map.shape[:2]
+    assert rectify_map.shape == (H, W, 2)
+    assert x.max() < W and y.max() < H
+    return rectify_map[y, x]
+
+
+def event_window_indices(time_array: np.ndarray, time_start_us: int, time_end_us: int) -> Tuple[int, int]:
+    """EventSlicer.get_time_indices_offsets, eventslicer.py:99-158: [i0, i1) with time_start <= t[i0:i1] < time_end on a sorted
+    array (the reference scans linearly; same result as two left-sided binary searches)."""
+    assert time_array.ndim == 1
+    if time_array[-1] < time_start_us:
+        return time_array.size, time_array.size
+    return int(np.searchsorted(time_array, time_start_us, side="left")), int(np.searchsorted(time_array, time_end_us, side="left"))
+
+
+def twostep_windows(forward_flow_timestamps: np.ndarray, index: int) -> List[Tuple[int, int]]:
+    """TwoStepSubSequence.__getitem__, twostep.py:49-66: (ts_from, ts_to) of the CURRENT flow interval and of the one before it
+    (extrapolated backwards by the same duration when `index` is the first sample)."""
+    out = []
+    ts_from = ts_to = None
+    for idx in (index, index - 1):
+        if 0 <= idx < len(forward_flow_timestamps):
+            ts_from, ts_to = int(forward_flow_timestamps[idx][0]), int(forward_flow_timestamps[idx][1])
+        else:
+            assert idx == index - 1 and ts_from is not None and ts_to is not None
+            dt = ts_to - ts_from
+            ts_to = ts_from
+            ts_from = ts_from - dt
+        out.append((ts_from, ts_to))
+    return out
+
+
+def construct_voxel_grid(events: Dict[str, np.ndarray], rectify_map: np.ndarray, num_bins: int, H: int, W: int, ts_from: int, ts_to: int) -> Tensor:
+    """BaseSubSequence._construct_voxel_grid (version 1 = extended window) + _get_events + _events_to_voxel_grid, base.py:121-204.
+    events: raw stream {'x','y' uint16, 'p' uint8, 't' int64 sorted}; stream start / final time = t[0] / t[-1]."""
+    dt = (ts_to - ts_from) / (num_bins - 1)
+    t_start, t_end = math.floor(ts_from - dt), math.ceil(ts_to + dt)            # representations.py:35-39
+    assert (ts_from - t_start) < 50000 and (t_end - ts_to) < 50000
+    t_all = events["t"]
+    start_us, final_us = int(t_all[0]), int(t_all[-1])
+    assert t_start > start_us - 50000 and t_end < final_us + 50000               # base.py:168-169
+    t_start, t_end = max(t_start, start_us), min(t_end, final_us)                # base.py:170-175
+    assert t_start < t_end
+    i0, i1 = event_window_indices(t_all, t_start, t_end)
+    x, y, p, t = events["x"][i0:i1], events["y"][i0:i1], events["p"][i0:i1], t_all[i0:i1]
+    xy = rectify_events(rectify_map, x, y)
+    return voxel_grid_convert(torch.from_numpy(xy[:, 0].astype("float32")), torch.from_numpy(xy[:, 1].astype("float32")),
+                              torch.from_numpy(p.astype("float32")), torch.from_numpy(t.astype("int64")), num_bins, H, W, ts_from, ts_to)
+
+
+def twostep_merge(ev_prev: Tensor, ev_cur: Tensor, normalize: bool = True, merge: bool = True) -> Tensor:
+    """twostep.py:79-92: drop the temporal slice the two grids share (after checking that they agree), normalise the merged grid."""
+    if merge:
+        assert (ev_prev[-1] - ev_cur[0]).flatten().abs().max() < 0.5
+        out = torch.cat((ev_prev, ev_cur[1:, ...]), dim=0)
+        return norm_voxel_grid(out) if normalize else out
+    grids = [norm_voxel_grid(g) for g in (ev_prev, ev_cur)] if normalize else [ev_prev, ev_cur]
+    return torch.stack(grids)
+
+
+def dsec_twostep_sample(events: Dict[str, np.ndarray], rectify_map: np.ndarray, forward_flow_timestamps: np.ndarray, index: int,
+                        num_bins: int, H: int, W: int, normalize: bool = True, merge: bool = True) -> Tensor:
+    """The EV_REPR entry of TwoStepSubSequence.__getitem__ (twostep.py:44-100) built from the raw event stream."""
+    (cf, ct), (pf, pt) = twostep_windows(forward_flow_timestamps, index)
+    cur = construct_voxel_grid(events, rectify_map, num_bins, H, W, cf, ct)
+    prev = construct_voxel_grid(events, rectify_map, num_bins, H, W, pf, pt)
+    return twostep_merge(prev, cur, normalize, merge)
+
+
+# --------------------------------------------------------------------------------------
 # Configs of BASELINE.json (SURVEY.md section 8 table)
 # --------------------------------------------------------------------------------------
 def model_config(name: str) -> Dict[str, Any]:

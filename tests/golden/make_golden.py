@@ -201,6 +201,26 @@ def main():
             pd[f"no_top_{tag}"] = np.bool_(no_top)
             assert np.array_equal(padder.unpad(y).numpy(), x)
         np.savez_compressed(os.path.join(out_dir, "padder.npz"), **pd)
+
+        # ---------------- DSEC two-step sample assembly (SURVEY f-1): the reference's TwoStepSubSequence.__getitem__ on an in-memory stream ----
+        dns = refshim.import_reference_dsec()
+        Hd, Wd, bins = 40, 56, 5
+        rs = np.random.RandomState(81)
+        n_ev = 30000
+        ev = dict(x=rs.randint(0, Wd, n_ev).astype(np.uint16), y=rs.randint(0, Hd, n_ev).astype(np.uint16),
+                  p=rs.randint(0, 2, n_ev).astype(np.uint8), t=np.sort(rs.randint(2_000_000, 2_400_000, n_ev)).astype(np.int64))
+        yy, xx = np.meshgrid(np.arange(Hd), np.arange(Wd), indexing="ij")
+        # rectification map: identity + smooth distortion + jitter, partly pointing OUTSIDE the image (dropped corners of the tri-linear splat)
+        rect = np.stack([xx * 1.03 - 1.2 + rs.uniform(-0.4, 0.4, (Hd, Wd)), yy * 0.97 + 0.8 + rs.uniform(-0.4, 0.4, (Hd, Wd))], -1).astype(np.float32)
+        ts = np.array([[2_100_000, 2_200_000], [2_200_000, 2_300_000]], dtype=np.int64)
+        ds = dict(x=ev["x"], y=ev["y"], p=ev["p"], t=ev["t"], rectify_map=rect, forward_flow_timestamps=ts, num_bins=np.int64(bins))
+        for tag, norm, merge in (("nm", True, True), ("m", False, True), ("n", True, False)):
+            drv = refshim.ReferenceTwoStepDriver(dns, ev, rect, ts, bins, Hd, Wd, normalize=norm, merge=merge)
+            for idx in (0, 1):
+                ds[f"sample_{tag}_{idx}"] = drv.sample(idx).numpy()
+        ds["offsets_2150000_2250000"] = np.array(dns.EventSlicer.get_time_indices_offsets(ev["t"], 2_150_000, 2_250_000), dtype=np.int64)
+        ds["offsets_past_end"] = np.array(dns.EventSlicer.get_time_indices_offsets(ev["t"], 2_500_000, 2_600_000), dtype=np.int64)
+        np.savez_compressed(os.path.join(out_dir, "dsec_twostep.npz"), **ds)
     print("golden fixtures written to", out_dir)
 
 

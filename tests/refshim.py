@@ -92,3 +92,87 @@ def import_reference():
     ns.n_pixel_error_masked, ns.predictions_from_lin_assumption = n_pixel_error_masked, predictions_from_lin_assumption
     ns.EPE_MULTI, ns.InputPadder = EPE_MULTI, InputPadder
     return ns
+
+
+def import_reference_dsec():
+    """The reference's DSEC sample-assembly classes.  Their modules import I/O libraries that are absent here
+    (h5py, imageio, cv2, skimage, torchvision); those are stubbed as EMPTY modules -- every function of theirs the assembly would
+    call (file reads) is replaced by the test's synthetic-data providers, the arithmetic is the reference's own."""
+    _install_stubs()
+    for name in ("h5py", "imageio", "cv2", "skimage"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["skimage"].img_as_ubyte = lambda x: x
+    sys.modules["h5py"].File = type("File", (), {})                              # only used in type annotations on this path
+    if "pytorch_lightning" not in sys.modules:                                   # utils/general.py:7 imports a callback class it never uses here
+        pl = types.ModuleType("pytorch_lightning")
+        plc = types.ModuleType("pytorch_lightning.callbacks")
+        plc.ModelCheckpoint = type("ModelCheckpoint", (), {})
+        pl.callbacks = plc
+        sys.modules["pytorch_lightning"], sys.modules["pytorch_lightning.callbacks"] = pl, plc
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tvt = types.ModuleType("torchvision.transforms")
+        tvt.ColorJitter = type("ColorJitter", (), {"__init__": lambda self, *a, **k: None})
+        tv.transforms = tvt
+        sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tvt
+    import torch
+    nthreads = torch.get_num_threads()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    from data.dsec.subsequence.base import BaseSubSequence
+    from data.dsec.subsequence import twostep as twostep_module
+    from data.dsec.eventslicer import EventSlicer
+    from data.utils.representations import VoxelGrid, norm_voxel_grid
+    from data.utils.keys import DataLoading, DataSetType
+    torch.set_num_threads(nthreads)
+    ns = types.SimpleNamespace(BaseSubSequence=BaseSubSequence, twostep_module=twostep_module, TwoStepSubSequence=twostep_module.TwoStepSubSequence,
+                               EventSlicer=EventSlicer, VoxelGrid=VoxelGrid, norm_voxel_grid=norm_voxel_grid, DataLoading=DataLoading,
+                               DataSetType=DataSetType)
+    return ns
+
+
+class ReferenceTwoStepDriver:
+    """Runs the reference's TwoStepSubSequence.__getitem__ on an in-memory event stream: a bare instance (no __init__, which
+    wants a DSEC directory) whose file readers are replaced by providers over synthetic arrays.  Everything between the readers
+    and the returned sample -- window arithmetic, event slicing offsets, rectification, voxel grid, merge, normalisation --
+    is reference code."""
+
+    def __init__(self, ns, events, rectify_map, forward_flow_timestamps, num_bins, H, W, normalize=True, merge=True):
+        import numpy as np
+        import torch
+        self.ns = ns
+        seq = ns.TwoStepSubSequence.__new__(ns.TwoStepSubSequence)
+        seq.height, seq.width, seq.num_bins = H, W, num_bins
+        seq.voxel_grid = ns.VoxelGrid(num_bins, H, W)
+        seq.normalize_voxel_grid = ns.norm_voxel_grid if normalize else None
+        seq.merge_grids = merge
+        seq.augmentor = None
+        seq.rectify_events_map = rectify_map
+        seq.version = 1
+        seq.load_voxel_grid = False
+        seq.img_dir_ev_left = None
+        seq.forward_flow_timestamps = forward_flow_timestamps
+        seq.forward_flow_list = [types.SimpleNamespace(stem=f"{2 * (i + 1):06d}") for i in range(len(forward_flow_timestamps))]
+        seq.h5f_opened = True                                                    # skip __open_h5f
+        t_all = events["t"]
+
+        class Slicer:                                                            # EventSlicer minus h5 I/O: same offset arithmetic
+            def get_start_time_us(self_inner):
+                return int(t_all[0])
+
+            def get_final_time_us(self_inner):
+                return int(t_all[-1])
+
+            def get_events(self_inner, t0, t1):
+                i0, i1 = ns.EventSlicer.get_time_indices_offsets(t_all, t0, t1)
+                return {k: events[k][i0:i1] for k in ("p", "x", "y", "t")}
+
+        seq.event_slicer = Slicer()
+        self.seq = seq
+        H_, W_ = H, W
+        ns.twostep_module.load_flow = lambda path: (np.zeros((H_, W_, 2), dtype="float32"), np.ones((H_, W_), dtype=bool))
+
+    def sample(self, index):
+        out = self.seq[index]
+        return out[self.ns.DataLoading.EV_REPR]

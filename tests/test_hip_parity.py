@@ -528,3 +528,51 @@ def test_validation_step_multiflow_vs_oracle():
             "val/epe_multi_lin": O.epe_masked_multi(lin, tg), "val/ae_multi_lin": O.ae_masked_multi(lin, tg)}
     for k, w in want.items():
         assert abs(float(res[k]) - float(w)) <= 1e-3 * max(1.0, abs(float(w))), (k, float(res[k]), float(w))
+
+
+# ------------------------------------------------------------------------------------------------- DSEC sample assembly
+def test_dsec_twostep_assembly_golden(golden_dir):
+    """Raw events -> rectification gather + tri-linear scatter (one kernel) -> merge -> normalise, vs the reference's outputs.
+    Tolerance: K1 accumulates with fp32 atomics in arbitrary order (the reference sequentially)."""
+    from bflow_amd.dsec import EventStream, TwoStepAssembler, event_window_indices
+    g = dict(np.load(os.path.join(golden_dir, "dsec_twostep.npz")))
+    rect, ts, bins = g["rectify_map"], g["forward_flow_timestamps"], int(g["num_bins"])
+    H, W = rect.shape[:2]
+    stream = EventStream(g["x"], g["y"], g["p"], g["t"])
+    for tag, norm, merge in (("nm", True, True), ("m", False, True), ("n", True, False)):
+        asm = TwoStepAssembler(bins, H, W, rect, normalize_voxel_grid=norm, merge_grids=merge)
+        for idx in (0, 1):
+            out = asm.assemble(stream, ts, idx)
+            np.testing.assert_allclose(out.cpu().numpy(), g[f"sample_{tag}_{idx}"], rtol=1e-4, atol=2e-5)
+    assert list(event_window_indices(g["t"], 2_150_000, 2_250_000)) == list(g["offsets_2150000_2250000"])
+    # an event outside the map is reported (the reference asserts in _rectify_events)
+    k = int(np.searchsorted(g["t"], 2_250_000))                  # inside the current window of sample 1
+    bad = EventStream(np.insert(g["x"], k, W).astype(np.uint16), np.insert(g["y"], k, 0).astype(np.uint16), np.insert(g["p"], k, 1).astype(np.uint8),
+                      np.insert(g["t"], k, 2_250_000).astype(np.int64))
+    with pytest.raises(AssertionError):
+        TwoStepAssembler(bins, H, W, rect).assemble(bad, ts, 1)
+
+
+def test_dsec_twostep_assembly_full_size_vs_oracle():
+    """DSEC size (480x640, 5 bins -> 9 channels), ~0.6 M events: GPU assembly vs the CPU restatement."""
+    from bflow_amd.dsec import EventStream, TwoStepAssembler
+    H, W, bins = 480, 640, 5
+    rs = np.random.RandomState(3)
+    n = 600_000
+    ev = dict(x=rs.randint(0, W, n).astype(np.uint16), y=rs.randint(0, H, n).astype(np.uint16), p=rs.randint(0, 2, n).astype(np.uint8),
+              t=np.sort(rs.randint(10_000_000, 10_260_000, n)).astype(np.int64))
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    rect = np.stack([xx * 1.01 - 3 + np.sin(yy / 40.0), yy * 0.99 + 2 + np.cos(xx / 50.0)], -1).astype(np.float32)
+    ts = np.array([[10_030_000, 10_130_000], [10_130_000, 10_230_000]], dtype=np.int64)
+    stream = EventStream(**ev)
+    raw = TwoStepAssembler(bins, H, W, rect, normalize_voxel_grid=False).assemble(stream, ts, 1)
+    ref_raw = O.dsec_twostep_sample(ev, rect, ts, 1, bins, H, W, normalize=False)
+    assert raw.shape == (9, H, W)
+    np.testing.assert_allclose(raw.cpu().numpy(), ref_raw.numpy(), rtol=1e-4, atol=5e-5)
+    # normalised: norm_voxel_grid only touches NON-ZERO cells (representations.py:10), and a cell whose contributions cancel is an
+    # exact 0 when summed sequentially but may keep a 1e-9 residue when summed by atomics in another order -- such a cell is then
+    # shifted by -mean/std.  Allow a handful of those, everything else to tolerance.
+    out = TwoStepAssembler(bins, H, W, rect).assemble(stream, ts, 1).cpu().numpy()
+    ref = O.dsec_twostep_sample(ev, rect, ts, 1, bins, H, W).numpy()
+    bad = ~np.isclose(out, ref, rtol=1e-4, atol=5e-5)
+    assert bad.sum() <= 20 and np.all(np.abs(ref_raw.numpy()[bad]) < 1e-6)

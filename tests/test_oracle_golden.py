@@ -171,6 +171,22 @@ def test_input_padder(golden_dir):
         assert torch.equal(O.input_unpad(y, pad), x)
 
 
+def test_dsec_twostep_assembly(golden_dir):
+    """SURVEY f-1: raw events -> rectify -> two voxel grids -> merge -> normalise, vs the reference's own __getitem__ outputs."""
+    g = _load(golden_dir, "dsec_twostep")
+    ev = {k: g[k] for k in ("x", "y", "p", "t")}
+    rect, ts, bins = g["rectify_map"], g["forward_flow_timestamps"], int(g["num_bins"])
+    H, W = rect.shape[:2]
+    for tag, norm, merge in (("nm", True, True), ("m", False, True), ("n", True, False)):
+        for idx in (0, 1):
+            out = O.dsec_twostep_sample(ev, rect, ts, idx, bins, H, W, normalize=norm, merge=merge)
+            np.testing.assert_array_equal(out.numpy(), g[f"sample_{tag}_{idx}"])
+    assert O.twostep_windows(ts, 0) == [(2_100_000, 2_200_000), (2_000_000, 2_100_000)]     # previous interval extrapolated
+    assert O.twostep_windows(ts, 1) == [(2_200_000, 2_300_000), (2_100_000, 2_200_000)]
+    assert list(O.event_window_indices(ev["t"], 2_150_000, 2_250_000)) == list(g["offsets_2150000_2250000"])
+    assert list(O.event_window_indices(ev["t"], 2_500_000, 2_600_000)) == list(g["offsets_past_end"])
+
+
 def test_param_inventory_counts():
     # SURVEY.md section 5: 5,344,832 parameters for the events-only DSEC model
     cfg = O.model_config("E_LU4_BD2")

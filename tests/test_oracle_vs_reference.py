@@ -94,3 +94,22 @@ def test_validation_metrics_and_padder(ref):
         y = rp.pad(x)
         pad = O.input_pad_amounts(hh, ww, 8, no_top)
         assert pad == rp._pad and torch.equal(y, O.input_pad(x, pad)) and torch.equal(rp.unpad(y), O.input_unpad(y, pad))
+
+
+def test_dsec_twostep_assembly_live():
+    """SURVEY f-1 against the live reference (TwoStepSubSequence.__getitem__ driven on an in-memory stream, tests/refshim.py)."""
+    import refshim
+    if not refshim.reference_available():
+        pytest.skip("reference not mounted")
+    dns = refshim.import_reference_dsec()
+    H, W, bins = 32, 48, 4
+    rs = np.random.RandomState(11)
+    n = 20000
+    ev = dict(x=rs.randint(0, W, n).astype(np.uint16), y=rs.randint(0, H, n).astype(np.uint16), p=rs.randint(0, 2, n).astype(np.uint8),
+              t=np.sort(rs.randint(4_900_000, 5_450_000, n)).astype(np.int64))
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    rect = np.stack([xx + rs.uniform(-2, 2, (H, W)), yy + rs.uniform(-2, 2, (H, W))], -1).astype(np.float32)
+    ts = np.array([[5_050_000, 5_150_000], [5_150_000, 5_250_000], [5_250_000, 5_350_000]], dtype=np.int64)
+    drv = refshim.ReferenceTwoStepDriver(dns, ev, rect, ts, bins, H, W)
+    for idx in range(3):
+        assert torch.equal(drv.sample(idx), O.dsec_twostep_sample(ev, rect, ts, idx, bins, H, W))
