@@ -114,7 +114,6 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = True   # MIOpen: pick the fastest algorithm per conv shape during warm-up
 
     def barrier():
         if world > 1:

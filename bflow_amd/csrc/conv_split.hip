@@ -51,7 +51,9 @@ struct ConvArgs {
     int CBo, cb_off, P_out;    // channel blocks / first channel block / rows per image of the output buffers
     const float *scale, *shift;   // per output channel or null
     int act;
-    double* stats;             // (B, Cout, 2) or null
+    double* stats;             // (R, B, Cout, 2) or null: workgroup w adds into replica w % R (spreads the fp64 atomics)
+    int stats_reps;            // R >= 1
+    long long stats_rep_stride;
     int gate;                  // 0 | 1 (zr) | 2 (blend): fused GRU gates, see bflow_conv_desc_t
     const _Float16 *gh, *gl;   // h planes (B, CBo, P_out, 32)
     const float* gz;           // z (B, CBo, P_out, 32)
@@ -206,7 +208,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                 double sum = 0.0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) sum += (double)p[w * BN];
-                atomicAdd(a.stats + ((long long)b * a.Cout + col) * 2 + which, sum);
+                atomicAdd(a.stats + (long long)(blockIdx.x % a.stats_reps) * a.stats_rep_stride + ((long long)b * a.Cout + col) * 2 + which, sum);
             }
         }
     }
@@ -802,6 +804,188 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Stem kernel: KS x KS stride-2 convolution of a FEW-channel fp32 NCHW tensor (the 7x7/2 entry convolution of BasicEncoder,
+// extractor.py:63,110: 5 / 8 / 25 / 41 / 3 input channels -> 64).  With so few channels a 32-channel k-block per tap would be
+// 85-97 % padding, and an im2col tensor in HBM would be 8x the input.  Instead the k index runs over (channel, tap) TIGHTLY
+// (K = C*KS*KS rounded up to 32 per chunk of <= 8 channels) and the im2col happens in LDS:
+//   * a workgroup owns an 8 x 16 output patch x 64 channels; per channel chunk its (2*8+KS-2) x (2*16+KS-2) fp32 input patch is
+//     loaded once (zero padded);
+//   * per k-block the 128 x 32 activation tile is BUILT in LDS by the vector ALU (gather through a k -> patch-offset table,
+//     fp32 -> hi/lo split, 16-B swizzled stores) into one of two tile buffers while the matrix cores consume the other;
+//   * weights are an ordinary packed (k-block, Cout_pad, 32) split tensor (the host presents them as a 1x1 convolution over
+//     K_total channels, chunk-major, (c, r, q) inside a chunk), streamed by LDS-DMA, double buffered;
+//   * same accumulator layout and epilogue as the other kernels (bias / folded BatchNorm / ReLU / statistics / f32 / split).
+// ---------------------------------------------------------------------------------------------------------------------
+struct StemArgs {
+    const float* x;            // (B, Cin, H, W) fp32
+    int Cin, H, W;
+    int chunk;                 // channels per chunk (<= 8)
+    int kblocks_per_chunk;     // ceil(chunk * KS * KS / 32) (the LAST chunk may hold fewer channels; its table marks the rest as zero)
+};
+
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs sa) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NT = 2, TH = 8, TW = 16;
+    constexpr int PR = STRIDE * (TH - 1) + KS, PC = STRIDE * (TW - 1) + KS;     // input patch rows / cols (21 x 37)
+    constexpr int MAXC = 8;
+    constexpr int A_TILE = 2 * CBM * 64;                  // 128 pixel rows x 64 B x (hi, lo)
+    constexpr int W_TILE = 2 * NT * 2048;                 // 64 weight rows x 64 B x (hi, lo)
+    constexpr int O_A = 0, O_W = 2 * A_TILE, O_P = O_W + 2 * W_TILE, O_T = O_P + MAXC * PR * PC * 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* patch = reinterpret_cast<float*>(lds + O_P);
+    int* koff = reinterpret_cast<int*>(lds + O_T);        // [kblocks_per_chunk * 32] patch offsets of the chunk's k values, -1 = zero
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.z;
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    int y0, x0, n0;
+    {
+        const int ntn = a.n_tiles;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int mt = (slot / ntn) * 8 + xcd;
+        if (mt >= tiles_x * tiles_y) return;
+        n0 = (slot - (slot / ntn) * ntn) * 32 * NT;
+        const int ty = mt / tiles_x;
+        y0 = ty * TH;
+        x0 = (mt - ty * tiles_x) * TW;
+    }
+    const int gy0 = y0 * STRIDE - a.pad_h, gx0 = x0 * STRIDE - a.pad_w;   // image position of patch element (0, 0)
+
+    // weights: 8 pieces (2 planes x 4 units of 16 rows) per k-block, 2 per wave: plane = wave >> 1, units (2 wave + j) & 3
+    const int urow = lane >> 2;
+    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    unsigned wvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wvo[j] = (unsigned)(((n0 + ((wave * 2 + j) & 3) * 16 + urow) * 32 + uchunk) * 2);
+    const int wtile_b = a.cout_pad * 64;
+    const int nchunks = (sa.Cin + sa.chunk - 1) / sa.chunk;
+    const int nkb = nchunks * sa.kblocks_per_chunk;
+    const rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)((wave >> 1) ? a.wl : a.wh), 0, nkb * wtile_b, 0x00020000);
+    char* const w_dst = lds + O_W + ((wave >> 1) ? NT * 2048 : 0);
+#define STEM_ISSUE_W(KB, BUF)                                                                                            \
+    {                                                                                                                    \
+        const int so_ = ((KB) < nkb ? (KB) : nkb - 1) * wtile_b;                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (BUF) * W_TILE + ((wave * 2 + j) & 3) * 1024), 16, wvo[j], so_, 0, 0); \
+    }
+
+    // builder: thread -> pixel p = tid & 127 of the patch, k half h = tid >> 7 (16 of the 32 k values of a k-block)
+    const int bp = tid & 127, bh = tid >> 7;
+    const int pbase = ((bp >> 4) * STRIDE) * PC + (bp & 15) * STRIDE;         // patch offset of the pixel's tap (0, 0)
+    const int bsw = (bp >> 2) & 3;
+    auto build_tile = [&](int kbl, int buf) {                                 // k-block kbl of the current chunk -> A tile `buf`
+        char* dst = lds + O_A + buf * A_TILE + bp * 64;
+        const int4* tk = reinterpret_cast<const int4*>(koff + kbl * 32 + bh * 16);   // 16 offsets: the same for every pixel of this half
+        int o[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int4 t4 = tk[g4];
+            o[4 * g4] = t4.x; o[4 * g4 + 1] = t4.y; o[4 * g4 + 2] = t4.z; o[4 * g4 + 3] = t4.w;
+        }
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = patch[pbase + max(o[i], 0)];        // branch-free: clamped address, select below
+#pragma unroll
+        for (int g8 = 0; g8 < 2; ++g8) {
+            half8 h8, l8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                _Float16 hi, lo;
+                split1(o[g8 * 8 + i] >= 0 ? v[g8 * 8 + i] : 0.f, hi, lo);
+                h8[i] = hi;
+                l8[i] = lo;
+            }
+            const int pos = ((bh * 2 + g8) ^ bsw) * 16;                      // swizzled 16-B chunk of the 64-B row
+            *reinterpret_cast<half8*>(dst + pos) = h8;
+            *reinterpret_cast<half8*>(dst + CBM * 64 + pos) = l8;
+        }
+    };
+
+    f32x16 hh[NT], xx[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            hh[n][r] = 0.f;
+            xx[n][r] = 0.f;
+        }
+
+    const int sw = (l31 >> 2) & 3;
+    const int aro = (wave * 32 + l31) * 64;
+    STEM_ISSUE_W(0, 0)
+    int kb = 0;                                                               // global k-block index (weights)
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const int c_first = ck * sa.chunk;
+        const int nch = min(sa.chunk, sa.Cin - c_first);
+        __syncthreads();                                                      // previous chunk's patch / table / tiles are drained
+        // ---- input patch of this chunk (zero outside the image) and its k -> offset table
+        {   // all loads of the thread are issued before the first one is consumed (a rolled loop would expose one HBM latency per element)
+            constexpr int NLD = (MAXC * PR * PC + CT - 1) / CT;
+            float pv[NLD];
+            const int total = nch * PR * PC;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int i = tid + j * CT;
+                const int c = i / (PR * PC), rem = i - c * (PR * PC);
+                const int pr = rem / PC, pc = rem - pr * PC;
+                const int gy = gy0 + pr, gx = gx0 + pc;
+                const bool ok = i < total && gy >= 0 && gy < sa.H && gx >= 0 && gx < sa.W;
+                const long long off = ok ? (((long long)b * sa.Cin + c_first + c) * sa.H + gy) * sa.W + gx : 0;
+                const float v = sa.x[off];
+                pv[j] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int i = tid + j * CT;
+                if (i < total) patch[i] = pv[j];
+            }
+        }
+        for (int k = tid; k < sa.kblocks_per_chunk * 32; k += CT) {
+            const int c = k / (KS * KS), rq = k - c * (KS * KS);
+            const int r = rq / KS, q = rq - r * KS;
+            koff[k] = c < nch ? (c * PR + r) * PC + q : -1;
+        }
+        __syncthreads();
+        build_tile(0, kb & 1);
+        for (int kbl = 0; kbl < sa.kblocks_per_chunk; ++kbl, ++kb) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // weight tile kb landed
+            __syncthreads();                                                  // ... everywhere; activation tile kb is complete
+            STEM_ISSUE_W(kb + 1, (kb + 1) & 1)
+            if (kbl + 1 < sa.kblocks_per_chunk) build_tile(kbl + 1, (kb + 1) & 1);   // VALU work under this block's MFMAs
+            const char* at = lds + O_A + (kb & 1) * A_TILE;
+            const char* wt = lds + O_W + (kb & 1) * W_TILE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int co = ((ks * 2 + kh) ^ sw) * 16;
+                const half8 xh = *reinterpret_cast<const half8*>(at + aro + co);
+                const half8 xl = *reinterpret_cast<const half8*>(at + CBM * 64 + aro + co);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int wo = (n * 32 + l31) * 64 + co;
+                    const half8 wh = *reinterpret_cast<const half8*>(wt + wo);
+                    const half8 wl = *reinterpret_cast<const half8*>(wt + NT * 2048 + wo);
+                    hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh[n], 0, 0, 0);
+                    xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, xx[n], 0, 0, 0);
+                    xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, xx[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef STEM_ISSUE_W
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int Wo = a.Wo, Ho = a.Ho, yw = y0 + wave * 2;
+    conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
+        const int y = yw + (row >> 4), x = x0 + (row & 15);
+        return (y < Ho && x < Wo) ? y * Wo + x : -1; }, n0, lane, wave, tid, true, reinterpret_cast<float*>(lds));
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // weights (Cout, Cin, KH, KW) fp32 -> split (KH*KW*CB, Cout_pad, 32), zero padded (k-tile-major)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ wh, _Float16* __restrict__ wl,
@@ -864,13 +1048,18 @@ struct NormArgs {
     _Float16 *oh, *ol; float* out_f32;
     int B, HW, C, CB, P; float eps;
     int tiles_per_block;   // consecutive 64-pixel tiles walked by one block (amortises the coefficient set-up on big grids)
+    int stats_reps;        // replicas of the statistics tables (summed here)
 };
 
 __device__ __forceinline__ void norm_coeffs(const double* stats, const float* scale, const float* shift, int b, int c, int C, int HW,
-                                            float eps, float& mul, float& add) {
+                                            float eps, float& mul, float& add, int reps, long long rep_stride) {
     if (c >= C) { mul = 0.f; add = 0.f; return; }   // padded channels of the last block stay zero
     if (stats) {   // F.instance_norm: biased variance, eps inside the sqrt
-        const double s1 = stats[((long long)b * C + c) * 2], s2 = stats[((long long)b * C + c) * 2 + 1];
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < reps; ++r) {
+            s1 += stats[r * rep_stride + ((long long)b * C + c) * 2];
+            s2 += stats[r * rep_stride + ((long long)b * C + c) * 2 + 1];
+        }
         const double mean = s1 / HW;
         double var = s2 / HW - mean * mean;
         var = var > 0.0 ? var : 0.0;
@@ -890,11 +1079,11 @@ __global__ __launch_bounds__(256) void norm_act_split_kernel(NormArgs p) {
     if (threadIdx.x < 32) {
         const int c = cb * 32 + threadIdx.x;
         float m, a2;
-        norm_coeffs(p.stats_a, p.scale_a, p.shift_a, b, c, p.C, p.HW, p.eps, m, a2);
+        norm_coeffs(p.stats_a, p.scale_a, p.shift_a, b, c, p.C, p.HW, p.eps, m, a2, p.stats_reps, (long long)p.B * p.C * 2);
         coef[0][threadIdx.x] = m;
         coef[1][threadIdx.x] = a2;
         if (p.b) {
-            norm_coeffs(p.stats_b, nullptr, nullptr, b, c, p.C, p.HW, p.eps, m, a2);
+            norm_coeffs(p.stats_b, nullptr, nullptr, b, c, p.C, p.HW, p.eps, m, a2, p.stats_reps, (long long)p.B * p.C * 2);
             coef[2][threadIdx.x] = m;
             coef[3][threadIdx.x] = a2;
         }
@@ -1023,6 +1212,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
                   "conv_split: bad output channel layout");
     a.CBo = out_c / 32; a.cb_off = d->out_channel_offset / 32; a.P_out = d->out_rows_per_image > 0 ? d->out_rows_per_image : Ho * Wo;
     a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
+    a.stats_reps = d->stats_replicas > 0 ? d->stats_replicas : 1; a.stats_rep_stride = (long long)d->B * d->Cout * 2;
     a.acc = d->acc_nchw;
     a.gate = d->gate; a.gh = (const _Float16*)d->gate_h_hi; a.gl = (const _Float16*)d->gate_h_lo; a.gz = d->gate_z;
     if (d->gate) {
@@ -1107,6 +1297,7 @@ extern "C" int bflow_norm_act_split(const bflow_norm_desc_t* d, bflow_stream_t s
     p.b = d->b; p.stats_b = d->stats_b; p.rh = (const _Float16*)d->res_hi; p.rl = (const _Float16*)d->res_lo; p.act_out = d->act_out;
     p.oh = (_Float16*)d->out_hi; p.ol = (_Float16*)d->out_lo; p.out_f32 = d->out_f32; p.B = d->B; p.HW = d->HW; p.C = d->C;
     p.CB = (d->C + 31) / 32; p.P = d->rows_per_image > 0 ? d->rows_per_image : d->HW; p.eps = d->eps;
+    p.stats_reps = d->stats_replicas > 0 ? d->stats_replicas : 1;
     const long long tiles = (long long)bflow::ceil_div(d->HW, 64) * p.CB * d->B;
     p.tiles_per_block = tiles >= 8192 ? 4 : tiles >= 4096 ? 2 : 1;       // keep >= ~2000 blocks in flight
     dim3 grid(bflow::ceil_div(d->HW, 64 * p.tiles_per_block), p.CB, d->B);
@@ -1122,4 +1313,37 @@ extern "C" int bflow_split_to_nchw(const void* x_hi, const void* x_lo, float* ou
     hipLaunchKernelGGL(split_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_hi, (const _Float16*)x_lo, out, HW,
                        C / 32, HW, c_first, c_count, out_batch_stride);
     return bflow::launch_status("split_to_nchw");
+}
+
+extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream) {
+    BFLOW_REQUIRE(d && d->x && d->w_hi && d->w_lo && d->B > 0 && d->Cin > 0 && d->H > 0 && d->W > 0 && d->Cout > 0, BFLOW_E_ARG,
+                  "conv_stem: bad arguments");
+    BFLOW_REQUIRE(d->ksize == 7 && d->stride == 2 && d->pad == 3, BFLOW_E_LIMIT, "conv_stem: only the 7x7 stride-2 pad-3 stem is built");
+    BFLOW_REQUIRE((d->out_hi && d->out_lo) || d->out_f32, BFLOW_E_ARG, "conv_stem: no output");
+    BFLOW_REQUIRE(d->cout_pad >= d->Cout && d->cout_pad % 64 == 0, BFLOW_E_ARG, "conv_stem: cout_pad must be a multiple of 64 >= Cout");
+    const int Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
+    BFLOW_REQUIRE(Ho > 0 && Wo > 0, BFLOW_E_ARG, "conv_stem: empty output");
+    StemArgs sa;
+    sa.x = d->x; sa.Cin = d->Cin; sa.H = d->H; sa.W = d->W;
+    sa.chunk = d->Cin < 8 ? d->Cin : 8;
+    sa.kblocks_per_chunk = (sa.chunk * d->ksize * d->ksize + 31) / 32;
+    BFLOW_REQUIRE(d->k_blocks == ((d->Cin + sa.chunk - 1) / sa.chunk) * sa.kblocks_per_chunk, BFLOW_E_ARG,
+                  "conv_stem: the packed weights hold %d k-blocks, expected %d (chunks of %d channels)", d->k_blocks,
+                  ((d->Cin + sa.chunk - 1) / sa.chunk) * sa.kblocks_per_chunk, sa.chunk);
+    ConvArgs a = {};
+    a.wh = (const _Float16*)d->w_hi; a.wl = (const _Float16*)d->w_lo;
+    a.H = d->H; a.W = d->W; a.Ho = Ho; a.Wo = Wo; a.Cout = d->Cout; a.cout_pad = d->cout_pad;
+    a.KH = a.KW = d->ksize; a.stride = d->stride; a.pad_h = a.pad_w = d->pad;
+    a.out_f32 = d->out_f32; a.oh = (_Float16*)d->out_hi; a.ol = (_Float16*)d->out_lo;
+    a.CBo = (d->Cout + 31) / 32; a.cb_off = 0; a.P_out = d->out_rows_per_image > 0 ? d->out_rows_per_image : Ho * Wo;
+    BFLOW_REQUIRE(a.P_out >= Ho * Wo, BFLOW_E_ARG, "conv_stem: out_rows_per_image < Ho*Wo");
+    a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
+    a.stats_reps = d->stats_replicas > 0 ? d->stats_replicas : 1; a.stats_rep_stride = (long long)d->B * d->Cout * 2;
+    a.n_tiles = bflow::ceil_div(d->Cout, 64);
+    const int patches = bflow::ceil_div(Ho, 8) * bflow::ceil_div(Wo, 16);
+    dim3 grid((patches + 7) / 8 * 8 * a.n_tiles, 1, d->B);
+    const int lds = 2 * (2 * CBM * 64) + 2 * (2 * 2 * 2048) + 8 * 21 * 37 * 4 + sa.kblocks_per_chunk * 32 * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel<7, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((conv_stem_kernel<7, 2>), grid, dim3(CT), lds, (hipStream_t)stream, a, sa);
+    return bflow::launch_status("conv_stem");
 }

@@ -6,6 +6,7 @@ hand-written kernels of the north star); what runs between them is arranged for 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Union
 
 import torch
@@ -13,6 +14,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import split as S
+
+STATS_R = 8
+STEM = os.environ.get("BFLOW_STEM", "hip")     # "miopen": the library 7x7 convolution instead of conv_stem_kernel (A/B only)
 
 
 def _make_norm(kind: str, channels: int) -> nn.Module:
@@ -104,30 +108,45 @@ class BasicEncoder(nn.Module):
     def forward_split(self, x: torch.Tensor, out_rows: Optional[int] = None, trunk_only: bool = False):
         """The same network on the split-fp16 MFMA engine (csrc/conv_split.hip): channels-last split activations, implicit-GEMM
         convolutions with bias / folded BatchNorm / ReLU / InstanceNorm statistics fused into their epilogues, and one
-        normalise+activate+residual kernel between convolutions.  Only the 7x7 stem stays on MIOpen (its tiny input-channel
-        count makes it ~5 % of the FLOPs).  x: (n, c_in, H, W) fp32 -> SplitTensor (n, H/8, W/8, out_dim); `out_rows` pads the
+        normalise+activate+residual kernel between convolutions; the 7x7 stem reads the fp32 NCHW input directly (im2col in LDS).  x: (n, c_in, H, W) fp32 -> SplitTensor (n, H/8, W/8, out_dim); `out_rows` pads the
         pixel rows of the result with zeros (K5 wants a multiple of 128)."""
         kind = self.norm_fn
         assert kind in ("instance", "batch"), kind
         n = x.shape[0]
         dev = x.device
-        # InstanceNorm statistics of all 15 normalised convolutions: ONE zero-filled arena per forward
-        arena = torch.zeros((15 * n * 128 * 2,), dtype=torch.float64, device=dev) if kind == "instance" else None
+        # InstanceNorm statistics of all 16 normalised convolutions: ONE zero-filled arena per forward.  Every table has STATS_R
+        # replicas (workgroup w adds into replica w % R; the normalisation kernel sums them): a few thousand workgroups adding
+        # fp64 atomics to the same 128 addresses per image serialise otherwise (+20 % on these launches, measured).
+        R = STATS_R
+        arena = torch.zeros((16 * R * n * 128 * 2,), dtype=torch.float64, device=dev) if kind == "instance" else None
         used = [0]
 
         def new_stats(c):
-            st = arena[used[0]:used[0] + n * c * 2].view(n, c, 2)
-            used[0] += n * c * 2
+            st = arena[used[0]:used[0] + R * n * c * 2].view(R, n, c, 2)
+            used[0] += R * n * c * 2
             return st
 
-        # ---- stem: 7x7/2 on MIOpen (NCHW fp32) -> norm + relu -> split NHWC
-        y = F.conv2d(x, self.conv1.weight, None, stride=2, padding=3)
-        _, c0, h0, w0 = y.shape
-        if kind == "instance":     # the conv bias cancels under InstanceNorm
-            cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, stats_a=S.plane_stats(y), act_a=S.ACT_RELU)
-        else:
+        # ---- stem: 7x7/2 straight from the fp32 NCHW input (im2col in LDS, csrc/conv_split.hip conv_stem_kernel)
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        if "stem" not in cache:
+            cache["stem"] = S.PackedStemWeight()
+        pk0 = cache["stem"].get(self.conv1.weight)
+        c0 = self.conv1.out_channels
+        h0, w0 = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1
+        if STEM == "miopen":       # the library convolution, kept for A/B
+            y = F.conv2d(x, self.conv1.weight, None, stride=2, padding=3)
+            if kind == "instance":
+                cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, stats_a=S.plane_stats(y), act_a=S.ACT_RELU)
+            else:
+                sc, sh = self._bn_affine(self.norm1, self.conv1.bias)
+                cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, scale_a=sc, shift_a=sh, act_a=S.ACT_RELU)
+        elif kind == "instance":   # the conv bias cancels under InstanceNorm; statistics come out of the epilogue
+            st0 = new_stats(c0)
+            _, f0 = S.conv_stem(x.contiguous(), pk0, stats=st0, want_split=False, want_f32=True)
+            cur, _ = S.norm_act(f0, (n, h0, w0, c0), stats_a=st0, act_a=S.ACT_RELU)
+        else:                      # folded BatchNorm + ReLU in the epilogue: the stem is ONE launch
             sc, sh = self._bn_affine(self.norm1, self.conv1.bias)
-            cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, scale_a=sc, shift_a=sh, act_a=S.ACT_RELU)
+            cur, _ = S.conv_stem(x.contiguous(), pk0, scale=sc, shift=sh, act=S.ACT_RELU)
 
         def conv_norm(name, conv, norm, src, stride, relu):
             """conv (+ bias) -> norm -> optional relu.  instance: returns (fp32 NHWC, stats) for the fused norm kernel;

@@ -24,7 +24,7 @@ MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -54,7 +54,17 @@ class ConvDesc(ctypes.Structure):
                 ("x_split_channels", ctypes.c_int), ("addend", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("act", ctypes.c_int), ("stats", ctypes.c_void_p),
                 ("gate", ctypes.c_int), ("gate_h_hi", ctypes.c_void_p), ("gate_h_lo", ctypes.c_void_p), ("gate_z", ctypes.c_void_p),
-                ("acc_nchw", ctypes.c_void_p)]
+                ("stats_replicas", ctypes.c_int), ("acc_nchw", ctypes.c_void_p)]
+
+
+class StemDesc(ctypes.Structure):
+    """struct bflow_stem_desc (include/bflow_hip.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p),
+                ("B", ctypes.c_int), ("Cin", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cout", ctypes.c_int),
+                ("cout_pad", ctypes.c_int), ("k_blocks", ctypes.c_int), ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int),
+                ("out_f32", ctypes.c_void_p), ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p), ("out_rows_per_image", ctypes.c_int),
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("act", ctypes.c_int), ("stats", ctypes.c_void_p),
+                ("stats_replicas", ctypes.c_int)]
 
 
 class NormDesc(ctypes.Structure):
@@ -63,7 +73,8 @@ class NormDesc(ctypes.Structure):
                 ("a_is_nchw", ctypes.c_int), ("act_a", ctypes.c_int), ("b", ctypes.c_void_p), ("stats_b", ctypes.c_void_p),
                 ("res_hi", ctypes.c_void_p), ("res_lo", ctypes.c_void_p), ("act_out", ctypes.c_int),
                 ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p), ("out_f32", ctypes.c_void_p),
-                ("B", ctypes.c_int), ("HW", ctypes.c_int), ("C", ctypes.c_int), ("eps", ctypes.c_float), ("rows_per_image", ctypes.c_int)]
+                ("B", ctypes.c_int), ("HW", ctypes.c_int), ("C", ctypes.c_int), ("eps", ctypes.c_float), ("rows_per_image", ctypes.c_int),
+                ("stats_replicas", ctypes.c_int)]
 
 
 _lib = None
@@ -92,6 +103,7 @@ def lib() -> ctypes.CDLL:
         "bflow_split_pack": [vp, vp, vp, i, i, i, i, vp],
         "bflow_corr_build_split": [vp, vp, vp, vp, vp, i, i, i, i, i, ll, vp],
         "bflow_conv_pack_weights": [vp, vp, vp, i, i, i, i, i, i, vp],
+        "bflow_conv_stem": [ctypes.POINTER(StemDesc), vp],
         "bflow_conv_split": [ctypes.POINTER(ConvDesc), vp],
         "bflow_plane_stats": [vp, vp, ll, i, vp],
         "bflow_norm_act_split": [ctypes.POINTER(NormDesc), vp],

@@ -112,6 +112,67 @@ class PackedConvWeight:
         return self.planes, self.meta
 
 
+def _stats_replicas(stats: Optional[torch.Tensor], B: int, C: int) -> int:
+    """Statistics tables are (B, C, 2) or (R, B, C, 2): R replicas that spread the epilogue's fp64 atomics (summed by norm_act)."""
+    if stats is None:
+        return 0
+    assert stats.is_contiguous() and tuple(stats.shape[-3:]) == (B, C, 2) and stats.dim() in (3, 4), tuple(stats.shape)
+    return stats.shape[0] if stats.dim() == 4 else 1
+
+
+class PackedStemWeight:
+    """The 7x7 stem filter (Cout, Cin, 7, 7) laid out for bflow_conv_stem: a 1x1 filter over K = chunks x (c_local, r, q) columns,
+    every chunk of min(Cin, 8) channels zero padded to a multiple of 32, then packed like any conv weight."""
+
+    def __init__(self):
+        self._key = None
+
+    def get(self, weight: torch.Tensor):
+        cout, cin, kh, kw = weight.shape
+        assert kh == kw == 7
+        key = (weight.data_ptr(), weight._version, str(weight.device))
+        if self._key != key:
+            chunk = min(cin, 8)
+            kpc = (chunk * kh * kw + 31) // 32 * 32
+            cols = []
+            w = weight.detach().float()
+            for c0 in range(0, cin, chunk):
+                blk = w[:, c0:c0 + chunk].reshape(cout, -1)                      # (c_local, r, q), c_local slowest
+                cols.append(torch.nn.functional.pad(blk, (0, kpc - blk.shape[1])))
+            wm = torch.cat(cols, dim=1).contiguous().view(cout, -1, 1, 1)
+            self._inner = PackedConvWeight()
+            planes, meta = self._inner.get(wm)
+            self._key, self.planes, self.meta = key, planes, (cout, cin, planes.shape[1], meta[4])   # (cout, cin, k_blocks, cout_pad)
+        return self.planes, self.meta
+
+
+def conv_stem(x: torch.Tensor, packed, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+              stats: Optional[torch.Tensor] = None, want_split: bool = True, want_f32: bool = False):
+    """7x7 / stride 2 / pad 3 convolution of a few-channel fp32 NCHW tensor (BasicEncoder.conv1) -> (split_out or None, blocked fp32 or
+    None), epilogue as `conv`.  `packed` = PackedStemWeight.get(weight)."""
+    planes, (cout, cin, k_blocks, cout_pad) = packed
+    B, C, H, W = x.shape
+    assert C == cin and x.dtype == torch.float32 and x.is_contiguous()
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    dev = x.device
+    out_split = SplitTensor.empty(B, Ho, Wo, cout, dev) if want_split else None
+    out_f32 = torch.empty((B, (cout + 31) // 32, Ho * Wo, 32), dtype=torch.float32, device=dev) if want_f32 else None
+    d = hip.StemDesc()
+    d.x, d.w_hi, d.w_lo = hip._dev(x, name="x"), planes[0].data_ptr(), planes[1].data_ptr()
+    d.B, d.Cin, d.H, d.W, d.Cout, d.cout_pad, d.k_blocks = B, C, H, W, cout, cout_pad, k_blocks
+    d.ksize, d.stride, d.pad = 7, 2, 3
+    d.out_f32 = None if out_f32 is None else out_f32.data_ptr()
+    d.out_hi = None if out_split is None else out_split.hi.data_ptr()
+    d.out_lo = None if out_split is None else out_split.lo.data_ptr()
+    d.scale = None if scale is None else hip._dev(scale, name="scale")
+    d.shift = None if shift is None else hip._dev(shift, name="shift")
+    d.act = act
+    d.stats = None if stats is None else hip._dev(stats, torch.float64, "stats")
+    d.stats_replicas = _stats_replicas(stats, B, cout)
+    hip._check(hip.lib().bflow_conv_stem(ctypes.byref(d), hip._stream()), "bflow_conv_stem")
+    return out_split, out_f32
+
+
 def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optional[torch.Tensor] = None,
          shift: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_split: Optional[SplitTensor] = None,
          out_f32: Optional[torch.Tensor] = None, channel_offset: int = 0, stats: Optional[torch.Tensor] = None,
@@ -171,6 +232,7 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
     d.shift = None if shift is None else hip._dev(shift, name="shift")
     d.act = act
     d.stats = None if stats is None else hip._dev(stats, torch.float64, "stats")
+    d.stats_replicas = _stats_replicas(stats, B, cout)
     if acc_nchw is not None:
         assert acc_nchw.dtype == torch.float32 and acc_nchw.is_contiguous() and tuple(acc_nchw.shape) == (B, cout, Ho, Wo) and stats is None
         d.acc_nchw = acc_nchw.data_ptr()
@@ -215,6 +277,9 @@ def norm_act(a: torch.Tensor, shape_bhwc, a_is_nchw: bool = False, stats_a: Opti
     assert out is None or out.rows == H * W
     d.out_f32 = None if out_f32 is None else hip._dev(out_f32, name="out_f32")
     d.B, d.HW, d.C, d.eps, d.rows_per_image = B, H * W, C, eps, H * W
+    ra, rb = _stats_replicas(stats_a, B, C), _stats_replicas(stats_b, B, C)
+    assert not (ra and rb) or ra == rb, "both statistics tables must use the same number of replicas"
+    d.stats_replicas = max(ra, rb)
     hip._check(hip.lib().bflow_norm_act_split(ctypes.byref(d), hip._stream()), "bflow_norm_act_split")
     return out, out_f32
 

@@ -104,11 +104,35 @@ typedef struct bflow_conv_desc {
                                          outputs (out_channel_stride = Ch, offset 0); out may alias h (blend, in place).       */
     const void *gate_h_hi, *gate_h_lo;
     const float* gate_z;
+    int stats_replicas;               /* R: `stats` is (R, B, Cout, 2) and workgroup w adds into replica w % R -- thousands of fp64
+                                         atomics on the same address serialise (measured: +20 % on the InstanceNorm convolutions);
+                                         bflow_norm_act_split sums the replicas.  0 = 1.                                       */
     float* acc_nchw;                  /* optional fp32 (B, Cout, Ho*Wo): acc += result (after scale/shift/addend/act); the UPDATED
                                          value is what out_f32 / out_hi/lo receive.  Fuses BezierCurves.delta_update_params
                                          (bezier.py:137-139) and the re-emission of the Bezier channel block into the head's last
                                          convolution.                                                                          */
 } bflow_conv_desc_t;
+/* bflow_conv_stem: the 7x7 stride-2 entry convolution of BasicEncoder (extractor.py:63,110) on a few-channel fp32 NCHW input
+ * (5 / 8 / 25 / 41 / 3 channels): im2col in LDS over a TIGHT k = (channel, tap) index instead of 32-channel blocks per tap.
+ *   x (B, Cin, H, W) fp32; weights: the (Cout, Cin, 7, 7) filter presented as a 1x1 convolution over K channels and packed with
+ *   bflow_conv_pack_weights, where K is built chunk by chunk (chunks of min(Cin, 8) channels): per chunk the columns
+ *   (c, r, q) -> c_local*49 + r*7 + q, zero padded to a multiple of 32; k_blocks = total K / 32.
+ *   Outputs / epilogue as bflow_conv_split: blocked fp32 and/or split (B, ceil(Cout/32), out_rows_per_image, 32), per-channel
+ *   scale / shift, act, InstanceNorm statistics.                                                                           */
+typedef struct bflow_stem_desc {
+    const float* x;
+    const void *w_hi, *w_lo;
+    int B, Cin, H, W, Cout, cout_pad, k_blocks;
+    int ksize, stride, pad;           /* 7, 2, 3 */
+    float* out_f32;
+    void *out_hi, *out_lo;
+    int out_rows_per_image;           /* 0 = Ho*Wo */
+    const float *scale, *shift;
+    int act;
+    double* stats;
+    int stats_replicas;               /* as in bflow_conv_desc_t */
+} bflow_stem_desc_t;
+int bflow_conv_stem(const bflow_stem_desc_t* desc, bflow_stream_t stream);
 int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
                             int cout_pad, int cin_pad, bflow_stream_t stream);
 int bflow_conv_split(const bflow_conv_desc_t* desc, bflow_stream_t stream);
@@ -128,6 +152,7 @@ typedef struct bflow_norm_desc {
     void *out_hi, *out_lo; float* out_f32;
     int B, HW, C; float eps;
     int rows_per_image;               /* pixel rows per image of the blocked tensors; 0 = HW                     */
+    int stats_replicas;               /* stats_a / stats_b are (R, B, C, 2) tables to be summed; 0 = 1           */
 } bflow_norm_desc_t;
 int bflow_plane_stats(const float* x, double* stats, long long planes, int HW, bflow_stream_t stream);
 int bflow_norm_act_split(const bflow_norm_desc_t* desc, bflow_stream_t stream);

@@ -576,3 +576,30 @@ def test_dsec_twostep_assembly_full_size_vs_oracle():
     ref = O.dsec_twostep_sample(ev, rect, ts, 1, bins, H, W).numpy()
     bad = ~np.isclose(out, ref, rtol=1e-4, atol=5e-5)
     assert bad.sum() <= 20 and np.all(np.abs(ref_raw.numpy()[bad]) < 1e-6)
+
+
+@pytest.mark.parametrize("cin,H,W,B", [(5, 96, 128, 2), (8, 70, 90, 1), (25, 64, 80, 1), (41, 48, 64, 2), (3, 52, 44, 1)])
+def test_conv_stem_vs_fp64(cin, H, W, B):
+    """7x7/2 entry convolution (im2col in LDS over a tight (channel, tap) k index; 1-6 channel chunks) vs an fp64 reference,
+    incl. odd sizes / ragged patches, both epilogues (statistics + fp32, folded affine + ReLU + split)."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(cin)
+    x = rs.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((64, cin, 7, 7)) / np.sqrt(cin * 49)).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride=2, padding=3)
+    mag = torch.nn.functional.conv2d(torch.from_numpy(np.abs(x)).double(), torch.from_numpy(np.abs(w)).double(), None, stride=2, padding=3) + 1.0
+    pk = S.PackedStemWeight().get(cu(w))
+    Ho, Wo = ref.shape[2:]
+    stats = torch.zeros((B, 64, 2), dtype=torch.float64, device=DEV)
+    _, f = S.conv_stem(cu(x), pk, stats=stats, want_split=False, want_f32=True)
+    got = S.blocked_f32_to_nhwc(f, Ho, Wo, 64).permute(0, 3, 1, 2).cpu().double()
+    err = float(((got - ref).abs() / mag).max())
+    print(f"stem {cin}->64 {H}x{W}: err/sum|x||w| {err:.2e}")
+    assert err < 5e-7
+    np.testing.assert_allclose(stats[..., 0].cpu().numpy(), ref.sum(dim=(2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(stats[..., 1].cpu().numpy(), (ref * ref).sum(dim=(2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    sc, sh = rs.uniform(0.5, 1.5, 64).astype(np.float32), rs.standard_normal(64).astype(np.float32)
+    o, _ = S.conv_stem(cu(x), pk, scale=cu(sc), shift=cu(sh), act=S.ACT_RELU)
+    want = torch.relu(ref * torch.from_numpy(sc).double().view(1, -1, 1, 1) + torch.from_numpy(sh).double().view(1, -1, 1, 1))
+    gs = o.float_nhwc().permute(0, 3, 1, 2).cpu().double()
+    assert float(((gs - want).abs() / (mag * 1.5 + 1.0)).max()) < 1e-6

@@ -27,7 +27,7 @@ def build(model, vox, cfg, low_params=None):
         n5, c0, h0, w0 = y.shape
         cur, _ = S.norm_act(y, (n5, h0, w0, c0), a_is_nchw=True, stats_a=S.plane_stats(y), act_a=S.ACT_RELU)
         pk = S.PackedConvWeight().get(model.fnet_ev.layer1[0].conv1.weight)
-        st = torch.zeros((n5, 64, 2), dtype=torch.float64, device=dev)
+        st = torch.zeros((8, n5, 64, 2), dtype=torch.float64, device=dev)      # 8 replicas, as the encoder uses them
         o32 = torch.empty((n5, 2, h0 * w0, 32), dtype=torch.float32, device=dev)
         out.append(dict(key="roofline", name=CONV_NAME, regex="conv_halo_kernel", bound="mfma",
                         launch=lambda: S.conv(cur, pk, stride=1, padding=1, want_split=False, out_f32=o32, stats=st),
