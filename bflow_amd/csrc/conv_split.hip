@@ -110,15 +110,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
             const long long ob = (((long long)b * a.CBo + a.cb_off + (n0 >> 5) + n) * a.P_out) * 32 + ch;
             const long long ab = (((long long)b * ((a.Cout + 31) >> 5) + (n0 >> 5) + n) * a.P_out) * 32 + ch;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            float4 raws[4];                                  // all four slab reads (and addend loads) in flight before the first is consumed
+            float4 ads[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) raws[it] = *reinterpret_cast<const float4*>(stg + (it * 8 + rr) * RS + ch);
+            if (a.addend) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m_ = pixel_of(it * 8 + rr);
+                    ads[it] = *reinterpret_cast<const float4*>(a.addend + ab + (long long)(m_ >= 0 ? m_ : 0) * 32);
+                }
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 8 + rr;
                 const int m = pixel_of(row);
                 const bool mok = m >= 0;
-                const float4 raw = *reinterpret_cast<const float4*>(stg + row * RS + ch);
+                const float4 raw = raws[it];
                 float v[4] = {raw.x * sc[0] + sh[0], raw.y * sc[1] + sh[1], raw.z * sc[2] + sh[2], raw.w * sc[3] + sh[3]};
                 if (a.addend && mok) {
-                    const float4 ad = *reinterpret_cast<const float4*>(a.addend + ab + (long long)m * 32);
+                    const float4 ad = ads[it];
                     v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
                 }
 #pragma unroll
