@@ -73,7 +73,6 @@ struct ConvArgs {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 #define CONV_STG_STRIDE 36                       // floats per staged pixel row (32 + 4 pad)
-#define CONV_STG_BYTES (4 * 32 * CONV_STG_STRIDE * 4)
 
 // `pixel_of(row)` maps row 0..31 of the wave's slab to the pixel row of the output image (or -1: outside, not written).
 // Sum over the 8 lanes that share lane & 7 (xor 8, 16, 32) on the vector ALU: DPP row rotation inside a 16-lane row, then the
@@ -96,14 +95,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                                               int lane, int wave, int tid, bool writer, float* red) {
     constexpr int BN = 32 * NT;
     constexpr int RS = CONV_STG_STRIDE;
-    float* stg = red + 2 * NW * BN + wave * (32 * RS);    // this wave's slab, behind the statistics scratch [2][NW][BN]
+    float* const stg0 = red + 2 * NW * BN + wave * NT * (32 * RS);   // this wave's NT slabs, behind the statistics scratch [2][NW][BN]
     const int kh = lane >> 5, l31 = lane & 31;
     const int rr = lane >> 3, ch = (lane & 7) * 4;        // read side: rows rr + 8*it, channels ch .. ch+3 of the block
     if (writer) {
+        // all channel blocks are staged first (one slab each): ONE write -> read round trip through LDS per wave
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int cbase = n0 + n * 32;
-            if (cbase >= a.Cout) break;                   // channel blocks past the padded output are never written
+            if (n0 + n * 32 >= a.Cout) break;
+            float* stg = stg0 + n * (32 * RS);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r0 = 4 * j;
@@ -111,8 +111,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                     make_float4(hh[n][r0] + xx[n][r0] * LO_INV, hh[n][r0 + 1] + xx[n][r0 + 1] * LO_INV, hh[n][r0 + 2] + xx[n][r0 + 2] * LO_INV,
                                 hh[n][r0 + 3] + xx[n][r0 + 3] * LO_INV);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int cbase = n0 + n * 32;
+            if (cbase >= a.Cout) break;                   // channel blocks past the padded output are never written
+            const float* stg = stg0 + n * (32 * RS);
             float sc[4], sh[4];
             bool cok[4];
 #pragma unroll
@@ -217,8 +223,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                     }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();                // the slab is rewritten by the next channel block
         }
     }
     if (a.stats) {
