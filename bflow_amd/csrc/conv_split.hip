@@ -142,6 +142,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                     ads[it] = *reinterpret_cast<const float4*>(a.addend + ab + (long long)(m_ >= 0 ? m_ : 0) * 32);
                 }
             }
+            // gate operands (h as hi/lo halves, z) of the four row groups: same idea, one latency instead of four
+            const int cbk = (n0 >> 5) + n;
+            const bool r_half = a.gate == 1 && cbk >= a.CBo;
+            const bool need_h = a.gate == 2 || r_half;
+            const long long gbase = (((long long)b * a.CBo + (r_half ? cbk - a.CBo : cbk)) * a.P_out) * 32 + ch;
+            half4v g_hh[4], g_hl[4];
+            float4 g_z[4];
+            if (need_h) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m_ = pixel_of(it * 8 + rr);
+                    const long long go = gbase + (long long)(m_ >= 0 ? m_ : 0) * 32;
+                    g_hh[it] = *reinterpret_cast<const half4v*>(a.gh + go);
+                    g_hl[it] = *reinterpret_cast<const half4v*>(a.gl + go);
+                    if (a.gate == 2) g_z[it] = *reinterpret_cast<const float4*>(a.gz + go);
+                }
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 8 + rr;
@@ -172,16 +189,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                 if (mok && a.gate) {
                     // SepConvGRU gates (update.py:38-47).  Block index inside the (B, CBo, P, 32) gate buffers: the z half of a
                     // "zr" convolution and a "blend" convolution map 1:1, the r half is shifted down by CBo blocks.
-                    const int cbk = (n0 >> 5) + n;
-                    const bool r_half = a.gate == 1 && cbk >= a.CBo;
-                    const long long gb = (((long long)b * a.CBo + (r_half ? cbk - a.CBo : cbk)) * a.P_out + m) * 32 + ch;
+                    const long long gb = gbase + (long long)m * 32;
                     if (a.gate == 1 && !r_half) {
                         *reinterpret_cast<float4*>(a.out_f32 + gb) = make_float4(bflow::sigmoidf_(v[0]), bflow::sigmoidf_(v[1]),
                                                                                  bflow::sigmoidf_(v[2]), bflow::sigmoidf_(v[3]));
                     } else {
-                        const half4v hh4 = *reinterpret_cast<const half4v*>(a.gh + gb), hl4 = *reinterpret_cast<const half4v*>(a.gl + gb);
+                        const half4v hh4 = g_hh[it], hl4 = g_hl[it];
                         float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (a.gate == 2) z4 = *reinterpret_cast<const float4*>(a.gz + gb);
+                        if (a.gate == 2) z4 = g_z[it];
                         const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
                         half4v h4, l4;
 #pragma unroll
