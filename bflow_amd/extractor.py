@@ -1,8 +1,10 @@
 """Feature / context encoder (K4) -- the drop-in for models/raft_utils/extractor.py:5-125.
 
-Same module tree and parameter names as the reference (so its checkpoints load), inference only.  The dense
-convolutions are deliberately left to MIOpen through PyTorch-ROCm (not one of the
-hand-written kernels of the north star); what runs between them is arranged for few launches.
+Same module tree and parameter names as the reference (so its checkpoints load), inference only.  `forward_split` is the product
+path: every convolution runs on the hand-written split-fp16 MFMA engine (csrc/conv_split.hip: 7x7/2 stem with im2col in LDS,
+halo kernel for the 3x3s, generic kernel for stride 2 / 1x1), bias / folded BatchNorm / ReLU / InstanceNorm statistics live in the
+conv epilogues, and one normalise + activate + residual kernel sits between convolutions.  `forward` (MIOpen through PyTorch-ROCm)
+is kept for A/B runs only (BFLOW_CONV_ENGINE=miopen).
 """
 from __future__ import annotations
 

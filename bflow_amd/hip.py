@@ -3,7 +3,7 @@
 This is the only place the package touches the C ABI.  Every wrapper
   * requires CUDA(HIP)-resident, contiguous tensors of the declared dtype,
   * passes raw `data_ptr()`s plus sizes, and torch's CURRENT stream (so launches are captured by hipGraph
-    stream capture and ordered with the MIOpen convolutions torch enqueues on the same stream),
+    stream capture and ordered with whatever else torch enqueues on the same stream),
   * raises `BflowHipError` on a non-zero status.
 
 There is NO fallback: if the shared library is missing or a tensor lives on the CPU the call fails loudly.

@@ -4,12 +4,14 @@ Same constructor (`RAFTSpline(config['model'])`), same `forward(voxel_grid, imag
 signature and return types, same parameter names (`fnet_ev.*, fnet_img.*, cnet.*, update_block.*`) so the public
 checkpoints load through `load_state_dict`.  What differs is how the hot path is executed:
 
-    encoders            MIOpen convolutions via PyTorch-ROCm                                   (K4)
-    correlation volume  bflow_corr_build_f32: fp32-MFMA GEMM, one launch per reference group   (K5)
-    pyramid             bflow_corr_pool2x2                                                     (K6)
-    per iteration       bflow_corr_lookup_bezier (Bezier evaluation + coords0 + 9x9 gather fused), MIOpen convs with
-                        bias/activation/concat/GRU gates folded into the HIP element-wise kernels (K7-K12)
-    last iteration      mask head + bflow_cvx_upsample                                         (K13)
+    encoders            split-fp16 MFMA conv engine (bflow_conv_stem / bflow_conv_split + bflow_norm_act_split); the context
+                        encoder runs on a side stream under the 5-image feature encoder                    (K4)
+    correlation volume  bflow_corr_build_split on the encoder's own output layout (exact fp32 MFMA variant kept) (K5)
+    pyramid             bflow_corr_pool2x2                                                                   (K6)
+    per iteration       bflow_corr_lookup_bezier_split (Bezier evaluation + coords0 + 9x9 gather fused, written in the conv
+                        engine's layout), 10 engine convolutions with bias / activation / concatenation / GRU gates /
+                        parameter update in their epilogues (K7-K12)
+    last iteration      mask head + bflow_cvx_upsample                                                       (K13)
 
 The whole forward is free of host synchronisation, so `enable_hipgraph()` captures it once per input signature into
 a hipGraph (bflow_amd/graph.py) and replays it; eager execution stays available for debugging and stage timing.

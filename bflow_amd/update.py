@@ -1,12 +1,14 @@
 """Update block (K9-K11) -- drop-in for models/raft_spline/update.py:8-126 with the reference's parameter names.
 
-Inference only.  `BasicUpdateBlock.step()` runs one GRU/Bezier iteration on caller-provided workspaces with the
-dense convolutions on MIOpen (bias-free calls) and everything between them in the fused HIP element-wise kernels
-of csrc/update_ops.hip:
-  * no torch.cat: the convs read hx = [h | inp | motion] and rhx = [r*h | inp | motion] in place,
-  * convz and convr are one 256-channel convolution,
-  * conv bias + relu / sigmoid / tanh / GRU blend are folded into the element-wise kernels,
+Inference only.  `step_split()` is the product path: one GRU/Bezier iteration on the split-fp16 MFMA conv engine
+(csrc/conv_split.hip) over blocked split workspaces:
+  * no torch.cat: channel-block offsets and two-source convolutions ([h | M], [r*h | M]),
+  * convz and convr are one 256-channel convolution; the loop-invariant context share of the six gate convolutions is
+    evaluated once per frame and enters as an epilogue addend,
+  * sigmoid / r*h / the GRU blend / `bezier += delta` and the re-emission of the Bezier channel block are conv epilogues,
+  * the 7x7 Bezier convolution is an im2col + 1x1 GEMM; the look-up + correlation branch runs next to the Bezier branch,
   * the mask head only runs when its output is consumed (last iteration in test mode; raft.py:193-195).
+`step()` (MIOpen convolutions + the element-wise kernels of csrc/update_ops.hip) is kept for A/B runs (BFLOW_UPDATE_ENGINE=miopen).
 """
 from __future__ import annotations
 
