@@ -603,3 +603,80 @@ def test_conv_stem_vs_fp64(cin, H, W, B):
     want = torch.relu(ref * torch.from_numpy(sc).double().view(1, -1, 1, 1) + torch.from_numpy(sh).double().view(1, -1, 1, 1))
     gs = o.float_nhwc().permute(0, 3, 1, 2).cpu().double()
     assert float(((gs - want).abs() / (mag * 1.5 + 1.0)).max()) < 1e-6
+
+
+def test_conv_engine_random_shapes_vs_fp64():
+    """Randomised sweep over the conv engine's dispatch space (halo / 8-wave halo / generic / stem kernels; ragged patches, odd sizes,
+    channel counts that are not multiples of 32, batch > 1, every epilogue option) against fp64 references."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(2024)
+    kinds = [((3, 3), 1), ((1, 5), 1), ((5, 1), 1), ((1, 1), 1), ((3, 3), 2), ((1, 1), 2)]
+    for trial in range(24):
+        (kh, kw), stride = kinds[trial % len(kinds)]
+        B = int(rs.randint(1, 4))
+        H, W = int(rs.randint(5, 70)), int(rs.randint(5, 90))
+        if trial % 6 == 0:
+            H, W, B = int(rs.randint(90, 130)), int(rs.randint(120, 170)), 2          # enough patches for the 64-channel halo tile
+        cin = int(rs.choice([32, 64, 96, 160, 288]))
+        cout = int(rs.choice([4, 32, 64, 96, 126, 128, 192, 256]))
+        pad = (kh // 2, kw // 2)
+        x = rs.standard_normal((B, cin, H, W)).astype(np.float32)
+        w = (rs.standard_normal((cout, cin, kh, kw)) / np.sqrt(cin * kh * kw)).astype(np.float32)
+        bias = rs.standard_normal(cout).astype(np.float32)
+        scale = rs.uniform(0.5, 1.5, cout).astype(np.float32)
+        act = int(rs.randint(0, 3))
+        tx, tw = torch.from_numpy(x).double(), torch.from_numpy(w).double()
+        ref = torch.nn.functional.conv2d(tx, tw, None, stride=stride, padding=pad)
+        mag = torch.nn.functional.conv2d(tx.abs(), tw.abs(), None, stride=stride, padding=pad) + 1.0
+        ref = ref * torch.from_numpy(scale).double().view(1, -1, 1, 1) + torch.from_numpy(bias).double().view(1, -1, 1, 1)
+        use_addend = bool(rs.randint(0, 2))
+        Ho, Wo = ref.shape[2:]
+        addend = None
+        if use_addend:
+            add_nchw = rs.standard_normal((B, cout, Ho, Wo)).astype(np.float32)
+            ref = ref + torch.from_numpy(add_nchw).double()
+            blk = np.zeros((B, (cout + 31) // 32, Ho * Wo, 32), dtype=np.float32)
+            blk.reshape(B, -1, Ho * Wo, 32)[:] = np.pad(add_nchw.reshape(B, cout, Ho * Wo), ((0, 0), (0, (-cout) % 32), (0, 0))) \
+                .reshape(B, -1, 32, Ho * Wo).transpose(0, 1, 3, 2)
+            addend = cu(blk)
+        ref = torch.relu(ref) if act == 1 else torch.tanh(ref) if act == 2 else ref
+        xs = S.from_nchw(cu(x))
+        pk = S.PackedConvWeight().get(cu(w))
+        o_split, o_f32 = S.conv(xs, pk, stride=stride, padding=pad, scale=cu(scale), shift=cu(bias), act=act, addend=addend, want_f32=True)
+        got = S.blocked_f32_to_nhwc(o_f32, Ho, Wo, cout).permute(0, 3, 1, 2).cpu().double()
+        got_s = o_split.float_nhwc().permute(0, 3, 1, 2).cpu().double()
+        tol = (mag * 1.5 + 2.0)
+        e1, e2 = float(((got - ref).abs() / tol).max()), float(((got_s - ref).abs() / tol).max())
+        assert e1 < 6e-7 and e2 < 1.2e-6, (trial, (kh, kw), stride, B, H, W, cin, cout, act, use_addend, e1, e2)
+        # padded channels of the last block are zeros, not garbage
+        if cout % 32:
+            assert float(o_split.planes[:, :, -1, :, cout % 32:].abs().max()) == 0.0
+
+
+def test_pipeline_raw_events_to_metrics():
+    """The three stages either side of the network chained on the GPU: raw DSEC-style events -> two-step voxel assembly (f-1) ->
+    RAFTSpline forward -> validation metrics (f-3); compared with the same chain on the CPU oracle."""
+    from bflow_amd.dsec import EventStream, TwoStepAssembler
+    from bflow_amd.validation import DataLoading, DataSetType, Validator
+    cfg, sd, m = _small_model("E_LU4_BD2")
+    H, W, bins = 176, 208, cfg["num_bins"]["correlation"]
+    rs = np.random.RandomState(12)
+    n = 150_000
+    ev = dict(x=rs.randint(0, W, n).astype(np.uint16), y=rs.randint(0, H, n).astype(np.uint16), p=rs.randint(0, 2, n).astype(np.uint8),
+              t=np.sort(rs.randint(1_000_000, 1_260_000, n)).astype(np.int64))
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    rect = np.stack([xx + 0.3 * np.sin(yy / 9.0), yy + 0.3 * np.cos(xx / 11.0)], -1).astype(np.float32)
+    ts = np.array([[1_030_000, 1_130_000], [1_130_000, 1_230_000]], dtype=np.int64)
+    vox = TwoStepAssembler(bins, H, W, rect).assemble(EventStream(**ev), ts, 1)
+    assert vox.shape == (2 * bins - 1, H, W)
+    gt = synthetic.gt_flow(1, H, W, seed=4)
+    v = Validator(m, cfg)
+    out = v.validation_step({DataLoading.FLOW: cu(gt), DataLoading.EV_REPR: vox[None], DataLoading.DATASET_TYPE: [DataSetType.DSEC]})
+    res = v.compute()
+    ovox = O.dsec_twostep_sample(ev, rect, ts, 1, bins, H, W)
+    _, up = O.forward(sd, cfg, ovox[None], None, iters=cfg["num_iter"]["test"], test_mode=True)
+    flow = O.bezier_flow(up, 1.0)
+    # the voxel grids agree to the K1 atomics tolerance, hence the flows to a few 1e-4 px at most
+    assert float(O.epe_masked(out["pred"].cpu(), flow)) < 5e-3
+    want = float(O.epe_masked(flow, torch.from_numpy(gt)))
+    assert abs(float(res["val/epe"]) - want) < 5e-3 * max(1.0, want)
