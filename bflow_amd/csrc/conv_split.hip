@@ -863,6 +863,10 @@ struct StemArgs {
     int Cin, H, W;
     int chunk;                 // channels per chunk (<= 8)
     int kblocks_per_chunk;     // ceil(chunk * KS * KS / 32) (the LAST chunk may hold fewer channels; its table marks the rest as zero)
+    // channel windows of a wider source tensor (B_src, C_src, H, W): image n reads channels [win[n / B_src], + Cin) of source image
+    // n % B_src -- RAFTSpline.gen_voxel_grids (raft.py:88-99) followed by torch.cat, without the copy.  B_src = 0: x is plain.
+    int B_src, C_src;
+    int win[8];
 };
 
 template <int KS, int STRIDE>
@@ -971,8 +975,9 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
             float pv[NLD];
             const int total = nch * PR * PC;
             const long long img = (long long)sa.H * sa.W;
-            const rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.x + ((long long)b * sa.Cin + c_first) * img), 0,
-                                                                  (int)(nch * img * 4), 0x00020000);
+            const long long x_base = sa.B_src > 0 ? ((long long)(b % sa.B_src) * sa.C_src + sa.win[b / sa.B_src] + c_first) * img
+                                                  : ((long long)b * sa.Cin + c_first) * img;
+            const rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.x + x_base), 0, (int)(nch * img * 4), 0x00020000);
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int i = tid + j * CT;
@@ -1374,6 +1379,17 @@ extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream
     sa.x = d->x; sa.Cin = d->Cin; sa.H = d->H; sa.W = d->W;
     sa.chunk = d->Cin < 8 ? d->Cin : 8;
     sa.kblocks_per_chunk = (sa.chunk * d->ksize * d->ksize + 31) / 32;
+    sa.B_src = 0; sa.C_src = d->Cin;
+    for (int i = 0; i < 8; ++i) sa.win[i] = 0;
+    if (d->n_windows > 0) {
+        BFLOW_REQUIRE(d->n_windows <= 8 && d->window_starts && d->B % d->n_windows == 0 && d->src_channels >= d->Cin, BFLOW_E_ARG,
+                      "conv_stem: bad channel windows");
+        sa.B_src = d->B / d->n_windows; sa.C_src = d->src_channels;
+        for (int i = 0; i < d->n_windows; ++i) {
+            BFLOW_REQUIRE(d->window_starts[i] >= 0 && d->window_starts[i] + d->Cin <= d->src_channels, BFLOW_E_ARG, "conv_stem: window %d out of range", i);
+            sa.win[i] = d->window_starts[i];
+        }
+    }
     BFLOW_REQUIRE(d->k_blocks == ((d->Cin + sa.chunk - 1) / sa.chunk) * sa.kblocks_per_chunk, BFLOW_E_ARG,
                   "conv_stem: the packed weights hold %d k-blocks, expected %d (chunks of %d channels)", d->k_blocks,
                   ((d->Cin + sa.chunk - 1) / sa.chunk) * sa.kblocks_per_chunk, sa.chunk);

@@ -107,7 +107,7 @@ class BasicEncoder(nn.Module):
             cache[id(norm)] = hit
         return hit[1], hit[2]
 
-    def forward_split(self, x: torch.Tensor, out_rows: Optional[int] = None, trunk_only: bool = False):
+    def forward_split(self, x, out_rows: Optional[int] = None, trunk_only: bool = False):
         """The same network on the split-fp16 MFMA engine (csrc/conv_split.hip): channels-last split activations, implicit-GEMM
         convolutions with bias / folded BatchNorm / ReLU / InstanceNorm statistics fused into their epilogues, and one
         normalise+activate+residual kernel between convolutions; the 7x7 stem reads the fp32 NCHW input directly (im2col in LDS).  x: (n, c_in, H, W) fp32 -> SplitTensor (n, H/8, W/8, out_dim); `out_rows` pads the
@@ -135,8 +135,9 @@ class BasicEncoder(nn.Module):
         pk0 = cache["stem"].get(self.conv1.weight)
         c0 = self.conv1.out_channels
         h0, w0 = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1
+        xin = x if isinstance(x, S.ChannelWindows) else x.contiguous()
         if STEM == "miopen":       # the library convolution, kept for A/B
-            y = F.conv2d(x, self.conv1.weight, None, stride=2, padding=3)
+            y = F.conv2d(x.materialize() if isinstance(x, S.ChannelWindows) else x, self.conv1.weight, None, stride=2, padding=3)
             if kind == "instance":
                 cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, stats_a=S.plane_stats(y), act_a=S.ACT_RELU)
             else:
@@ -144,11 +145,11 @@ class BasicEncoder(nn.Module):
                 cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, scale_a=sc, shift_a=sh, act_a=S.ACT_RELU)
         elif kind == "instance":   # the conv bias cancels under InstanceNorm; statistics come out of the epilogue
             st0 = new_stats(c0)
-            _, f0 = S.conv_stem(x.contiguous(), pk0, stats=st0, want_split=False, want_f32=True)
+            _, f0 = S.conv_stem(xin, pk0, stats=st0, want_split=False, want_f32=True)
             cur, _ = S.norm_act(f0, (n, h0, w0, c0), stats_a=st0, act_a=S.ACT_RELU)
         else:                      # folded BatchNorm + ReLU in the epilogue: the stem is ONE launch
             sc, sh = self._bn_affine(self.norm1, self.conv1.bias)
-            cur, _ = S.conv_stem(x.contiguous(), pk0, scale=sc, shift=sh, act=S.ACT_RELU)
+            cur, _ = S.conv_stem(xin, pk0, scale=sc, shift=sh, act=S.ACT_RELU)
 
         def conv_norm(name, conv, norm, src, stride, relu):
             """conv (+ bias) -> norm -> optional relu.  instance: returns (fp32 NHWC, stats) for the fused norm kernel;

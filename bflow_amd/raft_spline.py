@@ -211,7 +211,10 @@ class RAFTSpline(nn.Module):
             if engine_update:
                 ws = ub.new_split_workspace(B, h, w, device)
                 ws.overlap = tm is None
-                ub.set_context_split(ws, self.cnet.forward_split(context_input.contiguous(), trunk_only=True), self.cnet.conv2)
+                ctx_in = context_input
+                if self.fnet_img is None:      # the context bins are the LAST channels of the voxel grid: one window, read in place
+                    ctx_in = S.ChannelWindows(voxel_grid, [voxel_grid.shape[1] - self.nbins_context], self.nbins_context)
+                ub.set_context_split(ws, self.cnet.forward_split(ctx_in, trunk_only=True), self.cnet.conv2)
             elif engine:
                 ws = ub.new_workspace(B, h, w, device)
                 ws.set_context_split(self.cnet.forward_split(context_input.contiguous()))
@@ -225,7 +228,12 @@ class RAFTSpline(nn.Module):
         # ---- feature encoders + correlation volumes
         if self.fnet_ev is not None:
             if tm: tm.start("fnet_ev")
-            corr_ev = encode_pair(self.fnet_ev, torch.cat(grids, dim=0), B, self.ev_corr_levels)   # [reference | targets]
+            if engine and self.fnet_ev.conv2.out_channels % 64 == 0 and len(grids) <= 8:
+                # [reference | targets] = channel windows of the voxel grid, read in place by the stem kernel (no torch.cat)
+                stacked = S.ChannelWindows(voxel_grid, [0] + list(self.ev_corr_target_indices), self.nbins_corr)
+            else:
+                stacked = torch.cat(grids, dim=0)
+            corr_ev = encode_pair(self.fnet_ev, stacked, B, self.ev_corr_levels)
             if tm: tm.stop("fnet_ev")
         if self.fnet_img is not None:
             if tm: tm.start("fnet_img")

@@ -146,12 +146,30 @@ class PackedStemWeight:
         return self.planes, self.meta
 
 
-def conv_stem(x: torch.Tensor, packed, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+class ChannelWindows:
+    """A stacked batch of channel windows of one source tensor, never materialised: image n = source image n % B_src, channels
+    [starts[n // B_src], + width) -- what RAFTSpline.gen_voxel_grids + torch.cat(dim=0) build (raft.py:88-99,121)."""
+
+    def __init__(self, source: torch.Tensor, starts, width: int):
+        assert source.dim() == 4 and source.dtype == torch.float32 and source.is_contiguous()
+        assert 1 <= len(starts) <= 8 and all(0 <= s_ and s_ + width <= source.shape[1] for s_ in starts)
+        self.source, self.starts, self.width = source, [int(s_) for s_ in starts], width
+        self.shape = (len(starts) * source.shape[0], width, source.shape[2], source.shape[3])
+        self.device = source.device
+
+    def materialize(self) -> torch.Tensor:
+        return torch.cat([self.source[:, s_:s_ + self.width] for s_ in self.starts], dim=0)
+
+
+def conv_stem(x, packed, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = ACT_NONE,
               stats: Optional[torch.Tensor] = None, want_split: bool = True, want_f32: bool = False):
-    """7x7 / stride 2 / pad 3 convolution of a few-channel fp32 NCHW tensor (BasicEncoder.conv1) -> (split_out or None, blocked fp32 or
-    None), epilogue as `conv`.  `packed` = PackedStemWeight.get(weight)."""
+    """7x7 / stride 2 / pad 3 convolution of a few-channel fp32 NCHW tensor or ChannelWindows (BasicEncoder.conv1) -> (split_out or
+    None, blocked fp32 or None), epilogue as `conv`.  `packed` = PackedStemWeight.get(weight)."""
     planes, (cout, cin, k_blocks, cout_pad) = packed
+    windows = x if isinstance(x, ChannelWindows) else None
     B, C, H, W = x.shape
+    if windows is not None:
+        x = windows.source
     assert C == cin and x.dtype == torch.float32 and x.is_contiguous()
     Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     dev = x.device
@@ -169,6 +187,10 @@ def conv_stem(x: torch.Tensor, packed, scale: Optional[torch.Tensor] = None, shi
     d.act = act
     d.stats = None if stats is None else hip._dev(stats, torch.float64, "stats")
     d.stats_replicas = _stats_replicas(stats, B, cout)
+    if windows is not None:
+        d.n_windows, d.src_channels = len(windows.starts), x.shape[1]
+        starts = (ctypes.c_int * len(windows.starts))(*windows.starts)
+        d.window_starts = starts
     hip._check(hip.lib().bflow_conv_stem(ctypes.byref(d), hip._stream()), "bflow_conv_stem")
     return out_split, out_f32
 

@@ -131,6 +131,11 @@ typedef struct bflow_stem_desc {
     int act;
     double* stats;
     int stats_replicas;               /* as in bflow_conv_desc_t */
+    int n_windows;                    /* > 0: x is a wider source (B / n_windows, src_channels, H, W) and image n of the batch reads
+                                         channels [window_starts[n / (B / n_windows)], + Cin) of source image n % (B / n_windows):
+                                         gen_voxel_grids + torch.cat (raft.py:88-99,121) without materialising the stacked batch   */
+    int src_channels;
+    const int* window_starts;         /* host array, n_windows <= 8 entries */
 } bflow_stem_desc_t;
 int bflow_conv_stem(const bflow_stem_desc_t* desc, bflow_stream_t stream);
 int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
