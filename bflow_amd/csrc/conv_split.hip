@@ -90,11 +90,17 @@ __device__ __forceinline__ float sum_lanes_mod8(float v) {
     return x + y;
 }
 
-template <int NT, int NW = 4, typename PixelOf>
+// GROUPS = 2 (8-wave split-k kernel): group 0 holds the combined accumulators and stages them; after a workgroup barrier BOTH
+// groups walk the slab of their pixel slab index `wave` -- group g takes row groups 2g, 2g+1 -- so the sigmoid / tanh / split
+// work of the read side is spread over all 8 waves instead of idling half of them.
+template <int NT, int NW = 4, int GROUPS = 1, typename PixelOf>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, PixelOf pixel_of, int n0,
-                                              int lane, int wave, int tid, bool writer, float* red) {
+                                              int lane, int wave, int tid, bool writer, float* red, int grp = 0) {
     constexpr int BN = 32 * NT;
     constexpr int RS = CONV_STG_STRIDE;
+    constexpr int NIT = 4 / GROUPS;                       // row groups of 8 pixels per wave on the read side
+    const int it0 = grp * NIT;
+    const int wave_all = wave + 4 * grp;                  // statistics scratch is per wave of the whole workgroup
     float* const stg0 = red + 2 * NW * BN + wave * NT * (32 * RS);   // this wave's NT slabs, behind the statistics scratch [2][NW][BN]
     const int kh = lane >> 5, l31 = lane & 31;
     const int rr = lane >> 3, ch = (lane & 7) * 4;        // read side: rows rr + 8*it, channels ch .. ch+3 of the block
@@ -112,8 +118,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                                 hh[n][r0 + 3] + xx[n][r0 + 3] * LO_INV);
             }
         }
+    }
+    if (GROUPS == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+    if (writer || GROUPS > 1) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int cbase = n0 + n * 32;
@@ -131,14 +143,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
             const long long ob = (((long long)b * a.CBo + a.cb_off + (n0 >> 5) + n) * a.P_out) * 32 + ch;
             const long long ab = (((long long)b * ((a.Cout + 31) >> 5) + (n0 >> 5) + n) * a.P_out) * 32 + ch;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            float4 raws[4];                                  // all four slab reads (and addend loads) in flight before the first is consumed
-            float4 ads[4];
+            float4 raws[NIT];                                // all slab reads (and addend loads) in flight before the first is consumed
+            float4 ads[NIT];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) raws[it] = *reinterpret_cast<const float4*>(stg + (it * 8 + rr) * RS + ch);
+            for (int it = 0; it < NIT; ++it) raws[it] = *reinterpret_cast<const float4*>(stg + ((it0 + it) * 8 + rr) * RS + ch);
             if (a.addend) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int m_ = pixel_of(it * 8 + rr);
+                for (int it = 0; it < NIT; ++it) {
+                    const int m_ = pixel_of((it0 + it) * 8 + rr);
                     ads[it] = *reinterpret_cast<const float4*>(a.addend + ab + (long long)(m_ >= 0 ? m_ : 0) * 32);
                 }
             }
@@ -147,12 +159,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
             const bool r_half = a.gate == 1 && cbk >= a.CBo;
             const bool need_h = a.gate == 2 || r_half;
             const long long gbase = (((long long)b * a.CBo + (r_half ? cbk - a.CBo : cbk)) * a.P_out) * 32 + ch;
-            half4v g_hh[4], g_hl[4];
-            float4 g_z[4];
+            half4v g_hh[NIT], g_hl[NIT];
+            float4 g_z[NIT];
             if (need_h) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int m_ = pixel_of(it * 8 + rr);
+                for (int it = 0; it < NIT; ++it) {
+                    const int m_ = pixel_of((it0 + it) * 8 + rr);
                     const long long go = gbase + (long long)(m_ >= 0 ? m_ : 0) * 32;
                     g_hh[it] = *reinterpret_cast<const half4v*>(a.gh + go);
                     g_hl[it] = *reinterpret_cast<const half4v*>(a.gl + go);
@@ -160,8 +172,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                 }
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = it * 8 + rr;
+            for (int it = 0; it < NIT; ++it) {
+                const int row = (it0 + it) * 8 + rr;
                 const int m = pixel_of(row);
                 const bool mok = m >= 0;
                 const float4 raw = raws[it];
@@ -233,8 +245,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                     s1[k] = sum_lanes_mod8(s1[k]);
                     s2[k] = sum_lanes_mod8(s2[k]);
                     if (lane < 8) {
-                        red[(0 * NW + wave) * BN + n * 32 + ch + k] = s1[k];
-                        red[(1 * NW + wave) * BN + n * 32 + ch + k] = s2[k];
+                        red[(0 * NW + wave_all) * BN + n * 32 + ch + k] = s1[k];
+                        red[(1 * NW + wave_all) * BN + n * 32 + ch + k] = s2[k];
                     }
                 }
             }
@@ -839,9 +851,9 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) xx[0][r] = x1[r] + x2[r];
     const int W = a.W, H = a.H, yw = y0 + wave * 2;
-    conv_epilogue<1>(a, hh, xx, b, [=](int row) {
+    conv_epilogue<1, 8, 2>(a, hh, xx, b, [=](int row) {
         const int y = yw + (row >> 4), x = x0 + (row & 15);
-        return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, grp == 0, reinterpret_cast<float*>(lds));
+        return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, grp == 0, reinterpret_cast<float*>(lds), grp);
 #endif
 }
 
