@@ -463,8 +463,8 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
 
     // ---- epilogue (lane = pixel wave*32 + l31 of this tile) --------------------------------------------------------------
     const int mw = m0 + wave * 32;
-    conv_epilogue<NT>(a, hh, xx, b, [=](int row) { return mw + row < HoWo ? mw + row : -1; }, n0, lane, wave, tid, writer,
-                      reinterpret_cast<float*>(lds));
+    conv_epilogue<NT, 4 * KG, KG>(a, hh, xx, b, [=](int row) { return mw + row < HoWo ? mw + row : -1; }, n0, lane, wave, tid, writer,
+                                  reinterpret_cast<float*>(lds), grp);
 #endif
 }
 
