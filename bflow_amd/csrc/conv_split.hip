@@ -90,9 +90,9 @@ __device__ __forceinline__ float sum_lanes_mod8(float v) {
     return x + y;
 }
 
-// GROUPS = 2 (8-wave split-k kernel): group 0 holds the combined accumulators and stages them; after a workgroup barrier BOTH
-// groups walk the slab of their pixel slab index `wave` -- group g takes row groups 2g, 2g+1 -- so the sigmoid / tanh / split
-// work of the read side is spread over all 8 waves instead of idling half of them.
+// GROUPS = 2 (8-wave split-k kernels): each k-group stages ITS partial sums in its own slab set; after ONE workgroup barrier both
+// groups walk the two slabs of their pixel slab index `wave` -- group g takes row groups 2g, 2g+1 and adds the two partials -- so
+// the k-split is combined for free on the read side and the sigmoid / tanh / split work is spread over all 8 waves.
 template <int NT, int NW = 4, int GROUPS = 1, typename PixelOf>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, PixelOf pixel_of, int n0,
                                               int lane, int wave, int tid, bool writer, float* red, int grp = 0) {
@@ -101,15 +101,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
     constexpr int NIT = 4 / GROUPS;                       // row groups of 8 pixels per wave on the read side
     const int it0 = grp * NIT;
     const int wave_all = wave + 4 * grp;                  // statistics scratch is per wave of the whole workgroup
-    float* const stg0 = red + 2 * NW * BN + wave * NT * (32 * RS);   // this wave's NT slabs, behind the statistics scratch [2][NW][BN]
+    float* const stg0 = red + 2 * NW * BN + wave * NT * (32 * RS);   // the NT slabs of pixel slab `wave` (group 0's partial sums),
+    constexpr int GSTRIDE = 4 * NT * (32 * RS);                      // group 1's set lies GSTRIDE floats further; behind the statistics scratch
     const int kh = lane >> 5, l31 = lane & 31;
     const int rr = lane >> 3, ch = (lane & 7) * 4;        // read side: rows rr + 8*it, channels ch .. ch+3 of the block
-    if (writer) {
+    if (writer || GROUPS > 1) {
         // all channel blocks are staged first (one slab each): ONE write -> read round trip through LDS per wave
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             if (n0 + n * 32 >= a.Cout) break;
-            float* stg = stg0 + n * (32 * RS);
+            float* stg = stg0 + grp * GSTRIDE + n * (32 * RS);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r0 = 4 * j;
@@ -147,6 +148,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
             float4 ads[NIT];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) raws[it] = *reinterpret_cast<const float4*>(stg + ((it0 + it) * 8 + rr) * RS + ch);
+            if (GROUPS > 1) {                                // + the other k-group's partial sums
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const float4 o4 = *reinterpret_cast<const float4*>(stg + GSTRIDE + ((it0 + it) * 8 + rr) * RS + ch);
+                    raws[it].x += o4.x; raws[it].y += o4.y; raws[it].z += o4.z; raws[it].w += o4.w;
+                }
+            }
             if (a.addend) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
@@ -441,24 +449,7 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();              // all LDS-DMA traffic has landed: the ring can be reused for the reduction
 
-    // ---- combine the k-groups through LDS (group 1 publishes acc = hh + xx/2048, group 0 adds it) ---------------------------
-    if (KG == 2) {
-        float* xch = reinterpret_cast<float*>(lds) + 2 * 4 * BN;   // behind the statistics scratch; [wave][n][r][lane]
-        if (grp == 1) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xch[((wave * NT + n) * 16 + r) * 64 + lane] = hh[n][r] + xx[n][r] * LO_INV;
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hh[n][r] += xch[((wave * NT + n) * 16 + r) * 64 + lane];
-        }
-        __syncthreads();                           // the exchange area is reused by the epilogue's staging slabs
-    }
+    // ---- with KG = 2 the k-groups are combined on the read side of the epilogue (each group stages its partial sums)
     const bool writer = (grp == 0);
 
     // ---- epilogue (lane = pixel wave*32 + l31 of this tile) --------------------------------------------------------------
@@ -833,20 +824,7 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- combine the two k-halves through LDS, then group 0 runs the shared epilogue -------------------------------------
-    {
-        float* xch = reinterpret_cast<float*>(lds) + 2 * 4 * 32;
-        if (grp == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64 + lane] = hh[0][r] + (x1[r] + x2[r]) * LO_INV;
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hh[0][r] += xch[(wave * 16 + r) * 64 + lane];
-        }
-        __syncthreads();
-    }
+    // ---- the two k-halves are combined on the read side of the shared epilogue (each group stages its partial sums)
     f32x16 xx[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) xx[0][r] = x1[r] + x2[r];
