@@ -21,13 +21,13 @@ All files were produced on a `gpurun` MI355X box by `tools/collect_profiles.sh` 
 
 | Quantity | Value |
 |---|---|
-| frames/s, 1 GPU, hipGraph replay | **{b["value"]:.1f}** ({b["ms_per_step"]:.2f} ms/frame) on the profiled box; 217–224 across boxes; batch 8: 300–314 frames/s |
+| frames/s, 1 GPU, hipGraph replay | **{b["value"]:.1f}** ({b["ms_per_step"]:.2f} ms/frame) on the profiled box; 234–248 across boxes; batch 8: 300–314 frames/s |
 | ms per GRU iteration (marginal, under replay) | **{b["ms_per_gru_iter"]:.2f}** (first working version with MIOpen fp32 convs: 0.51) |
 | fixed part (encoders + volume + pyramid + up-sampling) | {b["ms_fixed_part"]:.1f} ms (first version: 5.2 ms) |
 | parity, HIP path vs reference goldens / CPU oracle | EPE 1.6e-6 … 1e-5 px; full-size C2 1.2e-5 px at mean ‖flow‖ 18.6 px (bar: 1e-3) |
 | CPU baseline (oracle = op-for-op port, torch CPU fp32, {cb["cores"]} threads = the box's cgroup quota) | {cb["value"]:.2f} frames/s ({cb["ms_per_frame"]:.0f} ms/frame) |
 
-Trajectory this round (frames/s): 88 → 130 → 145 → 185 → 204 → 212 → 217 → 221 (DESIGN.md §8 names the step behind each number).
+Trajectory this round (frames/s): 88 → 130 → 145 → 185 → 204 → 212 → 217 → 221 → 234–248 (DESIGN.md §8 names the step behind each number).
 
 Kernel rooflines (algorithmic work ÷ hipEvent-timed average launch, same operands as the workload):
 
