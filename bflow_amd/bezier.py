@@ -123,6 +123,9 @@ class BezierCurves:
     # -- evaluation (bezier.py:165-216) -----------------------------------------------------------------
     def create_upsampled(self, mask: torch.Tensor) -> "BezierCurves":
         """[N, dim, H/8, W/8] -> [N, dim, H, W] by convex combination (bezier.py:81-84, raft_utils/utils.py:33-48)."""
+        if torch.is_grad_enabled() and (self._params.requires_grad or mask.requires_grad):
+            from .training import cvx_upsample                # differentiable K13 (csrc/backward.hip)
+            return BezierCurves(cvx_upsample(self._params, mask))
         return BezierCurves(hip.cvx_upsample(self._params.contiguous(), mask.contiguous()))
 
     def get_flow_from_reference(self, time: Union[float, int, List[float], np.ndarray]) -> torch.Tensor:
@@ -142,8 +145,8 @@ class BezierCurves:
             assert isinstance(time, np.ndarray)
         assert time.dtype == "float64" and time.size > 0 and time.min() >= 0 and time.max() <= 1
         coef = polynomial_coefficients(time, degree)
-        if self._params.is_cuda:
+        if self._params.is_cuda and not (torch.is_grad_enabled() and self._params.requires_grad):
             flows = hip.bezier_eval(self._params.contiguous().float(), coef, add_coords0=False)
         else:  # host-resident container (see module docstring)
-            flows = torch.einsum("bdphw,tp->tbdhw", pv, torch.from_numpy(coef))
+            flows = torch.einsum("bdphw,tp->tbdhw", pv, torch.from_numpy(coef).to(pv.device))
         return flows[0] if scalar else flows

@@ -29,6 +29,8 @@ EXPORTS = (
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
     "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_scatter_rectified", "bflow_maxabs_diff",
+    "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
+    "bflow_l1_masked_grad",
 )
 
 
@@ -133,6 +135,12 @@ def lib() -> ctypes.CDLL:
         "bflow_flow_metrics_accumulate": [vp, vp, vp, i, i, ll, f, f, f, vp, vp],
         "bflow_traj_len": [vp, vp, i, i, i, ll, vp],
         "bflow_pad_replicate": [vp, vp, ll, i, i, i, i, i, i, vp],
+        "bflow_corr_lookup_bwd": [ctypes.POINTER(PlaneDesc), ctypes.POINTER(vp), i, vp, i, vp, vp, i, i, i, vp],
+        "bflow_corr_lookup_bezier_bwd": [ctypes.POINTER(PlaneDesc), ctypes.POINTER(vp), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, vp],
+        "bflow_corr_pool2x2_bwd": [vp, vp, ll, i, i, vp],
+        "bflow_cvx_upsample_bwd": [vp, vp, vp, vp, vp, vp, i, i, i, i, vp],
+        "bflow_l1_masked_accumulate": [vp, vp, vp, i, i, ll, vp, vp],
+        "bflow_l1_masked_grad": [vp, vp, vp, i, i, ll, vp, vp, f, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -451,6 +459,84 @@ def pad_replicate(x: torch.Tensor, pad: Sequence[int]) -> torch.Tensor:
 # (alive until after the join), branch-local temporaries are stream-ordered on the side stream.
 # ----------------------------------------------------------------------------------------------------------------------
 _side_streams = {}
+
+
+# ------------------------------------------------------------------------------------------------ training path (f-4)
+def make_grad_table(tensors: Sequence[torch.Tensor]):
+    """HOST array of device pointers to the per-plane gradient slabs (same order as make_plane_table)."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for k, t in enumerate(tensors):
+        arr[k] = _dev(t, name=f"grad_plane{k}")
+    return arr
+
+
+def corr_lookup_bwd(table, grad_table, coords: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:
+    """-> per-plane coordinate gradients (P, B, 2, h1, w1); the plane gradients are accumulated in place."""
+    T, B, two, h1, w1 = coords.shape
+    P = len(table)
+    assert two == 2 and grad_out.shape == (B, P * 81, h1, w1) and len(grad_table) == P
+    gc = torch.empty((P, B, 2, h1, w1), dtype=torch.float32, device=coords.device)
+    _check(lib().bflow_corr_lookup_bwd(table, grad_table, P, _dev(coords, name="coords"), T, _dev(grad_out, name="grad_out"), _dev(gc),
+                                       B, h1, w1, _stream()), "bflow_corr_lookup_bwd")
+    return gc
+
+
+def corr_lookup_bezier_bwd(table, grad_table, params: torch.Tensor, coef: np.ndarray, grad_out: torch.Tensor) -> torch.Tensor:
+    B, C2, h1, w1 = params.shape
+    T, deg = coef.shape
+    P = len(table)
+    assert C2 == 2 * deg and coef.dtype == np.float32 and coef.flags["C_CONTIGUOUS"]
+    assert grad_out.shape == (B, P * 81, h1, w1) and len(grad_table) == P
+    gc = torch.empty((P, B, 2, h1, w1), dtype=torch.float32, device=params.device)
+    _check(lib().bflow_corr_lookup_bezier_bwd(table, grad_table, P, _dev(params, name="params"),
+                                              coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), T, deg, _dev(grad_out, name="grad_out"),
+                                              _dev(gc), B, h1, w1, _stream()), "bflow_corr_lookup_bezier_bwd")
+    return gc
+
+
+def corr_pool2x2_bwd(grad_cur: torch.Tensor, grad_prev: torch.Tensor):
+    """grad_prev (M, h, w) += 0.25 * grad_cur (M, h//2, w//2) spread over the 2x2 cells."""
+    M, h, w = grad_prev.shape
+    assert grad_cur.shape == (M, h // 2, w // 2)
+    _check(lib().bflow_corr_pool2x2_bwd(_dev(grad_cur, name="grad_cur"), _dev(grad_prev, name="grad_prev"), M, h, w, _stream()),
+           "bflow_corr_pool2x2_bwd")
+
+
+def cvx_upsample_bwd(grad_up: torch.Tensor, data: torch.Tensor, mask: torch.Tensor):
+    B, C, h, w = data.shape
+    assert mask.shape == (B, 576, h, w) and grad_up.shape == (B, C, 8 * h, 8 * w)
+    gd = torch.empty_like(data, dtype=torch.float32)
+    gm = torch.empty_like(mask, dtype=torch.float32)
+    scratch = torch.empty(B * C * 72 * h * w, dtype=torch.float32, device=data.device)
+    _check(lib().bflow_cvx_upsample_bwd(_dev(grad_up, name="grad_up"), _dev(data, name="data"), _dev(mask, name="mask"), _dev(gd), _dev(gm),
+                                        _dev(scratch), B, C, h, w, _stream()), "bflow_cvx_upsample_bwd")
+    return gd, gm
+
+
+def _valid_ptr(valid: Optional[torch.Tensor], count: int):
+    if valid is None:
+        return None
+    assert valid.dtype in (torch.bool, torch.uint8) and valid.numel() == count
+    return _dev(valid.view(torch.uint8) if valid.dtype == torch.bool else valid, torch.uint8, "valid")
+
+
+def l1_masked_accumulate(src: torch.Tensor, tgt: torch.Tensor, valid: Optional[torch.Tensor], acc: torch.Tensor):
+    B, C = src.shape[:2]
+    HW = int(np.prod(src.shape[2:]))
+    assert src.shape == tgt.shape
+    _check(lib().bflow_l1_masked_accumulate(_dev(src, name="src"), _dev(tgt, name="tgt"), _valid_ptr(valid, B * HW), B, C, HW,
+                                            _dev(acc, torch.float64, "acc"), _stream()), "bflow_l1_masked_accumulate")
+
+
+def l1_masked_grad(src: torch.Tensor, tgt: torch.Tensor, valid: Optional[torch.Tensor], acc: torch.Tensor,
+                   upstream: Optional[torch.Tensor], weight: float) -> torch.Tensor:
+    B, C = src.shape[:2]
+    HW = int(np.prod(src.shape[2:]))
+    grad = torch.empty_like(src)
+    _check(lib().bflow_l1_masked_grad(_dev(src, name="src"), _dev(tgt, name="tgt"), _valid_ptr(valid, B * HW), B, C, HW,
+                                      _dev(acc, torch.float64, "acc"), _opt(upstream, "upstream"), float(weight), _dev(grad), _stream()),
+           "bflow_l1_masked_grad")
+    return grad
 
 
 class Branch:

@@ -101,6 +101,7 @@ class RAFTSpline(nn.Module):
         self._coef = None
         self._graphs = None
         self.stage_timer: Optional[StageTimer] = None
+        self._probe = None            # tools only: callable(name) invoked at stage boundaries inside the captured forward
 
     # ---------------------------------------------------------------------------------------- reference API
     def freeze_bn(self):
@@ -151,7 +152,10 @@ class RAFTSpline(nn.Module):
             raise hip.BflowHipError("RAFTSpline (bflow_amd) runs on MI355X only: move the inputs and the module to the GPU "
                                     "(the CPU restatement lives in oracle/ and is test infrastructure)")
         if self.training:
-            raise hip.BflowHipError("bflow_amd.RAFTSpline implements the inference path; call .eval() (training is out of scope)")
+            # differentiable forward (HIP forward/backward for K5-K7/K13, torch autograd for the convolutions)
+            from .training import forward_train
+            low, ups = forward_train(self, voxel_grid, images, iters, None if flow_init is None else flow_init.get_params())
+            return (BezierCurves(low), ups[-1]) if test_mode else ups
         with torch.no_grad():
             init = None if flow_init is None else flow_init.get_params()
             if self._graphs is not None and self.stage_timer is None:
@@ -167,6 +171,7 @@ class RAFTSpline(nn.Module):
         """raft.py:101-200 on the HIP kernels.  No host<->device synchronisation anywhere (hipGraph-capturable)."""
         hdim, cdim = self.hidden_dim, self.context_dim
         tm = self.stage_timer
+        pr = self._probe
         corr_ev = corr_img = None
         context_input = None
 
@@ -208,6 +213,7 @@ class RAFTSpline(nn.Module):
             and ub.context_dim % 32 == 0 and ub.bezier_planes <= 32
         if tm: tm.start("cnet")
         with hip.Branch(tm is None) as cnet_branch:
+            if pr: pr("cnet.begin")
             if engine_update:
                 ws = ub.new_split_workspace(B, h, w, device)
                 ws.overlap = tm is None
@@ -223,9 +229,11 @@ class RAFTSpline(nn.Module):
                 trunk = self.cnet(context_input.contiguous(), project=False)
                 cnet = torch.nn.functional.conv2d(trunk, self.cnet.conv2.weight)     # bias folded into the split kernel
                 ws.set_context(cnet, self.cnet.conv2.bias)
+            if pr: pr("cnet.end")
         if tm: tm.stop("cnet")
 
         # ---- feature encoders + correlation volumes
+        if pr: pr("fnet.begin")
         if self.fnet_ev is not None:
             if tm: tm.start("fnet_ev")
             if engine and self.fnet_ev.conv2.out_channels % 64 == 0 and len(grids) <= 8:
@@ -245,10 +253,13 @@ class RAFTSpline(nn.Module):
             assert flow_init.shape == bezier.shape
             bezier += flow_init                                               # raft.py:152-153
 
+        if pr: pr("fnet.end")
         if tm: tm.start("corr computation")
         corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img)
         if tm: tm.stop("corr computation")
+        if pr: pr("corr.end")
         cnet_branch.join()
+        if pr: pr("joined")
 
         coef = self._coefficients()
         corr_feat = corr_block.new_output_split() if (engine_update and tm is None) else corr_block.new_output()
@@ -280,4 +291,5 @@ class RAFTSpline(nn.Module):
             if tm: tm.stop("update (per iter)")
             if tm: tm.stop("1 iter")
         if tm: tm.stop("all iters")
+        if pr: pr("iters.end")
         return bezier, ups

@@ -1,0 +1,337 @@
+"""Training path: `test_mode=False` forward with gradients, the L1 sequence losses and the training step.
+
+What runs where:
+    K5 correlation volume, K6 pyramid, K7 look-up, K13 convex up-sampling, masked L1   forward AND backward on the HIP kernels
+                                                                                       (csrc/backward.hip: hand-written adjoints)
+    K5 backward (two plain GEMMs per target, K = N)                                     rocBLAS through torch.matmul
+    convolutions / norms / GRU gates                                                    torch (MIOpen) under autograd -- the split-fp16
+                                                                                       conv engine is an inference engine (no backward)
+
+Reference: RAFTSpline.forward with test_mode=False (models/raft_spline/raft.py:101-200), utils/losses.py:6-62,
+RAFTSplineModule.training_step / configure_optimizers (modules/raft_spline.py:64-188,321-356).
+
+The 4-D volume gradient is the one large object of the backward pass (368.6 MB per sample at DSEC size); every look-up of every
+GRU iteration adds its sparse patch gradients INTO ONE buffer owned by the correlation block (instead of autograd materialising
+and summing one dense volume gradient per iteration), and a token tensor threads the autograd dependency so that the volume's own
+backward (pooling adjoint, then the two GEMMs) runs after the last look-up has contributed.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .bezier import BezierCurves, polynomial_coefficients
+from .corr import CorrBlockParallelMultiTarget, CorrComputation
+from .validation import DataLoading, DataSetType, _get
+
+
+# ----------------------------------------------------------------------------------------------- correlation block with gradients
+class TrainCorrBlock:
+    """groups: [(fmap1 (B,D,h,w), fmap2 (T,B,D,h,w), levels list)] -- events first, then frames (corr.py:276-305)."""
+
+    def __init__(self, groups: Sequence[Tuple[torch.Tensor, torch.Tensor, Sequence[int]]]):
+        self._levels = [list(int(v) for v in g[2]) for g in groups]
+        self._group_sizes = [int(g[1].shape[0]) for g in groups]
+        self._inner: Optional[CorrBlockParallelMultiTarget] = None
+        self._grads: Optional[List[torch.Tensor]] = None
+        self._grad_table = None
+        flat: List[torch.Tensor] = []
+        for f1, f2, _ in groups:
+            assert f1.ndim == 4 and f2.ndim == 5 and f1.shape == f2.shape[1:]
+            flat += [f1, f2]
+        self.token = _CorrBlockFn.apply(self, *flat)
+
+    # -- forward (inside _CorrBlockFn.forward: no graph is recorded)
+    def _build(self, fmaps: Sequence[torch.Tensor]):
+        ccs = []
+        for g, lv in enumerate(self._levels):
+            ccs.append(CorrComputation(fmaps[2 * g].float().contiguous(), fmaps[2 * g + 1].float().contiguous(), lv))
+        cc = ccs[0]
+        for other in ccs[1:]:
+            cc = cc + other
+        self._inner = CorrBlockParallelMultiTarget(corr_computation_events=cc)
+        self._plane_targets = [p["target"] for p in self._inner._planes]
+
+    @property
+    def num_planes(self) -> int:
+        return self._inner.num_planes
+
+    def _ensure_grads(self):
+        if self._grads is None:
+            self._grads = [torch.zeros_like(t) for t, _ in self._inner._pyramid]
+            per_plane = []
+            for lvl, (_, tidx) in enumerate(self._inner._pyramid):
+                for k in range(len(tidx)):
+                    per_plane.append(self._grads[lvl][k])
+            self._grad_table = hip.make_grad_table(per_plane)
+        return self._grad_table
+
+    # -- backward of the volume: pooling adjoint coarse -> fine, then dC -> d(fmaps)
+    def _backward_volume(self, fmaps: Sequence[torch.Tensor]) -> List[Optional[torch.Tensor]]:
+        if self._grads is None:
+            return [None] * len(fmaps)
+        pyr = self._inner._pyramid
+        for lvl in range(len(pyr) - 1, 0, -1):
+            _, idx = pyr[lvl]
+            _, prev_idx = pyr[lvl - 1]
+            for k, t in enumerate(idx):
+                hip.corr_pool2x2_bwd(self._grads[lvl][k], self._grads[lvl - 1][prev_idx.index(t)])
+        g0 = self._grads[0]                                    # (T, B*N, h, w)
+        T = g0.shape[0]
+        out: List[Optional[torch.Tensor]] = []
+        t0 = 0
+        for g, tg in enumerate(self._group_sizes):
+            f1, f2 = fmaps[2 * g], fmaps[2 * g + 1]
+            B, D, h, w = f1.shape
+            N = h * w
+            dC = g0[t0:t0 + tg].view(tg, B, N, N)               # dC[t,b,n,m]: n = reference pixel, m = target pixel
+            a = f1.float().reshape(B, D, N)
+            b = f2.float().reshape(tg, B, D, N)
+            s = 1.0 / math.sqrt(D)
+            gf1 = torch.matmul(b, dC.transpose(-1, -2)).sum(dim=0).mul_(s)      # (B, D, N): sum_t f2[t] @ dC[t]^T
+            gf2 = torch.matmul(a.unsqueeze(0), dC).mul_(s)                     # (tg, B, D, N): f1 @ dC[t]
+            out += [gf1.view(B, D, h, w).to(f1.dtype), gf2.view(tg, B, D, h, w).to(f2.dtype)]
+            t0 += tg
+        assert t0 == T
+        self._grads = None                                     # one backward per forward
+        self._grad_table = None
+        return out
+
+    def lookup_bezier(self, params: torch.Tensor, coef: np.ndarray) -> torch.Tensor:
+        """(B, 2*deg, h, w) Bezier parameters -> (B, P*81, h, w) correlation features, differentiable in params and the volume."""
+        return _LookupBezierFn.apply(self, coef, params, self.token)
+
+
+class _CorrBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, block: TrainCorrBlock, *fmaps):
+        block._build([f.detach() for f in fmaps])
+        ctx.block = block
+        ctx.save_for_backward(*fmaps)
+        return torch.zeros(1, dtype=torch.float32, device=fmaps[0].device)
+
+    @staticmethod
+    def backward(ctx, _grad_token):
+        grads = ctx.block._backward_volume(ctx.saved_tensors)
+        return (None, *grads)
+
+
+class _LookupBezierFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, block: TrainCorrBlock, coef: np.ndarray, params: torch.Tensor, token: torch.Tensor):
+        p = params.detach().float().contiguous()
+        out = block._inner.lookup_bezier(p, coef)
+        ctx.block, ctx.coef = block, coef
+        ctx.save_for_backward(p)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (p,) = ctx.saved_tensors
+        block, coef = ctx.block, ctx.coef
+        inner = block._inner
+        gc = hip.corr_lookup_bezier_bwd(inner._table, block._ensure_grads(), p, coef, grad_out.float().contiguous())
+        T, deg = coef.shape
+        B, _, h, w = p.shape
+        gt = torch.zeros((T, B, 2, h, w), dtype=torch.float32, device=p.device)
+        for k, t in enumerate(block._plane_targets):          # planes of one target (its pyramid levels), fixed order
+            gt[t] += gc[k]
+        cf = torch.from_numpy(coef).to(p.device)
+        gp = torch.einsum("tbdhw,tp->bdphw", gt, cf).reshape(B, 2 * deg, h, w)
+        return None, None, gp, torch.zeros(1, dtype=torch.float32, device=p.device)
+
+
+class _CvxUpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data: torch.Tensor, mask: torch.Tensor):
+        d, m = data.detach().float().contiguous(), mask.detach().float().contiguous()
+        ctx.save_for_backward(d, m)
+        return hip.cvx_upsample(d, m)
+
+    @staticmethod
+    def backward(ctx, grad_up):
+        d, m = ctx.saved_tensors
+        gd, gm = hip.cvx_upsample_bwd(grad_up.float().contiguous(), d, m)
+        return gd, gm
+
+
+def cvx_upsample(data: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """Differentiable K13 (raft_utils/utils.py:33-48)."""
+    return _CvxUpsampleFn.apply(data, mask)
+
+
+# ----------------------------------------------------------------------------------------------- losses (utils/losses.py)
+class _L1MaskedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, source: torch.Tensor, target: torch.Tensor, valid: Optional[torch.Tensor]):
+        s, t = source.detach().float().contiguous(), target.detach().float().contiguous()
+        v = None if valid is None else valid.contiguous()
+        acc = torch.zeros(2, dtype=torch.float64, device=s.device)
+        hip.l1_masked_accumulate(s, t, v, acc)
+        ctx.save_for_backward(s, t, acc) if v is None else ctx.save_for_backward(s, t, acc, v)
+        ctx.masked = v is not None
+        return (acc[0] / acc[1]).float()
+
+    @staticmethod
+    def backward(ctx, upstream):
+        saved = ctx.saved_tensors
+        s, t, acc = saved[:3]
+        v = saved[3] if ctx.masked else None
+        g = hip.l1_masked_grad(s, t, v, acc, upstream.float().contiguous().view(1), 1.0)
+        return g, None, None
+
+
+def l1_loss_channel_masked(source: torch.Tensor, target: torch.Tensor, valid_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """losses.py:6-22: mean over (valid) positions of the channel-summed absolute difference."""
+    assert source.ndim > 2 and source.shape == target.shape
+    if valid_mask is not None:
+        assert valid_mask.shape[0] == target.shape[0] and valid_mask.ndim == target.ndim - 1 and valid_mask.dtype == torch.bool
+        assert tuple(valid_mask.shape) == (source.shape[0],) + tuple(source.shape[2:])
+    return _L1MaskedFn.apply(source, target, valid_mask)
+
+
+def l1_seq_loss_channel_masked(source_list: Sequence[torch.Tensor], target: torch.Tensor, valid_mask: Optional[torch.Tensor] = None,
+                               gamma: float = 0.8) -> torch.Tensor:
+    """losses.py:24-40: sum_i gamma^(I-1-i) * l1(source_i)."""
+    n = len(source_list)
+    loss = 0
+    for i, src in enumerate(source_list):
+        loss = loss + gamma ** (n - i - 1) * l1_loss_channel_masked(src, target, valid_mask)
+    return loss
+
+
+def l1_multi_seq_loss_channel_masked(src_list_list: Sequence[Sequence[torch.Tensor]], target_list: Sequence[torch.Tensor],
+                                     valid_mask_list: Optional[Sequence[torch.Tensor]] = None, gamma: float = 0.8) -> torch.Tensor:
+    """losses.py:42-62: per iteration the mean over the M supervision targets, weighted like the sequence loss."""
+    loss = 0
+    n_iters = len(src_list_list)
+    for it, sources in enumerate(src_list_list):
+        assert len(sources) > 0 and len(sources) == len(target_list)
+        it_loss = 0
+        for k, src in enumerate(sources):
+            it_loss = it_loss + l1_loss_channel_masked(src, target_list[k], None if valid_mask_list is None else valid_mask_list[k])
+        loss = loss + gamma ** (n_iters - it - 1) * (it_loss / len(sources))
+    return loss
+
+
+# ----------------------------------------------------------------------------------------------- the training forward
+def _update_block_train(ub, net, inp, corr, bezier):
+    """BasicUpdateBlock.forward (update.py:116-126) on torch convolutions; z|r share one launch per GRU half."""
+    enc, gru = ub.encoder, ub.gru
+    cor = F.relu(enc.convc2(F.relu(enc.convc1(corr))))
+    bez = F.relu(enc.convf2(F.relu(enc.convf1(bezier))))
+    motion = torch.cat([F.relu(enc.conv(torch.cat([cor, bez], dim=1))), bezier], dim=1)
+    x = torch.cat([inp, motion], dim=1)
+    hd = ub.hidden_dim
+    for sfx in ("1", "2"):
+        cz, cr, cq = (getattr(gru, f"conv{g}{sfx}") for g in "zrq")
+        zr = F.conv2d(torch.cat([net, x], dim=1), torch.cat([cz.weight, cr.weight], dim=0), torch.cat([cz.bias, cr.bias], dim=0),
+                      padding=cz.padding)
+        z, r = torch.sigmoid(zr[:, :hd]), torch.sigmoid(zr[:, hd:])
+        q = torch.tanh(cq(torch.cat([r * net, x], dim=1)))
+        net = (1 - z) * net + z * q
+    delta = ub.bezier_head.conv2(F.relu(ub.bezier_head.conv1(net)))
+    mask = 0.25 * ub.mask(net)
+    return net, mask, delta
+
+
+def forward_train(model, voxel_grid: Optional[torch.Tensor], images: Optional[List[torch.Tensor]], iters: int,
+                  flow_init: Optional[torch.Tensor]) -> Tuple[torch.Tensor, List[BezierCurves]]:
+    """raft.py:101-200 under autograd: (low-resolution parameters, one up-sampled BezierCurves per GRU iteration)."""
+    hdim, cdim = model.hidden_dim, model.context_dim
+    groups = []
+    context_input = None
+    if model.fnet_ev is not None:
+        assert voxel_grid is not None
+        voxel_grid = voxel_grid.contiguous().float()
+        grids, context_input = model.gen_voxel_grids(voxel_grid)
+        fm = [f.float() for f in model.fnet_ev(list(grids))]
+        groups.append((fm[0], torch.stack(fm[1:], dim=0), list(model.ev_corr_levels)))
+    if model.fnet_img is not None:
+        assert images is not None and len(images) == 2
+        images = [2 * (x.float().contiguous() / 255) - 1 for x in images]
+        fi = [f.float() for f in model.fnet_img(list(images))]
+        groups.append((fi[0], fi[1].unsqueeze(0), [int(model.img_corr_params["levels"])]))
+        context_input = images[0] if context_input is None else torch.cat((context_input, images[0]), dim=-3)
+    assert context_input is not None
+    B, _, H, W = context_input.shape
+    assert H % 8 == 0 and W % 8 == 0
+    h, w = H // 8, W // 8
+
+    cnet = model.cnet(context_input.contiguous())
+    net, inp = torch.split(cnet, [hdim, cdim], dim=1)
+    net, inp = torch.tanh(net), torch.relu(inp)
+
+    block = TrainCorrBlock(groups)
+    params = torch.zeros((B, 2 * model.bezier_degree, h, w), dtype=torch.float32, device=context_input.device)
+    if flow_init is not None:
+        params = params + flow_init
+    coef = model._coefficients()
+    ups: List[BezierCurves] = []
+    for _ in range(iters):
+        if model.detach_bezier:                                  # raft.py:167-168
+            params = params.detach()
+        corr = block.lookup_bezier(params, coef)
+        net, mask, delta = _update_block_train(model.update_block, net, inp, corr, params)
+        params = params + delta                                  # bezier.py:137-139
+        ups.append(BezierCurves(cvx_upsample(params, mask)))
+    return params, ups
+
+
+# ----------------------------------------------------------------------------------------------- the training step
+def configure_optimizers(model: torch.nn.Module, train_params: Dict[str, Any]):
+    """modules/raft_spline.py:321-356: AdamW (+ linear OneCycleLR stepped per optimiser step)."""
+    opt = torch.optim.AdamW(model.parameters(), lr=train_params["learning_rate"], weight_decay=train_params["weight_decay"])
+    sch_p = train_params["lr_scheduler"]
+    if not sch_p["use"]:
+        return opt, None
+    total = sch_p["total_steps"]
+    assert total is not None and total > 0
+    sch = torch.optim.lr_scheduler.OneCycleLR(optimizer=opt, max_lr=train_params["learning_rate"], total_steps=total + 100,
+                                              pct_start=sch_p["pct_start"], cycle_momentum=False, anneal_strategy="linear")
+    return opt, sch
+
+
+class TrainStep:
+    """RAFTSplineModule.training_step (modules/raft_spline.py:64-188) without the Lightning harness: batch dict -> outputs with
+    'loss' (call .backward() on it).  DSEC: L1 sequence loss of flow(1.0) over the iterations; MultiFlow: the multi-target sequence
+    loss at the GT timestamps, or -- with multi_loss off -- the reference's sequence loss over the LAST iteration's per-timestamp
+    predictions against the last GT (:148-153)."""
+
+    def __init__(self, model, num_iter_train: int, use_events: bool = True, use_images: bool = False, multi_loss: bool = True):
+        self.model, self.iters = model, int(num_iter_train)
+        self.use_events, self.use_images, self.multi_loss = use_events, use_images, multi_loss
+
+    def __call__(self, batch: Dict[Any, Any]) -> Dict[str, Any]:
+        gt = _get(batch, DataLoading.FLOW)
+        valid = _get(batch, DataLoading.FLOW_VALID)
+        ev = _get(batch, DataLoading.EV_REPR)
+        images = _get(batch, DataLoading.IMG) if self.use_images else None
+        ref = ev if ev is not None else images[0]
+        if ref.shape[-2] % 8 or ref.shape[-1] % 8:
+            raise NotImplementedError("training inputs must be multiples of 8 (modules/raft_spline.py:80-82)")
+        ds = _get(batch, DataLoading.DATASET_TYPE)[0]
+        ds = getattr(ds, "name", ds)
+        preds: List[BezierCurves] = self.model(voxel_grid=ev if self.use_events else None, images=images, iters=self.iters,
+                                               test_mode=False)
+        out: Dict[str, Any] = {"bezier_prediction": preds[-1].detach()}
+        if ds == DataSetType.DSEC.name:
+            flows = [p.get_flow_from_reference(1.0) for p in preds]
+            out.update(loss=l1_seq_loss_channel_masked(flows, gt, valid), pred=flows[-1], gt=gt, gt_valid=valid)
+            return out
+        if ds == DataSetType.MULTIFLOW2D.name:
+            times = []
+            for ts in _get(batch, DataLoading.FLOW_TIMESTAMPS):   # one (N,) tensor per GT: equal along the batch (:135-139)
+                if ts.numel() > 1:
+                    assert 0 <= (ts[1:] - ts[:-1]).abs().mean().item() < 0.001
+                times.append(float(ts[0].item()))
+            flows = [[p.get_flow_from_reference(t) for t in times] for p in preds]
+            loss = l1_multi_seq_loss_channel_masked(flows, gt) if self.multi_loss else l1_seq_loss_channel_masked(flows[-1], gt[-1])
+            out.update(loss=loss, pred=flows[-1][-1], gt=gt)
+            return out
+        raise NotImplementedError(ds)

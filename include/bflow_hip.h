@@ -329,6 +329,34 @@ int bflow_traj_len(const float* targets, float* out, int M, int B, int C, long l
 int bflow_pad_replicate(const float* x, float* out, long long planes, int H, int W, int pad_left, int pad_right, int pad_top,
                         int pad_bottom, bflow_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Training path: adjoints of K7 / K6 / K13 and the masked L1 of the sequence losses.  The reference gets them
+ * from autograd over F.grid_sample (raft_utils/utils.py:5-21, corr.py:307-351), F.avg_pool2d (corr.py:108-125), unfold + softmax
+ * (utils.py:33-48) and abs/sum/mean (utils/losses.py:6-22).  All deterministic (no fp atomics on shared addresses).
+ *   bflow_corr_lookup(_bezier)_bwd: planes = the FORWARD plane table; grad_planes = HOST array of P device pointers, the gradient of
+ *       every plane (same shape as the plane), ACCUMULATED in place (the caller zeroes it once per step: the volume gradient sums
+ *       over all GRU iterations); grad_out (B, P*81, h1, w1); grad_coords (P, B, 2, h1, w1) is WRITTEN per plane -- the caller sums
+ *       the planes of a target (and applies the Bezier coefficients for the fused variant).
+ *   bflow_corr_pool2x2_bwd: grad_prev (M, h, w) += 0.25 * grad_cur (M, h/2, w/2) over the 2x2 cells (odd tail row/column: none).
+ *   bflow_cvx_upsample_bwd: grad_up (B, C, 8h, 8w), data (B, C, h, w), mask (B, 576, h, w) logits as given to bflow_cvx_upsample with
+ *       mask_bias = NULL, mask_scale = 1 -> grad_data (B, C, h, w), grad_mask (B, 576, h, w); scratch: B*C*72*h*w floats.
+ *   bflow_l1_masked_accumulate: acc[0] += sum over valid positions of sum_c |src - tgt|, acc[1] += #valid positions (valid NULL = all);
+ *       src, tgt (B, C, HW); acc device double[2] zeroed by the caller; loss = acc[0] / acc[1]  (losses.py:12-22).
+ *   bflow_l1_masked_grad: grad (B, C, HW) = weight * upstream[0] / acc[1] * sign(src - tgt) on valid positions, 0 elsewhere
+ *       (upstream: device float[1] or NULL = 1).                                                                                 */
+int bflow_corr_lookup_bwd(const bflow_plane_t* planes, float* const* grad_planes, int P, const float* coords, int T,
+                          const float* grad_out, float* grad_coords, int B, int h1, int w1, bflow_stream_t stream);
+int bflow_corr_lookup_bezier_bwd(const bflow_plane_t* planes, float* const* grad_planes, int P, const float* params, const float* coef,
+                                 int T, int deg, const float* grad_out, float* grad_coords, int B, int h1, int w1,
+                                 bflow_stream_t stream);
+int bflow_corr_pool2x2_bwd(const float* grad_cur, float* grad_prev, long long M, int h, int w, bflow_stream_t stream);
+int bflow_cvx_upsample_bwd(const float* grad_up, const float* data, const float* mask, float* grad_data, float* grad_mask,
+                           float* scratch, int B, int C, int h, int w, bflow_stream_t stream);
+int bflow_l1_masked_accumulate(const float* src, const float* tgt, const unsigned char* valid, int B, int C, long long HW,
+                               double* acc, bflow_stream_t stream);
+int bflow_l1_masked_grad(const float* src, const float* tgt, const unsigned char* valid, int B, int C, long long HW,
+                         const double* acc, const float* upstream, float weight, float* grad, bflow_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -166,12 +166,13 @@ def make_state_dict(cfg: Dict[str, Any], seed: int = 0, gain: float = 1.0) -> St
 # --------------------------------------------------------------------------------------
 # K4: feature / context encoder
 # --------------------------------------------------------------------------------------
-def _norm(sd: StateDict, name: str, x: Tensor, kind: str) -> Tensor:
+def _norm(sd: StateDict, name: str, x: Tensor, kind: str, training: bool = False) -> Tensor:
     if kind == "instance":  # nn.InstanceNorm2d defaults: eps=1e-5, no affine, no running stats
         return F.instance_norm(x, eps=1e-5)
-    if kind == "batch":     # eval mode (Lightning validate -> eval; raft.py:75-78 freeze_bn)
+    if kind == "batch":     # eval: running statistics (Lightning validate -> eval).  train: batch statistics + running-stat update
+        #                     (momentum 0.1) -- freeze_bn (raft.py:75-78) is defined but never called by the reference's training
         return F.batch_norm(x, sd[f"{name}.running_mean"], sd[f"{name}.running_var"],
-                            sd[f"{name}.weight"], sd[f"{name}.bias"], training=False, eps=1e-5)
+                            sd[f"{name}.weight"], sd[f"{name}.bias"], training=training, momentum=0.1, eps=1e-5)
     if kind == "none":
         return x
     raise NotImplementedError(kind)
@@ -181,26 +182,26 @@ def _conv(sd: StateDict, name: str, x: Tensor, stride=1, padding=0) -> Tensor:
     return F.conv2d(x, sd[f"{name}.weight"], sd[f"{name}.bias"], stride=stride, padding=padding)
 
 
-def _residual_block(sd: StateDict, p: str, x: Tensor, kind: str, stride: int) -> Tensor:
+def _residual_block(sd: StateDict, p: str, x: Tensor, kind: str, stride: int, training: bool = False) -> Tensor:
     """models/raft_utils/extractor.py:47-55."""
-    y = torch.relu(_norm(sd, f"{p}.norm1", _conv(sd, f"{p}.conv1", x, stride=stride, padding=1), kind))
-    y = torch.relu(_norm(sd, f"{p}.norm2", _conv(sd, f"{p}.conv2", y, padding=1), kind))
+    y = torch.relu(_norm(sd, f"{p}.norm1", _conv(sd, f"{p}.conv1", x, stride=stride, padding=1), kind, training))
+    y = torch.relu(_norm(sd, f"{p}.norm2", _conv(sd, f"{p}.conv2", y, padding=1), kind, training))
     if stride != 1:
-        x = _norm(sd, f"{p}.norm3", _conv(sd, f"{p}.downsample.0", x, stride=stride), kind)
+        x = _norm(sd, f"{p}.norm3", _conv(sd, f"{p}.downsample.0", x, stride=stride), kind, training)
     return torch.relu(x + y)
 
 
-def encoder(sd: StateDict, prefix: str, x: Union[Tensor, Sequence[Tensor]], kind: str):
+def encoder(sd: StateDict, prefix: str, x: Union[Tensor, Sequence[Tensor]], kind: str, training: bool = False):
     """BasicEncoder.forward, models/raft_utils/extractor.py:103-125.  A list input is concatenated along the
     batch axis (:106-110) and split again (:122-123)."""
     is_list = isinstance(x, (list, tuple))
     if is_list:
         nb, length = x[0].shape[0], len(x)
         x = torch.cat(list(x), dim=0)
-    x = torch.relu(_norm(sd, f"{prefix}.norm1", _conv(sd, f"{prefix}.conv1", x, stride=2, padding=3), kind))
+    x = torch.relu(_norm(sd, f"{prefix}.norm1", _conv(sd, f"{prefix}.conv1", x, stride=2, padding=3), kind, training))
     for li, stride in ((1, 1), (2, 2), (3, 2)):
-        x = _residual_block(sd, f"{prefix}.layer{li}.0", x, kind, stride)
-        x = _residual_block(sd, f"{prefix}.layer{li}.1", x, kind, 1)
+        x = _residual_block(sd, f"{prefix}.layer{li}.0", x, kind, stride, training)
+        x = _residual_block(sd, f"{prefix}.layer{li}.1", x, kind, 1, training)
     x = _conv(sd, f"{prefix}.conv2", x)
     if is_list:
         return list(torch.split(x, [nb] * length, dim=0))
@@ -374,10 +375,11 @@ def lookup_times(cfg: Dict[str, Any]) -> List[float]:
 
 def forward(sd: StateDict, cfg: Dict[str, Any], voxel_grid: Optional[Tensor] = None,
             images: Optional[List[Tensor]] = None, iters: int = 12, flow_init: Optional[Tensor] = None,
-            test_mode: bool = False, return_intermediates: bool = False):
+            test_mode: bool = False, return_intermediates: bool = False, training: bool = False):
     """RAFTSpline.forward, models/raft_spline/raft.py:101-200.
     Returns (bezier_low_params, bezier_up_params) if test_mode else [bezier_up_params per iteration]
-    (the reference wraps these tensors in BezierCurves)."""
+    (the reference wraps these tensors in BezierCurves).  training=True: BatchNorm on batch statistics (module.train()); the
+    function is plain differentiable torch, so autograd over it is the gradient oracle of the training path."""
     assert voxel_grid is not None or images is not None
     assert iters > 0
     hdim, cdim = cfg["hidden"]["dim"], cfg["context"]["dim"]
@@ -392,15 +394,15 @@ def forward(sd: StateDict, cfg: Dict[str, Any], voxel_grid: Optional[Tensor] = N
         idxs = [0] + list(cfg["correlation"]["ev"]["target_indices"])        # raft.py:93-94
         grids = [voxel_grid[:, i:i + ncorr] for i in idxs]
         context_input = voxel_grid[:, -nctx:]
-        fm = [x.float() for x in encoder(sd, "fnet_ev", grids, fnorm)]
+        fm = [x.float() for x in encoder(sd, "fnet_ev", grids, fnorm, training)]
         groups.append((fm[0], torch.stack(fm[1:], dim=0), list(cfg["correlation"]["ev"]["levels"])))
     if cfg["use_boundary_images"]:
         assert len(images) == 2
         images = [2 * (x.float().contiguous() / 255) - 1 for x in images]    # raft.py:134
-        fi = encoder(sd, "fnet_img", images, fnorm)
+        fi = encoder(sd, "fnet_img", images, fnorm, training)
         groups.append((fi[0], fi[1].unsqueeze(0), [int(cfg["correlation"]["img"]["levels"])]))
         context_input = images[0] if context_input is None else torch.cat((context_input, images[0]), dim=-3)
-    cnet = encoder(sd, "cnet", context_input, cnorm)
+    cnet = encoder(sd, "cnet", context_input, cnorm, training)
     net, inp = torch.split(cnet, [hdim, cdim], dim=1)
     net, inp = torch.tanh(net), torch.relu(inp)
 
@@ -426,6 +428,8 @@ def forward(sd: StateDict, cfg: Dict[str, Any], voxel_grid: Optional[Tensor] = N
     inter = []
     bezier_up = None
     for itr in range(iters):
+        if cfg.get("detach_bezier", False):                                  # raft.py:167-168
+            bezier = bezier.detach()
         flows = bezier_flow(bezier, times)
         coords1 = coords0 + flows
         corr_feat = corr_lookup(pyramid, coords1)
@@ -692,6 +696,41 @@ def dsec_twostep_sample(events: Dict[str, np.ndarray], rectify_map: np.ndarray, 
     cur = construct_voxel_grid(events, rectify_map, num_bins, H, W, cf, ct)
     prev = construct_voxel_grid(events, rectify_map, num_bins, H, W, pf, pt)
     return twostep_merge(prev, cur, normalize, merge)
+
+
+# --------------------------------------------------------------------------------------
+# Training losses: utils/losses.py
+# --------------------------------------------------------------------------------------
+def l1_loss_channel_masked(source: Tensor, target: Tensor, valid_mask: Optional[Tensor] = None) -> Tensor:
+    """utils/losses.py:6-22: |source - target| summed over channels, averaged over the valid positions (all if no mask)."""
+    assert source.ndim > 2 and source.shape == target.shape
+    per_pos = (source - target).abs().sum(dim=1)
+    if valid_mask is None:
+        return per_pos.mean()
+    assert valid_mask.dtype == torch.bool and valid_mask.shape == per_pos.shape
+    return per_pos[valid_mask].sum() / valid_mask.sum()
+
+
+def l1_seq_loss_channel_masked(source_list, target: Tensor, valid_mask: Optional[Tensor] = None, gamma: float = 0.8):
+    """utils/losses.py:24-40: prediction i of I weighted by gamma^(I-1-i)."""
+    total = 0
+    count = len(source_list)
+    for i, src in enumerate(source_list):
+        total = total + gamma ** (count - i - 1) * l1_loss_channel_masked(src, target, valid_mask)
+    return total
+
+
+def l1_multi_seq_loss_channel_masked(src_list_list, target_list, valid_mask_list=None, gamma: float = 0.8):
+    """utils/losses.py:42-62: per iteration the mean loss over the M supervision targets, iterations weighted as above."""
+    total = 0
+    n_iters = len(src_list_list)
+    for it, per_iter in enumerate(src_list_list):
+        assert len(per_iter) > 0 and len(per_iter) == len(target_list)
+        acc = 0
+        for m, src in enumerate(per_iter):
+            acc = acc + l1_loss_channel_masked(src, target_list[m], None if valid_mask_list is None else valid_mask_list[m])
+        total = total + gamma ** (n_iters - it - 1) * (acc / len(per_iter))
+    return total
 
 
 # --------------------------------------------------------------------------------------

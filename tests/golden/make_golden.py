@@ -57,8 +57,92 @@ def corr_case_inputs(seed, B, D, h, w, T):
     return f1, f2, coords.astype(np.float32)
 
 
+# (config, B, H, W, iters, loss kind) -- training-mode forward + loss + backward of the REFERENCE
+TRAIN_CASES = {
+    "train_E_LU4_BD2": ("E_LU4_BD2", 2, 128, 160, 3, "dsec"),
+    "train_E_I_LU4_BD2": ("E_I_LU4_BD2", 1, 128, 160, 2, "dsec"),
+    "train_E_LU5_BD10": ("E_LU5_BD10", 1, 128, 128, 2, "multiflow"),
+}
+GRAD_STRIDE = 97          # every parameter gradient is stored as (L2 norm, sum, every 97th element)
+
+
+def train_targets(B, H, W, kind, seed=99):
+    """Ground truth of the synthetic training sample: DSEC = one flow + valid mask, MultiFlow = 3 flows at times .4, .7, 1."""
+    rs = np.random.RandomState(seed)
+    if kind == "dsec":
+        return [synthetic.gt_flow(B, H, W, seed=seed)], [rs.rand(B, H, W) < 0.8], [1.0]
+    times = [0.4, 0.7, 1.0]
+    return [synthetic.gt_flow(B, H, W, seed=seed + k) * t for k, t in enumerate(times)], None, times
+
+
+def training_goldens(ns, out_dir):
+    T = torch.from_numpy
+    # ---------------- losses (utils/losses.py) ----------------
+    rs = np.random.RandomState(91)
+    ls = {}
+    srcs = [rs.standard_normal((2, 2, 12, 16)).astype(np.float32) for _ in range(4)]
+    tgt = rs.standard_normal((2, 2, 12, 16)).astype(np.float32)
+    srcs[1][0, :, 3, 4] = tgt[0, :, 3, 4]                      # exact zeros of the difference (sign(0) = 0 in the gradient)
+    valid = rs.rand(2, 12, 16) < 0.7
+    ls.update(tgt=tgt, valid=valid, **{f"src{i}": a for i, a in enumerate(srcs)})
+    ts = [T(a).requires_grad_(True) for a in srcs]
+    ls["l1_masked"] = ns.l1_loss_channel_masked(ts[0], T(tgt), T(valid)).detach().numpy()
+    ls["l1_unmasked"] = ns.l1_loss_channel_masked(ts[0], T(tgt)).detach().numpy()
+    for tag, m, gamma in (("seq_masked", T(valid), 0.8), ("seq_unmasked", None, 0.8), ("seq_masked_g085", T(valid), 0.85)):
+        for t in ts:
+            t.grad = None
+        loss = ns.l1_seq_loss_channel_masked(ts, T(tgt), m, gamma=gamma)
+        loss.backward()
+        ls[tag] = loss.detach().numpy()
+        for i, t in enumerate(ts):
+            ls[f"{tag}_grad{i}"] = t.grad.numpy().copy()
+    tgts = [rs.standard_normal((2, 2, 12, 16)).astype(np.float32) for _ in range(3)]
+    valids = [rs.rand(2, 12, 16) < 0.6 for _ in range(3)]
+    multi = [[rs.standard_normal((2, 2, 12, 16)).astype(np.float32) for _ in range(3)] for _ in range(2)]
+    for m, a in enumerate(tgts):
+        ls[f"mtgt{m}"], ls[f"mvalid{m}"] = a, valids[m]
+    for it, row in enumerate(multi):
+        for m, a in enumerate(row):
+            ls[f"msrc{it}_{m}"] = a
+    ls["multi_masked"] = ns.l1_multi_seq_loss_channel_masked([[T(a) for a in r] for r in multi], [T(a) for a in tgts], [T(v) for v in valids]).numpy()
+    ls["multi_unmasked"] = ns.l1_multi_seq_loss_channel_masked([[T(a) for a in r] for r in multi], [T(a) for a in tgts]).numpy()
+    np.savez_compressed(os.path.join(out_dir, "losses.npz"), **ls)
+
+    # ---------------- training-mode forward + loss + backward of the reference model ----------------
+    for fname, (cname, B, H, W, iters, kind) in TRAIN_CASES.items():
+        cfg = O.model_config(cname)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ns.RAFTSpline(cfg).train()
+        model.load_state_dict(O.make_state_dict(cfg, seed=0))
+        vox, imgs = e2e_inputs(cfg, B, H, W)
+        gts, valids, times = train_targets(B, H, W, kind)
+        preds = model(voxel_grid=vox, images=imgs, iters=iters, test_mode=False)
+        if kind == "dsec":
+            flows = [p.get_flow_from_reference(1.0) for p in preds]
+            loss = ns.l1_seq_loss_channel_masked(flows, T(gts[0]), T(valids[0]))
+        else:
+            flows = [[p.get_flow_from_reference(t) for t in times] for p in preds]
+            loss = ns.l1_multi_seq_loss_channel_masked(flows, [T(g) for g in gts])
+        loss.backward()
+        out = dict(config=cname, B=B, H=H, W=W, iters=iters, kind=kind, loss=loss.detach().numpy(),
+                   last_params_sub=preds[-1].get_params().detach()[:, :, ::4, ::4].numpy())
+        for name, prm in model.named_parameters():
+            g = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+            out[f"gnorm/{name}"] = g.norm().double().numpy()
+            out[f"gsum/{name}"] = g.double().sum().numpy()
+            out[f"gsub/{name}"] = g.flatten()[::GRAD_STRIDE].numpy().copy()
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean") or name.endswith("running_var"):
+                out[f"buf/{name}"] = buf.detach().numpy().copy()
+        np.savez_compressed(os.path.join(out_dir, fname + ".npz"), **out)
+        print(fname, "loss", float(loss))
+
+
 def main():
     ns = refshim.import_reference()
+    if len(sys.argv) > 2 and sys.argv[1] == "--only" and sys.argv[2] == "training":
+        training_goldens(ns, HERE)
+        return
     torch.manual_seed(0)
     out_dir = HERE
 
@@ -221,6 +305,7 @@ def main():
         ds["offsets_2150000_2250000"] = np.array(dns.EventSlicer.get_time_indices_offsets(ev["t"], 2_150_000, 2_250_000), dtype=np.int64)
         ds["offsets_past_end"] = np.array(dns.EventSlicer.get_time_indices_offsets(ev["t"], 2_500_000, 2_600_000), dtype=np.int64)
         np.savez_compressed(os.path.join(out_dir, "dsec_twostep.npz"), **ds)
+    training_goldens(ns, out_dir)
     print("golden fixtures written to", out_dir)
 
 

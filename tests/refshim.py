@@ -76,6 +76,7 @@ def import_reference():
     from utils.metrics import (epe_masked, epe_masked_multi, ae_masked, ae_masked_multi, n_pixel_error_masked, predictions_from_lin_assumption,
                                EPE_MULTI)
     from modules.utils import InputPadder
+    from utils.losses import l1_loss_channel_masked, l1_seq_loss_channel_masked, l1_multi_seq_loss_channel_masked
     ns.RAFTSpline = RAFTSpline
     ns.BezierCurves = BezierCurves
     ns.BasicUpdateBlock = BasicUpdateBlock
@@ -91,6 +92,8 @@ def import_reference():
     ns.epe_masked_multi, ns.ae_masked, ns.ae_masked_multi = epe_masked_multi, ae_masked, ae_masked_multi
     ns.n_pixel_error_masked, ns.predictions_from_lin_assumption = n_pixel_error_masked, predictions_from_lin_assumption
     ns.EPE_MULTI, ns.InputPadder = EPE_MULTI, InputPadder
+    ns.l1_loss_channel_masked, ns.l1_seq_loss_channel_masked = l1_loss_channel_masked, l1_seq_loss_channel_masked
+    ns.l1_multi_seq_loss_channel_masked = l1_multi_seq_loss_channel_masked
     return ns
 
 

@@ -1,0 +1,207 @@
+"""Training path on the GPU: the hand-written adjoints (csrc/backward.hip) against autograd over the CPU oracle,
+and the full training step (forward + sequence loss + backward) against the gradients of the REFERENCE itself
+(tests/golden/train_*.npz, losses.npz).  Floating point: tolerances are written at every comparison."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bflow_amd
+from bflow_amd import hip, training
+from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
+from bflow_amd.validation import DataLoading, DataSetType
+from oracle import raft_spline_oracle as O
+
+import train_common as TC
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _lookup_case(seed, B, D, h, w, T):
+    rs = np.random.RandomState(seed)
+    f1 = rs.standard_normal((B, D, h, w)).astype(np.float32)
+    f2 = rs.standard_normal((T, B, D, h, w)).astype(np.float32)
+    ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    base = np.stack([xs, ys], 0).astype(np.float32)
+    # generic fractional positions (the bilinear kernel is not differentiable AT integer coordinates), some far outside the plane
+    flow = (rs.standard_normal((T, B, 2, h, w)) * 3.0 + 0.37).astype(np.float32)
+    flow[:, :, :, 0, 0] = -50.3
+    flow[:, :, :, -1, -1] = 40.7
+    return f1, f2, (base[None, None] + flow).astype(np.float32)
+
+
+@pytest.mark.parametrize("levels,shape", [([1, 2, 3], (2, 32, 10, 12)), ([1, 1, 1, 4], (1, 64, 17, 26))])
+def test_lookup_and_pool_backward_match_oracle_autograd(levels, shape):
+    B, D, h, w = shape
+    T = len(levels)
+    f1, f2, coords = _lookup_case(11 + T, B, D, h, w, T)
+    rs = np.random.RandomState(5)
+    # ---- oracle: autograd through avg_pool2d pyramid + grid_sample look-up
+    vol = O.corr_volume(torch.from_numpy(f1), torch.from_numpy(f2)).detach().requires_grad_(True)
+    co = torch.from_numpy(coords).clone().requires_grad_(True)
+    out = O.corr_lookup(O.corr_pyramid(vol, levels), co)
+    gout = rs.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(gout))
+    # ---- HIP: forward block, adjoint kernels
+    blk = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(cu(f1), cu(f2), num_levels_per_target=levels))
+    np.testing.assert_allclose(blk(cu(coords)).cpu().numpy(), out.detach().numpy(), rtol=1e-5, atol=5e-5)
+    grads = [torch.zeros_like(t) for t, _ in blk._pyramid]
+    per_plane = [grads[lvl][k] for lvl, (_, idx) in enumerate(blk._pyramid) for k in range(len(idx))]
+    table = hip.make_grad_table(per_plane)
+    gc = hip.corr_lookup_bwd(blk._table, table, cu(coords), cu(gout))
+    gcoords = torch.zeros((T, B, 2, h, w), device=DEV)
+    for k, p in enumerate(blk._planes):
+        gcoords[p["target"]] += gc[k]
+    scale = float(co.grad.abs().max())
+    # coordinate gradient: differences of volume values (O(6), fp32) times 81 x P window weights
+    assert float((gcoords.cpu() - co.grad).abs().max()) < 2e-4 * scale
+    for lvl in range(len(blk._pyramid) - 1, 0, -1):
+        _, idx = blk._pyramid[lvl]
+        _, prev = blk._pyramid[lvl - 1]
+        for k, t in enumerate(idx):
+            hip.corr_pool2x2_bwd(grads[lvl][k], grads[lvl - 1][prev.index(t)])
+    gv = grads[0].cpu().view(vol.grad.shape)
+    assert float((gv - vol.grad).abs().max()) < 1e-5 * float(vol.grad.abs().max()) + 1e-6
+    # deterministic: a second pass adds exactly the same numbers
+    grads2 = [torch.zeros_like(t) for t, _ in blk._pyramid]
+    table2 = hip.make_grad_table([grads2[lvl][k] for lvl, (_, idx) in enumerate(blk._pyramid) for k in range(len(idx))])
+    gc2 = hip.corr_lookup_bwd(blk._table, table2, cu(coords), cu(gout))
+    assert torch.equal(gc, gc2)
+
+
+def test_lookup_bezier_backward_matches_oracle_autograd():
+    """Fused Bezier evaluation + look-up: gradient w.r.t. the Bezier parameters through the autograd Function of the product."""
+    B, D, h, w, deg = 2, 32, 12, 16, 3
+    levels, times = [1, 1, 3], [0.25, 0.5, 1.0]
+    rs = np.random.RandomState(21)
+    f1 = rs.standard_normal((B, D, h, w)).astype(np.float32)
+    f2 = rs.standard_normal((3, B, D, h, w)).astype(np.float32)
+    params = (rs.standard_normal((B, 2 * deg, h, w)) * 2.0 + 0.21).astype(np.float32)
+    # oracle
+    a, b = torch.from_numpy(f1).requires_grad_(True), torch.from_numpy(f2).requires_grad_(True)
+    p = torch.from_numpy(params).requires_grad_(True)
+    coords = O.coords_grid(B, h, w) + O.bezier_flow(p, times)
+    out = O.corr_lookup(O.corr_pyramid(O.corr_volume(a, b), levels), coords)
+    gout = rs.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(gout))
+    # product
+    ga, gb, gp = cu(f1).requires_grad_(True), cu(f2).requires_grad_(True), cu(params).requires_grad_(True)
+    blk = training.TrainCorrBlock([(ga, gb, levels)])
+    from bflow_amd.bezier import polynomial_coefficients
+    coef = polynomial_coefficients(np.asarray(times, dtype="float64"), deg)
+    res = blk.lookup_bezier(gp, coef)
+    np.testing.assert_allclose(res.detach().cpu().numpy(), out.detach().numpy(), rtol=1e-5, atol=5e-5)
+    res.backward(cu(gout))
+    for mine, ref in ((gp.grad, p.grad), (ga.grad, a.grad), (gb.grad, b.grad)):
+        assert float((mine.cpu() - ref).abs().max()) < 3e-4 * float(ref.abs().max())
+
+
+def test_cvx_upsample_backward_matches_oracle_autograd():
+    rs = np.random.RandomState(31)
+    B, C, h, w = 2, 4, 6, 9
+    data = rs.standard_normal((B, C, h, w)).astype(np.float32)
+    mask = (rs.standard_normal((B, 576, h, w)) * 2).astype(np.float32)
+    d, m = torch.from_numpy(data).requires_grad_(True), torch.from_numpy(mask).requires_grad_(True)
+    up = O.cvx_upsample(d, m)
+    gup = rs.standard_normal(tuple(up.shape)).astype(np.float32)
+    up.backward(torch.from_numpy(gup))
+    gd, gm = cu(data).requires_grad_(True), cu(mask).requires_grad_(True)
+    mine = training.cvx_upsample(gd, gm)
+    np.testing.assert_allclose(mine.detach().cpu().numpy(), up.detach().numpy(), rtol=1e-5, atol=1e-5)
+    mine.backward(cu(gup))
+    assert float((gd.grad.cpu() - d.grad).abs().max()) < 1e-5 * float(d.grad.abs().max())
+    assert float((gm.grad.cpu() - m.grad).abs().max()) < 1e-5 * float(m.grad.abs().max())
+
+
+def test_losses_match_reference_golden(golden_dir):
+    d = g(golden_dir, "losses")
+    srcs = [cu(d[f"src{i}"]).requires_grad_(True) for i in range(4)]
+    tgt, valid = cu(d["tgt"]), cu(d["valid"])
+    assert abs(float(training.l1_loss_channel_masked(srcs[0], tgt, valid)) - float(d["l1_masked"])) < 1e-6
+    assert abs(float(training.l1_loss_channel_masked(srcs[0], tgt)) - float(d["l1_unmasked"])) < 1e-6
+    for tag, m, gamma in (("seq_masked", valid, 0.8), ("seq_unmasked", None, 0.8), ("seq_masked_g085", valid, 0.85)):
+        for s in srcs:
+            s.grad = None
+        loss = training.l1_seq_loss_channel_masked(srcs, tgt, m, gamma=gamma)
+        loss.backward()
+        assert abs(float(loss) - float(d[tag])) < 1e-5      # fp64 accumulation here, fp32 tree sum in the reference
+        for i, s in enumerate(srcs):
+            assert np.abs(s.grad.cpu().numpy() - d[f"{tag}_grad{i}"]).max() < 1e-8
+    tgts = [cu(d[f"mtgt{m}"]) for m in range(3)]
+    valids = [cu(d[f"mvalid{m}"]) for m in range(3)]
+    multi = [[cu(d[f"msrc{it}_{m}"]) for m in range(3)] for it in range(2)]
+    assert abs(float(training.l1_multi_seq_loss_channel_masked(multi, tgts, valids)) - float(d["multi_masked"])) < 1e-5
+    assert abs(float(training.l1_multi_seq_loss_channel_masked(multi, tgts)) - float(d["multi_unmasked"])) < 1e-5
+
+
+def _product_model(cfg):
+    model = bflow_amd.RAFTSpline(cfg)
+    model.load_state_dict(O.make_state_dict(cfg, seed=0))
+    return model.to(DEV).train()
+
+
+@pytest.mark.parametrize("name", TC.TRAIN_CASES)
+def test_training_step_gradients_match_reference_golden(golden_dir, name):
+    """model.train() forward (test_mode=False), sequence loss and backward on the GPU against the reference's own loss, parameter
+    gradients and BatchNorm running statistics.  fp32 MIOpen convolutions vs fp32 CPU convolutions: 1e-2 of each parameter's
+    gradient scale (the check is per element of a strided subsample and per parameter norm)."""
+    d = g(golden_dir, name)
+    cfg = O.model_config(str(d["config"]))
+    B, H, W, iters, kind = int(d["B"]), int(d["H"]), int(d["W"]), int(d["iters"]), str(d["kind"])
+    model = _product_model(cfg)
+    vox, imgs = TC.inputs(cfg, B, H, W)
+    gts, valids, times = TC.train_targets(B, H, W, kind)
+    preds = model(voxel_grid=vox.to(DEV), images=None if imgs is None else [i.to(DEV) for i in imgs], iters=iters, test_mode=False)
+    assert len(preds) == iters
+    if kind == "dsec":
+        loss = training.l1_seq_loss_channel_masked([p.get_flow_from_reference(1.0) for p in preds], cu(gts[0]), cu(valids[0]))
+    else:
+        flows = [[p.get_flow_from_reference(t) for t in times] for p in preds]
+        loss = training.l1_multi_seq_loss_channel_masked(flows, [cu(x) for x in gts])
+    loss.backward()
+    assert abs(float(loss) - float(d["loss"])) < 1e-4 * abs(float(d["loss"]))
+    assert np.abs(preds[-1].get_params().detach()[:, :, ::4, ::4].cpu().numpy() - d["last_params_sub"]).max() < 1e-3
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()}
+    worst = TC.check_grads(grads, d, rel=2e-3)
+    print(f"{name}: worst scaled gradient error {worst:.2e}")
+    for k, v in model.named_buffers():
+        if f"buf/{k}" in d:
+            assert np.abs(v.cpu().numpy() - d[f"buf/{k}"]).max() < 1e-4
+
+
+def test_train_step_and_optimizer():
+    """TrainStep (training_step without Lightning) + AdamW/OneCycleLR as configure_optimizers builds them: two steps run, the loss
+    is finite and every parameter with a gradient moves."""
+    cfg = O.model_config("E_LU4_BD2")
+    model = _product_model(cfg)
+    B, H, W = 1, 128, 160
+    vox, _ = TC.inputs(cfg, B, H, W)
+    gts, valids, _ = TC.train_targets(B, H, W, "dsec")
+    batch = {DataLoading.FLOW: cu(gts[0]), DataLoading.FLOW_VALID: cu(valids[0]), DataLoading.EV_REPR: vox.to(DEV),
+             DataLoading.DATASET_TYPE: [DataSetType.DSEC]}
+    step = training.TrainStep(model, num_iter_train=2)
+    opt, sch = training.configure_optimizers(model, dict(learning_rate=1e-4, weight_decay=1e-4,
+                                                         lr_scheduler=dict(use=True, total_steps=10, pct_start=0.3)))
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    losses = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        out = step(batch)
+        out["loss"].backward()
+        opt.step()
+        sch.step()
+        losses.append(float(out["loss"]))
+    assert all(np.isfinite(losses))
+    moved = sum(int(not torch.equal(before[k], p.detach())) for k, p in model.named_parameters())
+    assert moved > 100
+    assert out["pred"].shape == (B, 2, H, W) and out["bezier_prediction"].get_params().requires_grad is False

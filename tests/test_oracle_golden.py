@@ -195,3 +195,41 @@ def test_param_inventory_counts():
             if not k.endswith(("running_mean", "running_var", "num_batches_tracked")) and ".downsample.1." not in k)
     assert n == 5344832
     assert O.num_corr_planes(cfg) == 567 and O.num_corr_planes(O.model_config("E_I_LU5_BD10")) == 972
+
+
+# ----------------------------------------------------------------------------------------------- training path
+def test_losses_match_reference_golden(golden_dir):
+    g = _load(golden_dir, "losses")
+    T = torch.from_numpy
+    srcs = [T(g[f"src{i}"]).requires_grad_(True) for i in range(4)]
+    tgt, valid = T(g["tgt"]), T(g["valid"])
+    assert abs(float(O.l1_loss_channel_masked(srcs[0], tgt, valid)) - float(g["l1_masked"])) < 1e-6
+    assert abs(float(O.l1_loss_channel_masked(srcs[0], tgt)) - float(g["l1_unmasked"])) < 1e-6
+    for tag, m, gamma in (("seq_masked", valid, 0.8), ("seq_unmasked", None, 0.8), ("seq_masked_g085", valid, 0.85)):
+        for s in srcs:
+            s.grad = None
+        loss = O.l1_seq_loss_channel_masked(srcs, tgt, m, gamma=gamma)
+        loss.backward()
+        assert abs(float(loss) - float(g[tag])) < 1e-5
+        for i, s in enumerate(srcs):
+            assert np.abs(s.grad.numpy() - g[f"{tag}_grad{i}"]).max() < 1e-8
+    tgts = [T(g[f"mtgt{m}"]) for m in range(3)]
+    valids = [T(g[f"mvalid{m}"]) for m in range(3)]
+    multi = [[T(g[f"msrc{it}_{m}"]) for m in range(3)] for it in range(2)]
+    assert abs(float(O.l1_multi_seq_loss_channel_masked(multi, tgts, valids)) - float(g["multi_masked"])) < 1e-5
+    assert abs(float(O.l1_multi_seq_loss_channel_masked(multi, tgts)) - float(g["multi_unmasked"])) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["train_E_LU4_BD2", "train_E_I_LU4_BD2", "train_E_LU5_BD10"])
+def test_training_step_gradients_match_reference_golden(golden_dir, name):
+    """Training-mode forward (BatchNorm on batch statistics) + sequence loss + autograd of the oracle == the reference's."""
+    import train_common as TC
+    g = _load(golden_dir, name)
+    cfg = O.model_config(str(g["config"]))
+    loss, grads, bufs, last = TC.oracle_train_step(cfg, int(g["B"]), int(g["H"]), int(g["W"]), int(g["iters"]), str(g["kind"]))
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert np.abs(last[:, :, ::4, ::4].numpy() - g["last_params_sub"]).max() < 1e-4
+    TC.check_grads(grads, g, rel=2e-4)
+    for k, v in bufs.items():
+        if f"buf/{k}" in g:
+            assert np.abs(v.numpy() - g[f"buf/{k}"]).max() < 1e-5
