@@ -190,3 +190,58 @@ def test_two_rank_gloo_shard_equivalence():
     t1, t2 = np.array(one["table"]), np.array(two["table"])
     assert t1.shape == (9, 2) and t1[0, 1] == 4 and np.allclose(t1, t2, rtol=0, atol=1e-9)
     assert abs(t1[0, 0] - one["sum"]) < 1e-9                      # row 0 is the EPE state
+
+
+_DDP_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch
+torch.set_num_threads(2)
+from bflow_amd import dist as bdist
+rank, world, local = bdist.init_from_env("gloo")
+torch.manual_seed(100 + rank)                       # different initial weights per rank: the broadcast must make them equal
+net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(),
+                          torch.nn.Conv2d(8, 2, 1)).double()
+unused = torch.nn.Parameter(torch.ones(5, dtype=torch.float64))   # a parameter that never gets a gradient
+net.register_parameter("unused", unused)
+bdist.broadcast_module_state(net, src=0)
+buckets = bdist.GradientBuckets(net, bucket_bytes=2048)           # small buckets: several all-reduces in flight during backward
+G = 4
+per = bdist.per_gpu_batch_size(G, world)
+start, stop = bdist.shard_range(G, rank, world)
+gen = torch.Generator().manual_seed(7)
+x = torch.randn(G, 3, 12, 10, generator=gen, dtype=torch.float64); y = torch.randn(G, 2, 12, 10, generator=gen, dtype=torch.float64)
+for step in range(2):                                # second step: the bucket bookkeeping resets
+    net.zero_grad(set_to_none=True)
+    loss = (net(x[start:stop]) - y[start:stop]).abs().sum(1).mean()
+    loss.backward()
+    buckets.finish()
+flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in net.parameters()])
+w = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+if rank == 0:
+    print("RESULT " + json.dumps(dict(grad=flat.tolist(), weights=w.tolist(), buckets=buckets.num_buckets, per=per)))
+import torch.distributed as d
+if d.is_initialized():
+    d.barrier(); d.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_gradient_buckets():
+    """SURVEY 8(f-4), DDP: the rank-averaged gradient of 2 ranks x 2 samples == the gradient of 1 rank x 4 samples (the loss is a
+    mean over samples), with the bucketed asynchronous all-reduce launched from the backward hooks; weights follow rank 0."""
+    def run(world, port):
+        code = _DDP_WORKER.format(root=ROOT)
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        import json
+        return json.loads([l for l in outs[0].splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
+    one, two = run(1, 29641), run(2, 29642)
+    assert one["per"] == 4 and two["per"] == 2 and two["buckets"] >= 3
+    assert np.allclose(one["weights"], two["weights"], rtol=0, atol=0)
+    assert np.allclose(one["grad"], two["grad"], rtol=0, atol=1e-12)
+    with pytest.raises(AssertionError, match="divisible"):
+        bdist.per_gpu_batch_size(6, 4)
