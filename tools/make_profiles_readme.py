@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 b = json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
 p = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["kernels"]
 r, rk, rl, cb = b["roofline"], b["roofline_corr_build"], b["roofline_lookup"], b["cpu_baseline"]
+train = open(os.path.join(ROOT, "profiles", "r01_train_probe.txt")).read().strip().replace("train step ", "")
 txt = f'''# profiles/ — measured evidence, MI355X (gfx950), round 1
 
 All files were produced on a `gpurun` MI355X box by `tools/collect_profiles.sh` from this repository at the round-1 head
@@ -15,6 +16,7 @@ All files were produced on a `gpurun` MI355X box by `tools/collect_profiles.sh` 
 | `r01_bench.json` | `python bench.py --steps 30 --warmup 5` | the BENCH line: {b["value"]:.1f} frames/s, {b["ms_per_step"]:.2f} ms/frame, {b["ms_per_gru_iter"]:.2f} ms per GRU iteration at BASELINE configs[1] (E_LU4_BD2, 640×480, B=1, 12 iters); rooflines; CPU baseline {cb["value"]:.2f} frames/s on the box's {cb["cores"]}-core quota (×{b["gpu_over_cpu"]:.0f}) |
 | `r01_rocprofv3_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline` (top 45 rows of the kernel stats) | per-kernel totals/averages over the same command: every row is a kernel of this repository (no library convolution or GEMM on the product path) or torch's copy / fill plumbing |
 | `r01_pmc_{{FETCH,WRITE}}_SIZE_<key>.csv` | `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) on `tools/roofline_probe.py --key <key>` — the same launchers `bench.py` times (`tools/roofline_kernels.py`); last 5 launches of the kernel | HBM-side traffic per launch of the three roofline kernels |
+| `r01_train_probe.txt`, `r01_train_rocprofv3_kernel_stats.csv` | `python tools/train_probe.py 10`; `rocprofv3 --kernel-trace --stats -- python tools/train_probe.py 5` (top 30 rows) | training path (SURVEY §8 f-4) at the reference's DSEC training shape (batch 3, crop 288×384, 12 iterations, AdamW): {train} |
 | `r01_pmc.json` | `tools/pmc_to_json.py` on the six CSVs | bytes per launch incl. the gfx950 ×2 FETCH_SIZE correction for wide coalesced streams (MI355X_MICROARCH.md §HBM); `bench.py` copies `traffic` from here |
 
 ## Round-1 numbers (C2 = E_LU4_BD2 events-only, DSEC 640×480, batch 1, 12 iterations)
