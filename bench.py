@@ -27,7 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import bflow_amd  # noqa: E402
-from bflow_amd import configs, dist as bdist, hip, synthetic  # noqa: E402
+from bflow_amd import configs, dist as bdist, synthetic  # noqa: E402
 from bflow_amd.metrics import epe_masked  # noqa: E402
 from bflow_amd.weights import deterministic_state_dict  # noqa: E402
 

@@ -8,7 +8,7 @@ tests.  16 B per rank: latency-bound, issued once per evaluation, outside any ti
 from __future__ import annotations
 
 import os
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist

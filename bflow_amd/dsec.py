@@ -15,8 +15,7 @@ covering [t_start, t_end); `EventStream` wraps an in-memory, time-sorted stream 
 """
 from __future__ import annotations
 
-import math
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Tuple
 
 import numpy as np
 import torch

@@ -9,7 +9,7 @@ is kept for A/B runs only (BFLOW_CONV_ENGINE=miopen).
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Optional, Sequence, Union
+from typing import Dict, Optional, Sequence, Union
 
 import torch
 import torch.nn as nn

@@ -10,7 +10,7 @@ valid because they only depend on the signature (shapes, config) and on buffers 
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch

@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hip
-from .bezier import BezierCurves, polynomial_coefficients
+from .bezier import BezierCurves
 from .corr import CorrBlockParallelMultiTarget, CorrComputation
 from .validation import DataLoading, DataSetType, _get
 

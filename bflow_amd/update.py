@@ -14,7 +14,6 @@ from __future__ import annotations
 
 from typing import Any, Dict, Optional
 
-import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

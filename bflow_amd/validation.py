@@ -13,12 +13,11 @@ All arithmetic runs in HIP kernels (bflow_amd/metrics.py, hip.pad_replicate); th
 from __future__ import annotations
 
 from enum import Enum, IntEnum, auto
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List
 
 import torch
 
 from . import hip
-from .bezier import BezierCurves
 from .metrics import AE_MULTI, EPE_MULTI, SingleFlowMetrics, predictions_from_lin_assumption
 
 

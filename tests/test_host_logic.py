@@ -42,6 +42,18 @@ def test_host_side_abi_functions_and_error_reporting():
         hip.bezier_coeffs([1.5], 2)
     with pytest.raises(hip.BflowHipError, match="degree"):
         hip.bezier_coeffs([0.5], 99)
+    # argument validation of the training entry points happens before any launch: callable without a GPU
+    L = hip.lib()
+    assert L.bflow_corr_pool2x2_bwd(None, None, 1, 4, 4, None) != 0 and b"corr_pool2x2_bwd" in L.bflow_last_error_string()
+    assert L.bflow_cvx_upsample_bwd(None, None, None, None, None, None, 1, 4, 2, 2, None) != 0
+    assert L.bflow_l1_masked_accumulate(None, None, None, 1, 2, 16, None, None) != 0 and b"l1_masked_accumulate" in L.bflow_last_error_string()
+    assert L.bflow_corr_lookup_bwd(None, None, 0, None, 1, None, None, 1, 4, 4, None) != 0
+
+
+def test_training_mode_has_no_cpu_fallback_either():
+    m = bflow_amd.RAFTSpline(configs.model_config("E_LU4_BD2")).train()
+    with pytest.raises(hip.BflowHipError):
+        m(voxel_grid=torch.zeros(1, 9, 64, 64), iters=1, test_mode=False)
 
 
 def test_no_cpu_fallback():
