@@ -62,6 +62,8 @@ TRAIN_CASES = {
     "train_E_LU4_BD2": ("E_LU4_BD2", 2, 128, 160, 3, "dsec"),
     "train_E_I_LU4_BD2": ("E_I_LU4_BD2", 1, 128, 160, 2, "dsec"),
     "train_E_LU5_BD10": ("E_LU5_BD10", 1, 128, 128, 2, "multiflow"),
+    # detach_bezier=True (raft.py:167-168) and a warm start through flow_init (raft.py:152-153)
+    "train_E_LU4_BD2_detach_init": ("E_LU4_BD2", 1, 128, 160, 3, "dsec"),
 }
 GRAD_STRIDE = 97          # every parameter gradient is stored as (L2 norm, sum, every 97th element)
 
@@ -73,6 +75,10 @@ def train_targets(B, H, W, kind, seed=99):
         return [synthetic.gt_flow(B, H, W, seed=seed)], [rs.rand(B, H, W) < 0.8], [1.0]
     times = [0.4, 0.7, 1.0]
     return [synthetic.gt_flow(B, H, W, seed=seed + k) * t for k, t in enumerate(times)], None, times
+
+
+def train_flow_init(B, C, h, w, seed=55):
+    return (np.random.RandomState(seed).standard_normal((B, C, h, w)) * 1.5).astype(np.float32)
 
 
 def training_goldens(ns, out_dir):
@@ -111,12 +117,16 @@ def training_goldens(ns, out_dir):
     # ---------------- training-mode forward + loss + backward of the reference model ----------------
     for fname, (cname, B, H, W, iters, kind) in TRAIN_CASES.items():
         cfg = O.model_config(cname)
+        flow_init = None
+        if fname.endswith("detach_init"):
+            cfg["detach_bezier"] = True
+            flow_init = ns.BezierCurves(torch.from_numpy(train_flow_init(B, 2 * cfg["bezier_degree"], H // 8, W // 8)))
         with contextlib.redirect_stdout(io.StringIO()):
             model = ns.RAFTSpline(cfg).train()
         model.load_state_dict(O.make_state_dict(cfg, seed=0))
         vox, imgs = e2e_inputs(cfg, B, H, W)
         gts, valids, times = train_targets(B, H, W, kind)
-        preds = model(voxel_grid=vox, images=imgs, iters=iters, test_mode=False)
+        preds = model(voxel_grid=vox, images=imgs, iters=iters, flow_init=flow_init, test_mode=False)
         if kind == "dsec":
             flows = [p.get_flow_from_reference(1.0) for p in preds]
             loss = ns.l1_seq_loss_channel_masked(flows, T(gts[0]), T(valids[0]))

@@ -9,6 +9,7 @@ import torch
 
 import bflow_amd
 from bflow_amd import hip, training
+from bflow_amd.bezier import BezierCurves
 from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
 from bflow_amd.validation import DataLoading, DataSetType
 from oracle import raft_spline_oracle as O
@@ -127,8 +128,8 @@ def test_losses_match_reference_golden(golden_dir):
     d = g(golden_dir, "losses")
     srcs = [cu(d[f"src{i}"]).requires_grad_(True) for i in range(4)]
     tgt, valid = cu(d["tgt"]), cu(d["valid"])
-    assert abs(float(training.l1_loss_channel_masked(srcs[0], tgt, valid)) - float(d["l1_masked"])) < 1e-6
-    assert abs(float(training.l1_loss_channel_masked(srcs[0], tgt)) - float(d["l1_unmasked"])) < 1e-6
+    assert abs(float(training.l1_loss_channel_masked(srcs[0], tgt, valid).detach()) - float(d["l1_masked"])) < 1e-6
+    assert abs(float(training.l1_loss_channel_masked(srcs[0], tgt).detach()) - float(d["l1_unmasked"])) < 1e-6
     for tag, m, gamma in (("seq_masked", valid, 0.8), ("seq_unmasked", None, 0.8), ("seq_masked_g085", valid, 0.85)):
         for s in srcs:
             s.grad = None
@@ -156,12 +157,13 @@ def test_training_step_gradients_match_reference_golden(golden_dir, name):
     gradients and BatchNorm running statistics.  fp32 MIOpen convolutions vs fp32 CPU convolutions: 1e-2 of each parameter's
     gradient scale (the check is per element of a strided subsample and per parameter norm)."""
     d = g(golden_dir, name)
-    cfg = O.model_config(str(d["config"]))
     B, H, W, iters, kind = int(d["B"]), int(d["H"]), int(d["W"]), int(d["iters"]), str(d["kind"])
+    cfg, init = TC.case_setup(name, O.model_config(str(d["config"])), B, H, W)
     model = _product_model(cfg)
     vox, imgs = TC.inputs(cfg, B, H, W)
     gts, valids, times = TC.train_targets(B, H, W, kind)
-    preds = model(voxel_grid=vox.to(DEV), images=None if imgs is None else [i.to(DEV) for i in imgs], iters=iters, test_mode=False)
+    preds = model(voxel_grid=vox.to(DEV), images=None if imgs is None else [i.to(DEV) for i in imgs], iters=iters,
+                  flow_init=None if init is None else BezierCurves(cu(init)), test_mode=False)
     assert len(preds) == iters
     if kind == "dsec":
         loss = training.l1_seq_loss_channel_masked([p.get_flow_from_reference(1.0) for p in preds], cu(gts[0]), cu(valids[0]))

@@ -220,13 +220,14 @@ def test_losses_match_reference_golden(golden_dir):
     assert abs(float(O.l1_multi_seq_loss_channel_masked(multi, tgts)) - float(g["multi_unmasked"])) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["train_E_LU4_BD2", "train_E_I_LU4_BD2", "train_E_LU5_BD10"])
+@pytest.mark.parametrize("name", ["train_E_LU4_BD2", "train_E_I_LU4_BD2", "train_E_LU5_BD10", "train_E_LU4_BD2_detach_init"])
 def test_training_step_gradients_match_reference_golden(golden_dir, name):
     """Training-mode forward (BatchNorm on batch statistics) + sequence loss + autograd of the oracle == the reference's."""
     import train_common as TC
     g = _load(golden_dir, name)
-    cfg = O.model_config(str(g["config"]))
-    loss, grads, bufs, last = TC.oracle_train_step(cfg, int(g["B"]), int(g["H"]), int(g["W"]), int(g["iters"]), str(g["kind"]))
+    cfg, init = TC.case_setup(name, O.model_config(str(g["config"])), int(g["B"]), int(g["H"]), int(g["W"]))
+    loss, grads, bufs, last = TC.oracle_train_step(cfg, int(g["B"]), int(g["H"]), int(g["W"]), int(g["iters"]), str(g["kind"]),
+                                                   flow_init=init)
     assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
     assert np.abs(last[:, :, ::4, ::4].numpy() - g["last_params_sub"]).max() < 1e-4
     TC.check_grads(grads, g, rel=2e-4)

@@ -5,7 +5,7 @@ import torch
 from bflow_amd import synthetic
 from oracle import raft_spline_oracle as O
 
-TRAIN_CASES = ["train_E_LU4_BD2", "train_E_I_LU4_BD2", "train_E_LU5_BD10"]
+TRAIN_CASES = ["train_E_LU4_BD2", "train_E_I_LU4_BD2", "train_E_LU5_BD10", "train_E_LU4_BD2_detach_init"]
 GRAD_STRIDE = 97
 
 
@@ -18,6 +18,14 @@ def train_targets(B, H, W, kind, seed=99):
     return [synthetic.gt_flow(B, H, W, seed=seed + k) * t for k, t in enumerate(times)], None, times
 
 
+def case_setup(name, cfg, B, H, W):
+    """(cfg possibly with detach_bezier, flow_init array or None) -- mirrors tests/golden/make_golden.py."""
+    if name.endswith("detach_init"):
+        cfg = dict(cfg, detach_bezier=True)
+        return cfg, (np.random.RandomState(55).standard_normal((B, 2 * cfg["bezier_degree"], H // 8, W // 8)) * 1.5).astype(np.float32)
+    return cfg, None
+
+
 def inputs(cfg, B, H, W):
     C = cfg["num_bins"]["context"] + cfg["num_bins"]["correlation"] - 1
     vox = torch.from_numpy(synthetic.voxel_grid(B, C, H, W, seed=1234))
@@ -28,7 +36,7 @@ def inputs(cfg, B, H, W):
     return vox, imgs
 
 
-def oracle_train_step(cfg, B, H, W, iters, kind, seed=0):
+def oracle_train_step(cfg, B, H, W, iters, kind, seed=0, flow_init=None):
     """Training-mode forward + loss + backward on the CPU oracle -> (loss, {param: grad}, {buffer: value}, last prediction)."""
     sd = {k: v.clone() for k, v in O.make_state_dict(cfg, seed=seed).items()}
     shapes = O.param_shapes(cfg)
@@ -37,7 +45,8 @@ def oracle_train_step(cfg, B, H, W, iters, kind, seed=0):
         sd[k].requires_grad_(True)
     vox, imgs = inputs(cfg, B, H, W)
     gts, valids, times = train_targets(B, H, W, kind)
-    ups = O.forward(sd, cfg, vox, imgs, iters=iters, test_mode=False, training=True)
+    ups = O.forward(sd, cfg, vox, imgs, iters=iters, test_mode=False, training=True,
+                    flow_init=None if flow_init is None else torch.from_numpy(flow_init))
     if kind == "dsec":
         flows = [O.bezier_flow(u, 1.0) for u in ups]
         loss = O.l1_seq_loss_channel_masked(flows, torch.from_numpy(gts[0]), torch.from_numpy(valids[0]))
