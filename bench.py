@@ -165,7 +165,7 @@ def main():
             "epe_vs_synthetic_gt": round(float(epe_mean), 4), "epe_ranks_gathered": int(epe_cnt),
         }
 
-    # ---- single-GPU extras: ms/GRU-iter, roofline of the dominant hand-written kernel, CPU baseline
+    # ---- extras outside the timed region: ms/GRU-iter (N=1), rooflines of the hand-written kernels (rank 0), CPU baseline (N=1)
     if world == 1:
         def step6():
             return model(voxel_grid=vox, iters=ITERS // 2, test_mode=True)
@@ -177,6 +177,7 @@ def main():
         out["ms_per_gru_iter"] = round((t12 - t6) / (ITERS // 2) * 1e3, 4)
         out["ms_fixed_part"] = round((t12 - ITERS * (t12 - t6) / (ITERS // 2)) * 1e3, 4)
 
+    if rank == 0:
         # ---- rooflines of the hand-written kernels (tools/roofline_kernels.py), each timed with hipEvents on the launch stream on
         # the operands of this very workload (the timed region above is graph replays, inside which events cannot be recorded)
         from tools.roofline_kernels import build as roofline_kernels
@@ -210,7 +211,7 @@ def main():
                 r["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
             out[k["key"]] = r
             k.clear()
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, torch.from_numpy(vox_np[:1]))
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
 

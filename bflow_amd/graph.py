@@ -10,6 +10,7 @@ valid because they only depend on the signature (shapes, config) and on buffers 
 """
 from __future__ import annotations
 
+import gc
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -29,8 +30,18 @@ class _Captured:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.low, self.ups = model._forward_impl(self.static_voxel, self.static_images, iters, self.static_init, test_mode)
+        # The cyclic garbage collector must not run inside the capture: if it finalises an OLDER captured graph there (a model
+        # that went out of scope, e.g. the previous test's), hipGraphExecDestroy is refused while the stream is capturing and
+        # torch's destructor aborts the process.  Collect now, keep the collector off until the capture has ended.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.low, self.ups = model._forward_impl(self.static_voxel, self.static_images, iters, self.static_init, test_mode)
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def replay(self, voxel_grid, images, flow_init):
         if voxel_grid is not None:

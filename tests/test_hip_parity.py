@@ -351,6 +351,31 @@ def test_e2e_full_size_dsec_vs_oracle():
     assert e < EPE_TOL
 
 
+@pytest.mark.parametrize("cname,B,H,W,iters,check", [
+    ("E_LU5_BD10", 1, 384, 384, 4, [0]),            # BASELINE C1 at its own size (the reference's CPU-runnable case)
+    ("E_I_LU4_BD2", 2, 480, 640, 12, [0, 1]),       # C3-shaped (events + boundary images, M-to-N volume), batch 2 of its 8
+    ("E_LU4_BD2", 8, 480, 640, 12, [0, 7]),         # C4: batch 8 per GPU; samples are independent, so two of them are checked
+])
+def test_e2e_baseline_configs_full_size_vs_oracle(cname, B, H, W, iters, check):
+    """The other BASELINE configurations at full size (hipGraph replay) against the CPU oracle run per checked sample."""
+    cfg, m, sd = _model(cname)
+    m.enable_hipgraph()
+    C = cfg["num_bins"]["context"] + cfg["num_bins"]["correlation"] - 1
+    vox = torch.from_numpy(synthetic.voxel_grid(B, C, H, W, seed=7))
+    imgs = None
+    if cfg["use_boundary_images"]:
+        a, b = synthetic.image_pair(B, H, W, seed=8)
+        imgs = [torch.from_numpy(a), torch.from_numpy(b)]
+    low, up = m(voxel_grid=vox.to(DEV), images=None if imgs is None else [i.to(DEV) for i in imgs], iters=iters, test_mode=True)
+    flow = up.get_flow_from_reference(1.0).cpu()
+    for i in check:
+        with torch.inference_mode():
+            _, rup = O.forward(sd, cfg, vox[i:i + 1], None if imgs is None else [x[i:i + 1] for x in imgs], iters=iters, test_mode=True)
+        e = float(O.epe_masked(flow[i:i + 1], O.bezier_flow(rup, 1.0)))
+        print(f"{cname} B={B} {H}x{W} sample {i}: EPE vs oracle = {e:.3e} px")
+        assert e < EPE_TOL
+
+
 def test_cpu_inputs_fail_loudly():
     cfg, m, sd = _model("E_LU4_BD2")
     with pytest.raises(hip.BflowHipError):
