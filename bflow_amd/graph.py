@@ -59,9 +59,18 @@ class GraphCache:
     """One captured graph per (shapes, dtypes, iters, test_mode, has flow_init).  Outputs are the graph's static buffers:
     they are overwritten by the next replay of the same signature (clone them to keep them)."""
 
+    MAX_GRAPHS = 8      # signatures kept; a graph owns all of its intermediates (>= 0.4 GB per DSEC-sized sample)
+
     def __init__(self, model):
         self.model = model
         self._graphs: Dict[Tuple, _Captured] = {}
+        self._weights_key = None
+
+    def _weights_signature(self):
+        """Storage + in-place version of every parameter and buffer.  The engine's packed weights (and folded BatchNorm terms) are
+        frozen into a captured graph; load_state_dict / optimizer steps / .to() after the capture must invalidate it."""
+        m = self.model
+        return tuple((t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
 
     @staticmethod
     def _sig(t: Optional[torch.Tensor]):
@@ -70,10 +79,16 @@ class GraphCache:
     def run(self, voxel_grid, images, iters: int, flow_init, test_mode: bool):
         key = (self._sig(voxel_grid), None if images is None else tuple(self._sig(x) for x in images), int(iters),
                self._sig(flow_init), bool(test_mode))
-        cap = self._graphs.get(key)
+        wkey = self._weights_signature()
+        if wkey != self._weights_key:
+            self._graphs.clear()                 # destroyed here, outside any capture
+            self._weights_key = wkey
+        cap = self._graphs.pop(key, None)
         if cap is None:
+            while len(self._graphs) >= self.MAX_GRAPHS:
+                self._graphs.pop(next(iter(self._graphs)))      # least recently used first (dict order = recency, see below)
             cap = _Captured(self.model, voxel_grid, images, iters, flow_init, test_mode)
-            self._graphs[key] = cap
+        self._graphs[key] = cap                  # (re-)insert at the end: most recently used
         return cap.replay(voxel_grid, images, flow_init)
 
     def clear(self):

@@ -154,9 +154,11 @@ class RAFTSpline(nn.Module):
         if self.training:
             # differentiable forward (HIP forward/backward for K5-K7/K13, torch autograd for the convolutions)
             from .training import forward_train
-            low, ups = forward_train(self, voxel_grid, images, iters, None if flow_init is None else flow_init.get_params())
+            with torch.cuda.device(ref.device):
+                low, ups = forward_train(self, voxel_grid, images, iters, None if flow_init is None else flow_init.get_params())
             return (BezierCurves(low), ups[-1]) if test_mode else ups
-        with torch.no_grad():
+        # kernels are launched on the CURRENT device's stream: make the inputs' device current for the duration of the call
+        with torch.cuda.device(ref.device), torch.no_grad():
             init = None if flow_init is None else flow_init.get_params()
             if self._graphs is not None and self.stage_timer is None:
                 low, ups = self._graphs.run(voxel_grid, images, iters, init, test_mode)

@@ -376,6 +376,29 @@ def test_e2e_baseline_configs_full_size_vs_oracle(cname, B, H, W, iters, check):
         assert e < EPE_TOL
 
 
+def test_graph_recaptured_after_weight_update_and_lru():
+    """Packed weights are frozen into a captured graph: load_state_dict after the first forward must invalidate it (same output as
+    a fresh model), and the cache keeps at most MAX_GRAPHS signatures."""
+    cfg, m, sd = _model("E_LU4_BD2", seed=0)
+    m.enable_hipgraph()
+    vox = torch.from_numpy(synthetic.voxel_grid(1, 9, 96, 128, seed=3)).to(DEV)
+    _, up0 = m(voxel_grid=vox, iters=3, test_mode=True)
+    f0 = up0.get_flow_from_reference(1.0).clone()
+    m.load_state_dict(deterministic_state_dict(m, 5))                    # in place: same storage, new versions
+    _, up1 = m(voxel_grid=vox, iters=3, test_mode=True)
+    f1 = up1.get_flow_from_reference(1.0).clone()
+    _, fresh, _ = _model("E_LU4_BD2", seed=5)
+    _, upf = fresh(voxel_grid=vox, iters=3, test_mode=True)
+    assert float((f1 - f0).abs().max()) > 1e-3                           # the weights did change the result
+    assert float((f1 - upf.get_flow_from_reference(1.0)).abs().max()) < 1e-5
+    m._graphs.MAX_GRAPHS = 2
+    for it in (1, 2, 3, 1):
+        m(voxel_grid=vox, iters=it, test_mode=True)
+        assert len(m._graphs._graphs) <= 2
+    _, up3 = m(voxel_grid=vox, iters=3, test_mode=True)                  # evicted above, captured again
+    assert float((up3.get_flow_from_reference(1.0) - f1).abs().max()) < 1e-5
+
+
 def test_cpu_inputs_fail_loudly():
     cfg, m, sd = _model("E_LU4_BD2")
     with pytest.raises(hip.BflowHipError):
