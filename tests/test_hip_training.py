@@ -207,3 +207,41 @@ def test_train_step_and_optimizer():
     moved = sum(int(not torch.equal(before[k], p.detach())) for k, p in model.named_parameters())
     assert moved > 100
     assert out["pred"].shape == (B, 2, H, W) and out["bezier_prediction"].get_params().requires_grad is False
+
+
+def test_adjoint_identities_at_dsec_size():
+    """Size-independent property at BASELINE C2 size (60x80 grid, 4 targets, 7 pyramid planes, 368.6 MB volume): look-up, pooling and
+    up-sampling are LINEAR in the volume / the Bezier parameters, so <L x, y> == <x, L^T y> must hold for the adjoint kernels
+    (fp32 dot products accumulated in fp64; 1e-5 relative)."""
+    B, D, h, w, levels = 1, 256, 60, 80, [1, 1, 1, 4]
+    T = len(levels)
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    f1 = torch.randn(B, D, h, w, generator=gen).to(DEV)
+    f2 = torch.randn(T, B, D, h, w, generator=gen).to(DEV)
+    blk = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, num_levels_per_target=levels))
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    coords = (torch.stack([xs, ys], 0).float()[None, None] + torch.randn(T, B, 2, h, w, generator=gen) * 6.0 + 0.31).to(DEV)
+    out = blk(coords)                                              # L applied to the actual pyramid
+    y = torch.randn(out.shape, generator=gen).to(DEV)
+    grads = [torch.zeros_like(t) for t, _ in blk._pyramid]
+    table = hip.make_grad_table([grads[lvl][k] for lvl, (_, idx) in enumerate(blk._pyramid) for k in range(len(idx))])
+    hip.corr_lookup_bwd(blk._table, table, coords, y)
+    lhs = float((out.double() * y.double()).sum())
+    rhs = sum(float((t.double() * g.double()).sum()) for (t, _), g in zip(blk._pyramid, grads))
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), float(out.double().norm() * y.double().norm()) * 1e-3), (lhs, rhs)
+    # pooling: <pool(a), b> == <a, pool^T(b)>
+    a = blk._pyramid[0][0][3]                                      # (B*N, 60, 80) slab of the 4-level target
+    pooled = blk._pyramid[1][0][0]
+    bb = torch.randn(pooled.shape, generator=gen).to(DEV)
+    ga = torch.zeros_like(a)
+    hip.corr_pool2x2_bwd(bb, ga)
+    l2, r2 = float((pooled.double() * bb.double()).sum()), float((a.double() * ga.double()).sum())
+    assert abs(l2 - r2) < 1e-6 * float(pooled.double().norm() * bb.double().norm())
+    # convex up-sampling is linear in the data for a fixed mask
+    data = torch.randn(B, 4, h, w, generator=gen).to(DEV)
+    mask = (torch.randn(B, 576, h, w, generator=gen) * 2).to(DEV)
+    up = hip.cvx_upsample(data, mask)
+    gu = torch.randn(up.shape, generator=gen).to(DEV)
+    gd, _ = hip.cvx_upsample_bwd(gu, data, mask)
+    l3, r3 = float((up.double() * gu.double()).sum()), float((data.double() * gd.double()).sum())
+    assert abs(l3 - r3) < 1e-5 * float(up.double().norm() * gu.double().norm())
