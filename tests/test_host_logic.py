@@ -257,3 +257,25 @@ def test_two_rank_gloo_gradient_buckets():
     assert np.allclose(one["grad"], two["grad"], rtol=0, atol=1e-12)
     with pytest.raises(AssertionError, match="divisible"):
         bdist.per_gpu_batch_size(6, 4)
+
+
+def test_dropin_modules_resolve_to_this_package():
+    """INTEGRATION.md seam 1: with <repo>/dropin first on PYTHONPATH the reference's import lines (modules/raft_spline.py:9,13,
+    callbacks/logger.py:20, models/raft_spline/raft.py's own imports) resolve to bflow_amd.  Separate process: other tests import
+    the real reference under the same module names."""
+    code = r"""
+import sys
+sys.path[:0] = [{dropin!r}, {root!r}]
+from models.raft_spline.raft import RAFTSpline, BezierCurves
+from models.raft_spline.bezier import BezierCurves as B2
+from models.raft_utils.corr import CorrComputation, CorrBlockParallelMultiTarget
+from models.raft_utils.utils import cvx_upsample, coords_grid
+from utils.losses import l1_seq_loss_channel_masked, l1_multi_seq_loss_channel_masked, l1_loss_channel_masked
+import bflow_amd, bflow_amd.corr, bflow_amd.training
+assert RAFTSpline is bflow_amd.RAFTSpline and BezierCurves is bflow_amd.bezier.BezierCurves is B2
+assert CorrComputation is bflow_amd.corr.CorrComputation and CorrBlockParallelMultiTarget is bflow_amd.corr.CorrBlockParallelMultiTarget
+assert l1_seq_loss_channel_masked is bflow_amd.training.l1_seq_loss_channel_masked
+print("OK")
+""".format(dropin=os.path.join(ROOT, "dropin"), root=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout
