@@ -268,17 +268,21 @@ class BasicUpdateBlock(nn.Module):
             # z | r in one convolution; sigmoid, r * h (-> RH) and the final blend (-> H, in place) live in the conv epilogues
             S.conv(ws.H, zr_hm, x2=ws.M, padding=pad, addend=t_zr, gate=S.GATE_ZR, gate_h=ws.H, out_split=ws.RH, out_f32=ws.Z)
             S.conv(ws.RH, q_hm, x2=ws.M, padding=pad, addend=t_q, gate=S.GATE_BLEND, gate_h=ws.H, gate_z=ws.Z, out_split=ws.H)
-        # ---- heads (update.py:17-18,111-114,120-125)
+        # ---- heads (update.py:17-18,111-114,120-125).  The mask head (needed on the last iteration only in test mode) and the
+        # Bezier head both read the new hidden state and nothing of each other: two branches.
+        mask = None
+        with hip.Branch(ws.overlap and need_mask) as mask_branch:
+            if need_mask:
+                m1, _ = S.conv(ws.H, self._pk("mask0", lambda a=self.mask[0].weight: a), padding=1, shift=self.mask[0].bias, act=S.ACT_RELU)
+                m2, _ = S.conv(m1, self._pk("mask2", lambda a=self.mask[2].weight: a), shift=self.mask[2].bias)
+                mask = m2.to_nchw()
         bh = self.bezier_head
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
         # bezier += delta (bezier.py:137-139) and the new Bezier channel block of M are produced by the epilogue
         S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, acc_nchw=bezier, out_split=ws.M,
                channel_offset=self.motion_dim)
-        if not need_mask:
-            return None
-        m1, _ = S.conv(ws.H, self._pk("mask0", lambda a=self.mask[0].weight: a), padding=1, shift=self.mask[0].bias, act=S.ACT_RELU)
-        m2, _ = S.conv(m1, self._pk("mask2", lambda a=self.mask[2].weight: a), shift=self.mask[2].bias)
-        return m2.to_nchw()
+        mask_branch.join()
+        return mask
 
     def forward(self, net, inp, corr, bezier):
         """Reference-shaped call (update.py:116-126): returns (net, mask, delta_bezier) without mutating the inputs."""
