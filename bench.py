@@ -1,64 +1,276 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the RAFT-spline inference hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N == 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W               (N > 1, one rank per GPU, RCCL)
+    python bench.py --gpus N --steps K --warmup W
+        N == 1: runs in this process.
+        N  > 1: if WORLD_SIZE is not set the script re-launches itself as N ranks (one per GPU, RCCL) through
+                `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`;
+                launched that way by a driver it just runs as the rank it is.
 
-Metric (BASELINE.json): frames/s of the whole job + ms per GRU iteration, raft-spline E_LU4_BD2 (events only),
-DSEC 640x480, 12 iterations -- BASELINE configs[1] at N=1 (batch 1 per GPU); for N>1 every rank runs the same
-per-GPU batch on its own shard of the global batch (weak scaling, no data-path collective) and the per-rank
-EPE state is all-gathered once over RCCL after the timed region.
+Metric (BASELINE.json): frames/s of the whole job + ms per GRU iteration, raft-spline E_LU4_BD2 (events only), DSEC 640x480,
+12 iterations.
+  N = 1 : `value` = BASELINE configs[1] -- batch 1, one frame per step (weak-scaling anchor; also reported as `c2_weak`).
+  N > 1 : `value` = BASELINE configs[3] -- GLOBAL batch 64 sharded over the N ranks (64/N frames per rank and step, processed in
+          micro-batches of 8 = C4's per-GPU batch at N = 8): strong scaling, no data-path collective; `c2_weak` (batch 1 per GPU,
+          the N = 1 workload on every rank) is measured in the same run and reported next to it.  At N = 1 the same global-64
+          workload is reported as `c4_strong`, so that both curves have their N = 1 point.
+After the timed regions the per-rank EPE state is all-gathered once over RCCL (the path's single exchange step).
 
-One "step" = one forward (voxel grid resident in HBM -> full-resolution Bezier flow) over the per-GPU batch, replayed
-from a captured hipGraph.  Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement" for every field).
+One "step" = one forward (voxel grids resident in HBM -> full-resolution Bezier flow) over the rank's frames of that step,
+replayed from a captured hipGraph.  Prints ONE JSON line on rank 0 (DESIGN.md section "Measurement" explains every field).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import bflow_amd  # noqa: E402
-from bflow_amd import configs, dist as bdist, synthetic  # noqa: E402
-from bflow_amd.metrics import epe_masked  # noqa: E402
-from bflow_amd.weights import deterministic_state_dict  # noqa: E402
-
 H, W, ITERS, CFG = 480, 640, 12, "E_LU4_BD2"
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+GLOBAL_BATCH, MICRO_BATCH = 64, 8          # BASELINE configs[3]
 PEAK_SPLIT_TFLOPS = round(2500.0 / 3, 1)   # fp16 dense MFMA peak (~2.5 PFLOP/s) / 3 MFMA passes per fp32-class product
-PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
-def time_steps(fn, steps, barrier):
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    torch.cuda.synchronize()
-    barrier()
-    return time.perf_counter() - t0
+def kernel_source_hash() -> str:
+    """Hash of everything that determines the kernels' HBM traffic: the HIP sources and the ABI header.  profiles/r02_pmc.json
+    records it; bench.py only quotes the PMC traffic of kernels built from the SAME sources."""
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "bflow_amd", "csrc")
+    for f in sorted(os.listdir(cs)) + ["../../include/bflow_hip.h"]:
+        p = os.path.join(cs, f)
+        if os.path.isfile(p) and (f.endswith(".hip") or f.endswith(".h")):
+            h.update(f.encode())
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
-def kernel_event_ms(launch, n):
-    """Average duration (ms) of one launch, hipEvents recorded on the launch stream (torch's current stream)."""
-    evs = []
-    for _ in range(n):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        launch()
-        b.record()
-        evs.append((a, b))
-    torch.cuda.synchronize()
-    return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel rooflines and the secondary workloads")
+    return ap.parse_args()
+
+
+def relaunch(args) -> int:
+    """--gpus N > 1 without a torchrun environment: become the launcher of N ranks on this node."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL needs dmabuf IPC on this driver stack
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch(args))
+
+    import numpy as np
+    import torch
+
+    import bflow_amd
+    from bflow_amd import configs, dist as bdist, synthetic
+    from bflow_amd.metrics import epe_masked
+    from bflow_amd.weights import deterministic_state_dict
+
+    rank, world, local = bdist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with `python bench.py --gpus {args.gpus}` (self-launching) "
+                         f"or `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}`")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def time_steps(fn, steps):
+        """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks."""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
+    def kernel_event_ms(launch, n):
+        """Average duration (ms) of one launch, hipEvents recorded on the launch stream (torch's current stream)."""
+        evs = []
+        for _ in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            launch()
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    cfg = configs.model_config(CFG)
+    model = bflow_amd.RAFTSpline(cfg).eval()
+    sd = deterministic_state_dict(model, seed=0)
+    model.load_state_dict(sd)
+    model.to(dev)
+    if not args.no_graph:
+        model.enable_hipgraph()
+
+    # ---- workload A: C2, batch 1 per GPU (weak scaling); sample index = rank
+    vox1_np = synthetic.voxel_grid(1, 9, H, W, seed=1234, first_sample=rank)
+    vox1 = torch.from_numpy(vox1_np).to(dev)
+
+    def step_c2():
+        return model(voxel_grid=vox1, iters=ITERS, test_mode=True)
+
+    # ---- workload B: C4, global batch 64 -> contiguous shard of this rank, micro-batches of 8 (one captured graph, replayed per micro-batch)
+    assert GLOBAL_BATCH % (world * MICRO_BATCH) == 0 or world * MICRO_BATCH > GLOBAL_BATCH, "global batch 64 must split into micro-batches of 8"
+    s0, s1 = bdist.shard_range(GLOBAL_BATCH, rank, world)
+    micro = min(MICRO_BATCH, s1 - s0)
+    n_micro = (s1 - s0) // micro
+    vox8 = None
+
+    def setup_c4():
+        nonlocal vox8
+        # the shard's micro-batches share one resident buffer set: every micro-batch replays the same graph on its own frames
+        vox8 = [torch.from_numpy(synthetic.voxel_grid(micro, 9, H, W, seed=1234, first_sample=s0 + k * micro)).to(dev) for k in range(n_micro)]
+
+    def step_c4():
+        out = None
+        for v in vox8:
+            out = model(voxel_grid=v, iters=ITERS, test_mode=True)
+        return out
+
+    def measure(step, frames_per_step_per_rank, steps, warmup):
+        for _ in range(max(warmup, 1)):
+            step()
+        el = time_steps(step, steps)
+        return {"value": round(world * frames_per_step_per_rank * steps / el, 3), "ms_per_step": round(el / steps * 1e3, 4), "steps": steps}
+
+    primary_is_c4 = world > 1
+    res_c2 = res_c4 = None
+    if not primary_is_c4:
+        res_c2 = measure(step_c2, 1, args.steps, args.warmup)
+        if not args.no_extras:
+            setup_c4()
+            res_c4 = measure(step_c4, s1 - s0, max(2, min(args.steps, 6)), 1)
+    else:
+        setup_c4()
+        res_c4 = measure(step_c4, s1 - s0, args.steps, args.warmup)
+        res_c2 = measure(step_c2, 1, args.steps, args.warmup)
+
+    # ---- the path's single exchange step: per-rank EPE state all-gathered over RCCL (outside the timed regions)
+    low, up = step_c2()
+    gt = torch.from_numpy(synthetic.gt_flow(1, H, W, seed=99, first_sample=rank)).to(dev)
+    e = epe_masked(up.get_flow_from_reference(1.0).contiguous(), gt)
+    epe_mean, epe_sum, epe_cnt = bdist.reduce_epe(e.double(), torch.ones((), dtype=torch.float64, device=dev))
+
+    out = None
+    if rank == 0:
+        prim = res_c4 if primary_is_c4 else res_c2
+        wl_c2 = (f"raft-spline {CFG} events-only, DSEC-shaped voxel grid (9x{H}x{W}), batch 1/GPU, {ITERS} GRU iters (BASELINE configs[1]), "
+                 "random-init deterministic weights")
+        wl_c4 = (f"raft-spline {CFG} events-only, DSEC-shaped voxel grids (9x{H}x{W}), GLOBAL batch {GLOBAL_BATCH} sharded over {world} GPU(s) "
+                 f"({s1 - s0} frames per rank and step in micro-batches of {micro}), {ITERS} GRU iters (BASELINE configs[3]), random-init deterministic weights")
+        out = {
+            "metric": "frames/sec (whole node), raft-spline DSEC 640x480 12-iter",
+            "value": prim["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "strong" if primary_is_c4 else "weak",
+            "vs_baseline": None, "dtype": "f32 (split-fp16 pairs)",
+            "arithmetic": "fp32 values carried as split fp16 pairs (hi + lo*2^-11) on the fp16 matrix cores, fp32 accumulation; parity 1e-5 px EPE vs the fp32 CPU reference",
+            "data": "synthetic",
+            "config": {"workload": wl_c4 if primary_is_c4 else wl_c2, "global_batch": GLOBAL_BATCH if primary_is_c4 else world,
+                       "frames_per_rank_per_step": (s1 - s0) if primary_is_c4 else 1, "iters": ITERS, "hipgraph": not args.no_graph},
+            "c2_weak": dict(res_c2, unit="frames/s", workload=wl_c2, scaling="weak"),
+            "epe_vs_synthetic_gt": round(float(epe_mean), 4), "epe_ranks_gathered": int(epe_cnt),
+        }
+        if res_c4 is not None:
+            out["c4_strong"] = dict(res_c4, unit="frames/s", workload=wl_c4, scaling="strong")
+
+    # ---- extras outside the timed region: ms/GRU-iter (N=1), rooflines of the hand-written kernels (rank 0), CPU baseline (N=1)
+    if world == 1 and not args.no_extras:
+        def step6():
+            return model(voxel_grid=vox1, iters=ITERS // 2, test_mode=True)
+        for _ in range(3):
+            step6()
+        n_it = max(args.steps // 2, 5)
+        t12 = time_steps(step_c2, n_it) / n_it
+        t6 = time_steps(step6, n_it) / n_it
+        out["ms_per_gru_iter"] = round((t12 - t6) / (ITERS // 2) * 1e3, 4)
+        out["ms_fixed_part"] = round((t12 - ITERS * (t12 - t6) / (ITERS // 2)) * 1e3, 4)
+
+    if rank == 0 and not args.no_extras:
+        # rooflines of the hand-written kernels (tools/roofline_kernels.py), each timed with hipEvents on the launch stream on the operands
+        # of the C2 workload (the timed region above is graph replays, inside which events cannot be recorded)
+        from tools.roofline_kernels import build as roofline_kernels
+        vox8 = None
+        torch.cuda.empty_cache()
+        src_hash = kernel_source_hash()
+        try:
+            pmc_doc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+        except Exception:
+            pmc_doc = {}
+        pmc_ok = pmc_doc.get("kernel_source_hash") == src_hash
+        pmc = pmc_doc.get("kernels", {}) if pmc_ok else {}
+        out["kernel_source_hash"] = src_hash
+        for k in roofline_kernels(model, vox1, cfg, low.get_params()):
+            for _ in range(3):
+                k["launch"]()
+            ms = kernel_event_ms(k["launch"], max(args.steps, 10))
+            if k["bound"] == "mfma":
+                tf = k["flops"] / (ms * 1e-3) / 1e12
+                r = {"kernel": k["name"], "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / PEAK_SPLIT_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4), "flop_per_launch": k["flops"],
+                     "algorithmic_bytes_per_launch": k["bytes"],
+                     "note": "algorithmic (fp32-equivalent) FLOPs; the split scheme executes 3 fp16 MFMAs per product, so "
+                             "peak = 2500 TFLOP/s fp16 dense / 3"}
+            else:
+                gbs = k["bytes"] / (ms * 1e-3) / 1e9
+                r = {"kernel": k["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+                     "algorithmic_bytes_per_launch": k["bytes"]}
+                if k["flops"]:
+                    r["flop_per_launch"] = k["flops"]
+                    r["tflops_equivalent"] = round(k["flops"] / (ms * 1e-3) / 1e12, 1)
+            if k.get("note"):
+                r["note"] = k["note"]
+            # HBM traffic per launch cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the SAME launches
+            # (tools/collect_profiles.sh -> profiles/r02_pmc.json), and only when that file was collected on kernels built from these sources
+            if k["name"] in pmc:
+                r["traffic"] = pmc[k["name"]]["traffic"]
+                r["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; same kernel sources)"
+            elif pmc_doc and not pmc_ok:
+                r["traffic_source"] = "none: profiles/r02_pmc.json was collected on different kernel sources (re-run tools/collect_profiles.sh)"
+            out[k["key"]] = r
+            k.clear()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, torch.from_numpy(vox1_np[:1]))
+            out["gpu_over_cpu"] = round(out["c2_weak"]["value"] / out["cpu_baseline"]["value"], 1)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def usable_cores() -> int:
@@ -83,6 +295,8 @@ def usable_cores() -> int:
 def cpu_baseline(cfg, sd, vox_cpu, budget_s=25.0):
     """The CPU oracle (op-for-op restatement of the reference, pinned to it in the build container) on this host's cores.
     Bounded sample: 1 warm-up + up to 4 timed forwards of the same workload (one 640x480 frame, 12 iterations)."""
+    import numpy as np
+    import torch
     from oracle import raft_spline_oracle as O   # checker / baseline only -- never on the product path
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -98,128 +312,6 @@ def cpu_baseline(cfg, sd, vox_cpu, budget_s=25.0):
     return {"value": round(1.0 / sec, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} forwards of 1 frame (640x480, {ITERS} iters) after 1 warm-up, torch CPU fp32, {cores} threads",
             "ms_per_frame": round(sec * 1e3, 1)}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (BASELINE configs[1]: 1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
-    args = ap.parse_args()
-
-    rank, world, local = bdist.init_from_env("nccl")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    cfg = configs.model_config(CFG)
-    model = bflow_amd.RAFTSpline(cfg).eval()
-    sd = deterministic_state_dict(model, seed=0)
-    model.load_state_dict(sd)
-    model.to(dev)
-    if not args.no_graph:
-        model.enable_hipgraph()
-
-    B = args.batch
-    first = rank * B
-    vox_np = synthetic.voxel_grid(B, 9, H, W, seed=1234, first_sample=first)
-    vox = torch.from_numpy(vox_np).to(dev)
-
-    def step():
-        return model(voxel_grid=vox, iters=ITERS, test_mode=True)
-
-    for _ in range(max(args.warmup, 1)):
-        step()
-    elapsed = time_steps(step, args.steps, barrier)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
-    frames = world * B * args.steps
-    value = frames / elapsed
-
-    # ---- the path's single exchange step: per-rank EPE state all-gathered over RCCL (outside the timed region)
-    low, up = step()
-    gt = torch.from_numpy(synthetic.gt_flow(B, H, W, seed=99, first_sample=first)).to(dev)
-    e = epe_masked(up.get_flow_from_reference(1.0).contiguous(), gt)
-    epe_mean, epe_sum, epe_cnt = bdist.reduce_epe(e.double(), torch.ones((), dtype=torch.float64, device=dev))
-
-    out = None
-    if rank == 0:
-        out = {
-            "metric": "frames/sec (whole node), raft-spline DSEC 640x480 12-iter",
-            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "arithmetic": "fp32 values carried as split fp16 pairs (hi + lo*2^-11) on the fp16 matrix cores, fp32 accumulation; parity 1e-5 px EPE vs the fp32 CPU reference",
-            "data": "synthetic",
-            "config": {"workload": f"raft-spline {CFG} events-only, DSEC-shaped voxel grid (9x{H}x{W}), batch {B}/GPU, "
-                                   f"{ITERS} GRU iters (BASELINE configs[1]), random-init deterministic weights",
-                       "batch_per_gpu": B, "global_batch": world * B, "iters": ITERS, "hipgraph": not args.no_graph},
-            "epe_vs_synthetic_gt": round(float(epe_mean), 4), "epe_ranks_gathered": int(epe_cnt),
-        }
-
-    # ---- extras outside the timed region: ms/GRU-iter (N=1), rooflines of the hand-written kernels (rank 0), CPU baseline (N=1)
-    if world == 1:
-        def step6():
-            return model(voxel_grid=vox, iters=ITERS // 2, test_mode=True)
-        for _ in range(3):
-            step6()
-        n_it = max(args.steps // 2, 5)
-        t12 = time_steps(step, n_it, barrier) / n_it
-        t6 = time_steps(step6, n_it, barrier) / n_it
-        out["ms_per_gru_iter"] = round((t12 - t6) / (ITERS // 2) * 1e3, 4)
-        out["ms_fixed_part"] = round((t12 - ITERS * (t12 - t6) / (ITERS // 2)) * 1e3, 4)
-
-    if rank == 0:
-        # ---- rooflines of the hand-written kernels (tools/roofline_kernels.py), each timed with hipEvents on the launch stream on
-        # the operands of this very workload (the timed region above is graph replays, inside which events cannot be recorded)
-        from tools.roofline_kernels import build as roofline_kernels
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))["kernels"]
-        except Exception:
-            pmc = {}
-        for k in roofline_kernels(model, vox, cfg, low.get_params()):
-            for _ in range(3):
-                k["launch"]()
-            ms = kernel_event_ms(k["launch"], max(args.steps, 10))
-            if k["bound"] == "mfma":
-                tf = k["flops"] / (ms * 1e-3) / 1e12
-                r = {"kernel": k["name"], "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tf / PEAK_SPLIT_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4), "flop_per_launch": k["flops"],
-                     "algorithmic_bytes_per_launch": k["bytes"],
-                     "note": "algorithmic (fp32-equivalent) FLOPs; the split scheme executes 3 fp16 MFMAs per product, so "
-                             "peak = 2500 TFLOP/s fp16 dense / 3"}
-            else:
-                gbs = k["bytes"] / (ms * 1e-3) / 1e9
-                r = {"kernel": k["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
-                     "algorithmic_bytes_per_launch": k["bytes"]}
-                if k["flops"]:
-                    r["flop_per_launch"] = k["flops"]
-                    r["tflops_equivalent"] = round(k["flops"] / (ms * 1e-3) / 1e12, 1)
-            # HBM traffic per launch cannot be read from inside this process: it is taken from the committed rocprofv3 --pmc passes of
-            # the same launches (profiles/r01_pmc.json: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE)
-            if k["name"] in pmc and B == 1:
-                r["traffic"] = pmc[k["name"]]["traffic"]
-                r["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
-            out[k["key"]] = r
-            k.clear()
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, torch.from_numpy(vox_np[:1]))
-            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
-
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

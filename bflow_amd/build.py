@@ -6,9 +6,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def build(verbose: bool = True) -> str:
+def build(verbose: bool = True, force: bool = False) -> str:
+    """force=True recompiles every .hip (clean build); the default only rebuilds stale objects."""
     script = os.path.join(HERE, "csrc", "build.sh")
-    res = subprocess.run(["bash", script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    res = subprocess.run(["bash", script] + (["--force"] if force else []), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         sys.stdout.write(res.stdout)
     if res.returncode != 0:
@@ -17,4 +18,4 @@ def build(verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build()
+    build(force="--force" in sys.argv[1:])

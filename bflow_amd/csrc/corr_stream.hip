@@ -1,0 +1,367 @@
+// K5, streaming form: the all-pairs correlation volume as a register-stationary persistent kernel (gfx950 only).
+// Replaces CorrComputation._corr_dot_prod_util, models/raft_utils/corr.py:264-272 (+ the 1-to-N / M-to-N reshapes :237-262).
+//
+// Why another structure than the 256x128 tile kernel of split_gemm.hip: at DSEC size the volume (368.6 MB) costs ~50 us of HBM
+// writes and the 3-pass split-fp16 contraction ~60-85 us of matrix-core time (2.4 GHz ... the ~1.65 GHz this kernel sustains), so
+// the kernel only approaches either roof if the matrix cores run WHILE the stores drain.  A tile kernel alternates a k-loop (stores
+// idle) with an epilogue (matrix cores idle) in lock step on every CU.  Here nothing alternates:
+//   * one persistent 8-wave workgroup per CU.  A wave keeps 32 TARGET columns (all D <= 256 channels, hi and lo planes) in 128
+//     VGPRs for as long as it stays on its 256-column panel: the stationary operand costs neither LDS space nor LDS reads;
+//   * the REFERENCE rows stream through a 4-slot LDS ring in chunks of 32 rows (32 KB: all channels, hi + lo), fetched by LDS-DMA
+//     (buffer_load ... lds, 16 B / lane, source address pre-swizzled -> XOR-swizzled 64-B rows, conflict-free ds_read_b128), three
+//     chunks ahead, one 1-KB piece per k-step;
+//   * per chunk a wave runs 16 k-steps x 3 MFMAs (hi*hi, hi*lo, lo*hi) into one 32x32 accumulator pair while the PREVIOUS chunk's
+//     accumulators are scaled and stored, one register (two full 128-B lines) per k-step, between the MFMAs; the fragments of the
+//     next k-step (and, across the chunk boundary, of the next chunk) are read ahead.  The two waves of a SIMD keep its matrix
+//     pipe busy for each other; one s_barrier per chunk is the only synchronisation.  A workgroup writes 32 rows x 1 KB per chunk.
+// Work = (panel, chunk) items in panel-major order on an RX x PX grid of XCDs: an XCD owns one row slice of the reference (<= 2.5
+// MB, so that it stays in the XCD's L2 while 32 workgroups re-read it) for a contiguous range of panels; its workgroups take
+// contiguous, equally long ranges of that list.  A panel switch inside a range reloads the 128 registers (~25 k cycles: 256 KB per
+// CU at the ~10 B/clk a CU sustains on L2 misses); the grid keeps that to <= 1 per workgroup at DSEC size.
+//
+// vmcnt bookkeeping (gfx9 counts loads AND stores in vmcnt and retires them in order): per chunk a wave issues PW = KB/2 DMA pieces
+// and exactly 16 buffer stores (out-of-range ones are dropped by the buffer bounds check, not skipped), so "my pieces of chunk i+1
+// have landed" is a fixed s_waitcnt vmcnt(N) at the top of chunk i (see VMCNT_TOP).
+//
+// Measured on MI355X (round 2, tools/k5_probe.py): C2 (T=4, N=4800) 129-141 us vs 199-211 us for the tile kernel; steady state
+// 7150 cycles per 64 reference rows per CU against a matrix-core floor of 6144 (stores cost ~900 of the difference: with them
+// removed the same loop runs at 6250), 18 k cycles of prologue (first panel), 1.65 GHz sustained.
+#include "common.h"
+
+// STREAM_ABL (tools/k5_ablate.sh only; timing builds with WRONG results): 1 no stores, 2 no in-loop DMA, 3 no barrier / DMA wait,
+// 4 no MFMA, 5 no fragment reads
+#ifndef STREAM_ABL
+#define STREAM_ABL 0
+#endif
+#ifdef STREAM_STAMPS   // tools/k5_ablate.sh "stamps" build: s_memtime stamps of wave 0 of every workgroup (64 x u64 per workgroup)
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" __attribute__((visibility("default"))) void bflow_k5_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; }
+#define STAMP(i)                                                                                  \
+    if (a.stamps && tid == 0 && (i) < 62) a.stamps[blockIdx.x * 64 + (i)] = __builtin_readcyclecounter();
+#define STAMP_RT(i) \
+    if (a.stamps && tid == 0) a.stamps[blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define STAMP_RT(i)
+#define STAMP(i)
+#endif
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr float LO_INV = 1.0f / 2048.0f;
+constexpr int COLS_WG = 256;      // target columns held in registers per workgroup: 8 waves x 32
+constexpr int CHUNK = 32;         // reference rows per ring slot
+constexpr int SLOTS = 4;
+constexpr unsigned OOB = 0x80000000u;   // byte offset beyond any volume slab (N*N*4 < 2^31 is checked on the host)
+
+struct StreamArgs {
+    const _Float16 *f1h, *f1l, *f2h, *f2l;
+    float* out;
+    int T, B, N, Np;
+    long long f1_tstride;   // elements between the per-target f1 blocks (0 = one reference shared by all targets)
+    float scale;            // POW2: 1/sqrt(D) (exact) ; else sqrt(D)
+    int JP;                 // column panels per target matrix = ceil(N / 256)
+    int CH2;                // pairs of 32-row chunks = ceil(N / 64)
+    int n_pan;              // panels = T * B * JP
+    int RX;                 // XCD grid: RX row slices x (8 / RX) panel ranges
+    unsigned long long* stamps;   // STREAM_STAMPS builds only
+};
+
+struct Item {   // wave-uniform description of one (panel, chunk): 32 reference rows i0.. against the 256 columns of panel (t, b, jp)
+    int pan, t, b, jp, c, i0;
+};
+
+struct Cursor {   // position in the workgroup's item list; advanced without divisions
+    int pan, t, b, jp, c;
+};
+
+template <int KB, bool POW2>
+__global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // SLOTS x (4*KB KB) ring; the only shared object
+    constexpr int NS = 2 * KB;                 // k16 steps per chunk
+    constexpr int PW = KB / 2;                 // DMA pieces (1 KB) per wave per chunk
+    constexpr int SLOT_BYTES = 4 * KB * 1024;  // 32 columns x D x (hi + lo) fp16
+    constexpr int PLANE_BYTES = 2 * KB * 1024;
+    constexpr int ST_PER_STEP = 16 / NS > 0 ? 16 / NS : 1;
+    static_assert(16 % NS == 0 || NS % 16 == 0, "k-steps and accumulator registers must divide");
+    static_assert(NS <= 16, "D <= 256");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int D = KB * 32;
+
+    // ---- this workgroup's item range.  Items are 32-row chunks, handed out in PAIRS (64 rows) so that every workgroup runs an even
+    // number of chunks per panel (the two accumulator sets alternate roles).  The 8 XCDs form an RX x PX grid: XCD (rx, px) owns row
+    // slice rx of the reference (small enough to stay in its 4-MB L2 while 32 workgroups re-read it) for the contiguous range px of
+    // the panel list (panel-major = target-major, so XCD mates stream the same reference matrix and share panel loads through L2);
+    // its workgroups split that panel-major item list evenly.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int rx = xcd % a.RX, px = xcd / a.RX, PX = 8 / a.RX;
+    const int c_lo = 2 * (int)((long long)rx * a.CH2 / a.RX), c_hi = 2 * (int)((long long)(rx + 1) * a.CH2 / a.RX);
+    const int p_lo = (int)((long long)px * a.n_pan / PX), p_hi = (int)((long long)(px + 1) * a.n_pan / PX);
+    const int len = c_hi - c_lo;   // even
+    const long long pairs = (long long)(p_hi - p_lo) * (len >> 1);
+    const int start = 2 * (int)(pairs * idx / per_x), end = 2 * (int)(pairs * (idx + 1) / per_x);
+    const int n = end - start;     // even
+    if (n <= 0) return;
+
+    Cursor cur;
+    {
+        const int pan = p_lo + start / len;
+        cur.pan = pan;
+        cur.t = pan / (a.B * a.JP);
+        cur.b = (pan / a.JP) % a.B;
+        cur.jp = pan % a.JP;
+        cur.c = c_lo + start % len;
+    }
+    auto item_of = [&](const Cursor& k) -> Item {
+        Item r;
+        r.pan = k.pan;
+        r.t = k.t;
+        r.b = k.b;
+        r.jp = k.jp;
+        r.c = k.c;
+        r.i0 = k.c * CHUNK;
+        return r;
+    };
+    auto advance = [&](Cursor& k) {
+        if (++k.c == c_hi) {   // next panel, first chunk of this XCD's range
+            k.c = c_lo;
+            ++k.pan;
+            if (++k.jp == a.JP) {
+                k.jp = 0;
+                if (++k.b == a.B) {
+                    k.b = 0;
+                    ++k.t;
+                }
+            }
+        }
+    };
+    int fetched = 0;   // items handed out by next_item(); past the end the LAST item is repeated (its slot is never read)
+    auto next_item = [&]() -> Item {
+        if (fetched > 0 && fetched < n) advance(cur);
+        ++fetched;
+        return item_of(cur);
+    };
+
+    // ---- addressing: every global access goes through a buffer descriptor with a wave-uniform (SGPR) matrix / k-block offset and
+    // ONE per-lane VGPR offset, so that the address arithmetic costs scalar instructions and almost no vector registers
+    const unsigned f1_bytes = (unsigned)(((a.f1_tstride ? (long long)a.T : 1LL) * a.B * a.Np * D) * 2);
+    const unsigned f2_bytes = (unsigned)(((long long)a.T * a.B * a.Np * D) * 2);
+    const __amdgpu_buffer_rsrc_t r1h = __builtin_amdgcn_make_buffer_rsrc((void*)a.f1h, 0, f1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1l = __builtin_amdgcn_make_buffer_rsrc((void*)a.f1l, 0, f1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2h = __builtin_amdgcn_make_buffer_rsrc((void*)a.f2h, 0, f2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2l = __builtin_amdgcn_make_buffer_rsrc((void*)a.f2l, 0, f2_bytes, 0x00020000);
+    const unsigned kb_bytes = (unsigned)a.Np * 64u;   // one 32-deep k-block of one matrix
+
+    // ---- LDS-DMA of one chunk: piece q = wave*PW + j -> (plane, k-block, 16-row half); lane -> (row, 16-B slot) with the source
+    // chunk swizzled so that the lane-linear LDS image holds logical chunk c of row r at slot c ^ ((r >> 2) & 3)
+    const unsigned dma_lane = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    auto issue_piece = [&](const Item& im, int slot, int j) {
+        const unsigned mat = (unsigned)((im.t * a.f1_tstride + (long long)im.b * a.Np * D) * 2) + (unsigned)im.i0 * 64u;
+        const int q = wave * PW + j;
+        const int plane = q / (2 * KB), kb = (q % (2 * KB)) >> 1, half = q & 1;
+        const unsigned so = mat + (unsigned)kb * kb_bytes + (unsigned)half * 1024u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(plane ? r1l : r1h, (lptr_t)(lds + slot * SLOT_BYTES + q * 1024), 16, dma_lane, so, 0, 0);
+    };
+    auto issue = [&](const Item& im, int slot) {
+#pragma unroll
+        for (int j = 0; j < PW; ++j) issue_piece(im, slot, j);
+    };
+
+    // ---- target panel -> registers: lane holds column (wave*32 + l31) of the panel, 8 consecutive k per k16 step
+    half8 Bh[NS], Bl[NS];
+    auto load_panel = [&](int tb, int jp) {
+        int col = jp * COLS_WG + wave * 32 + l31;
+        col = col < a.Np ? col : a.Np - 1;   // columns >= N are never stored
+        const unsigned vo = (unsigned)col * 64u + (unsigned)kh * 16u;
+        const unsigned mat = (unsigned)(((long long)tb * a.Np * D) * 2);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const unsigned so = mat + (unsigned)(s >> 1) * kb_bytes;
+            Bh[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r2h, vo + (s & 1) * 32, so, 0));
+            Bl[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r2l, vo + (s & 1) * 32, so, 0));
+        }
+    };
+
+    // fragment read offsets inside a slot (bytes): row l31, logical chunk (s&1)*2 + kh
+    const int sw = (l31 >> 2) & 3;
+    const int fo_even = l31 * 64 + ((kh ^ sw) << 4), fo_odd = l31 * 64 + (((2 + kh) ^ sw) << 4);
+
+    // ---- store side: one accumulator register = rows (r&3) + 8*(r>>2) + 4*kh of the wave's 32, 32 consecutive columns
+    auto store_base = [&](const Item& im, __amdgpu_buffer_rsrc_t& rs) -> unsigned {
+        const int row = im.i0 + 4 * kh, col = im.jp * COLS_WG + wave * 32 + l31;
+        float* slab = a.out + (long long)(im.t * a.B + im.b) * a.N * a.N;
+        rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, a.N * a.N * 4, 0x00020000);
+        return col < a.N ? (unsigned)((row * a.N + col) * 4) : OOB;   // rows >= N fall off the end of the slab by themselves
+    };
+    const unsigned rowstep = (unsigned)a.N * 4u;
+
+    // ---- pipeline state --------------------------------------------------------------------------------------------------
+    STAMP(0)
+    STAMP_RT(62)
+    Item q0 = next_item(), q1 = next_item(), q2 = next_item();
+    issue(q0, 0);
+    issue(q1, 1);
+    issue(q2, 2);
+
+    f32x16 X_hh, X_xx, Y_hh, Y_xx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Y_hh[r] = Y_xx[r] = 0.f;
+    __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, 0x00020000);   // nothing to store yet: every store is dropped
+    unsigned pbase = OOB;
+
+    // One chunk.  On entry fh[0] / fl[0] hold (or are about to receive) the k-step-0 fragments of chunk `it`, read at the end of the
+    // previous chunk: the barrier at the top of chunk i orders "chunk i+1 has landed" (every wave waited for its own pieces of it
+    // first), so chunk i+1 may be read before the NEXT barrier and the matrix cores restart right behind it.  The DMA pieces of chunk
+    // it+3 go out one per k-step from step DMA_S0 on (their slot was last read in chunk it-1, which every wave left before this
+    // chunk's barrier); per k-step: prefetch the next fragments, 3 MFMAs, one accumulator register of the previous chunk scaled and
+    // stored.  vmcnt at the top = ops issued after this wave's last piece of chunk it+1 (in chunk it-2): the stores behind it there +
+    // the 16 stores and PW pieces of chunk it-1.
+    constexpr int DMA_S0 = NS >= 8 ? 2 : 1;
+    constexpr int VMCNT_TOP = (NS - (DMA_S0 + PW)) * ST_PER_STEP + 16 + PW;
+    static_assert(DMA_S0 + PW <= NS && VMCNT_TOP < 64, "DMA schedule");
+    half8 fh[2], fl[2];
+#define STREAM_STEP(CH_, CX_, PH_, PX_)                                                                                     \
+    {                                                                                                                       \
+        if (STREAM_ABL != 3) {                                                                                              \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT_TOP) : "memory");                                                \
+            __builtin_amdgcn_s_barrier();                                                                                   \
+        }                                                                                                                   \
+        const Item q3 = next_item();                                                                                        \
+        const char* sb = lds + (it & 3) * SLOT_BYTES;                                                                       \
+        const char* sn = lds + ((it + 1) & 3) * SLOT_BYTES;                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) CH_[r] = CX_[r] = 0.f;                                               \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                                    \
+            {   /* fragments of the next k-step (the next chunk's step 0 behind the last one) */                           \
+                const int sn_ = (s + 1) % NS;                                                                               \
+                const char* fp = (s + 1 < NS ? sb : sn) + (sn_ >> 1) * 2048 + ((sn_ & 1) ? fo_odd : fo_even);               \
+                if (STREAM_ABL != 5) {                                                                                      \
+                    fh[(s + 1) & 1] = *reinterpret_cast<const half8*>(fp);                                                  \
+                    fl[(s + 1) & 1] = *reinterpret_cast<const half8*>(fp + PLANE_BYTES);                                    \
+                }                                                                                                           \
+            }                                                                                                               \
+            const half8 ah = fh[s & 1], al = fl[s & 1];                                                                     \
+            if (STREAM_ABL != 4) {                                                                                          \
+                CH_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[s], CH_, 0, 0, 0);                                      \
+                CX_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[s], CX_, 0, 0, 0);                                      \
+                CX_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[s], CX_, 0, 0, 0);                                      \
+            } else {                                                                                                        \
+                CH_[s] += (float)ah[0] + (float)Bh[s][1];                                                                   \
+                CX_[s] += (float)al[0] + (float)Bl[s][1];                                                                   \
+            }                                                                                                               \
+            _Pragma("unroll") for (int u = 0; u < ST_PER_STEP; ++u) {                                                       \
+                const int r = s * ST_PER_STEP + u;                                                                          \
+                float v = fmaf(PX_[r], LO_INV, PH_[r]);                                                                     \
+                v = POW2 ? v * a.scale : v / a.scale;                                                                       \
+                const unsigned off = pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep;                                  \
+                if (STREAM_ABL != 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), prs, off, 0, 0); \
+                else asm volatile("" ::"v"(v), "v"(off));                                                                   \
+            }                                                                                                               \
+            if (STREAM_ABL != 2 && s >= DMA_S0 && s < DMA_S0 + PW) issue_piece(q3, (it + 3) & 3, s - DMA_S0);              \
+        }                                                                                                                   \
+        pbase = store_base(q0, prs);                                                                                        \
+        q0 = q1;                                                                                                            \
+        q1 = q2;                                                                                                            \
+        q2 = q3;                                                                                                            \
+        ++it;                                                                                                               \
+    }
+
+    int it = 0;
+    while (it < n) {
+        // (next) panel: its 256 target columns -> registers.  The compiler-visible vmcnt(0) covers the panel loads AND every DMA piece /
+        // store issued so far, so no wait for the panel registers appears inside the chunk loop (a static vmcnt there would also wait
+        // for the in-flight stores of every chunk) and the first chunks of the panel need no counted wait of their own.
+        load_panel(q0.t * a.B + q0.b, q0.jp);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (it == 0) {   // first chunk: nobody prefetched its k-step-0 fragments
+            __builtin_amdgcn_s_barrier();
+            fh[0] = *reinterpret_cast<const half8*>(lds + fo_even);
+            fl[0] = *reinterpret_cast<const half8*>(lds + PLANE_BYTES + fo_even);
+        }
+        STAMP(1 + it)
+        const int stop = min(n, it + (c_hi - q0.c));   // chunks of this panel in the workgroup's range: even
+        do {
+            STREAM_STEP(X_hh, X_xx, Y_hh, Y_xx)
+            STREAM_STEP(Y_hh, Y_xx, X_hh, X_xx)
+            STAMP(1 + it)
+        } while (it < stop);
+    }
+#undef STREAM_STEP
+
+    // ---- drain: the last chunk's accumulators
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = fmaf(Y_xx[r], LO_INV, Y_hh[r]);
+        v = POW2 ? v * a.scale : v / a.scale;
+        const unsigned off = pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), prs, off, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMA pieces must not outlive the workgroup's LDS
+    STAMP(61)
+    STAMP_RT(63)
+}
+
+template <int KB>
+int launch_kb(const StreamArgs& a, bool pow2, hipStream_t s) {
+    const int lds = SLOTS * 4 * KB * 1024;
+    if (pow2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_stream_kernel<KB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((corr_stream_kernel<KB, true>), dim3(256), dim3(512), lds, s, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_stream_kernel<KB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((corr_stream_kernel<KB, false>), dim3(256), dim3(512), lds, s, a);
+    }
+    return bflow::launch_status("corr_build_split(stream)");
+}
+
+}  // namespace
+
+namespace bflow {
+
+// true when the streaming kernel supports the shape (D in {64, 128, 256}); otherwise the caller uses the tile kernel
+bool corr_stream_supported(int T, int B, int D, int N, int Np) {
+    // 32-bit buffer offsets: one volume slab and each operand plane must stay below 2 GiB
+    return (D == 64 || D == 128 || D == 256) && (long long)N * N * 4 < (1LL << 31) && (long long)T * B * Np * D * 2 < (1LL << 31);
+}
+
+int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out, int T, int B, int D, int N, int Np,
+                       long long f1_target_stride, hipStream_t stream) {
+    StreamArgs a;
+    a.f1h = (const _Float16*)f1_hi;
+    a.f1l = (const _Float16*)f1_lo;
+    a.f2h = (const _Float16*)f2_hi;
+    a.f2l = (const _Float16*)f2_lo;
+    a.out = out;
+    a.T = T;
+    a.B = B;
+    a.N = N;
+    a.Np = Np;
+    a.f1_tstride = f1_target_stride;
+    const float sq = sqrtf((float)D);
+    int e;
+    const bool pow2 = frexpf(sq, &e) == 0.5f;   // sqrt(D) a power of two: x / sqrt(D) == x * (1 / sqrt(D)) bit for bit
+    a.scale = pow2 ? 1.0f / sq : sq;
+    a.JP = ceil_div(N, COLS_WG);
+    a.CH2 = ceil_div(N, 2 * CHUNK);
+    a.n_pan = T * B * a.JP;
+    a.RX = 1;   // row slice of one XCD: CH2 / RX pairs x 2 chunks x (D/32 * 4 KB) <= 2.5 MB
+    while (a.RX < 8 && (long long)ceil_div(a.CH2, a.RX) * 2 * (D / 32) * 4096 > (5LL << 19)) a.RX *= 2;
+#ifdef STREAM_STAMPS
+    a.stamps = g_stamp_buf;
+#else
+    a.stamps = nullptr;
+#endif
+    switch (D) {
+        case 64: return launch_kb<2>(a, pow2, stream);
+        case 128: return launch_kb<4>(a, pow2, stream);
+        default: return launch_kb<8>(a, pow2, stream);
+    }
+}
+
+}  // namespace bflow

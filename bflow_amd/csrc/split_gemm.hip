@@ -14,6 +14,7 @@
 //   bflow_corr_build_split: out[t,b,i,j] = <f1[.,b,i,:], f2[t,b,j,:]> / sqrt(D) on the packed operands, 128x128 block tile,
 //                          4 waves x (2x2 MFMA 32x32x16 tiles) x {hh, cross} accumulators, BK = 32, double-buffered LDS
 //                          (80-B padded rows: conflict-free ds_read_b128 fragments), one barrier per k-tile.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -237,6 +238,12 @@ __global__ __launch_bounds__(V2_T, 2) void corr_build_split_v2_kernel(const _Flo
 
 }  // namespace
 
+namespace bflow {
+bool corr_stream_supported(int T, int B, int D, int N, int Np);
+int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out, int T, int B, int D, int N, int Np,
+                       long long f1_target_stride, hipStream_t stream);
+}
+
 extern "C" int bflow_split_pack(const float* src, void* hi, void* lo, int R, int D, int N, int Np, bflow_stream_t stream) {
     BFLOW_REQUIRE(src && hi && lo && R > 0 && D > 0 && N > 0, BFLOW_E_ARG, "split_pack: bad arguments");
     BFLOW_REQUIRE(D % 8 == 0 && Np >= N && Np % 64 == 0, BFLOW_E_ARG, "split_pack: D %% 8 and Np %% 64 must be 0 (D=%d Np=%d)", D, Np);
@@ -250,6 +257,10 @@ extern "C" int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, cons
     BFLOW_REQUIRE(f1_hi && f1_lo && f2_hi && f2_lo && out, BFLOW_E_ARG, "corr_build_split: null pointer");
     BFLOW_REQUIRE(T > 0 && B > 0 && N > 0 && D > 0 && D % BK == 0 && Np >= N && Np % 128 == 0, BFLOW_E_ARG,
                   "corr_build_split: bad sizes T=%d B=%d D=%d N=%d Np=%d", T, B, D, N, Np);
+    // D in {64, 128, 256}: the A-stationary streaming kernel (corr_stream.hip); anything else: the 256x128 tile kernel below
+    static const bool force_tile = getenv("BFLOW_CORR_TILE_KERNEL") != nullptr;   // A/B timing only (tools/)
+    if (!force_tile && bflow::corr_stream_supported(T, B, D, N, Np))
+        return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, (hipStream_t)stream);
     BFLOW_REQUIRE((long long)T * B <= 65535, BFLOW_E_LIMIT, "corr_build_split: T*B too large");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_build_split_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               V2_STAGES * V2_STAGE);   // 144 KB of dynamic LDS; idempotent, per device

@@ -26,13 +26,21 @@ __global__ __launch_bounds__(256) void voxel_scatter_kernel(const XY* __restrict
         const int t0 = (int)tcl;
         const float value = 2.f * (float)pol[e] - 1.f;
         if (INT_XY) {
-            const int x = (int)xs[e], y = (int)ys[e];
+            // representations.py:85-94: only the time bin is masked; x / y enter through the FLAT index ht*wd*t + wd*y + x handed to
+            // Tensor.put_, which accepts [-numel, numel) (negative = from the end) and raises outside.  The same rule here: an index
+            // put_ would accept lands where put_ puts it, one it would raise on is dropped -- never an out-of-bounds write.
+            const long long x = (long long)xs[e], y = (long long)ys[e];
+            const long long numel = (long long)C * H * W;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int tl = t0 + dt;
                 if (tl >= 0 && tl < C && tf == tcl) {
-                    const float wgt = value * (1.f - fabsf((float)tl - t_norm));
-                    atomicAdd(grid + ((long long)tl * H + y) * W + x, wgt);
+                    long long idx = ((long long)tl * H + y) * W + x;
+                    if (idx < 0) idx += numel;
+                    if (idx >= 0 && idx < numel) {
+                        const float wgt = value * (1.f - fabsf((float)tl - t_norm));
+                        atomicAdd(grid + idx, wgt);
+                    }
                 }
             }
         } else {
@@ -191,6 +199,11 @@ extern "C" int bflow_voxel_scatter_f32xy(const float* x, const float* y, const s
 extern "C" int bflow_voxel_scatter_i16xy(const short* x, const short* y, const signed char* pol, const long long* t, long long n,
                                          long long t0c, long long t1c, float* grid, int C, int H, int W, bflow_stream_t stream) {
     return scatter<short>(x, y, pol, t, n, t0c, t1c, grid, C, H, W, stream, "voxel_scatter_i16xy");
+}
+
+extern "C" int bflow_voxel_scatter_i32xy(const int* x, const int* y, const signed char* pol, const long long* t, long long n,
+                                         long long t0c, long long t1c, float* grid, int C, int H, int W, bflow_stream_t stream) {
+    return scatter<int>(x, y, pol, t, n, t0c, t1c, grid, C, H, W, stream, "voxel_scatter_i32xy");
 }
 
 extern "C" int bflow_voxel_norm(float* grid, long long n, double* ws, bflow_stream_t stream) {

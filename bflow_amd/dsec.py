@@ -114,6 +114,7 @@ class TwoStepAssembler:
     # twostep.py:44-92 ------------------------------------------------------------------------------------------------
     def assemble(self, events, forward_flow_timestamps, index: int, check: bool = True) -> torch.Tensor:
         (cf, ct), (pf, pt) = twostep_windows(forward_flow_timestamps, index)
+        self._bad.zero_()     # the counter is per sample: one bad sample must not fail (or hide in) the following ones
         ev_cur = self.construct_voxel_grid(events, cf, ct)
         ev_prev = self.construct_voxel_grid(events, pf, pt)
         if check:

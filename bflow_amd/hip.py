@@ -27,7 +27,7 @@ EXPORTS = (
     "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
-    "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_norm", "bflow_epe_accumulate",
+    "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
     "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_scatter_rectified", "bflow_maxabs_diff",
     "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
     "bflow_l1_masked_grad",
@@ -128,6 +128,7 @@ def lib() -> ctypes.CDLL:
         "bflow_cvx_upsample": [vp, vp, vp, f, vp, i, i, i, i, vp],
         "bflow_voxel_scatter_f32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
         "bflow_voxel_scatter_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
+        "bflow_voxel_scatter_i32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
         "bflow_voxel_norm": [vp, ll, vp, vp],
         "bflow_voxel_scatter_rectified": [vp, vp, vp, vp, ll, vp, ll, ll, vp, i, i, i, vp, vp],
         "bflow_maxabs_diff": [vp, vp, ll, vp, vp],
@@ -375,8 +376,10 @@ def voxel_scatter(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.
         fn, px, py = lib().bflow_voxel_scatter_f32xy, _dev(x, torch.float32, "x"), _dev(y, torch.float32, "y")
     elif x.dtype == torch.int16:
         fn, px, py = lib().bflow_voxel_scatter_i16xy, _dev(x, torch.int16, "x"), _dev(y, torch.int16, "y")
+    elif x.dtype == torch.int32:
+        fn, px, py = lib().bflow_voxel_scatter_i32xy, _dev(x, torch.int32, "x"), _dev(y, torch.int32, "y")
     else:
-        raise BflowHipError(f"voxel_scatter: x/y dtype {x.dtype} unsupported (float32 or int16)")
+        raise BflowHipError(f"voxel_scatter: x/y dtype {x.dtype} unsupported (float32, int16 or int32)")
     _check(fn(px, py, ppol, pt, n, int(t0_center), int(t1_center), _dev(grid, name="grid"), C, H, W, _stream()), "bflow_voxel_scatter")
 
 

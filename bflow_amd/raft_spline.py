@@ -124,7 +124,9 @@ class RAFTSpline(nn.Module):
 
     # ---------------------------------------------------------------------------------------- execution control
     def enable_hipgraph(self, enabled: bool = True):
-        """Replay the forward from a captured hipGraph (one graph per input signature)."""
+        """Replay the forward from a captured hipGraph (one graph per input signature).
+        ALIASING: under replay the returned BezierCurves wrap the graph's static output buffers; the next forward with the same
+        signature overwrites them.  Clone (`curves.detach(clone=True)`) whatever must outlive the next call -- Validator does."""
         from .graph import GraphCache
         self._graphs = GraphCache(self) if enabled else None
         return self

@@ -53,7 +53,14 @@ class VoxelGrid(EventRepresentation):
             xs, ys = x.float().contiguous(), y.float().contiguous()
         else:
             assert not torch.is_floating_point(y)
-            xs, ys = x.to(torch.int16).contiguous(), y.to(torch.int16).contiguous()
+            # int8 / uint8 / int16 coordinates are widened or kept (no value can change); anything wider goes to the int32 kernel, so a
+            # coordinate > 32767 is never wrapped into the grid by a narrowing cast (the reference indexes with x.long())
+            narrow = x.dtype in (torch.int8, torch.uint8, torch.int16) and y.dtype in (torch.int8, torch.uint8, torch.int16)
+            xy_dtype = torch.int16 if narrow else torch.int32
+            if not narrow:
+                lim = 2 ** 31 - 1
+                x, y = x.clamp(-lim, lim), y.clamp(-lim, lim)      # int64 outliers saturate (and are then dropped by the flat-index rule)
+            xs, ys = x.to(xy_dtype).contiguous(), y.to(xy_dtype).contiguous()
         grid = torch.zeros((self.nb_channels, self.height, self.width), dtype=torch.float32, device=x.device)
         hip.voxel_scatter(xs, ys, pol.to(torch.int8).contiguous(), time.to(torch.int64).contiguous(), int(t0_center), int(t1_center), grid)
         return grid

@@ -229,9 +229,10 @@ class BasicUpdateBlock(nn.Module):
         for sfx in ("1", "2"):
             _, _, zr_inp, q_inp, zr_bias, q_bias, pad = self._gate_weights(sfx)
             bz = self.__dict__.setdefault("_bias_cache", {})
-            if ("zr" + sfx) not in bz or bz["zr" + sfx][0] != tuple(t._version for t in zr_bias.__defaults__):
+            bkey = tuple((t.data_ptr(), t._version, str(t.device)) for t in zr_bias.__defaults__)   # .to() / param swaps keep _version
+            if ("zr" + sfx) not in bz or bz["zr" + sfx][0] != bkey:
                 with torch.no_grad():
-                    bz["zr" + sfx] = (tuple(t._version for t in zr_bias.__defaults__), zr_bias().contiguous())
+                    bz["zr" + sfx] = (bkey, zr_bias().contiguous())
             _, t_zr = S.conv(ws.INP, zr_inp, padding=pad, shift=bz["zr" + sfx][1], want_split=False, want_f32=True)
             _, t_q = S.conv(ws.INP, q_inp, padding=pad, shift=q_bias, want_split=False, want_f32=True)
             terms.append((t_zr, t_q))

@@ -282,11 +282,17 @@ int bflow_cvx_upsample(const float* data, const float* mask, const float* mask_b
  * K1  event voxel grid: signed tri-linear (float x/y) or temporal-linear (integer x/y) scatter-add.
  * Replaces VoxelGrid.convert, data/utils/representations.py:64-111.  `grid` (C,H,W) must be zeroed by the
  * caller (hipMemsetAsync); accumulation uses fp32 hardware atomics (order is not deterministic).
- *   x,y : fp32 (f32xy) or int16 (i16xy);  pol : int8 in {0,1};  t : int64 microseconds                  */
+ *   x,y : fp32 (f32xy), int16 (i16xy) or int32 (i32xy);  pol : int8 in {0,1};  t : int64 microseconds.
+ * Integer x/y follow the reference's FLAT index ht*wd*t + wd*y + x into Tensor.put_ (representations.py:85-94: only the time bin
+ * is masked): an index in [-C*H*W, C*H*W) lands where put_ puts it (negative = from the end), one put_ would raise on is dropped;
+ * no coordinate can cause an out-of-bounds write.                                                      */
 int bflow_voxel_scatter_f32xy(const float* x, const float* y, const signed char* pol, const long long* t,
                               long long n_events, long long t0_center, long long t1_center,
                               float* grid, int C, int H, int W, bflow_stream_t stream);
 int bflow_voxel_scatter_i16xy(const short* x, const short* y, const signed char* pol, const long long* t,
+                              long long n_events, long long t0_center, long long t1_center,
+                              float* grid, int C, int H, int W, bflow_stream_t stream);
+int bflow_voxel_scatter_i32xy(const int* x, const int* y, const signed char* pol, const long long* t,
                               long long n_events, long long t0_center, long long t1_center,
                               float* grid, int C, int H, int W, bflow_stream_t stream);
 
