@@ -117,39 +117,52 @@ class CorrComputation:
         return CorrComputation(fmap1=self._fmap1 + other._fmap1, fmap2=self._fmap2 + other._fmap2,
                                num_levels_per_target=[torch.tensor(lv) for lv in self._levels + other._levels])
 
-    def get_correlation_volume(self) -> torch.Tensor:
+    def tiled_supported(self) -> bool:
+        """The tiled-plane volume is written by the streaming K5 kernel only: split operands, D in {64, 128, 256}."""
+        return PRECISION == "split" and self.dim in (64, 128, 256)
+
+    def get_correlation_volume(self, tiled: bool = False) -> torch.Tensor:
         """(T, B*N, 1, h, w) fp32 -- corr.py:229-272.  One K5 launch per reference group, written straight into its
-        slice of the volume (the reference expands fmap1 per target and concatenates, corr.py:254-259)."""
+        slice of the volume (the reference expands fmap1 per target and concatenates, corr.py:254-259).
+        tiled=True: (T, B, N, tiled_plane_size(h, w)) with every plane stored as 4 x 8 tiles (the look-up's layout)."""
         B, D, h, w = self._bdhw
         N = h * w
         T = self.num_targets_overall
         device = self._packed[0][0].device if self._packed[0] is not None else self._fmap1[0].device
-        vol = torch.empty((T, B, N, N), dtype=torch.float32, device=device)
+        if tiled and not self.tiled_supported():
+            raise hip.BflowHipError(f"tiled correlation volume needs the split engine and D in (64, 128, 256); got D={D}, precision {PRECISION}")
+        vol = torch.empty((T, B, N, hip.tiled_plane_size(h, w) if tiled else N), dtype=torch.float32, device=device)
+        thw = (h, w) if tiled else None
         split = (PRECISION == "split") and D % 64 == 0
         t0 = 0
         for f1, f2, packed in zip(self._fmap1, self._fmap2, self._packed):
             tg = f2.shape[0]
             if packed is not None:
-                hip.corr_build_split(packed[0], packed[1], vol[t0:t0 + tg], tg, B, N, shared_f1=True)
+                hip.corr_build_split(packed[0], packed[1], vol[t0:t0 + tg], tg, B, N, shared_f1=True, tiled_hw=thw)
                 t0 += tg
                 continue
             f1 = f1.float().contiguous().view(B, D, N)
             f2 = f2.float().contiguous().view(tg * B, D, N)
-            if split:   # split-fp16 MFMA engine: HBM-write-bound
-                hip.corr_build_split(hip.split_pack(f1), hip.split_pack(f2), vol[t0:t0 + tg], tg, B, N, shared_f1=True)
+            if split:   # split-fp16 MFMA engine
+                hip.corr_build_split(hip.split_pack(f1), hip.split_pack(f2), vol[t0:t0 + tg], tg, B, N, shared_f1=True, tiled_hw=thw)
             else:       # exact-fp32 MFMA
                 hip.corr_build_f32(f1, f2.view(tg, B, D, N), vol[t0:t0 + tg])
             t0 += tg
-        return vol.view(T, B * N, 1, h, w)
+        return vol if tiled else vol.view(T, B * N, 1, h, w)
 
 
 class CorrBlockParallelMultiTarget:
     def __init__(self,
                  corr_computation_events: Optional[CorrComputation] = None,
                  corr_computation_frames: Optional[CorrComputation] = None,
-                 radius: int = 4):
+                 radius: int = 4,
+                 layout: str = "rows"):
+        """layout = "rows": the reference's (T, B*N, h_L, w_L) planes (any K5 variant; every look-up entry point).
+        layout = "tiled": planes stored as 4 x 8 tiles -- the inference product path (lookup_bezier_split); the reference-shaped
+        accessors untile on demand."""
         assert corr_computation_events is not None or corr_computation_frames is not None
         assert radius == hip.LOOKUP_RADIUS, "the look-up radius is 4 everywhere in the reference (raft.py:40, corr.py:279)"
+        assert layout in ("rows", "tiled")
         if corr_computation_frames is None:
             cc = corr_computation_events
         elif corr_computation_events is None:
@@ -161,26 +174,53 @@ class CorrBlockParallelMultiTarget:
         self._radius = radius
         self._batch = cc.batch
         self._hw = (cc.height, cc.width)
+        self._tiled = layout == "tiled"
+        self._rows_cache = None
         B, h, w = cc.batch, cc.height, cc.width
         N = h * w
 
-        base = cc.get_correlation_volume().view(len(levels), B * N, h, w)
+        if self._tiled:
+            base = cc.get_correlation_volume(tiled=True).view(len(levels), B * N, hip.tiled_plane_size(h, w))
+        else:
+            base = cc.get_correlation_volume().view(len(levels), B * N, h, w)
         # pyramid: corr.py:297-305 -- level L keeps the targets whose num_levels > L
         self._pyramid: List[Tuple[torch.Tensor, List[int]]] = [(base, list(range(len(levels))))]
+        self._level_hw: List[Tuple[int, int]] = [(h, w)]
         for num_levels in range(2, max(levels) + 1):
             prev, prev_idx = self._pyramid[-1]
             keep = [t for t, lv in enumerate(levels) if lv >= num_levels]
-            ph, pw = prev.shape[-2:]
-            cur = torch.empty((len(keep), B * N, ph // 2, pw // 2), dtype=torch.float32, device=base.device)
-            for k, t in enumerate(keep):
-                hip.corr_pool2x2(prev[prev_idx.index(t)], cur[k])
+            ph, pw = self._level_hw[-1]
+            if self._tiled:
+                cur = torch.empty((len(keep), B * N, hip.tiled_plane_size(ph // 2, pw // 2)), dtype=torch.float32, device=base.device)
+                for k, t in enumerate(keep):
+                    hip.corr_pool2x2_tiled(prev[prev_idx.index(t)], cur[k], ph, pw)
+            else:
+                cur = torch.empty((len(keep), B * N, ph // 2, pw // 2), dtype=torch.float32, device=base.device)
+                for k, t in enumerate(keep):
+                    hip.corr_pool2x2(prev[prev_idx.index(t)], cur[k])
             self._pyramid.append((cur, keep))
+            self._level_hw.append((ph // 2, pw // 2))
         planes = []
         for lvl, (tensor, tidx) in enumerate(self._pyramid):
             for k, t in enumerate(tidx):
-                planes.append(dict(tensor=tensor[k], level=lvl, target=t))
+                planes.append(dict(tensor=tensor[k], level=lvl, target=t, hw=self._level_hw[lvl] if self._tiled else None))
         self._planes = planes
         self._table = hip.make_plane_table(planes)
+
+    def _rows(self) -> "CorrBlockParallelMultiTarget":
+        """Row-major twin of a tiled block (reference-shaped accessors and the fp32 NCHW look-ups; built once, on demand)."""
+        if not self._tiled:
+            return self
+        if self._rows_cache is None:
+            twin = CorrBlockParallelMultiTarget.__new__(CorrBlockParallelMultiTarget)
+            twin.__dict__.update(self.__dict__)
+            twin._tiled, twin._rows_cache = False, None
+            twin._pyramid = [(hip.untile_planes(t, *hw), idx) for (t, idx), hw in zip(self._pyramid, self._level_hw)]
+            twin._planes = [dict(tensor=twin._pyramid[p["level"]][0][twin._pyramid[p["level"]][1].index(p["target"])], level=p["level"],
+                                 target=p["target"], hw=None) for p in self._planes]
+            twin._table = hip.make_plane_table(twin._planes)
+            self._rows_cache = twin
+        return self._rows_cache
 
     @property
     def num_planes(self) -> int:
@@ -188,7 +228,7 @@ class CorrBlockParallelMultiTarget:
 
     def pyramid_level(self, level: int) -> Tuple[torch.Tensor, List[int]]:
         """(T_L, B*N, 1, h_L, w_L) tensor (reference CorrData.corr layout) and its base-target indices."""
-        t, idx = self._pyramid[level]
+        t, idx = self._rows()._pyramid[level]
         return t.unsqueeze(2), list(idx)
 
     def new_output(self) -> torch.Tensor:
@@ -201,14 +241,14 @@ class CorrBlockParallelMultiTarget:
             coords = torch.stack(list(coords), dim=0)
         assert coords.ndim == 5 and coords.shape[0] == self._num_targets_base
         out = self.new_output() if out is None else out
-        hip.corr_lookup(self._table, coords.float().contiguous(), out)
+        hip.corr_lookup(self._rows()._table, coords.float().contiguous(), out)
         return out
 
     def lookup_bezier(self, params: torch.Tensor, coef: np.ndarray, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fused get_flow_from_reference + coords0 + look-up (raft.py:180-184): coords are never materialised."""
         assert coef.shape[0] == self._num_targets_base
         out = self.new_output() if out is None else out
-        hip.corr_lookup_bezier(self._table, params, coef, out)
+        hip.corr_lookup_bezier(self._rows()._table, params, coef, out)
         return out
 
     def new_output_split(self):
@@ -220,5 +260,5 @@ class CorrBlockParallelMultiTarget:
     def lookup_bezier_split(self, params: torch.Tensor, coef: np.ndarray, out):
         """lookup_bezier writing the conv engine's blocked split layout directly (no NCHW intermediate)."""
         assert coef.shape[0] == self._num_targets_base
-        hip.corr_lookup_bezier_split(self._table, params, coef, out.planes)
+        hip.corr_lookup_bezier_split(self._table, params, coef, out.planes, tiled=self._tiled)
         return out

@@ -33,11 +33,7 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 constexpr int CBM = 128, CT = 256;
 
-__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
-    const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;   // matrix cores flush fp16 subnormal inputs
-    hi = (_Float16)h;
-    lo = (_Float16)((x - h) * LO_SCALE);
-}
+using bflow::split1;   // common.h: saturating hi/lo split
 
 struct ConvArgs {
     const _Float16 *xh, *xl;   // (B, CB1, P_in, 32): channel blocks [0, CB1)

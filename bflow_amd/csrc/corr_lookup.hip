@@ -203,20 +203,20 @@ __global__ __launch_bounds__(LTHREADS) void corr_lookup_kernel(LookupArgs args, 
                 half8 h8, l8;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float x = sp[k0 + k];
-                    const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;   // fp16 subnormals are flushed by the MFMA
-                    h8[k] = (_Float16)h;
-                    l8[k] = (_Float16)((x - h) * 2048.0f);
+                    _Float16 hh, ll;
+                    bflow::split1(sp[k0 + k], hh, ll);
+                    h8[k] = hh;
+                    l8[k] = ll;
                 }
                 *reinterpret_cast<half8*>(oh + o) = h8;
                 *reinterpret_cast<half8*>(ol + o) = l8;
             } else {
                 for (int k = 0; k < 8; ++k) {                   // ragged chunk shared with the neighbouring plane's workgroup
                     if (k0 + k < 0 || k0 + k >= NCH) continue;
-                    const float x = sp[k0 + k];
-                    const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;
-                    oh[o + k] = (_Float16)h;
-                    ol[o + k] = (_Float16)((x - h) * 2048.0f);
+                    _Float16 hh, ll;
+                    bflow::split1(sp[k0 + k], hh, ll);
+                    oh[o + k] = hh;
+                    ol[o + k] = ll;
                 }
             }
         }
@@ -311,6 +311,23 @@ extern "C" int bflow_corr_lookup_bezier(const bflow_plane_t* planes, int P, cons
     dim3 grid(bflow::ceil_div((long long)h1 * w1, TILE), P, B);
     launch_lookup<true>(grid, (hipStream_t)stream, a, params, out, B, h1, w1);
     return bflow::launch_status("corr_lookup_bezier");
+}
+
+namespace bflow {
+int pool_tiled_launch(const void* in, void* out, long long planes, int h, int w, bool f16, hipStream_t stream);
+int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg, void* out_hi, void* out_lo,
+                       int channel_blocks, int rows_per_image, int B, int h1, int w1, bool f16_planes, hipStream_t stream);
+}
+
+extern "C" int bflow_corr_pool2x2_tiled(const float* in, float* out, long long planes, int h, int w, bflow_stream_t stream) {
+    return bflow::pool_tiled_launch(in, out, planes, h, w, false, (hipStream_t)stream);
+}
+
+extern "C" int bflow_corr_lookup_bezier_split_tiled(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
+                                                    void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
+                                                    bflow_stream_t stream) {
+    return bflow::lookup_tile_launch(planes, P, params, coef, T, deg, out_hi, out_lo, channel_blocks, rows_per_image, B, h1, w1, false,
+                                     (hipStream_t)stream);
 }
 
 extern "C" int bflow_corr_lookup_bezier_split(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,

@@ -1,0 +1,300 @@
+// K6 + K7 (+K8, K14) on TILED planes: the product path of inference.
+// Reference: CorrData.get_downsampled (models/raft_utils/corr.py:108-125), CorrBlockParallelMultiTarget.__call__ (corr.py:307-351),
+// bilinear_sampler (models/raft_utils/utils.py:5-21; F.grid_sample bilinear / zeros / align_corners=True),
+// BezierCurves.get_flow_from_reference + coords0 (raft.py:180-181).
+//
+// Layout.  Every query pixel owns a PRIVATE h_L x w_L plane of the 4-D volume and a look-up reads one <= 12 x 12 neighbourhood of it.
+// With row-major planes that is 12 row segments of 48 B, each pulling one or two 128-B lines: ~2.1 KB of lines for 400 B of taps, and
+// the first look-up kernel (corr_lookup.hip) ran at 1.5-1.9 TB/s algorithmic at every size because HBM was busy moving those lines.
+// Here a plane is stored as ceil(h/4) x ceil(w/8) TILES of 4 x 8 elements (tile-row-major, row-major inside a tile; one fp32 tile =
+// one 128-B line), written directly by the correlation build (corr_stream.hip: a wave's 32 stationary columns are one tile) and by the
+// pooling kernel below: the same neighbourhood is ~9 lines, every one of them used.
+//
+// Look-up kernel:
+//   * a workgroup owns TP consecutive query pixels and ALL P planes; pair = (plane, pixel).  Phase A: Bezier evaluation -> sampling
+//     centre and patch origin per pair;
+//   * phase B: the gather is pure LDS-DMA: a patch is 12 rows x UPR aligned 16-B units (fp32: 4 units = 16 columns, fp16: 3 units = 24
+//     columns; a unit never crosses a tile row), the flat unit list IS the LDS image, so a wave instruction moves 64 units = 1 KB with
+//     no VGPR round trip, no LDS-write instruction and no masks: units outside the tile grid are redirected to the slab's first unit,
+//     and zero padding is applied through the WEIGHTS (a corner outside the plane gets weight 0; every stored value is finite);
+//   * the 18 taps of a pair (west / north index + two corner weights each; they sit behind the reference's normalise / un-normalise
+//     round trip, a true fp32 division) are computed once while the gather is in flight;
+//   * phase C: thread = (pair, window row) produces 9 samples into a channel-ordered staging tile; phase D: thread = (channel block,
+//     pixel, 8-channel chunk) converts to the split format and stores 16 B of hi + 16 B of lo in the conv engine's blocked layout
+//     (B, CB, rows, 32): 512 B contiguous per channel block and workgroup.
+//   * the volume element type is a template parameter: fp32 planes, or fp16 planes (bflow_corr_build_f16: BASELINE configs[4]).
+#include <cstdlib>
+#include "common.h"
+
+namespace {
+
+constexpr int R = BFLOW_LOOKUP_RADIUS;      // 4
+constexpr int WIN = 2 * R + 1;              // 9
+constexpr int NCH = WIN * WIN;              // 81
+constexpr int PATCH = 12;                   // rows floor(c)-5 .. floor(c)+6 cover every bilinear corner incl. round-off flips
+constexpr int TILE_H = 4, TILE_W = 8;       // plane tiling (elements)
+constexpr int THREADS = 256;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct TilePlane {
+    const void* base;
+    int h, w;
+    float inv_scale;
+    int target;
+};
+
+struct TileArgs {
+    TilePlane planes[BFLOW_MAX_PLANES];
+    float coef[BFLOW_MAX_TARGETS * BFLOW_MAX_DEGREE];
+    int P, T, deg;
+};
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float roundtrip(float x, int size) {   // see corr_lookup.hip: utils.py:13-14 + grid_sample's un-normalisation
+    const float sm1 = (float)(size - 1);
+    const float g = 2.0f * x / sm1 - 1.0f;
+    return (g + 1.0f) * (sm1 / 2.0f);
+}
+
+// element offset of (y, x) inside a tiled plane with `tw` tiles per tile row
+__device__ __forceinline__ int tiled_index(int y, int x, int tw) {
+    return (((y >> 2) * tw + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
+}
+
+template <typename VT, int TP>
+__global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args, const float* __restrict__ params, _Float16* __restrict__ oh,
+                                                                 _Float16* __restrict__ ol, int CBk, int Prow, int h1, int w1, int abl) {
+    constexpr int EPU = 16 / (int)sizeof(VT);          // elements per 16-B unit: 4 (fp32) / 8 (fp16)
+    constexpr int UPR = sizeof(VT) == 4 ? 4 : 3;       // units per patch row: columns [ox_al, ox_al + UPR*EPU) cover ox .. ox+11 for any alignment
+    constexpr int PCOLS = UPR * EPU;                   // 16 / 24
+    constexpr int UPP = PATCH * UPR;                   // units per pair: 48 / 36
+    constexpr int PELEMS = PATCH * PCOLS;              // patch elements per pair: 192 / 288
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // the only shared object; carved below (sizes follow P)
+    const int tid = threadIdx.x;
+    const int N = h1 * w1;
+    const int P = args.P;
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * TP;
+    const int npair = P * TP;                 // pair = plane * TP + pixel of the tile
+    const int cstride = ((P * NCH + 31) >> 5) * 32;   // staged channels per pixel (whole channel blocks)
+    // plane table (indexed per lane: a runtime index into the kernel-argument struct would spill the struct to scratch)
+    const char** s_base = reinterpret_cast<const char**>(smem);                   // [MAX_PLANES]
+    int* s_h = reinterpret_cast<int*>(smem + 8 * BFLOW_MAX_PLANES);                // [MAX_PLANES]
+    int* s_w = s_h + BFLOW_MAX_PLANES;                                             // [MAX_PLANES]
+    float* s_cx = reinterpret_cast<float*>(s_w + BFLOW_MAX_PLANES);                // [npair] sampling centres
+    float* s_cy = s_cx + npair;
+    int* s_ox = reinterpret_cast<int*>(s_cy + npair);                              // [npair] patch origins (x: aligned down to a unit)
+    int* s_oy = s_ox + npair;
+    int* s_at = s_oy + npair;                                // [npair][18]: patch-relative west index of the 9 columns, north index of the 9 rows
+    float* s_wt = reinterpret_cast<float*>(s_at + npair * 18);   // [npair][18][2]: (west, east) / (north, south) weights, ZERO where the corner
+                                                                 // lies outside the plane (= grid_sample's zero padding) or outside the patch
+    float* stage = s_wt + npair * 36;                        // [TP][cstride]: the tile's features in channel order
+    VT* patch = reinterpret_cast<VT*>(stage + TP * cstride);  // [npair][12][PCOLS] (+ 1 KB: the last DMA instruction's idle lanes land there)
+
+    // ---- phase A: thread = (plane, pixel) pair: Bezier evaluation -> sampling centre and patch origin ---------------------------
+    if (tid < P) {
+        s_base[tid] = reinterpret_cast<const char*>(args.planes[tid].base);
+        s_h[tid] = args.planes[tid].h;
+        s_w[tid] = args.planes[tid].w;
+    }
+    if (tid < npair) {
+        const int p = tid / TP, i = tid - p * TP;
+        const TilePlane pl = args.planes[p];
+        const int n = n0 + i;
+        float cx = 0.f, cy = 0.f;
+        if (n < N) {
+            // coords = coords0 + sum_i coef[t][i] * P_i   (bezier.py:185, raft.py:181); params (B, 2*deg, N)
+            const int deg = args.deg;
+            const float* pp = params + (long long)b * 2 * deg * N + n;
+            const float* cf = args.coef + pl.target * deg;
+            float fx = 0.f, fy = 0.f;
+            for (int k = 0; k < deg; ++k) {
+                fx = fmaf(pp[(long long)k * N], cf[k], fx);
+                fy = fmaf(pp[(long long)(deg + k) * N], cf[k], fy);
+            }
+            const int y = n / w1, x = n - y * w1;
+            cx = ((float)x + fx) * pl.inv_scale;   // corr.py:333 (division by 2^level == exact multiply)
+            cy = ((float)y + fy) * pl.inv_scale;
+        }
+        s_cx[tid] = cx;
+        s_cy[tid] = cy;
+        // patch origin from the (clamped) centre; far-away centres see an all-zero neighbourhood, as zero padding demands
+        const float ccx = fminf(fmaxf(cx, -64.f), (float)pl.w + 64.f);
+        const float ccy = fminf(fmaxf(cy, -64.f), (float)pl.h + 64.f);
+        const int ox = (int)floorf(ccx) - (R + 1);
+        s_ox[tid] = ox & ~(EPU - 1);              // floor to a unit boundary (two's complement: also for negative origins)
+        s_oy[tid] = (int)floorf(ccy) - (R + 1);
+    }
+    __syncthreads();
+
+    // ---- phase B: gather by LDS-DMA: unit u = (pair, row, unit of the row), 64 consecutive units per wave instruction ---------------
+    {
+        const int units = npair * UPP;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        for (int u0 = wave * 64; u0 < units && !(abl & 1); u0 += THREADS) {
+            const int u = min(u0 + lane, units - 1);
+            const int pair = u / UPP, ru = u - pair * UPP;
+            const int r = ru / UPR, k = ru - r * UPR;
+            const int p = pair / TP, i = pair - p * TP;
+            const int th = (s_h[p] + TILE_H - 1) >> 2, tw = (s_w[p] + TILE_W - 1) >> 3;
+            const int gy = s_oy[pair] + r, gx = s_ox[pair] + k * EPU;
+            const bool in = gy >= 0 && gy < th * TILE_H && gx >= 0 && gx < tw * TILE_W;   // inside the tile grid (pads included)
+            const long long plane = (long long)b * N + min(n0 + i, N - 1);               // pixels past the end re-read the last one (never stored)
+            const long long off = plane * (th * tw * 32) + (in ? tiled_index(gy, gx, tw) : 0);
+            const char* src = s_base[p] + off * (long long)sizeof(VT);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(reinterpret_cast<char*>(patch) + u0 * 16), 16, 0, 0);
+        }
+    }
+    // tap tables while the gather is in flight: item = (pair, axis, tap)
+    for (int it = tid; it < npair * 18 && !(abl & 8); it += THREADS) {
+        const int pair = it / 18, a = it - pair * 18;
+        const int p = pair / TP;
+        const bool isy = a >= WIN;
+        const int d = isy ? a - WIN : a;
+        const int size = isy ? s_h[p] : s_w[p];
+        float ic = roundtrip((isy ? s_cy[pair] : s_cx[pair]) + (float)(d - R), size);
+        ic = fminf(fmaxf(ic, -1.0e4f), 1.0e4f);
+        const float f0 = floorf(ic);
+        const float w1_ = ic - f0, w0_ = 1.f - w1_;     // far (east / south) and near (west / north) corner weights
+        const int g0 = (int)f0;                         // plane coordinate of the near corner
+        const int ai = g0 - (isy ? s_oy[pair] : s_ox[pair]);
+        const bool inpatch = ai >= 0 && ai + 1 < (isy ? PATCH : PCOLS);
+        s_at[it] = inpatch ? ai : 0;
+        s_wt[2 * it] = (inpatch && g0 >= 0 && g0 < size) ? w0_ : 0.f;
+        s_wt[2 * it + 1] = (inpatch && g0 + 1 >= 0 && g0 + 1 < size) ? w1_ : 0.f;
+    }
+    // pad channels of the last channel block are written as zeros
+    for (int it = tid; it < TP * (cstride - P * NCH); it += THREADS) {
+        const int i = it / (cstride - P * NCH), c = it - i * (cstride - P * NCH);
+        stage[i * cstride + P * NCH + c] = 0.f;
+    }
+    __syncthreads();   // (the compiler drains the DMA with vmcnt(0) in front of it)
+
+    // ---- phase C: interpolation.  unit = (pair, window row): 9 samples -> stage[pixel][plane*81 + row*9 ..] -------------------------
+    for (int it = tid; it < npair * WIN && !(abl & 2); it += THREADS) {
+        const int pair = it / WIN, ky = it - pair * WIN;
+        const int p = pair / TP, i = pair - p * TP;
+        const int* at = s_at + pair * 18;
+        const float* wt = s_wt + pair * 36;
+        const float wn = wt[2 * (WIN + ky)], ws = wt[2 * (WIN + ky) + 1];
+        const VT* row = patch + pair * PELEMS + at[WIN + ky] * PCOLS;
+        float* dst = stage + i * cstride + p * NCH + ky * WIN;
+#pragma unroll
+        for (int kx = 0; kx < WIN; ++kx) {
+            const float ww = wt[2 * kx], we = wt[2 * kx + 1];
+            const VT* q = row + at[kx];
+            // utils.py:19 / grid_sample: nw*I_nw + ne*I_ne + sw*I_sw + se*I_se, weights as products of the axis weights
+            float v = (float)q[0] * (ww * wn);
+            v += (float)q[1] * (we * wn);
+            v += (float)q[PCOLS] * (ww * ws);
+            v += (float)q[PCOLS + 1] * (we * ws);
+            dst[kx] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase D: output in memory order.  item = (channel block, pixel, 8-channel chunk), chunk fastest: 16 B of hi + 16 B of lo ----------
+    const int items = (cstride >> 5) * TP * 4;
+    for (int it = tid; it < items && !(abl & 4); it += THREADS) {
+        const int chunk = it & 3, i = (it >> 2) % TP, cb = it / (4 * TP);
+        const int n = n0 + i;
+        if (n >= N) continue;
+        const float* sp = stage + i * cstride + cb * 32 + chunk * 8;
+        half8 h8, l8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 hh, ll;
+            bflow::split1(sp[j], hh, ll);
+            h8[j] = hh;
+            l8[j] = ll;
+        }
+        const long long o = (((long long)b * CBk + cb) * Prow + n) * 32 + chunk * 8;
+        *reinterpret_cast<half8*>(oh + o) = h8;
+        *reinterpret_cast<half8*>(ol + o) = l8;
+    }
+}
+
+// ---- K6 on tiled planes: 2x2 mean, floor on odd sizes (corr.py:119), tiled in -> tiled out; pad positions of the output are zero -------
+template <typename VT>
+__global__ __launch_bounds__(256) void corr_pool2x2_tiled_kernel(const VT* __restrict__ in, VT* __restrict__ out, long long planes, int h, int w) {
+    const int ho = h / 2, wo = w / 2;
+    const int twi = (w + TILE_W - 1) >> 3, thi = (h + TILE_H - 1) >> 2;
+    const int two = (wo + TILE_W - 1) >> 3, tho = (ho + TILE_H - 1) >> 2;
+    const int psi = thi * twi * 32, pso = tho * two * 32;
+    const long long total = planes * pso;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long pl = idx / pso;
+        const int e = (int)(idx - pl * pso);
+        const int tile = e >> 5, ty = tile / two, tx = tile - ty * two;
+        const int y = ty * 4 + ((e >> 3) & 3), x = tx * 8 + (e & 7);
+        float v = 0.f;
+        if (y < ho && x < wo) {
+            const VT* q = in + pl * psi;
+            // F.avg_pool2d accumulates the window row-major and divides by the window size (4: exact)
+            v = ((((float)q[tiled_index(2 * y, 2 * x, twi)] + (float)q[tiled_index(2 * y, 2 * x + 1, twi)]) +
+                  (float)q[tiled_index(2 * y + 1, 2 * x, twi)]) + (float)q[tiled_index(2 * y + 1, 2 * x + 1, twi)]) * 0.25f;
+        }
+        out[idx] = (VT)v;
+    }
+}
+
+}  // namespace
+
+namespace bflow {
+
+int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg, void* out_hi, void* out_lo,
+                       int channel_blocks, int rows_per_image, int B, int h1, int w1, bool f16_planes, hipStream_t stream) {
+    BFLOW_REQUIRE(planes && P > 0 && T > 0, BFLOW_E_ARG, "corr_lookup: bad plane table");
+    BFLOW_REQUIRE(P <= BFLOW_MAX_PLANES, BFLOW_E_LIMIT, "corr_lookup: %d planes > %d", P, BFLOW_MAX_PLANES);
+    BFLOW_REQUIRE(T <= BFLOW_MAX_TARGETS, BFLOW_E_LIMIT, "corr_lookup: %d targets > %d", T, BFLOW_MAX_TARGETS);
+    BFLOW_REQUIRE(deg >= 1 && deg <= BFLOW_MAX_DEGREE, BFLOW_E_LIMIT, "corr_lookup_bezier_split: degree %d", deg);
+    BFLOW_REQUIRE(params && coef && out_hi && out_lo && B > 0 && h1 > 0 && w1 > 0, BFLOW_E_ARG, "corr_lookup_bezier_split: bad arguments");
+    BFLOW_REQUIRE(B <= 65535, BFLOW_E_LIMIT, "corr_lookup_bezier_split: batch %d", B);
+    BFLOW_REQUIRE(channel_blocks * 32 >= P * NCH && rows_per_image >= h1 * w1, BFLOW_E_ARG, "corr_lookup_bezier_split: output too small");
+    TileArgs a;
+    a.P = P;
+    a.T = T;
+    a.deg = deg;
+    for (int p = 0; p < P; ++p) {
+        BFLOW_REQUIRE(planes[p].base && planes[p].h > 0 && planes[p].w > 0 && planes[p].level >= 0 && planes[p].level < 16 && planes[p].target >= 0 &&
+                          planes[p].target < T,
+                      BFLOW_E_ARG, "corr_lookup: bad descriptor for plane %d", p);
+        a.planes[p].base = planes[p].base;
+        a.planes[p].h = planes[p].h;
+        a.planes[p].w = planes[p].w;
+        a.planes[p].inv_scale = 1.0f / (float)(1 << planes[p].level);
+        a.planes[p].target = planes[p].target;
+    }
+    for (int i = 0; i < T * deg; ++i) a.coef[i] = coef[i];
+    static const int tp_env = [] { const char* e = getenv("BFLOW_LOOKUP_TP"); return e ? atoi(e) : 0; }();   // tools: tile size A/B
+    const int tp = (tp_env == 4 || tp_env == 8) ? tp_env : 8;
+    static const int abl = [] { const char* e = getenv("BFLOW_LOOKUP_ABL"); return e ? atoi(e) : 0; }();   // tools: phase ablation (timing only)
+    const int cstride = ((P * NCH + 31) >> 5) * 32;
+    const int lds = 16 * BFLOW_MAX_PLANES + P * tp * (4 + 18 + 36) * 4 + P * tp * PATCH * 16 * (f16_planes ? 3 : 4) + tp * cstride * 4 + 1024;
+    dim3 grid(ceil_div((long long)h1 * w1, tp), B);
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, a, params, (_Float16*)out_hi, (_Float16*)out_lo, channel_blocks, rows_per_image, h1, w1, abl);
+    };
+    if (f16_planes) {
+        if (tp == 4) go(corr_lookup_tile_kernel<_Float16, 4>);
+        else go(corr_lookup_tile_kernel<_Float16, 8>);
+    } else {
+        if (tp == 4) go(corr_lookup_tile_kernel<float, 4>);
+        else go(corr_lookup_tile_kernel<float, 8>);
+    }
+    return launch_status("corr_lookup_bezier_split");
+}
+
+int pool_tiled_launch(const void* in, void* out, long long planes, int h, int w, bool f16, hipStream_t stream) {
+    BFLOW_REQUIRE(in && out && planes > 0 && h >= 2 && w >= 2, BFLOW_E_ARG, "corr_pool2x2_tiled: bad arguments");
+    const long long total = planes * (ceil_div(h / 2, TILE_H) * ceil_div(w / 2, TILE_W) * 32);
+    const int grid = stream_grid(total, 256) * 4;
+    if (f16) hipLaunchKernelGGL(corr_pool2x2_tiled_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, (const _Float16*)in, (_Float16*)out, planes, h, w);
+    else hipLaunchKernelGGL(corr_pool2x2_tiled_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)in, (float*)out, planes, h, w);
+    return launch_status("corr_pool2x2_tiled");
+}
+
+}  // namespace bflow

@@ -68,6 +68,8 @@ struct StreamArgs {
     int CH2;                // pairs of 32-row chunks = ceil(N / 64)
     int n_pan;              // panels = T * B * JP
     int RX;                 // XCD grid: RX row slices x (8 / RX) panel ranges
+    int ph, pw;             // > 0: tiled planes (bflow_hip.h: 4x8 tiles); 0: row-major (N, N) slabs
+    int PS;                 // elements of one plane of the volume: N (row-major) or tiles * 32
     unsigned long long* stamps;   // STREAM_STAMPS builds only
 };
 
@@ -177,8 +179,16 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     // ---- target panel -> registers: lane holds column (wave*32 + l31) of the panel, 8 consecutive k per k16 step
     half8 Bh[NS], Bl[NS];
     auto load_panel = [&](int tb, int jp) {
-        int col = jp * COLS_WG + wave * 32 + l31;
-        col = col < a.Np ? col : a.Np - 1;   // columns >= N are never stored
+        int col = jp * COLS_WG + wave * 32 + l31;   // row-major planes: 32 consecutive target pixels per wave
+        if (a.pw > 0) {
+            // tiled planes: the wave's 32 columns are the 4 x 8 pixels of ONE tile, so that an accumulator register is one 128-B line of
+            // the tiled plane.  Pad positions of edge tiles take a clamped (valid) pixel: they hold finite values nobody weights.
+            const int tw = (a.pw + 7) >> 3, tile = jp * 8 + wave;
+            const int ty = tile / tw, tx = tile - ty * tw;
+            const int y = min(ty * 4 + (l31 >> 3), a.ph - 1), x = min(tx * 8 + (l31 & 7), a.pw - 1);
+            col = y * a.pw + x;
+        }
+        col = col < a.Np ? col : a.Np - 1;   // columns >= N (row-major) / tiles past the plane are never stored
         const unsigned vo = (unsigned)col * 64u + (unsigned)kh * 16u;
         const unsigned mat = (unsigned)(((long long)tb * a.Np * D) * 2);
 #pragma unroll
@@ -195,12 +205,12 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
 
     // ---- store side: one accumulator register = rows (r&3) + 8*(r>>2) + 4*kh of the wave's 32, 32 consecutive columns
     auto store_base = [&](const Item& im, __amdgpu_buffer_rsrc_t& rs) -> unsigned {
-        const int row = im.i0 + 4 * kh, col = im.jp * COLS_WG + wave * 32 + l31;
-        float* slab = a.out + (long long)(im.t * a.B + im.b) * a.N * a.N;
-        rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, a.N * a.N * 4, 0x00020000);
-        return col < a.N ? (unsigned)((row * a.N + col) * 4) : OOB;   // rows >= N fall off the end of the slab by themselves
+        const int row = im.i0 + 4 * kh, col = im.jp * COLS_WG + wave * 32 + l31;   // tiled: col = tile * 32 + position in the tile
+        float* slab = a.out + (long long)(im.t * a.B + im.b) * a.N * a.PS;
+        rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, a.N * a.PS * 4, 0x00020000);
+        return col < a.PS ? (unsigned)((row * a.PS + col) * 4) : OOB;   // rows >= N fall off the end of the slab by themselves
     };
-    const unsigned rowstep = (unsigned)a.N * 4u;
+    const unsigned rowstep = (unsigned)a.PS * 4u;
 
     // ---- pipeline state --------------------------------------------------------------------------------------------------
     STAMP(0)
@@ -326,12 +336,13 @@ namespace bflow {
 
 // true when the streaming kernel supports the shape (D in {64, 128, 256}); otherwise the caller uses the tile kernel
 bool corr_stream_supported(int T, int B, int D, int N, int Np) {
-    // 32-bit buffer offsets: one volume slab and each operand plane must stay below 2 GiB
-    return (D == 64 || D == 128 || D == 256) && (long long)N * N * 4 < (1LL << 31) && (long long)T * B * Np * D * 2 < (1LL << 31);
+    // 32-bit buffer offsets: one volume slab (tiled planes are < 1.2x larger: 2^30.7 B) and each operand plane must stay below 2 GiB
+    return (D == 64 || D == 128 || D == 256) && (long long)N * N * 4 < (3LL << 29) && (long long)T * B * Np * D * 2 < (1LL << 31);
 }
 
+// plane_h x plane_w > 0 (= N): the volume is written as TILED planes (see bflow_corr_build_split_tiled); 0, 0: row-major (T, B, N, N)
 int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out, int T, int B, int D, int N, int Np,
-                       long long f1_target_stride, hipStream_t stream) {
+                       long long f1_target_stride, int plane_h, int plane_w, hipStream_t stream) {
     StreamArgs a;
     a.f1h = (const _Float16*)f1_hi;
     a.f1l = (const _Float16*)f1_lo;
@@ -347,7 +358,10 @@ int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, 
     int e;
     const bool pow2 = frexpf(sq, &e) == 0.5f;   // sqrt(D) a power of two: x / sqrt(D) == x * (1 / sqrt(D)) bit for bit
     a.scale = pow2 ? 1.0f / sq : sq;
-    a.JP = ceil_div(N, COLS_WG);
+    a.ph = plane_h;
+    a.pw = plane_w;
+    a.PS = plane_w > 0 ? ceil_div(plane_h, 4) * ceil_div(plane_w, 8) * 32 : N;
+    a.JP = ceil_div(a.PS, COLS_WG);
     a.CH2 = ceil_div(N, 2 * CHUNK);
     a.n_pan = T * B * a.JP;
     a.RX = 1;   // row slice of one XCD: CH2 / RX pairs x 2 chunks x (D/32 * 4 KB) <= 2.5 MB

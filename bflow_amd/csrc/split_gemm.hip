@@ -23,16 +23,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr float LO_SCALE = 2048.0f;           // 2^11
 constexpr float LO_INV = 1.0f / 2048.0f;
 
-// The matrix cores flush fp16 subnormal INPUTS, so `hi` must never be subnormal: below 2^-14 the whole value goes into
-// the (pre-scaled) `lo` term, which stays normal down to 2^-25 (anything smaller contributes < 3e-8 absolute).
-__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
-    const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;
-    hi = (_Float16)h;
-    lo = (_Float16)((x - h) * LO_SCALE);
-}
+using bflow::split1;   // common.h: saturating hi/lo split
 
 // ---------------------------------------------------------------------------------------------------------------
 // pack: transpose (D, N) -> (Np, D) and split.  Block = 64 pixels x 64 features.
@@ -241,7 +234,7 @@ __global__ __launch_bounds__(V2_T, 2) void corr_build_split_v2_kernel(const _Flo
 namespace bflow {
 bool corr_stream_supported(int T, int B, int D, int N, int Np);
 int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out, int T, int B, int D, int N, int Np,
-                       long long f1_target_stride, hipStream_t stream);
+                       long long f1_target_stride, int plane_h, int plane_w, hipStream_t stream);
 }
 
 extern "C" int bflow_split_pack(const float* src, void* hi, void* lo, int R, int D, int N, int Np, bflow_stream_t stream) {
@@ -260,7 +253,7 @@ extern "C" int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, cons
     // D in {64, 128, 256}: the A-stationary streaming kernel (corr_stream.hip); anything else: the 256x128 tile kernel below
     static const bool force_tile = getenv("BFLOW_CORR_TILE_KERNEL") != nullptr;   // A/B timing only (tools/)
     if (!force_tile && bflow::corr_stream_supported(T, B, D, N, Np))
-        return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, (hipStream_t)stream);
+        return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, 0, 0, (hipStream_t)stream);
     BFLOW_REQUIRE((long long)T * B <= 65535, BFLOW_E_LIMIT, "corr_build_split: T*B too large");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_build_split_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               V2_STAGES * V2_STAGE);   // 144 KB of dynamic LDS; idempotent, per device
@@ -269,4 +262,19 @@ extern "C" int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, cons
                        (const _Float16*)f1_lo, (const _Float16*)f2_hi, (const _Float16*)f2_lo, out, B, D, N, Np, f1_target_stride,
                        sqrtf((float)D));
     return bflow::launch_status("corr_build_split");
+}
+
+// The same volume with TILED planes (the product path of inference): plane (h x w) of query pixel i is stored as ceil(h/4) x ceil(w/8)
+// tiles of 4 x 8 elements (128 B = one cache line; tile-row-major, row-major inside a tile), so that the 12 x 12 neighbourhood the
+// look-up gathers is ~9 full lines instead of 12 x 1.4 partial ones.  out: (T, B, N, tiles * 32) fp32; pad positions of edge tiles
+// hold finite values.  Only the streaming kernel writes this layout: D in {64, 128, 256}, else BFLOW_E_ARG (use the row-major entry).
+extern "C" int bflow_corr_build_split_tiled(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out, int T, int B,
+                                            int D, int h, int w, int Np, long long f1_target_stride, bflow_stream_t stream) {
+    BFLOW_REQUIRE(f1_hi && f1_lo && f2_hi && f2_lo && out, BFLOW_E_ARG, "corr_build_split_tiled: null pointer");
+    const int N = h * w;
+    BFLOW_REQUIRE(T > 0 && B > 0 && h > 0 && w > 0 && Np >= N && Np % 128 == 0, BFLOW_E_ARG, "corr_build_split_tiled: bad sizes T=%d B=%d h=%d w=%d Np=%d", T,
+                  B, h, w, Np);
+    BFLOW_REQUIRE(bflow::corr_stream_supported(T, B, D, N, Np), BFLOW_E_ARG, "corr_build_split_tiled: needs D in {64, 128, 256} and < 2 GiB slabs (D=%d N=%d)",
+                  D, N);
+    return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, h, w, (hipStream_t)stream);
 }

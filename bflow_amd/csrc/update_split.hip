@@ -10,11 +10,7 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr float LO_SCALE = 2048.0f;
 
-__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
-    const float h = (fabsf(x) >= 6.103515625e-05f) ? (float)(_Float16)x : 0.0f;
-    hi = (_Float16)h;
-    lo = (_Float16)((x - h) * LO_SCALE);
-}
+using bflow::split1;   // common.h: saturating hi/lo split
 
 __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);

@@ -24,7 +24,7 @@ MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
     "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -105,6 +105,9 @@ def lib() -> ctypes.CDLL:
         "bflow_corr_build_f32": [vp, vp, vp, i, i, i, i, ll, vp],
         "bflow_split_pack": [vp, vp, vp, i, i, i, i, vp],
         "bflow_corr_build_split": [vp, vp, vp, vp, vp, i, i, i, i, i, ll, vp],
+        "bflow_corr_build_split_tiled": [vp, vp, vp, vp, vp, i, i, i, i, i, i, ll, vp],
+        "bflow_corr_pool2x2_tiled": [vp, vp, ll, i, i, vp],
+        "bflow_corr_lookup_bezier_split_tiled": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_conv_pack_weights": [vp, vp, vp, i, i, i, i, i, i, vp],
         "bflow_conv_stem": [ctypes.POINTER(StemDesc), vp],
         "bflow_conv_split": [ctypes.POINTER(ConvDesc), vp],
@@ -217,15 +220,47 @@ def split_pack(src: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def corr_build_split(p1: torch.Tensor, p2: torch.Tensor, out: torch.Tensor, T: int, B: int, N: int, shared_f1: bool):
-    """p1 = split_pack(f1 viewed (B or T*B, D, N)), p2 = split_pack(f2 viewed (T*B, D, N)); out (T, B, N, N)."""
+TILE_H, TILE_W = 4, 8    # tiled volume planes (include/bflow_hip.h, bflow_corr_build_split_tiled)
+
+
+def tiled_plane_size(h: int, w: int) -> int:
+    """Elements of one h x w plane in the tiled layout (4 x 8 tiles, edge tiles padded)."""
+    return ((h + TILE_H - 1) // TILE_H) * ((w + TILE_W - 1) // TILE_W) * TILE_H * TILE_W
+
+
+def untile_planes(t: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """(..., tiled_plane_size(h, w)) -> (..., h, w) row-major copy (debug / reference-shaped accessors only)."""
+    th, tw = (h + TILE_H - 1) // TILE_H, (w + TILE_W - 1) // TILE_W
+    lead = t.shape[:-1]
+    v = t.reshape(*lead, th, tw, TILE_H, TILE_W).transpose(-3, -2).reshape(*lead, th * TILE_H, tw * TILE_W)
+    return v[..., :h, :w].contiguous()
+
+
+def corr_build_split(p1: torch.Tensor, p2: torch.Tensor, out: torch.Tensor, T: int, B: int, N: int, shared_f1: bool,
+                     tiled_hw: Optional[Sequence[int]] = None):
+    """p1 = split_pack(f1 viewed (B or T*B, D, N)), p2 = split_pack(f2 viewed (T*B, D, N)); out (T, B, N, N), or with
+    tiled_hw = (h, w), h*w == N: out (T, B, N, tiled_plane_size(h, w)) -- every plane stored as 4 x 8 tiles."""
     _, R2, KB, Np, _32 = p2.shape
     D = KB * 32
-    assert R2 == T * B and p1.shape[1] == (B if shared_f1 else T * B) and out.shape == (T, B, N, N)
+    assert R2 == T * B and p1.shape[1] == (B if shared_f1 else T * B)
     assert p1.dtype == torch.float16 and p2.dtype == torch.float16 and p1.is_cuda and p2.is_cuda
     assert p1[0].is_contiguous() and p1[1].is_contiguous() and p2[0].is_contiguous() and p2[1].is_contiguous()
-    _check(lib().bflow_corr_build_split(p1[0].data_ptr(), p1[1].data_ptr(), p2[0].data_ptr(), p2[1].data_ptr(), _dev(out, name="out"),
-                                        T, B, D, N, Np, 0 if shared_f1 else B * Np * D, _stream()), "bflow_corr_build_split")
+    if tiled_hw is None:
+        assert out.shape == (T, B, N, N)
+        _check(lib().bflow_corr_build_split(p1[0].data_ptr(), p1[1].data_ptr(), p2[0].data_ptr(), p2[1].data_ptr(), _dev(out, name="out"),
+                                            T, B, D, N, Np, 0 if shared_f1 else B * Np * D, _stream()), "bflow_corr_build_split")
+    else:
+        h, w = int(tiled_hw[0]), int(tiled_hw[1])
+        assert h * w == N and out.shape == (T, B, N, tiled_plane_size(h, w))
+        _check(lib().bflow_corr_build_split_tiled(p1[0].data_ptr(), p1[1].data_ptr(), p2[0].data_ptr(), p2[1].data_ptr(), _dev(out, name="out"),
+                                                  T, B, D, h, w, Np, 0 if shared_f1 else B * Np * D, _stream()), "bflow_corr_build_split_tiled")
+
+
+def corr_pool2x2_tiled(src: torch.Tensor, dst: torch.Tensor, h: int, w: int):
+    """src (planes, tiled_plane_size(h, w)) -> dst (planes, tiled_plane_size(h//2, w//2)): 2x2 mean on tiled planes."""
+    planes = src.numel() // tiled_plane_size(h, w)
+    assert src.shape[-1] == tiled_plane_size(h, w) and dst.shape[-1] == tiled_plane_size(h // 2, w // 2) and dst.numel() == planes * dst.shape[-1]
+    _check(lib().bflow_corr_pool2x2_tiled(_dev(src, name="src"), _dev(dst, name="dst"), planes, h, w, _stream()), "bflow_corr_pool2x2_tiled")
 
 
 def corr_pool2x2(src: torch.Tensor, dst: torch.Tensor):
@@ -237,12 +272,14 @@ def corr_pool2x2(src: torch.Tensor, dst: torch.Tensor):
 
 
 def make_plane_table(planes: Sequence[dict]):
-    """planes: [{tensor: (B*N, h, w) slab, level: int, target: int}] -> ctypes array (keeps no reference to tensors)."""
+    """planes: [{tensor: (B*N, h, w) slab -- or (B*N, tiled size) with "hw": (h, w) for tiled planes --, level: int, target: int}]
+    -> ctypes array (keeps no reference to tensors)."""
     arr = (PlaneDesc * len(planes))()
     for k, p in enumerate(planes):
         t = p["tensor"]
         arr[k].base = _dev(t, name=f"plane{k}")
-        arr[k].h, arr[k].w = int(t.shape[-2]), int(t.shape[-1])
+        hw = p.get("hw")
+        arr[k].h, arr[k].w = (int(t.shape[-2]), int(t.shape[-1])) if hw is None else (int(hw[0]), int(hw[1]))
         arr[k].level, arr[k].target = int(p["level"]), int(p["target"])
     return arr
 
@@ -266,17 +303,19 @@ def corr_lookup_bezier(table, params: torch.Tensor, coef: np.ndarray, out: torch
                                           T, deg, _dev(out, name="out"), B, h1, w1, _stream()), "bflow_corr_lookup_bezier")
 
 
-def corr_lookup_bezier_split(table, params: torch.Tensor, coef: np.ndarray, out_planes: torch.Tensor):
-    """out_planes: (2, B, CBk, rows, 32) fp16 (hi, lo), zero-initialised once by the caller (pad channels are never written)."""
+def corr_lookup_bezier_split(table, params: torch.Tensor, coef: np.ndarray, out_planes: torch.Tensor, tiled: bool = False):
+    """out_planes: (2, B, CBk, rows, 32) fp16 (hi, lo), zero-initialised once by the caller (pad channels are never written by the row-major
+    kernel).  tiled: the plane table describes tiled planes (bflow_corr_build_split_tiled / bflow_corr_pool2x2_tiled)."""
     B, C2, h1, w1 = params.shape
     T, deg = coef.shape
     assert C2 == 2 * deg and coef.dtype == np.float32 and coef.flags["C_CONTIGUOUS"]
     P = len(table)
     assert out_planes.dtype == torch.float16 and out_planes.is_contiguous() and out_planes.shape[0] == 2 and out_planes.shape[1] == B \
         and out_planes.shape[4] == 32 and out_planes.shape[2] * 32 >= P * 81 and out_planes.shape[3] >= h1 * w1
-    _check(lib().bflow_corr_lookup_bezier_split(table, P, _dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                                                T, deg, out_planes[0].data_ptr(), out_planes[1].data_ptr(), out_planes.shape[2],
-                                                out_planes.shape[3], B, h1, w1, _stream()), "bflow_corr_lookup_bezier_split")
+    fn = lib().bflow_corr_lookup_bezier_split_tiled if tiled else lib().bflow_corr_lookup_bezier_split
+    _check(fn(table, P, _dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+              T, deg, out_planes[0].data_ptr(), out_planes[1].data_ptr(), out_planes.shape[2],
+              out_planes.shape[3], B, h1, w1, _stream()), "bflow_corr_lookup_bezier_split" + ("_tiled" if tiled else ""))
 
 
 # ------------------------------------------------------------------------------------------------ K8

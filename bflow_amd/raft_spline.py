@@ -259,7 +259,10 @@ class RAFTSpline(nn.Module):
 
         if pr: pr("fnet.end")
         if tm: tm.start("corr computation")
-        corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img)
+        # product path (engine look-up inside the step): tiled planes; the stage-timed / library variants keep the reference's row-major planes
+        tiled = engine_update and tm is None and all(c is None or c.tiled_supported() for c in (corr_ev, corr_img))
+        corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img,
+                                                  layout="tiled" if tiled else "rows")
         if tm: tm.stop("corr computation")
         if pr: pr("corr.end")
         cnet_branch.join()

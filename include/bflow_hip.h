@@ -57,7 +57,15 @@ int bflow_corr_build_f32(const float* f1, const float* f2, float* out,
  *                           Np = N rounded up to a multiple of 128, D % 8 == 0
  *   bflow_corr_build_split: f1_* (B, Np, D) [f1_target_stride == 0] or per-target blocks f1_target_stride elements
  *                           apart; f2_* (T, B, Np, D); out (T, B, N, N) fp32; D % 32 == 0                        */
+/* bflow_corr_build_split_tiled: the same volume with TILED planes, the layout of the inference product path.  The h x w plane of a query
+ * pixel is stored as ceil(h/4) x ceil(w/8) tiles of 4 x 8 elements (one fp32 tile = one 128-B line; tiles in row-major order, row-major
+ * inside a tile):  element (y, x) at ((y/4)*ceil(w/8) + x/8)*32 + (y%4)*8 + x%8, plane stride = tiles*32.  out (T, B, N, tiles*32) fp32;
+ * pad positions of edge tiles hold finite values.  D in {64, 128, 256} only (written by the streaming kernel, csrc/corr_stream.hip).
+ * Why: the look-up gathers a 12 x 12 neighbourhood per (pixel, plane); row-major that is 12 partial lines (~2.1 KB moved for 400 B
+ * used), tiled ~9 full lines.                                                                                                          */
 int bflow_split_pack(const float* src, void* hi, void* lo, int R, int D, int N, int Np, bflow_stream_t stream);
+int bflow_corr_build_split_tiled(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out,
+                                 int T, int B, int D, int h, int w, int Np, long long f1_target_stride, bflow_stream_t stream);
 int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out,
                            int T, int B, int D, int N, int Np, long long f1_target_stride, bflow_stream_t stream);
 
@@ -215,6 +223,14 @@ int bflow_corr_lookup_bezier(const bflow_plane_t* planes, int P, const float* pa
 int bflow_corr_lookup_bezier_split(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
                                    void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
                                    bflow_stream_t stream);
+/* ... on TILED planes (bflow_corr_build_split_tiled / bflow_corr_pool2x2_tiled): `base` of a descriptor points at (B*N, tiles*32) tiled
+ * planes, h / w stay the LOGICAL plane size.  One workgroup = 8 query pixels x all planes, LDS-DMA gather of aligned 16-B units, zero
+ * padding applied through the tap weights; every channel of the last channel block is written (pads as zeros).
+ * bflow_corr_pool2x2_tiled: K6 (2x2 mean, floor on odd sizes) tiled -> tiled; pad positions of the output are zero.                    */
+int bflow_corr_lookup_bezier_split_tiled(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
+                                         void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
+                                         bflow_stream_t stream);
+int bflow_corr_pool2x2_tiled(const float* in, float* out, long long planes, int h, int w, bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K8  Bezier polynomial coefficients C(deg,i) (1-t)^(deg-i) t^i, i = 1..deg, computed in fp64 on the HOST

@@ -2,7 +2,7 @@
 
 `build(model, vox, cfg)` returns a list of dicts {key, name, regex, bound, launch, flops, bytes}: `launch()` enqueues ONE launch of the
 kernel on torch's current stream.  bench.py times them with hipEvents; tools/roofline_probe.py runs them under
-`rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex <regex>` to produce profiles/r01_pmc.json.
+`rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex <regex>` to produce profiles/r02_pmc.json.
 """
 import torch
 
@@ -10,7 +10,7 @@ from bflow_amd import hip, split as S
 from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
 
 CONV_NAME = "conv_halo_kernel<2,3,3> (encoder layer1 3x3 64->64, 5x240x320)"
-K5_NAME = "corr_build_split_v2_kernel"
+K5_NAME = "corr_stream_kernel<8, true> (bflow_corr_build_split, D = 256)"
 LOOKUP_NAME = "corr_lookup_kernel<fused bezier, split out>"
 
 
@@ -41,7 +41,7 @@ def build(model, vox, cfg, low_params=None):
         T = len(grids) - 1
         planes = model.fnet_ev.forward_split(x5, out_rows=hip.padded_rows(N)).planes
         vol = torch.empty((T, B, N, N), device=dev)
-        out.append(dict(key="roofline_corr_build", name=K5_NAME, regex="corr_build_split", bound="hbm",
+        out.append(dict(key="roofline_corr_build", name=K5_NAME, regex="corr_stream_kernel", bound="hbm",
                         launch=lambda: hip.corr_build_split(planes[:, :B], planes[:, B:], vol, T, B, N, shared_f1=True),
                         flops=2.0 * T * B * D * N * N, bytes=4.0 * ((1 + T) * B * D * N + T * B * N * N)))
         # (3) the look-up gather (HBM-bound), 24.33 MB algorithmic per sample-iteration at C2: 100 taps read + 81 values written
