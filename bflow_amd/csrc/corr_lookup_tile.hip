@@ -33,7 +33,6 @@ constexpr int WIN = 2 * R + 1;              // 9
 constexpr int NCH = WIN * WIN;              // 81
 constexpr int PATCH = 12;                   // rows floor(c)-5 .. floor(c)+6 cover every bilinear corner incl. round-off flips
 constexpr int TILE_H = 4, TILE_W = 8;       // plane tiling (elements)
-constexpr int THREADS = 256;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -63,7 +62,7 @@ __device__ __forceinline__ int tiled_index(int y, int x, int tw) {
     return (((y >> 2) * tw + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
 }
 
-template <typename VT, int TP>
+template <typename VT, int TP, int THREADS>
 __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args, const float* __restrict__ params, _Float16* __restrict__ oh,
                                                                  _Float16* __restrict__ ol, int CBk, int Prow, int h1, int w1, int abl) {
     constexpr int EPU = 16 / (int)sizeof(VT);          // elements per 16-B unit: 4 (fp32) / 8 (fp16)
@@ -78,6 +77,7 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     const int b = blockIdx.y;
     const int n0 = blockIdx.x * TP;
     const int npair = P * TP;                 // pair = plane * TP + pixel of the tile
+    const bool swz_on = !(abl & 16);
     const int cstride = ((P * NCH + 31) >> 5) * 32;   // staged channels per pixel (whole channel blocks)
     // plane table (indexed per lane: a runtime index into the kernel-argument struct would spill the struct to scratch)
     const char** s_base = reinterpret_cast<const char**>(smem);                   // [MAX_PLANES]
@@ -139,7 +139,10 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
             const int r = ru / UPR, k = ru - r * UPR;
             const int p = pair / TP, i = pair - p * TP;
             const int th = (s_h[p] + TILE_H - 1) >> 2, tw = (s_w[p] + TILE_W - 1) >> 3;
-            const int gy = s_oy[pair] + r, gx = s_ox[pair] + k * EPU;
+            // LDS position (pair, r, k) holds source unit k ^ swz(r, pair): spreads the interpolation's reads over the banks (a patch row is
+            // 64 B and a patch 768 B, so without it rows alternate between two bank groups and all pairs share them)
+            const int ks = (UPR == 4 && swz_on) ? (k ^ (((r >> 1) ^ pair) & 3)) : k;
+            const int gy = s_oy[pair] + r, gx = s_ox[pair] + ks * EPU;
             const bool in = gy >= 0 && gy < th * TILE_H && gx >= 0 && gx < tw * TILE_W;   // inside the tile grid (pads included)
             const long long plane = (long long)b * N + min(n0 + i, N - 1);               // pixels past the end re-read the last one (never stored)
             const long long off = plane * (th * tw * 32) + (in ? tiled_index(gy, gx, tw) : 0);
@@ -179,17 +182,20 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
         const int* at = s_at + pair * 18;
         const float* wt = s_wt + pair * 36;
         const float wn = wt[2 * (WIN + ky)], ws = wt[2 * (WIN + ky) + 1];
-        const VT* row = patch + pair * PELEMS + at[WIN + ky] * PCOLS;
+        const int ay = at[WIN + ky];
+        const VT* row0 = patch + pair * PELEMS + ay * PCOLS;
+        const VT* row1 = row0 + PCOLS;
+        const int z0 = (UPR == 4 && swz_on) ? ((((ay >> 1) ^ pair) & 3) << 2) : 0, z1 = (UPR == 4 && swz_on) ? (((((ay + 1) >> 1) ^ pair) & 3) << 2) : 0;
         float* dst = stage + i * cstride + p * NCH + ky * WIN;
 #pragma unroll
         for (int kx = 0; kx < WIN; ++kx) {
             const float ww = wt[2 * kx], we = wt[2 * kx + 1];
-            const VT* q = row + at[kx];
+            const int c0 = at[kx], c1 = c0 + 1;
             // utils.py:19 / grid_sample: nw*I_nw + ne*I_ne + sw*I_sw + se*I_se, weights as products of the axis weights
-            float v = (float)q[0] * (ww * wn);
-            v += (float)q[1] * (we * wn);
-            v += (float)q[PCOLS] * (ww * ws);
-            v += (float)q[PCOLS + 1] * (we * ws);
+            float v = (float)row0[c0 ^ z0] * (ww * wn);
+            v += (float)row0[c1 ^ z0] * (we * wn);
+            v += (float)row1[c0 ^ z1] * (ww * ws);
+            v += (float)row1[c1 ^ z1] * (we * ws);
             dst[kx] = v;
         }
     }
@@ -268,22 +274,26 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
         a.planes[p].target = planes[p].target;
     }
     for (int i = 0; i < T * deg; ++i) a.coef[i] = coef[i];
-    static const int tp_env = [] { const char* e = getenv("BFLOW_LOOKUP_TP"); return e ? atoi(e) : 0; }();   // tools: tile size A/B
-    const int tp = (tp_env == 4 || tp_env == 8) ? tp_env : 8;
-    static const int abl = [] { const char* e = getenv("BFLOW_LOOKUP_ABL"); return e ? atoi(e) : 0; }();   // tools: phase ablation (timing only)
+    // tile = 2 query pixels x all planes, 256 threads: 16-33 KB of LDS per workgroup -> 5-8 workgroups per CU (measured best of
+    // {2, 4, 8} pixels x {128, 256} threads at every BASELINE shape; BFLOW_LOOKUP_TP / BFLOW_LOOKUP_ABL are timing knobs for tools/)
+    static const int tp_env = [] { const char* e = getenv("BFLOW_LOOKUP_TP"); return e ? atoi(e) : 0; }();
+    static const int abl = [] { const char* e = getenv("BFLOW_LOOKUP_ABL"); return e ? atoi(e) : 0; }();
+    const int tp = (tp_env == 2 || tp_env == 4 || tp_env == 8) ? tp_env : 2;
     const int cstride = ((P * NCH + 31) >> 5) * 32;
     const int lds = 16 * BFLOW_MAX_PLANES + P * tp * (4 + 18 + 36) * 4 + P * tp * PATCH * 16 * (f16_planes ? 3 : 4) + tp * cstride * 4 + 1024;
     dim3 grid(ceil_div((long long)h1 * w1, tp), B);
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, stream, a, params, (_Float16*)out_hi, (_Float16*)out_lo, channel_blocks, rows_per_image, h1, w1, abl);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, params, (_Float16*)out_hi, (_Float16*)out_lo, channel_blocks, rows_per_image, h1, w1, abl);
     };
     if (f16_planes) {
-        if (tp == 4) go(corr_lookup_tile_kernel<_Float16, 4>);
-        else go(corr_lookup_tile_kernel<_Float16, 8>);
+        if (tp == 2) go(corr_lookup_tile_kernel<_Float16, 2, 256>);
+        else if (tp == 4) go(corr_lookup_tile_kernel<_Float16, 4, 256>);
+        else go(corr_lookup_tile_kernel<_Float16, 8, 256>);
     } else {
-        if (tp == 4) go(corr_lookup_tile_kernel<float, 4>);
-        else go(corr_lookup_tile_kernel<float, 8>);
+        if (tp == 2) go(corr_lookup_tile_kernel<float, 2, 256>);
+        else if (tp == 4) go(corr_lookup_tile_kernel<float, 4, 256>);
+        else go(corr_lookup_tile_kernel<float, 8, 256>);
     }
     return launch_status("corr_lookup_bezier_split");
 }

@@ -180,6 +180,56 @@ def test_lookup_fused_bezier_matches_unfused(deg):
     assert sp.planes.shape[2] == (C + 31) // 32 and float(sp.planes[:, :, -1, :, C % 32:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,D,h,w,levels", [(2, 64, 9, 11, [1, 2, 3]), (1, 128, 15, 20, [1, 4]), (1, 256, 60, 80, [1, 1, 1, 4]), (2, 256, 33, 40, [2])])
+def test_tiled_volume_and_pyramid_equal_row_major(B, D, h, w, levels):
+    """The inference product path stores every plane as 4 x 8 tiles (bflow_corr_build_split_tiled, bflow_corr_pool2x2_tiled).  Untiled, the
+    volume and every pyramid level must equal the row-major build BIT FOR BIT (same MFMA chains, same 2x2 means), for plane sizes that are
+    no multiples of the tile (9x11, 15x20 -> 7x10 -> 3x5, 33x40) and at DSEC size."""
+    T = len(levels)
+    rs = np.random.RandomState(11)
+    f1, f2 = cu(rs.standard_normal((B, D, h, w)).astype(np.float32)), cu(rs.standard_normal((T, B, D, h, w)).astype(np.float32))
+    rows = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, levels))
+    tiled = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, levels), layout="tiled")
+    assert tiled._tiled and tiled._pyramid[0][0].shape[-1] == hip.tiled_plane_size(h, w)
+    for lvl in range(max(levels)):
+        a, ia = rows.pyramid_level(lvl)
+        b, ib = tiled.pyramid_level(lvl)
+        assert ia == ib and a.shape == b.shape
+        assert torch.equal(a, b), f"level {lvl}: max diff {(a - b).abs().max().item():.3e}"
+    # pad positions of edge tiles are finite (the look-up multiplies them by zero weights)
+    assert all(bool(torch.isfinite(t).all()) for t, _ in tiled._pyramid)
+
+
+@pytest.mark.parametrize("deg,B,h,w,levels", [(2, 2, 18, 22, [1, 2, 4]), (10, 1, 15, 20, [1, 1, 3]), (2, 1, 60, 80, [1, 1, 1, 4])])
+def test_lookup_tiled_split_vs_oracle(deg, B, h, w, levels):
+    """The tile look-up kernel (LDS-DMA gather of aligned 16-B units from tiled planes, zero padding through the tap weights) against the
+    oracle's bilinear_sampler look-up: coordinates inside, on the border, negative, integer-valued and far outside (all-zero windows)."""
+    T, D = len(levels), 64
+    rs = np.random.RandomState(5)
+    f1, f2 = cu(rs.standard_normal((B, D, h, w)).astype(np.float32)), cu(rs.standard_normal((T, B, D, h, w)).astype(np.float32))
+    params = (rs.standard_normal((B, 2 * deg, h, w)) * 2).astype(np.float32)
+    params[:, :, 0, :3] *= 60.0            # far outside: every tap is padding
+    params[:, :, 1, :] = np.round(params[:, :, 1, :])   # integer coordinates (weights exactly 0 / 1)
+    params[:, :, -1, :] = np.abs(params[:, :, -1, :]) + 3.0   # pushed over the bottom / right border
+    times = [(i + 1) / T for i in range(T)]
+    coef = hip.bezier_coeffs(times, deg)
+    blk = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, levels), layout="tiled")
+    sp = blk.lookup_bezier_split(cu(params), coef, blk.new_output_split())
+    C = blk.num_planes * 81
+    got = sp.float_nhwc()[..., :C].permute(0, 3, 1, 2).cpu()
+    coords = O.coords_grid(B, h, w) + O.bezier_flow(torch.from_numpy(params), times)
+    ref = O.corr_lookup(O.corr_pyramid(O.corr_volume(f1.cpu(), f2.cpu()), levels), coords)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=5e-5)
+    far = ref.abs().amax(dim=1) == 0.0                   # pixels whose every tap of every plane is padding: exact zeros, not "small"
+    assert bool(far.any()) and float(got.permute(0, 2, 3, 1)[far].abs().max()) == 0.0
+    # pad channels of the last channel block are written as zeros
+    assert float(sp.planes[:, :, -1, :, C % 32:].abs().max()) == 0.0 if C % 32 else True
+    # and the row-major one-plane kernel gives the same features from the same operands
+    rows = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, levels))
+    sp2 = rows.lookup_bezier_split(cu(params), coef, rows.new_output_split())
+    assert (sp2.float_nhwc() - sp.float_nhwc()).abs().max().item() < 2e-6
+
+
 # ------------------------------------------------------------------------------------------------- K8 / K13
 @pytest.mark.parametrize("deg", [2, 10])
 def test_bezier_golden(golden_dir, deg):
