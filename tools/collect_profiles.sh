@@ -18,7 +18,7 @@ python "$REPO/tools/pmc_to_json.py" "$OUT" "$OUT/r02_pmc.json" > /dev/null
 python - "$OUT" <<'PY'
 import csv, sys, os
 d = sys.argv[1]
-for key, rx in (("roofline", "conv_halo_kernel"), ("roofline_corr_build", "corr_build_split"), ("roofline_lookup", "corr_lookup_kernel")):
+for key, rx in (("roofline", "conv_halo_kernel"), ("roofline_corr_build", "corr_stream_kernel"), ("roofline_lookup", "corr_lookup_tile_kernel")):
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         p = os.path.join(d, f"{key}_{c}.csv")
         rows = list(csv.DictReader(open(p)))

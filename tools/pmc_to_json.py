@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d, outp = sys.argv[1], sys.argv[2]
 NAMES = {"roofline": ("conv_halo_kernel<2,3,3> (encoder layer1 3x3 64->64, 5x240x320)", "conv_halo_kernel", True, 196755456.0),
          "roofline_corr_build": ("corr_stream_kernel<8, true> (bflow_corr_build_split, D = 256)", "corr_stream_kernel", True, 393216000.0),
-         "roofline_lookup": ("corr_lookup_kernel<fused bezier, split out>", "corr_lookup_kernel", False, 24326400.0)}
+         "roofline_lookup": ("corr_lookup_tile_kernel<float, 2, 256> (fused bezier, tiled planes, split out)", "corr_lookup_tile_kernel", True, 24326400.0)}
 def avg(path, counter, regex):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and regex in r["Kernel_Name"]]
     vals = vals[-5:]                      # the probe's own launches are the last ones (the warm-up forward also runs these kernels)

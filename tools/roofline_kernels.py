@@ -11,7 +11,7 @@ from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
 
 CONV_NAME = "conv_halo_kernel<2,3,3> (encoder layer1 3x3 64->64, 5x240x320)"
 K5_NAME = "corr_stream_kernel<8, true> (bflow_corr_build_split, D = 256)"
-LOOKUP_NAME = "corr_lookup_kernel<fused bezier, split out>"
+LOOKUP_NAME = "corr_lookup_tile_kernel<float, 2, 256> (fused bezier, tiled planes, split out)"
 
 
 def build(model, vox, cfg, low_params=None):
@@ -47,11 +47,11 @@ def build(model, vox, cfg, low_params=None):
         # (3) the look-up gather (HBM-bound), 24.33 MB algorithmic per sample-iteration at C2: 100 taps read + 81 values written
         #     (4 B each; the split output is also 4 B per value) per (pixel, plane)
         cc = CorrComputation.from_packed(planes[:, :B], planes[:, B:], B, D, h8, w8, cfg["correlation"]["ev"]["levels"])
-        cblk = CorrBlockParallelMultiTarget(corr_computation_events=cc)
+        cblk = CorrBlockParallelMultiTarget(corr_computation_events=cc, layout="tiled")   # the product path's layout
         params = (torch.randn(B, 2 * model.bezier_degree, h8, w8, device=dev) * 4 if low_params is None else low_params.clone())
         feat = cblk.new_output_split()
         coef = model._coefficients()
-        out.append(dict(key="roofline_lookup", name=LOOKUP_NAME, regex="corr_lookup_kernel", bound="hbm",
+        out.append(dict(key="roofline_lookup", name=LOOKUP_NAME, regex="corr_lookup_tile_kernel", bound="hbm",
                         launch=lambda: cblk.lookup_bezier_split(params, coef, feat),
                         flops=None, bytes=4.0 * B * N * cblk.num_planes * (100 + 81), keep=(cblk, vol, planes)))
     return out
