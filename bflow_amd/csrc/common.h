@@ -36,8 +36,8 @@ static inline int reduce_grid(long long work_items, int block) {
 // ---- the split-fp16 number format of the matrix-core path -------------------------------------------------------
 // x ~= hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11): ~22 significant bits.  Supported range (stated in bflow_hip.h):
 //   |x| <= 65504 (fp16 max): larger magnitudes SATURATE to +-65504 instead of becoming hi = inf, lo = NaN; NaN stays NaN;
-//   |x| <  2^-14: hi = 0 (the matrix cores flush fp16 subnormal INPUTS) and the whole value lives in the pre-scaled lo, which is
-//                 normal down to 2^-25 and then denormalises gracefully (absolute error <= 2^-36 ~ 1.5e-11 there).
+//   |x| <  2^-14: hi = 0 (the matrix cores flush fp16 subnormal INPUTS) and the whole value lives in the pre-scaled lo: 11 significant
+//                 bits, i.e. an absolute error <= 2^-14 * 2^-11 = 3e-8 (lo itself is normal down to |x| = 2^-25).
 constexpr float SPLIT_LO_SCALE = 2048.0f, SPLIT_LO_INV = 1.0f / 2048.0f, SPLIT_MAX = 65504.0f;
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     const float xc = __builtin_fminf(__builtin_fmaxf(x, -SPLIT_MAX), SPLIT_MAX);   // v_med3-class clamp; passes NaN through below

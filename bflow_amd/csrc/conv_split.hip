@@ -30,7 +30,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
+constexpr float LO_INV = 1.0f / 2048.0f;
 constexpr int CBM = 128, CT = 256;
 
 using bflow::split1;   // common.h: saturating hi/lo split

@@ -8,7 +8,6 @@
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-constexpr float LO_SCALE = 2048.0f;
 
 using bflow::split1;   // common.h: saturating hi/lo split
 

@@ -3,12 +3,11 @@
 Same module tree and parameter names as the reference (so its checkpoints load), inference only.  `forward_split` is the product
 path: every convolution runs on the hand-written split-fp16 MFMA engine (csrc/conv_split.hip: 7x7/2 stem with im2col in LDS,
 halo kernel for the 3x3s, generic kernel for stride 2 / 1x1), bias / folded BatchNorm / ReLU / InstanceNorm statistics live in the
-conv epilogues, and one normalise + activate + residual kernel sits between convolutions.  `forward` (MIOpen through PyTorch-ROCm)
-is kept for A/B runs only (BFLOW_CONV_ENGINE=miopen).
+conv epilogues, and one normalise + activate + residual kernel sits between convolutions.  `forward` is the plain nn.Module forward
+(torch ops): the differentiable training path (bflow_amd/training.py) runs on it under autograd; inference never does.
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, Optional, Sequence, Union
 
 import torch
@@ -18,7 +17,6 @@ import torch.nn.functional as F
 from . import split as S
 
 STATS_R = 8
-STEM = os.environ.get("BFLOW_STEM", "hip")     # "miopen": the library 7x7 convolution instead of conv_stem_kernel (A/B only)
 
 
 def _make_norm(kind: str, channels: int) -> nn.Module:
@@ -136,14 +134,7 @@ class BasicEncoder(nn.Module):
         c0 = self.conv1.out_channels
         h0, w0 = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1
         xin = x if isinstance(x, S.ChannelWindows) else x.contiguous()
-        if STEM == "miopen":       # the library convolution, kept for A/B
-            y = F.conv2d(x.materialize() if isinstance(x, S.ChannelWindows) else x, self.conv1.weight, None, stride=2, padding=3)
-            if kind == "instance":
-                cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, stats_a=S.plane_stats(y), act_a=S.ACT_RELU)
-            else:
-                sc, sh = self._bn_affine(self.norm1, self.conv1.bias)
-                cur, _ = S.norm_act(y, (n, h0, w0, c0), a_is_nchw=True, scale_a=sc, shift_a=sh, act_a=S.ACT_RELU)
-        elif kind == "instance":   # the conv bias cancels under InstanceNorm; statistics come out of the epilogue
+        if kind == "instance":     # the conv bias cancels under InstanceNorm; statistics come out of the epilogue
             st0 = new_stats(c0)
             _, f0 = S.conv_stem(xin, pk0, stats=st0, want_split=False, want_f32=True)
             cur, _ = S.norm_act(f0, (n, h0, w0, c0), stats_a=st0, act_a=S.ACT_RELU)

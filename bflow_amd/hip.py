@@ -25,8 +25,8 @@ ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
     "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
-    "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", "bflow_concat2_act", "bflow_bias_act_inplace",
-    "bflow_gru_rh", "bflow_gru_blend", "bflow_tanh_relu_split", "bflow_add_delta", "bflow_cvx_upsample",
+    "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", 
+    "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
     "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_scatter_rectified", "bflow_maxabs_diff",
     "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
@@ -122,12 +122,6 @@ def lib() -> ctypes.CDLL:
         "bflow_corr_lookup_bezier_split": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_bezier_coeffs": [ctypes.POINTER(ctypes.c_double), i, i, ctypes.POINTER(ctypes.c_float)],
         "bflow_bezier_eval": [vp, ctypes.POINTER(ctypes.c_float), i, i, i, i, i, i, vp, vp],
-        "bflow_concat2_act": [vp, ll, i, vp, i, vp, ll, i, vp, i, vp, ll, vp, ll, i, i, vp],
-        "bflow_bias_act_inplace": [vp, ll, vp, i, i, i, i, vp],
-        "bflow_gru_rh": [vp, ll, vp, vp, ll, vp, ll, i, i, i, vp],
-        "bflow_gru_blend": [vp, ll, vp, vp, ll, vp, vp, ll, vp, ll, i, i, i, vp],
-        "bflow_tanh_relu_split": [vp, ll, vp, i, i, vp, ll, vp, ll, i, i, vp],
-        "bflow_add_delta": [vp, vp, vp, i, i, i, vp],
         "bflow_cvx_upsample": [vp, vp, vp, f, vp, i, i, i, i, vp],
         "bflow_voxel_scatter_f32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
         "bflow_voxel_scatter_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
@@ -336,62 +330,6 @@ def bezier_eval(params: torch.Tensor, coef: np.ndarray, add_coords0: bool = Fals
     _check(lib().bflow_bezier_eval(_dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), T, deg, B, h, w,
                                    int(add_coords0), _dev(out), _stream()), "bflow_bezier_eval")
     return out
-
-
-# ------------------------------------------------------------------------------------------------ K9 / K10 / K12
-def concat2_act(a: torch.Tensor, bias_a, act_a: int, b: Optional[torch.Tensor], bias_b, act_b: int,
-                dst1: torch.Tensor, dst2: Optional[torch.Tensor] = None):
-    B, Ca = a.shape[:2]
-    HW = int(np.prod(a.shape[2:]))
-    Cb = 0 if b is None else b.shape[1]
-    pa, sa = _slice(a, "a")
-    pb, sb = (None, 0) if b is None else _slice(b, "b")
-    p1, s1 = _slice(dst1, "dst1")
-    p2, s2 = (None, 0) if dst2 is None else _slice(dst2, "dst2")
-    assert dst1.shape[1] == Ca + Cb and (dst2 is None or dst2.shape[1] == Ca + Cb)
-    _check(lib().bflow_concat2_act(pa, sa, Ca, _opt(bias_a, "bias_a"), act_a, pb, sb, Cb, _opt(bias_b, "bias_b"), act_b,
-                                   p1, s1, p2, s2, B, HW, _stream()), "bflow_concat2_act")
-
-
-def bias_act_inplace(x: torch.Tensor, bias: Optional[torch.Tensor], act: int):
-    B, C = x.shape[:2]
-    px, sx = _slice(x, "x")
-    _check(lib().bflow_bias_act_inplace(px, sx, _opt(bias, "bias"), act, B, C, int(np.prod(x.shape[2:])), _stream()),
-           "bflow_bias_act_inplace")
-
-
-def gru_rh(r_pre: torch.Tensor, bias_r, h: torch.Tensor, rh: torch.Tensor):
-    B, C = h.shape[:2]
-    pr, sr = _slice(r_pre, "r_pre")
-    ph, sh = _slice(h, "h")
-    po, so = _slice(rh, "rh")
-    _check(lib().bflow_gru_rh(pr, sr, _opt(bias_r, "bias_r"), ph, sh, po, so, B, C, int(np.prod(h.shape[2:])), _stream()), "bflow_gru_rh")
-
-
-def gru_blend(z_pre: torch.Tensor, bias_z, q_pre: torch.Tensor, bias_q, h: torch.Tensor, h2: Optional[torch.Tensor] = None):
-    B, C = h.shape[:2]
-    pz, sz = _slice(z_pre, "z_pre")
-    pq, sq = _slice(q_pre, "q_pre")
-    ph, sh = _slice(h, "h")
-    p2, s2 = (None, 0) if h2 is None else _slice(h2, "h2")
-    _check(lib().bflow_gru_blend(pz, sz, _opt(bias_z, "bias_z"), pq, sq, _opt(bias_q, "bias_q"), ph, sh, p2, s2, B, C,
-                                 int(np.prod(h.shape[2:])), _stream()), "bflow_gru_blend")
-
-
-def tanh_relu_split(cnet: torch.Tensor, bias, c_h: int, c_i: int, net: torch.Tensor, inp: torch.Tensor):
-    B = cnet.shape[0]
-    pc, sc = _slice(cnet, "cnet")
-    pn, sn = _slice(net, "net")
-    pi, si = _slice(inp, "inp")
-    _check(lib().bflow_tanh_relu_split(pc, sc, _opt(bias, "bias"), c_h, c_i, pn, sn, pi, si, B, int(np.prod(cnet.shape[2:])), _stream()),
-           "bflow_tanh_relu_split")
-
-
-def add_delta(params: torch.Tensor, delta: torch.Tensor, bias: Optional[torch.Tensor]):
-    B, C = params.shape[:2]
-    assert params.shape == delta.shape
-    _check(lib().bflow_add_delta(_dev(params, name="params"), _dev(delta, name="delta"), _opt(bias, "bias"), B, C,
-                                 int(np.prod(params.shape[2:])), _stream()), "bflow_add_delta")
 
 
 # ------------------------------------------------------------------------------------------------ K13

@@ -19,7 +19,6 @@ Inputs must live on the GPU: there is no CPU fallback (the CPU restatement lives
 """
 from __future__ import annotations
 
-import os
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -34,11 +33,6 @@ from .extractor import BasicEncoder
 from .timers import StageTimer
 from .update import BasicUpdateBlock
 
-
-# Encoder arithmetic: "split" = split-fp16 MFMA engine (csrc/conv_split.hip; fp32-class accuracy), "miopen" = fp32 MIOpen
-# convolutions through torch.  Both are parity-tested; override with BFLOW_CONV_ENGINE.
-CONV_ENGINE = os.environ.get("BFLOW_CONV_ENGINE", "split")
-UPDATE_ENGINE = os.environ.get("BFLOW_UPDATE_ENGINE", "split")   # GRU / motion-encoder / head convolutions: "split" | "miopen"
 
 
 class RAFTSpline(nn.Module):
@@ -170,6 +164,24 @@ class RAFTSpline(nn.Module):
             return BezierCurves(low), BezierCurves(ups[-1])
         return [BezierCurves(u) for u in ups]
 
+    def check_engine_support(self):
+        """Inference runs on the hand-written HIP engine ONLY.  A configuration it cannot run is refused here, loudly, instead of being
+        routed to a library: there is no MIOpen / rocBLAS / CPU path in this package's inference forward."""
+        bad = []
+        for name in ("fnet_ev", "fnet_img", "cnet"):
+            net = getattr(self, name)
+            if net is None:
+                continue
+            if net.norm_fn not in ("instance", "batch"):
+                bad.append(f"{name}.norm_fn = {net.norm_fn!r} (the engine fuses InstanceNorm statistics / folded BatchNorm only)")
+            if name != "cnet" and net.conv2.out_channels not in (64, 128, 256):
+                bad.append(f"{name} output dim {net.conv2.out_channels} (the correlation kernels take 64, 128 or 256 feature channels)")
+        if self.fnet_ev is not None and len(self.ev_corr_target_indices) + 1 > 8:
+            bad.append(f"{len(self.ev_corr_target_indices)} event targets (the stem reads at most 8 channel windows in place)")
+        if bad:
+            raise hip.BflowHipError("RAFTSpline: configuration not supported by the HIP engine: " + "; ".join(bad))
+        self.update_block.check_engine_support()
+
     # ---------------------------------------------------------------------------------------- the hot path
     def _forward_impl(self, voxel_grid, images, iters: int, flow_init: Optional[torch.Tensor], test_mode: bool):
         """raft.py:101-200 on the HIP kernels.  No host<->device synchronisation anywhere (hipGraph-capturable)."""
@@ -179,21 +191,16 @@ class RAFTSpline(nn.Module):
         corr_ev = corr_img = None
         context_input = None
 
-        engine = CONV_ENGINE == "split" and self.fnet_ev is not None and self.fnet_ev.norm_fn in ("instance", "batch") \
-            and self.cnet.norm_fn in ("instance", "batch")
+        self.check_engine_support()
 
         def encode_pair(net, x, n_ref, levels):
-            """Feature encoder on a stacked batch [reference | targets] -> CorrComputation."""
+            """Feature encoder on a stacked batch [reference | targets] -> CorrComputation.  The last convolution writes K5's operand
+            format directly: (2, nb, D/32, Np, 32), tail rows zero."""
             nb, _, Hh, Ww = x.shape
             h8, w8 = Hh // 8, Ww // 8
             D = net.conv2.out_channels
-            T = nb // n_ref - 1
-            if engine and D % 64 == 0:
-                # the last convolution writes K5's operand format directly: (2, nb, D/32, Np, 32), tail rows zero
-                planes = net.forward_split(x, out_rows=hip.padded_rows(h8 * w8)).planes
-                return CorrComputation.from_packed(planes[:, :n_ref], planes[:, n_ref:], n_ref, D, h8, w8, levels)
-            fm = net(x).float()
-            return CorrComputation(fm[:n_ref], fm[n_ref:].view(T, n_ref, *fm.shape[1:]), num_levels_per_target=levels)
+            planes = net.forward_split(x, out_rows=hip.padded_rows(h8 * w8)).planes
+            return CorrComputation.from_packed(planes[:, :n_ref], planes[:, n_ref:], n_ref, D, h8, w8, levels)
 
         # ---- inputs of the three encoders (raft.py:118-141)
         grids = None
@@ -213,26 +220,15 @@ class RAFTSpline(nn.Module):
 
         # ---- context encoder on a side stream: a batch-1 chain of small launches that hides under the 5-image feature encoder
         ub = self.update_block
-        engine_update = engine and UPDATE_ENGINE == "split" and ub.hidden_dim % 32 == 0 and ub.motion_dim % 32 == 0 \
-            and ub.context_dim % 32 == 0 and ub.bezier_planes <= 32
         if tm: tm.start("cnet")
         with hip.Branch(tm is None) as cnet_branch:
             if pr: pr("cnet.begin")
-            if engine_update:
-                ws = ub.new_split_workspace(B, h, w, device)
-                ws.overlap = tm is None
-                ctx_in = context_input
-                if self.fnet_img is None:      # the context bins are the LAST channels of the voxel grid: one window, read in place
-                    ctx_in = S.ChannelWindows(voxel_grid, [voxel_grid.shape[1] - self.nbins_context], self.nbins_context)
-                ub.set_context_split(ws, self.cnet.forward_split(ctx_in, trunk_only=True), self.cnet.conv2)
-            elif engine:
-                ws = ub.new_workspace(B, h, w, device)
-                ws.set_context_split(self.cnet.forward_split(context_input.contiguous()))
-            else:
-                ws = ub.new_workspace(B, h, w, device)
-                trunk = self.cnet(context_input.contiguous(), project=False)
-                cnet = torch.nn.functional.conv2d(trunk, self.cnet.conv2.weight)     # bias folded into the split kernel
-                ws.set_context(cnet, self.cnet.conv2.bias)
+            ws = ub.new_split_workspace(B, h, w, device)
+            ws.overlap = tm is None
+            ctx_in = context_input
+            if self.fnet_img is None:      # the context bins are the LAST channels of the voxel grid: one window, read in place
+                ctx_in = S.ChannelWindows(voxel_grid, [voxel_grid.shape[1] - self.nbins_context], self.nbins_context)
+            ub.set_context_split(ws, self.cnet.forward_split(ctx_in, trunk_only=True), self.cnet.conv2)
             if pr: pr("cnet.end")
         if tm: tm.stop("cnet")
 
@@ -240,11 +236,8 @@ class RAFTSpline(nn.Module):
         if pr: pr("fnet.begin")
         if self.fnet_ev is not None:
             if tm: tm.start("fnet_ev")
-            if engine and self.fnet_ev.conv2.out_channels % 64 == 0 and len(grids) <= 8:
-                # [reference | targets] = channel windows of the voxel grid, read in place by the stem kernel (no torch.cat)
-                stacked = S.ChannelWindows(voxel_grid, [0] + list(self.ev_corr_target_indices), self.nbins_corr)
-            else:
-                stacked = torch.cat(grids, dim=0)
+            # [reference | targets] = channel windows of the voxel grid, read in place by the stem kernel (no torch.cat)
+            stacked = S.ChannelWindows(voxel_grid, [0] + list(self.ev_corr_target_indices), self.nbins_corr)
             corr_ev = encode_pair(self.fnet_ev, stacked, B, self.ev_corr_levels)
             if tm: tm.stop("fnet_ev")
         if self.fnet_img is not None:
@@ -259,44 +252,34 @@ class RAFTSpline(nn.Module):
 
         if pr: pr("fnet.end")
         if tm: tm.start("corr computation")
-        # product path (engine look-up inside the step): tiled planes; the stage-timed / library variants keep the reference's row-major planes
-        tiled = engine_update and tm is None and all(c is None or c.tiled_supported() for c in (corr_ev, corr_img))
-        corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img,
-                                                  layout="tiled" if tiled else "rows")
+        corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img, layout="tiled")
         if tm: tm.stop("corr computation")
         if pr: pr("corr.end")
         cnet_branch.join()
         if pr: pr("joined")
 
         coef = self._coefficients()
-        corr_feat = corr_block.new_output_split() if (engine_update and tm is None) else corr_block.new_output()
-        if engine_update:
-            S.bezier_update(bezier, None, ws.M, ub.motion_dim // 32)     # emit the initial Bezier channel block
+        corr_feat = corr_block.new_output_split()
+        S.bezier_update(bezier, None, ws.M, ub.motion_dim // 32)     # emit the initial Bezier channel block
         ups: List[torch.Tensor] = []
         if tm: tm.start("all iters")
         for itr in range(iters):
-            if tm: tm.start("1 iter")
             need_mask = (not test_mode) or itr == iters - 1
-            if engine_update and tm is None:
+            if tm is None:
                 # the look-up runs inside the step, next to the (independent) Bezier branch of the motion encoder
                 mask = ub.step_split(ws, lambda: corr_block.lookup_bezier_split(bezier, coef, out=corr_feat), bezier, need_mask)
-                if need_mask:
-                    ups.append(hip.cvx_upsample(bezier, mask, None, 0.25))
-                continue
-            if tm: tm.start("corr lookup (per iter)")          # includes 'get_flow (per iter)': fused into the gather
-            corr_block.lookup_bezier(bezier, coef, out=corr_feat)
-            if tm: tm.stop("corr lookup (per iter)")
-            if tm: tm.start("update (per iter)")
-            if engine_update:
-                mask = ub.step_split(ws, corr_feat, bezier, need_mask)
-                if need_mask:
-                    ups.append(hip.cvx_upsample(bezier, mask, None, 0.25))
             else:
-                raw_mask = ub.step(ws, corr_feat, bezier, need_mask)
-                if need_mask:
-                    ups.append(hip.cvx_upsample(bezier, raw_mask, ub.mask[2].bias, 0.25))
-            if tm: tm.stop("update (per iter)")
-            if tm: tm.stop("1 iter")
+                # stage timing (eager): the same kernels, the look-up timed on its own, no side-stream overlap
+                tm.start("1 iter")
+                tm.start("corr lookup (per iter)")          # includes 'get_flow (per iter)': fused into the gather
+                corr_block.lookup_bezier_split(bezier, coef, out=corr_feat)
+                tm.stop("corr lookup (per iter)")
+                tm.start("update (per iter)")
+                mask = ub.step_split(ws, corr_feat, bezier, need_mask)
+                tm.stop("update (per iter)")
+                tm.stop("1 iter")
+            if need_mask:
+                ups.append(hip.cvx_upsample(bezier, mask, None, 0.25))
         if tm: tm.stop("all iters")
         if pr: pr("iters.end")
         return bezier, ups

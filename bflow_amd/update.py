@@ -8,7 +8,9 @@ Inference only.  `step_split()` is the product path: one GRU/Bezier iteration on
   * sigmoid / r*h / the GRU blend / `bezier += delta` and the re-emission of the Bezier channel block are conv epilogues,
   * the 7x7 Bezier convolution is an im2col + 1x1 GEMM; the look-up + correlation branch runs next to the Bezier branch,
   * the mask head only runs when its output is consumed (last iteration in test mode; raft.py:193-195).
-`step()` (MIOpen convolutions + the element-wise kernels of csrc/update_ops.hip) is kept for A/B runs (BFLOW_UPDATE_ENGINE=miopen).
+`forward()` is the reference-shaped call (update.py:116-126): it builds a workspace from NCHW tensors and runs the SAME `step_split`,
+so op-level tests against the oracle exercise the product path.  There is no library (MIOpen) variant in this package; the
+configurations the engine cannot run raise `BflowHipError` (`check_engine_support`).
 """
 from __future__ import annotations
 
@@ -16,8 +18,6 @@ from typing import Any, Dict, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
-
 from . import hip
 from . import split as S
 
@@ -64,39 +64,6 @@ class BasicMotionEncoder(nn.Module):
         return out
 
 
-class UpdateWorkspace:
-    """Caller-owned buffers of one forward: the two concatenated GRU inputs and the contiguous hidden state."""
-
-    def __init__(self, batch: int, hdim: int, cdim: int, mdim: int, h: int, w: int, device):
-        self.hdim, self.cdim, self.mdim = hdim, cdim, mdim
-        ctot = hdim + cdim + mdim
-        self.hx = torch.empty((batch, ctot, h, w), dtype=torch.float32, device=device)
-        self.rhx = torch.empty((batch, ctot, h, w), dtype=torch.float32, device=device)
-        self.net = torch.empty((batch, hdim, h, w), dtype=torch.float32, device=device)
-        self.corbez = torch.empty((batch, 256, h, w), dtype=torch.float32, device=device)
-
-    def set_context(self, cnet: torch.Tensor, bias: Optional[torch.Tensor]):
-        """net = tanh(cnet[:, :hdim]), inp = relu(cnet[:, hdim:])  (raft.py:145-147) written into hx; inp mirrored to rhx."""
-        h0, c0 = self.hdim, self.cdim
-        hip.tanh_relu_split(cnet, bias, h0, c0, self.hx[:, :h0], self.hx[:, h0:h0 + c0])
-        self.rhx[:, h0:h0 + c0].copy_(self.hx[:, h0:h0 + c0])
-        self.net.copy_(self.hx[:, :h0])
-
-
-def _set_context_split(self, cnet_split):
-    """Context features straight from the split-fp16 encoder: (B, h, w, hdim+cdim) split NHWC -> NCHW slices of hx."""
-    h0, c0 = self.hdim, self.cdim
-    cnet_split.to_nchw(0, h0, out=self.hx[:, :h0])
-    cnet_split.to_nchw(h0, c0, out=self.hx[:, h0:h0 + c0])
-    self.hx[:, :h0].tanh_()
-    self.hx[:, h0:h0 + c0].relu_()
-    self.rhx[:, h0:h0 + c0].copy_(self.hx[:, h0:h0 + c0])
-    self.net.copy_(self.hx[:, :h0])
-
-
-UpdateWorkspace.set_context_split = _set_context_split
-
-
 class SplitWorkspace:
     """Buffers of one forward when the update block runs on the split-fp16 engine (blocked channels-last split tensors)."""
 
@@ -123,58 +90,17 @@ class BasicUpdateBlock(nn.Module):
         self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=self.context_dim + self.motion_dim)
         self.bezier_head = BezierHead(model_params["bezier_degree"], input_dim=hidden_dim, hidden_dim=256)
         self.mask = nn.Sequential(nn.Conv2d(hidden_dim, 256, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(256, 64 * 9, 1, padding=0))
-        self._fused = None
 
-    # merged z|r weights; rebuilt when any source parameter changed (load_state_dict, .to(), ...)
-    def _fused_weights(self):
-        g = self.gru
-        key = tuple((p.data_ptr(), p._version) for p in (g.convz1.weight, g.convr1.weight, g.convz2.weight, g.convr2.weight))
-        if self._fused is None or self._fused[0] != key:
-            with torch.no_grad():
-                wzr1 = torch.cat([g.convz1.weight, g.convr1.weight], dim=0).contiguous()
-                wzr2 = torch.cat([g.convz2.weight, g.convr2.weight], dim=0).contiguous()
-            self._fused = (key, wzr1, wzr2)
-        return self._fused[1], self._fused[2]
-
-    def new_workspace(self, batch: int, h: int, w: int, device) -> UpdateWorkspace:
-        return UpdateWorkspace(batch, self.hidden_dim, self.context_dim, self.motion_dim, h, w, device)
-
-    def step(self, ws: UpdateWorkspace, corr: torch.Tensor, bezier: torch.Tensor, need_mask: bool):
-        """One iteration of update.py:116-126 on the workspace; `bezier` (B, 2*deg, h, w) is updated IN PLACE with the
-        predicted delta (bezier.py:137-139).  Returns the raw mask-head output (before bias and the 0.25 scale, both folded
-        into the up-sampling kernel) or None."""
-        enc, g = self.encoder, self.gru
-        h0, c0 = self.hidden_dim, self.context_dim
-        xo = h0 + c0  # first motion-feature channel inside hx / rhx
-        # ---- motion encoder (update.py:88-97)
-        c1 = F.conv2d(corr, enc.convc1.weight)
-        hip.bias_act_inplace(c1, enc.convc1.bias, hip.ACT_RELU)
-        c2 = F.conv2d(c1, enc.convc2.weight, padding=1)
-        f1 = F.conv2d(bezier, enc.convf1.weight, padding=3)
-        hip.bias_act_inplace(f1, enc.convf1.bias, hip.ACT_RELU)
-        f2 = F.conv2d(f1, enc.convf2.weight, padding=1)
-        hip.concat2_act(c2, enc.convc2.bias, hip.ACT_RELU, f2, enc.convf2.bias, hip.ACT_RELU, ws.corbez)
-        m = F.conv2d(ws.corbez, enc.conv.weight, padding=1)
-        hip.concat2_act(m, enc.conv.bias, hip.ACT_RELU, bezier, None, hip.ACT_NONE, ws.hx[:, xo:], ws.rhx[:, xo:])
-        # ---- separable conv-GRU (update.py:33-48): horizontal 1x5, then vertical 5x1
-        wzr1, wzr2 = self._fused_weights()
-        hview, rhview = ws.hx[:, :h0], ws.rhx[:, :h0]
-        for wzr, cz, cr, cq, pad, last in ((wzr1, g.convz1, g.convr1, g.convq1, (0, 2), False),
-                                           (wzr2, g.convz2, g.convr2, g.convq2, (2, 0), True)):
-            zr = F.conv2d(ws.hx, wzr, padding=pad)
-            hip.gru_rh(zr[:, h0:], cr.bias, hview, rhview)
-            q = F.conv2d(ws.rhx, cq.weight, padding=pad)
-            hip.gru_blend(zr[:, :h0], cz.bias, q, cq.bias, hview, ws.net if last else None)
-        # ---- heads (update.py:17-18,111-114,120-125)
-        d1 = F.conv2d(ws.net, self.bezier_head.conv1.weight, padding=1)
-        hip.bias_act_inplace(d1, self.bezier_head.conv1.bias, hip.ACT_RELU)
-        d2 = F.conv2d(d1, self.bezier_head.conv2.weight, padding=1)
-        hip.add_delta(bezier, d2, self.bezier_head.conv2.bias)
-        if not need_mask:
-            return None
-        m1 = F.conv2d(ws.net, self.mask[0].weight, padding=1)
-        hip.bias_act_inplace(m1, self.mask[0].bias, hip.ACT_RELU)
-        return F.conv2d(m1, self.mask[2].weight)
+    def check_engine_support(self):
+        """The split-fp16 engine works on 32-channel blocks; the Bezier block must fit one.  Anything else is refused loudly
+        (there is no library fall-back)."""
+        bad = []
+        if self.hidden_dim % 32 or self.motion_dim % 32 or self.context_dim % 32:
+            bad.append(f"hidden / motion / context dims must be multiples of 32 (got {self.hidden_dim}, {self.motion_dim}, {self.context_dim})")
+        if self.bezier_planes > 32:
+            bad.append(f"2 * bezier_degree = {self.bezier_planes} > 32 (the Bezier parameters travel as one 32-channel block)")
+        if bad:
+            raise hip.BflowHipError("BasicUpdateBlock: configuration not supported by the HIP conv engine: " + "; ".join(bad))
 
     # ------------------------------------------------------------------------------------------------ split-fp16 engine
     def _pk(self, name: str, weight_fn, cin_pad=None):
@@ -225,6 +151,11 @@ class BasicUpdateBlock(nn.Module):
         def w_inp(a=conv2.weight): return a[hd:]
         S.conv(trunk, self._pk("cnet_net", w_net), shift=conv2.bias[:hd].contiguous(), act=S.ACT_TANH, out_split=ws.H)
         ws.INP, _ = S.conv(trunk, self._pk("cnet_inp", w_inp), shift=conv2.bias[hd:].contiguous(), act=S.ACT_RELU)
+        self._hoist_inp_terms(ws)
+
+    def _hoist_inp_terms(self, ws: SplitWorkspace):
+        """The `inp` (context) channels are the same in every iteration: their share of the six gate convolutions (+ the gate biases)
+        is evaluated once per frame and enters the per-iteration convolutions as an epilogue addend (update.py:34-37)."""
         terms = []
         for sfx in ("1", "2"):
             _, _, zr_inp, q_inp, zr_bias, q_bias, pad = self._gate_weights(sfx)
@@ -286,16 +217,17 @@ class BasicUpdateBlock(nn.Module):
         return mask
 
     def forward(self, net, inp, corr, bezier):
-        """Reference-shaped call (update.py:116-126): returns (net, mask, delta_bezier) without mutating the inputs."""
+        """Reference-shaped call (update.py:116-126): (net, inp, corr, bezier) NCHW fp32 -> (net, mask, delta_bezier) without mutating
+        the inputs.  Runs the product path: a split workspace is filled from the NCHW tensors and ONE `step_split` is executed."""
+        self.check_engine_support()
         B, _, h, w = net.shape
-        ws = self.new_workspace(B, h, w, net.device)
-        h0, c0 = self.hidden_dim, self.context_dim
-        ws.hx[:, :h0].copy_(net)
-        ws.hx[:, h0:h0 + c0].copy_(inp)
-        ws.rhx[:, h0:h0 + c0].copy_(inp)
-        ws.net.copy_(net)
-        before = bezier.clone()
-        after = bezier.clone()
-        raw = self.step(ws, corr.contiguous(), after, need_mask=True)
-        mask = 0.25 * (raw + self.mask[2].bias.view(1, -1, 1, 1))
-        return ws.net, mask, after - before
+        ws = self.new_split_workspace(B, h, w, net.device)
+        ws.overlap = False
+        ws.H = S.from_nchw(net.float().contiguous())
+        ws.INP = S.from_nchw(inp.float().contiguous())
+        self._hoist_inp_terms(ws)
+        before = bezier.float().contiguous()
+        after = before.clone()
+        S.bezier_update(after, None, ws.M, self.motion_dim // 32)       # emit the Bezier channel block of the GRU input
+        mask = self.step_split(ws, corr.float().contiguous(), after, need_mask=True)
+        return ws.H.to_nchw(), 0.25 * mask, after - before

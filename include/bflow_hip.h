@@ -15,6 +15,12 @@
  *   - return value 0 = OK, > 0 = hipError_t of the failed launch, < 0 = argument error (BFLOW_E_*);
  *     nothing throws across the ABI.  bflow_last_error_string() describes the last failure on this thread;
  *   - tensors are dense, row-major ("NCHW contiguous") fp32 unless stated otherwise.
+ *   - SPLIT FORMAT (every "split" / hi-lo tensor of the matrix-core path): value = hi + lo * 2^-11 with two fp16 planes, ~22
+ *     significant bits.  Supported dynamic range of a stored value: |x| <= 65504 -- larger magnitudes SATURATE to +-65504 (never
+ *     inf / NaN; NaN inputs stay NaN); 2^-14 <= |x|: 22 bits; |x| < 2^-14: 11 bits (absolute error <= 3e-8).  Products are
+ *     accumulated in fp32, so only what is WRITTEN in this format is limited (activations, GRU state, packed weights, look-up output);
+ *     pre-normalisation convolution outputs (InstanceNorm statistics, folded BatchNorm) are fp32.  tests/test_hip_parity.py:
+ *     test_split_format_*, test_engine_with_large_and_tiny_activations, test_forward_with_rescaled_weights_vs_oracle.
  */
 #ifndef BFLOW_HIP_H
 #define BFLOW_HIP_H
@@ -243,48 +249,6 @@ int bflow_bezier_coeffs(const double* times, int T, int deg, float* coef_out);
  *   out : (T, B, 2, h, w)                                                                              */
 int bflow_bezier_eval(const float* params, const float* coef, int T, int deg, int B, int h, int w,
                       int add_coords0, float* out, bflow_stream_t stream);
-
-/* ---------------------------------------------------------------------------------------------------
- * K9/K10 element-wise pieces of the update block, written so that no torch.cat / bias-add / activation
- * launch is needed: the convolutions (MIOpen, bias-free) read the channel-concatenated buffers
- * hx = [h | x] and rhx = [r*h | x] directly, and every conv bias + activation is folded into the next
- * element-wise kernel.  All tensors are (B, C, HW) slices addressed by an element batch stride; `bias_*`
- * are per-channel device vectors or NULL.  act: 0 = identity, 1 = relu.
- *
- * bflow_concat2_act:  dst[b, c]      = act_a(a[b, c] + bias_a[c])            c <  Ca
- *                     dst[b, Ca + c] = act_b(b[b, c] + bias_b[c])            c <  Cb
- * written to dst1 and (if not NULL) dst2.  Used for cat([cor, bez]) (update.py:94), cat([out, bezier])
- * (update.py:96-97) and cat([inp, motion_features]) (update.py:118).                                      */
-int bflow_concat2_act(const float* a, long long a_bs, int Ca, const float* bias_a, int act_a,
-                      const float* b, long long b_bs, int Cb, const float* bias_b, int act_b,
-                      float* dst1, long long dst1_bs, float* dst2, long long dst2_bs,
-                      int B, int HW, bflow_stream_t stream);
-
-/* bflow_bias_act_inplace:  x[b,c] = act(x[b,c] + bias[c])        (conv bias + F.relu, update.py:89-92,18) */
-int bflow_bias_act_inplace(float* x, long long x_bs, const float* bias, int act, int B, int C, int HW,
-                           bflow_stream_t stream);
-
-/* bflow_gru_rh:  rh = sigmoid(r_pre + bias_r) * h                         (update.py:36-37 / :43-44)    */
-int bflow_gru_rh(const float* r_pre, long long r_bs, const float* bias_r, const float* h, long long h_bs,
-                 float* rh, long long rh_bs, int B, int C, int HW, bflow_stream_t stream);
-
-/* bflow_gru_blend:  z = sigmoid(z_pre + bias_z); h = (1 - z) * h + z * tanh(q_pre + bias_q), in place
- *                                                                           (update.py:35,37-38 / :42,44-45)
- * h2 (may be NULL) receives a second copy of the new state.                                             */
-int bflow_gru_blend(const float* z_pre, long long z_bs, const float* bias_z, const float* q_pre, long long q_bs,
-                    const float* bias_q, float* h, long long h_bs, float* h2, long long h2_bs,
-                    int B, int C, int HW, bflow_stream_t stream);
-
-/* bflow_tanh_relu_split: net = tanh(cnet[:, :C_h] + bias), inp = relu(cnet[:, C_h:C_h+C_i] + bias)
- *                                                                                     (raft.py:145-147) */
-int bflow_tanh_relu_split(const float* cnet, long long cnet_bs, const float* bias, int C_h, int C_i,
-                          float* net, long long net_bs, float* inp, long long inp_bs,
-                          int B, int HW, bflow_stream_t stream);
-
-/* K12  params[b,c] += delta[b,c] + bias[c]   (bias of the last head conv, update.py:18, folded into
- * BezierCurves.delta_update_params, bezier.py:137-139).  Dense (B, C, HW) tensors.                       */
-int bflow_add_delta(float* params, const float* delta, const float* bias, int B, int C, int HW,
-                    bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K13  convex up-sampling x8: softmax over the 9 taps of mask_scale*mask, 3x3 neighbourhood of 8*data,

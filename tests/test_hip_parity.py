@@ -310,33 +310,121 @@ def _model(cname, seed=0):
     return cfg, m.to(DEV), sd
 
 
-def test_update_block_step_vs_oracle():
-    cfg, m, sd = _model("E_LU4_BD2")
+@pytest.mark.parametrize("cname,deg,planes", [("E_LU4_BD2", 2, 567), ("E_LU5_BD10", 10, 648), ("E_I_LU4_BD2", 2, 891)])
+def test_update_block_step_split_vs_oracle(cname, deg, planes):
+    """ONE iteration of the PRODUCT update path against the oracle's BasicUpdateBlock.forward (update.py:116-126).
+    `BasicUpdateBlock.forward` fills a split workspace from the NCHW tensors and runs `step_split`: the hoisted `inp` terms of the six gate
+    convolutions, the merged z|r convolution with the sigmoid / r*h epilogue, the q convolution with the blend epilogue (both GRU
+    halves), the two-source convolutions [h | M] / [r*h | M], the im2col Bezier branch, the head with the `acc_nchw` (P += dP) epilogue
+    and the mask branch.  Degrees 2 and 10 (Bezier block of 4 / 20 channels), 7 / 8 / 11 correlation planes."""
+    cfg, m, sd = _model(cname)
     rs = np.random.RandomState(6)
     B, h, w = 2, 22, 26
     net = np.tanh(rs.standard_normal((B, 128, h, w))).astype(np.float32)
     inp = np.maximum(rs.standard_normal((B, 128, h, w)), 0).astype(np.float32)
-    corr = (rs.standard_normal((B, 567, h, w)) * 5).astype(np.float32)
-    bez = rs.standard_normal((B, 4, h, w)).astype(np.float32)
+    corr = (rs.standard_normal((B, planes, h, w)) * 5).astype(np.float32)
+    bez = rs.standard_normal((B, 2 * deg, h, w)).astype(np.float32)
     with torch.no_grad():
         n2, mask, delta = m.update_block(cu(net), cu(inp), cu(corr), cu(bez))
         rn, rm, rd = O.update_block(sd, *(torch.from_numpy(v) for v in (net, inp, corr, bez)))
     assert (n2.cpu() - rn).abs().max().item() < 5e-5
     assert (delta.cpu() - rd).abs().max().item() < 5e-5
     assert (mask.cpu() - rm).abs().max().item() < 5e-4
+    # a second iteration on the same workspace state must still follow the oracle (the epilogues update H / M / P in place)
+    with torch.no_grad():
+        n3, _, d3 = m.update_block(n2, cu(inp), cu(corr), cu(bez) + delta)
+        rn3, _, rd3 = O.update_block(sd, rn, torch.from_numpy(inp), torch.from_numpy(corr), torch.from_numpy(bez) + rd)
+    assert (n3.cpu() - rn3).abs().max().item() < 1e-4 and (d3.cpu() - rd3).abs().max().item() < 1e-4
 
 
-def test_encoder_vs_oracle():
+def test_encoder_product_path_vs_oracle():
+    """BasicEncoder.forward_split (the inference path: stem, halo and generic conv kernels, fused statistics / folded BatchNorm, norm_act)
+    vs the oracle, for the InstanceNorm feature encoder and the eval-mode BatchNorm context encoder."""
     cfg, m, sd = _model("E_I_LU4_BD2")
     x = torch.from_numpy(synthetic.voxel_grid(2, 5, 64, 96, seed=9))
     with torch.no_grad():
-        a = m.fnet_ev(x.to(DEV)).cpu()
+        a = m.fnet_ev.forward_split(x.to(DEV)).to_nchw().cpu()
         b = O.encoder(sd, "fnet_ev", x, "instance")
-        assert (a - b).abs().max().item() < 5e-4 * float(b.abs().max())
+        assert (a - b).abs().max().item() < 5e-5 * float(b.abs().max())
         xc = torch.from_numpy(synthetic.voxel_grid(2, 8, 64, 96, seed=10))
-        a = m.cnet(xc.to(DEV)).cpu()
+        a = m.cnet.forward_split(xc.to(DEV)).to_nchw().cpu()
         b = O.encoder(sd, "cnet", xc, "batch")
-        assert (a - b).abs().max().item() < 5e-4 * float(b.abs().max())
+        assert (a - b).abs().max().item() < 5e-5 * float(b.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------- dynamic range of the split format
+def test_split_format_saturates_and_keeps_tiny_values():
+    """x = hi + lo * 2^-11 (two fp16): |x| > 65504 saturates (no inf / NaN), NaN stays NaN; below 2^-14 (fp16's normal range: the matrix
+    cores flush subnormal inputs) hi = 0 and the value lives in the pre-scaled lo alone: 11 significant bits, absolute error <= 3e-8."""
+    from bflow_amd import split as S
+    v = torch.tensor([1e5, -3e7, 65504.0, 70000.0, 1e-7, -3e-6, 6.1e-5, 0.0, float("inf"), 1.2345678], device=DEV)
+    x = v.view(1, 10, 1, 1).repeat(1, 1, 2, 4).contiguous()
+    back = S.from_nchw(x).to_nchw()[0, :, 0, 0].cpu()
+    assert torch.isfinite(back).all()
+    assert back[0] == 65504.0 and back[1] == -65504.0 and back[2] == 65504.0 and back[3] == 65504.0 and back[8] == 65504.0
+    assert abs(float(back[4]) - 1e-7) < 1e-7 * 2 ** -10 and abs(float(back[5]) + 3e-6) < 3e-6 * 2 ** -10 and abs(float(back[6]) - 6.1e-5) < 3e-8
+    assert back[7] == 0.0 and abs(float(back[9]) - 1.2345678) < 3e-7
+    nan = S.from_nchw(torch.full((1, 32, 1, 1), float("nan"), device=DEV)).to_nchw()
+    assert torch.isnan(nan).all()
+
+
+def test_engine_with_large_and_tiny_activations():
+    """The conv engine on inputs far from unit scale: x * 1e4 (inputs up to ~5e4, just inside the format; products accumulate in fp32;
+    outputs beyond +-65504 saturate when written in the split format but stay exact as fp32), and x * 1e-6 (operands below the fp16
+    normal range live in `lo` with 11 bits)."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((1, 64, 24, 40)).astype(np.float32)
+    wgt = (rs.standard_normal((64, 64, 3, 3)) / 24).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wgt).double(), padding=1)
+    pk = S.PackedConvWeight().get(cu(wgt))
+    for scale, tol in ((1e4, 3e-6), (1e-6, 2e-3)):
+        xs = S.from_nchw(cu(x * np.float32(scale)))
+        sp, f32 = S.conv(xs, pk, padding=1, want_split=True, want_f32=True)
+        got = S.blocked_f32_to_nhwc(f32, 24, 40, 64).permute(0, 3, 1, 2).cpu().double()
+        r = ref * scale
+        assert torch.isfinite(got).all()
+        assert float((got - r).abs().max() / r.abs().max()) < tol, scale
+        back = sp.to_nchw().cpu().double()
+        assert torch.isfinite(back).all()
+        clipped = r.clamp(-65504.0, 65504.0)
+        assert float((back - clipped).abs().max() / clipped.abs().max()) < max(tol, 1e-6), scale
+        assert float(x.max() * scale) < 65504.0
+
+
+def test_forward_with_rescaled_weights_vs_oracle():
+    """Checkpoint-scale robustness.  Every convolution of the feature encoder x100 (InstanceNorm renormalises, but the pre-norm
+    activations that the epilogues see reach ~1e4), every convolution of the context encoder x100 with its BatchNorm running statistics
+    rescaled consistently (mean x100, var x1e4: same function, 100x larger pre-norm values folded into the epilogue's scale / shift), and
+    the projected correlation features x4 (volume entries x16): the flow must still follow the oracle within the 1e-3 px bar."""
+    cfg, m, sd = _model("E_LU4_BD2")
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for k, v in sd.items():
+        tok = k.split(".")
+        top = tok[0]
+        if top not in ("fnet_ev", "cnet") or k in (f"{top}.conv2.weight", f"{top}.conv2.bias"):   # (the 1x1 output projection stays)
+            continue
+        if v.dim() == 4:                                       # every convolution weight (3x3, 7x7 stem, 1x1 down-sampling)
+            sd2[k] = v * 100.0
+        elif top == "cnet":                                    # eval-mode BatchNorm: keep the function, scale what the epilogue sees
+            if tok[-1] == "running_mean":
+                sd2[k] = v * 100.0
+            elif tok[-1] == "running_var":
+                sd2[k] = v * 1.0e4
+            elif tok[-1] == "bias" and tok[-2] in ("conv1", "conv2", "0"):
+                sd2[k] = v * 100.0
+    for k in ("fnet_ev.conv2.weight", "fnet_ev.conv2.bias"):
+        sd2[k] = sd[k] * 4.0
+    m.load_state_dict(sd2)
+    vox = torch.from_numpy(synthetic.voxel_grid(1, 9, 128, 160, seed=21))
+    with torch.no_grad():
+        low, up = m(voxel_grid=vox.to(DEV), iters=4, test_mode=True)
+        rlow, rup = O.forward(sd2, cfg, vox, None, iters=4, test_mode=True)
+    flow, rflow = up.get_flow_from_reference(1.0).cpu(), O.bezier_flow(rup, 1.0)
+    assert torch.isfinite(flow).all()
+    epe = float(O.epe_masked(flow, rflow))
+    print(f"weights x100: EPE vs oracle {epe:.2e} px at mean |flow| {float(rflow.abs().mean()):.2f} px")
+    assert epe < EPE_TOL
 
 
 # ------------------------------------------------------------------------------------------------- end to end
@@ -497,22 +585,6 @@ def test_conv_split_engine_vs_fp64(cin, cout, k, stride, pad, H, W, B):
     # round trip back to NCHW
     back = o_split.to_nchw()
     assert (back.cpu().double() - got_s).abs().max().item() == 0.0
-
-
-def test_encoder_split_engine_vs_oracle():
-    """BasicEncoder on the split-fp16 engine (InstanceNorm fnet and eval-BatchNorm cnet) vs the CPU oracle."""
-    cfg, m, sd = _model("E_I_LU4_BD2")
-    x = torch.from_numpy(synthetic.voxel_grid(2, 5, 64, 96, seed=9))
-    with torch.no_grad():
-        a = m.fnet_ev.forward_split(x.to(DEV)).to_nchw().cpu()
-        b = O.encoder(sd, "fnet_ev", x, "instance")
-        ea = (a - b).abs().max().item() / float(b.abs().max())
-        xc = torch.from_numpy(synthetic.voxel_grid(2, 8, 64, 96, seed=10))
-        a2 = m.cnet.forward_split(xc.to(DEV)).to_nchw().cpu()
-        b2 = O.encoder(sd, "cnet", xc, "batch")
-        eb = (a2 - b2).abs().max().item() / float(b2.abs().max())
-    print(f"split-engine encoder: max err / max|ref|  fnet(instance) {ea:.2e}  cnet(batch) {eb:.2e}")
-    assert ea < 5e-5 and eb < 5e-5
 
 
 # ------------------------------------------------------------------------------------------------- SURVEY 8(f-3): validation harness

@@ -73,6 +73,27 @@ def test_no_cpu_fallback():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
 
 
+def test_unsupported_configurations_raise_instead_of_falling_back():
+    """Inference has no library / CPU path: a configuration the HIP engine cannot run is refused with BflowHipError."""
+    import copy
+    import pytest as _pt
+    from bflow_amd import configs, hip
+    base = configs.model_config("E_LU4_BD2")
+    cases = []
+    c = copy.deepcopy(base); c["feature"]["norm"] = "group"; cases.append((c, "norm_fn"))
+    c = copy.deepcopy(base); c["feature"]["dim"] = 96; cases.append((c, "output dim 96"))
+    c = copy.deepcopy(base); c["bezier_degree"] = 20; cases.append((c, "bezier_degree"))
+    c = copy.deepcopy(base); c["motion"]["dim"] = 100; cases.append((c, "multiples of 32"))
+    for cfg, needle in cases:
+        m = bflow_amd.RAFTSpline(cfg)
+        with _pt.raises(hip.BflowHipError) as ei:
+            m.check_engine_support()
+        assert needle in str(ei.value), (needle, str(ei.value))
+    bflow_amd.RAFTSpline(base).check_engine_support()     # every shipped configuration passes
+    for name in configs.EXPERIMENTS:
+        bflow_amd.RAFTSpline(configs.model_config(name)).check_engine_support()
+
+
 @pytest.mark.parametrize("name", list(configs.EXPERIMENTS))
 def test_config_tree_and_state_dict_compat(name):
     cfg = configs.model_config(name)
