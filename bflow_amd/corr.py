@@ -19,8 +19,11 @@ import torch
 
 from . import hip
 
-# Correlation-build arithmetic: "split" = split-fp16 MFMA engine (fp32-class accuracy, ~2^-22 per product; default),
-# "f32" = exact fp32 MFMA.  Both are parity-tested against the oracle; override with BFLOW_CORR_PRECISION.
+# Correlation arithmetic (all hand-written HIP; override the default with BFLOW_CORR_PRECISION or per block / per model):
+#   "split" : split-fp16 MFMA engine, fp32 volume -- fp32-class accuracy (~2^-22 per product); the default
+#   "f32"   : exact fp32 MFMA, fp32 volume (row-major planes only)
+#   "f16"   : plain fp16 operands, fp16 tiled volume (BASELINE configs[4]: "fp16 MFMA correlation"): half the volume bytes, a third of the
+#             matrix-core work, fp16 accuracy (2^-11 per operand and stored value) -- measured EPE vs the fp32 oracle: tests/, DESIGN.md
 PRECISION = os.environ.get("BFLOW_CORR_PRECISION", "split")
 
 _LIST_TYPES: Tuple[type, ...] = (list, tuple)
@@ -117,11 +120,13 @@ class CorrComputation:
         return CorrComputation(fmap1=self._fmap1 + other._fmap1, fmap2=self._fmap2 + other._fmap2,
                                num_levels_per_target=[torch.tensor(lv) for lv in self._levels + other._levels])
 
-    def tiled_supported(self) -> bool:
-        """The tiled-plane volume is written by the streaming K5 kernel only: split operands, D in {64, 128, 256}."""
-        return PRECISION == "split" and self.dim in (64, 128, 256)
+    def tiled_supported(self, precision: Optional[str] = None) -> bool:
+        """The tiled-plane volume is written by the streaming K5 kernel only: split operands with D in {64, 128, 256}, fp16 with D in
+        {128, 256}."""
+        precision = PRECISION if precision is None else precision
+        return (precision == "split" and self.dim in (64, 128, 256)) or (precision == "f16" and self.dim in (128, 256))
 
-    def get_correlation_volume(self, tiled: bool = False) -> torch.Tensor:
+    def get_correlation_volume(self, tiled: bool = False, precision: Optional[str] = None) -> torch.Tensor:
         """(T, B*N, 1, h, w) fp32 -- corr.py:229-272.  One K5 launch per reference group, written straight into its
         slice of the volume (the reference expands fmap1 per target and concatenates, corr.py:254-259).
         tiled=True: (T, B, N, tiled_plane_size(h, w)) with every plane stored as 4 x 8 tiles (the look-up's layout)."""
@@ -129,11 +134,16 @@ class CorrComputation:
         N = h * w
         T = self.num_targets_overall
         device = self._packed[0][0].device if self._packed[0] is not None else self._fmap1[0].device
-        if tiled and not self.tiled_supported():
-            raise hip.BflowHipError(f"tiled correlation volume needs the split engine and D in (64, 128, 256); got D={D}, precision {PRECISION}")
-        vol = torch.empty((T, B, N, hip.tiled_plane_size(h, w) if tiled else N), dtype=torch.float32, device=device)
+        precision = PRECISION if precision is None else precision
+        if precision not in ("split", "f32", "f16"):
+            raise ValueError(f"correlation precision {precision!r}: expected 'split', 'f32' or 'f16'")
+        if (tiled or precision == "f16") and not (tiled and self.tiled_supported(precision)):
+            raise hip.BflowHipError(f"correlation volume (tiled={tiled}, precision={precision!r}, D={D}): the tiled layout needs 'split' with D in "
+                                    "(64, 128, 256) or 'f16' with D in (128, 256); the fp16 volume exists in the tiled layout only")
+        vol = torch.empty((T, B, N, hip.tiled_plane_size(h, w) if tiled else N), dtype=torch.float16 if precision == "f16" else torch.float32,
+                          device=device)
         thw = (h, w) if tiled else None
-        split = (PRECISION == "split") and D % 64 == 0
+        split = precision in ("split", "f16") and D % 64 == 0
         t0 = 0
         for f1, f2, packed in zip(self._fmap1, self._fmap2, self._packed):
             tg = f2.shape[0]
@@ -156,10 +166,11 @@ class CorrBlockParallelMultiTarget:
                  corr_computation_events: Optional[CorrComputation] = None,
                  corr_computation_frames: Optional[CorrComputation] = None,
                  radius: int = 4,
-                 layout: str = "rows"):
+                 layout: str = "rows",
+                 precision: Optional[str] = None):
         """layout = "rows": the reference's (T, B*N, h_L, w_L) planes (any K5 variant; every look-up entry point).
         layout = "tiled": planes stored as 4 x 8 tiles -- the inference product path (lookup_bezier_split); the reference-shaped
-        accessors untile on demand."""
+        accessors untile on demand.  precision: None = module default (PRECISION); "f16" needs layout = "tiled"."""
         assert corr_computation_events is not None or corr_computation_frames is not None
         assert radius == hip.LOOKUP_RADIUS, "the look-up radius is 4 everywhere in the reference (raft.py:40, corr.py:279)"
         assert layout in ("rows", "tiled")
@@ -180,9 +191,10 @@ class CorrBlockParallelMultiTarget:
         N = h * w
 
         if self._tiled:
-            base = cc.get_correlation_volume(tiled=True).view(len(levels), B * N, hip.tiled_plane_size(h, w))
+            base = cc.get_correlation_volume(tiled=True, precision=precision).view(len(levels), B * N, hip.tiled_plane_size(h, w))
         else:
-            base = cc.get_correlation_volume().view(len(levels), B * N, h, w)
+            base = cc.get_correlation_volume(precision=precision).view(len(levels), B * N, h, w)
+        self._f16 = base.dtype == torch.float16
         # pyramid: corr.py:297-305 -- level L keeps the targets whose num_levels > L
         self._pyramid: List[Tuple[torch.Tensor, List[int]]] = [(base, list(range(len(levels))))]
         self._level_hw: List[Tuple[int, int]] = [(h, w)]
@@ -191,7 +203,7 @@ class CorrBlockParallelMultiTarget:
             keep = [t for t, lv in enumerate(levels) if lv >= num_levels]
             ph, pw = self._level_hw[-1]
             if self._tiled:
-                cur = torch.empty((len(keep), B * N, hip.tiled_plane_size(ph // 2, pw // 2)), dtype=torch.float32, device=base.device)
+                cur = torch.empty((len(keep), B * N, hip.tiled_plane_size(ph // 2, pw // 2)), dtype=base.dtype, device=base.device)
                 for k, t in enumerate(keep):
                     hip.corr_pool2x2_tiled(prev[prev_idx.index(t)], cur[k], ph, pw)
             else:
@@ -214,8 +226,8 @@ class CorrBlockParallelMultiTarget:
         if self._rows_cache is None:
             twin = CorrBlockParallelMultiTarget.__new__(CorrBlockParallelMultiTarget)
             twin.__dict__.update(self.__dict__)
-            twin._tiled, twin._rows_cache = False, None
-            twin._pyramid = [(hip.untile_planes(t, *hw), idx) for (t, idx), hw in zip(self._pyramid, self._level_hw)]
+            twin._tiled, twin._rows_cache, twin._f16 = False, None, False
+            twin._pyramid = [(hip.untile_planes(t.float(), *hw), idx) for (t, idx), hw in zip(self._pyramid, self._level_hw)]
             twin._planes = [dict(tensor=twin._pyramid[p["level"]][0][twin._pyramid[p["level"]][1].index(p["target"])], level=p["level"],
                                  target=p["target"], hw=None) for p in self._planes]
             twin._table = hip.make_plane_table(twin._planes)
@@ -260,5 +272,5 @@ class CorrBlockParallelMultiTarget:
     def lookup_bezier_split(self, params: torch.Tensor, coef: np.ndarray, out):
         """lookup_bezier writing the conv engine's blocked split layout directly (no NCHW intermediate)."""
         assert coef.shape[0] == self._num_targets_base
-        hip.corr_lookup_bezier_split(self._table, params, coef, out.planes, tiled=self._tiled)
+        hip.corr_lookup_bezier_split(self._table, params, coef, out.planes, tiled=self._tiled, f16_planes=self._f16)
         return out

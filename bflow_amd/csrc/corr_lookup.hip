@@ -323,6 +323,17 @@ extern "C" int bflow_corr_pool2x2_tiled(const float* in, float* out, long long p
     return bflow::pool_tiled_launch(in, out, planes, h, w, false, (hipStream_t)stream);
 }
 
+extern "C" int bflow_corr_pool2x2_tiled_f16(const void* in, void* out, long long planes, int h, int w, bflow_stream_t stream) {
+    return bflow::pool_tiled_launch(in, out, planes, h, w, true, (hipStream_t)stream);
+}
+
+extern "C" int bflow_corr_lookup_bezier_split_tiled_f16(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
+                                                        void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
+                                                        bflow_stream_t stream) {
+    return bflow::lookup_tile_launch(planes, P, params, coef, T, deg, out_hi, out_lo, channel_blocks, rows_per_image, B, h1, w1, true,
+                                     (hipStream_t)stream);
+}
+
 extern "C" int bflow_corr_lookup_bezier_split_tiled(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
                                                     void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
                                                     bflow_stream_t stream) {

@@ -81,13 +81,18 @@ struct Cursor {   // position in the workgroup's item list; advanced without div
     int pan, t, b, jp, c;
 };
 
-template <int KB, bool POW2>
+// F16 = true (bflow_corr_build_f16_tiled; BASELINE configs[4] "fp16 MFMA correlation"): plain fp16 operands (the hi planes alone), ONE
+// MFMA per k-step, fp16 volume: a third of the matrix-core work and half of the bytes; the lo planes are neither loaded nor staged.
+template <int KB, bool POW2, bool F16>
 __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // SLOTS x (4*KB KB) ring; the only shared object
     constexpr int NS = 2 * KB;                 // k16 steps per chunk
-    constexpr int PW = KB / 2;                 // DMA pieces (1 KB) per wave per chunk
-    constexpr int SLOT_BYTES = 4 * KB * 1024;  // 32 columns x D x (hi + lo) fp16
+    constexpr int NPL = F16 ? 1 : 2;           // operand planes
+    constexpr int PW = NPL * KB / 4;           // DMA pieces (1 KB) per wave per chunk
+    constexpr int SLOT_BYTES = NPL * 2 * KB * 1024;  // 32 rows x D x planes fp16
     constexpr int PLANE_BYTES = 2 * KB * 1024;
+    constexpr int OB = F16 ? 2 : 4;            // bytes per volume element
+    static_assert(PW >= 1, "F16 needs D >= 128");
     constexpr int ST_PER_STEP = 16 / NS > 0 ? 16 / NS : 1;
     static_assert(16 % NS == 0 || NS % 16 == 0, "k-steps and accumulator registers must divide");
     static_assert(NS <= 16, "D <= 256");
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
         for (int s = 0; s < NS; ++s) {
             const unsigned so = mat + (unsigned)(s >> 1) * kb_bytes;
             Bh[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r2h, vo + (s & 1) * 32, so, 0));
-            Bl[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r2l, vo + (s & 1) * 32, so, 0));
+            if (!F16) Bl[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r2l, vo + (s & 1) * 32, so, 0));
         }
     };
 
@@ -206,11 +211,24 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     // ---- store side: one accumulator register = rows (r&3) + 8*(r>>2) + 4*kh of the wave's 32, 32 consecutive columns
     auto store_base = [&](const Item& im, __amdgpu_buffer_rsrc_t& rs) -> unsigned {
         const int row = im.i0 + 4 * kh, col = im.jp * COLS_WG + wave * 32 + l31;   // tiled: col = tile * 32 + position in the tile
-        float* slab = a.out + (long long)(im.t * a.B + im.b) * a.N * a.PS;
-        rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, a.N * a.PS * 4, 0x00020000);
-        return col < a.PS ? (unsigned)((row * a.PS + col) * 4) : OOB;   // rows >= N fall off the end of the slab by themselves
+        char* slab = reinterpret_cast<char*>(a.out) + (long long)(im.t * a.B + im.b) * a.N * a.PS * OB;
+        rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, a.N * a.PS * OB, 0x00020000);
+        return col < a.PS ? (unsigned)((row * a.PS + col) * OB) : OOB;   // rows >= N fall off the end of the slab by themselves
     };
-    const unsigned rowstep = (unsigned)a.PS * 4u;
+    const unsigned rowstep = (unsigned)a.PS * (unsigned)OB;
+
+    auto store_reg = [&](float hh_, float xx_, const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+        float v = F16 ? hh_ : fmaf(xx_, LO_INV, hh_);
+        v = POW2 ? v * a.scale : v / a.scale;
+        if (STREAM_ABL == 1) {
+            asm volatile("" ::"v"(v), "v"(off));
+        } else if (F16) {
+            const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rs, off, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
+        }
+    };
 
     // ---- pipeline state --------------------------------------------------------------------------------------------------
     STAMP(0)
@@ -253,25 +271,23 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
                 const char* fp = (s + 1 < NS ? sb : sn) + (sn_ >> 1) * 2048 + ((sn_ & 1) ? fo_odd : fo_even);               \
                 if (STREAM_ABL != 5) {                                                                                      \
                     fh[(s + 1) & 1] = *reinterpret_cast<const half8*>(fp);                                                  \
-                    fl[(s + 1) & 1] = *reinterpret_cast<const half8*>(fp + PLANE_BYTES);                                    \
+                    if (!F16) fl[(s + 1) & 1] = *reinterpret_cast<const half8*>(fp + PLANE_BYTES);                          \
                 }                                                                                                           \
             }                                                                                                               \
             const half8 ah = fh[s & 1], al = fl[s & 1];                                                                     \
             if (STREAM_ABL != 4) {                                                                                          \
                 CH_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[s], CH_, 0, 0, 0);                                      \
-                CX_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[s], CX_, 0, 0, 0);                                      \
-                CX_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[s], CX_, 0, 0, 0);                                      \
+                if (!F16) {                                                                                                 \
+                    CX_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[s], CX_, 0, 0, 0);                                  \
+                    CX_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[s], CX_, 0, 0, 0);                                  \
+                }                                                                                                           \
             } else {                                                                                                        \
                 CH_[s] += (float)ah[0] + (float)Bh[s][1];                                                                   \
                 CX_[s] += (float)al[0] + (float)Bl[s][1];                                                                   \
             }                                                                                                               \
             _Pragma("unroll") for (int u = 0; u < ST_PER_STEP; ++u) {                                                       \
                 const int r = s * ST_PER_STEP + u;                                                                          \
-                float v = fmaf(PX_[r], LO_INV, PH_[r]);                                                                     \
-                v = POW2 ? v * a.scale : v / a.scale;                                                                       \
-                const unsigned off = pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep;                                  \
-                if (STREAM_ABL != 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), prs, off, 0, 0); \
-                else asm volatile("" ::"v"(v), "v"(off));                                                                   \
+                store_reg(PH_[r], PX_[r], prs, pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);                       \
             }                                                                                                               \
             if (STREAM_ABL != 2 && s >= DMA_S0 && s < DMA_S0 + PW) issue_piece(q3, (it + 3) & 3, s - DMA_S0);              \
         }                                                                                                                   \
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
         if (it == 0) {   // first chunk: nobody prefetched its k-step-0 fragments
             __builtin_amdgcn_s_barrier();
             fh[0] = *reinterpret_cast<const half8*>(lds + fo_even);
-            fl[0] = *reinterpret_cast<const half8*>(lds + PLANE_BYTES + fo_even);
+            if (!F16) fl[0] = *reinterpret_cast<const half8*>(lds + PLANE_BYTES + fo_even);
         }
         STAMP(1 + it)
         const int stop = min(n, it + (c_hi - q0.c));   // chunks of this panel in the workgroup's range: even
@@ -307,27 +323,23 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     // ---- drain: the last chunk's accumulators
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float v = fmaf(Y_xx[r], LO_INV, Y_hh[r]);
-        v = POW2 ? v * a.scale : v / a.scale;
-        const unsigned off = pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), prs, off, 0, 0);
+        store_reg(Y_hh[r], Y_xx[r], prs, pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMA pieces must not outlive the workgroup's LDS
     STAMP(61)
     STAMP_RT(63)
 }
 
-template <int KB>
+template <int KB, bool F16>
 int launch_kb(const StreamArgs& a, bool pow2, hipStream_t s) {
-    const int lds = SLOTS * 4 * KB * 1024;
-    if (pow2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_stream_kernel<KB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((corr_stream_kernel<KB, true>), dim3(256), dim3(512), lds, s, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_stream_kernel<KB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((corr_stream_kernel<KB, false>), dim3(256), dim3(512), lds, s, a);
-    }
-    return bflow::launch_status("corr_build_split(stream)");
+    const int lds = SLOTS * (F16 ? 2 : 4) * KB * 1024;
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, s, a);
+    };
+    if (pow2) go(corr_stream_kernel<KB, true, F16>);
+    else go(corr_stream_kernel<KB, false, F16>);
+    return bflow::launch_status(F16 ? "corr_build_f16_tiled(stream)" : "corr_build_split(stream)");
 }
 
 }  // namespace
@@ -341,14 +353,15 @@ bool corr_stream_supported(int T, int B, int D, int N, int Np) {
 }
 
 // plane_h x plane_w > 0 (= N): the volume is written as TILED planes (see bflow_corr_build_split_tiled); 0, 0: row-major (T, B, N, N)
-int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out, int T, int B, int D, int N, int Np,
-                       long long f1_target_stride, int plane_h, int plane_w, hipStream_t stream) {
+// f16 = true: f1_lo / f2_lo are ignored (may be null), `out` is an fp16 volume (D in {128, 256})
+int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, void* out, int T, int B, int D, int N, int Np,
+                       long long f1_target_stride, int plane_h, int plane_w, bool f16, hipStream_t stream) {
     StreamArgs a;
     a.f1h = (const _Float16*)f1_hi;
     a.f1l = (const _Float16*)f1_lo;
     a.f2h = (const _Float16*)f2_hi;
     a.f2l = (const _Float16*)f2_lo;
-    a.out = out;
+    a.out = (float*)out;
     a.T = T;
     a.B = B;
     a.N = N;
@@ -371,10 +384,11 @@ int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, 
 #else
     a.stamps = nullptr;
 #endif
+    if (f16) return D == 128 ? launch_kb<4, true>(a, pow2, stream) : launch_kb<8, true>(a, pow2, stream);
     switch (D) {
-        case 64: return launch_kb<2>(a, pow2, stream);
-        case 128: return launch_kb<4>(a, pow2, stream);
-        default: return launch_kb<8>(a, pow2, stream);
+        case 64: return launch_kb<2, false>(a, pow2, stream);
+        case 128: return launch_kb<4, false>(a, pow2, stream);
+        default: return launch_kb<8, false>(a, pow2, stream);
     }
 }
 

@@ -233,8 +233,8 @@ __global__ __launch_bounds__(V2_T, 2) void corr_build_split_v2_kernel(const _Flo
 
 namespace bflow {
 bool corr_stream_supported(int T, int B, int D, int N, int Np);
-int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, float* out, int T, int B, int D, int N, int Np,
-                       long long f1_target_stride, int plane_h, int plane_w, hipStream_t stream);
+int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, void* out, int T, int B, int D, int N, int Np,
+                       long long f1_target_stride, int plane_h, int plane_w, bool f16, hipStream_t stream);
 }
 
 extern "C" int bflow_split_pack(const float* src, void* hi, void* lo, int R, int D, int N, int Np, bflow_stream_t stream) {
@@ -253,7 +253,7 @@ extern "C" int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, cons
     // D in {64, 128, 256}: the A-stationary streaming kernel (corr_stream.hip); anything else: the 256x128 tile kernel below
     static const bool force_tile = getenv("BFLOW_CORR_TILE_KERNEL") != nullptr;   // A/B timing only (tools/)
     if (!force_tile && bflow::corr_stream_supported(T, B, D, N, Np))
-        return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, 0, 0, (hipStream_t)stream);
+        return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, 0, 0, false, (hipStream_t)stream);
     BFLOW_REQUIRE((long long)T * B <= 65535, BFLOW_E_LIMIT, "corr_build_split: T*B too large");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_build_split_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               V2_STAGES * V2_STAGE);   // 144 KB of dynamic LDS; idempotent, per device
@@ -276,5 +276,20 @@ extern "C" int bflow_corr_build_split_tiled(const void* f1_hi, const void* f1_lo
                   B, h, w, Np);
     BFLOW_REQUIRE(bflow::corr_stream_supported(T, B, D, N, Np), BFLOW_E_ARG, "corr_build_split_tiled: needs D in {64, 128, 256} and < 2 GiB slabs (D=%d N=%d)",
                   D, N);
-    return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, h, w, (hipStream_t)stream);
+    return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, h, w, false, (hipStream_t)stream);
+}
+
+// BASELINE configs[4] ("fp16 MFMA correlation ... HBM-bound 4D volume stress"): the volume from PLAIN fp16 operands (the hi planes of the
+// split tensors: features rounded to fp16), one fp16 MFMA pass with fp32 accumulation, stored as fp16 tiled planes: a third of the
+// matrix-core work and half of the bytes of bflow_corr_build_split_tiled, at fp16 accuracy (2^-11 per operand and per stored value).
+// f1_hi (B | T*B, D/32, Np, 32) fp16, f2_hi (T*B, D/32, Np, 32) fp16, out (T, B, N, tiles*32) fp16.  D in {128, 256}.
+extern "C" int bflow_corr_build_f16_tiled(const void* f1_hi, const void* f2_hi, void* out, int T, int B, int D, int h, int w, int Np,
+                                          long long f1_target_stride, bflow_stream_t stream) {
+    BFLOW_REQUIRE(f1_hi && f2_hi && out, BFLOW_E_ARG, "corr_build_f16_tiled: null pointer");
+    const int N = h * w;
+    BFLOW_REQUIRE(T > 0 && B > 0 && h > 0 && w > 0 && Np >= N && Np % 128 == 0, BFLOW_E_ARG, "corr_build_f16_tiled: bad sizes T=%d B=%d h=%d w=%d Np=%d", T, B,
+                  h, w, Np);
+    BFLOW_REQUIRE((D == 128 || D == 256) && bflow::corr_stream_supported(T, B, D, N, Np), BFLOW_E_ARG,
+                  "corr_build_f16_tiled: needs D in {128, 256} and < 2 GiB slabs (D=%d N=%d)", D, N);
+    return bflow::corr_stream_launch(f1_hi, nullptr, f2_hi, nullptr, out, T, B, D, N, Np, f1_target_stride, h, w, true, (hipStream_t)stream);
 }

@@ -24,7 +24,7 @@ MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -107,6 +107,9 @@ def lib() -> ctypes.CDLL:
         "bflow_corr_build_split": [vp, vp, vp, vp, vp, i, i, i, i, i, ll, vp],
         "bflow_corr_build_split_tiled": [vp, vp, vp, vp, vp, i, i, i, i, i, i, ll, vp],
         "bflow_corr_pool2x2_tiled": [vp, vp, ll, i, i, vp],
+        "bflow_corr_pool2x2_tiled_f16": [vp, vp, ll, i, i, vp],
+        "bflow_corr_build_f16_tiled": [vp, vp, vp, i, i, i, i, i, i, ll, vp],
+        "bflow_corr_lookup_bezier_split_tiled_f16": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_corr_lookup_bezier_split_tiled": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_conv_pack_weights": [vp, vp, vp, i, i, i, i, i, i, vp],
         "bflow_conv_stem": [ctypes.POINTER(StemDesc), vp],
@@ -239,7 +242,13 @@ def corr_build_split(p1: torch.Tensor, p2: torch.Tensor, out: torch.Tensor, T: i
     assert R2 == T * B and p1.shape[1] == (B if shared_f1 else T * B)
     assert p1.dtype == torch.float16 and p2.dtype == torch.float16 and p1.is_cuda and p2.is_cuda
     assert p1[0].is_contiguous() and p1[1].is_contiguous() and p2[0].is_contiguous() and p2[1].is_contiguous()
-    if tiled_hw is None:
+    if out.dtype == torch.float16:
+        assert tiled_hw is not None, "the fp16 volume exists in the tiled layout only"
+        h, w = int(tiled_hw[0]), int(tiled_hw[1])
+        assert h * w == N and out.shape == (T, B, N, tiled_plane_size(h, w)) and out.is_cuda and out.is_contiguous()
+        _check(lib().bflow_corr_build_f16_tiled(p1[0].data_ptr(), p2[0].data_ptr(), out.data_ptr(), T, B, D, h, w, Np,
+                                                0 if shared_f1 else B * Np * D, _stream()), "bflow_corr_build_f16_tiled")
+    elif tiled_hw is None:
         assert out.shape == (T, B, N, N)
         _check(lib().bflow_corr_build_split(p1[0].data_ptr(), p1[1].data_ptr(), p2[0].data_ptr(), p2[1].data_ptr(), _dev(out, name="out"),
                                             T, B, D, N, Np, 0 if shared_f1 else B * Np * D, _stream()), "bflow_corr_build_split")
@@ -254,6 +263,10 @@ def corr_pool2x2_tiled(src: torch.Tensor, dst: torch.Tensor, h: int, w: int):
     """src (planes, tiled_plane_size(h, w)) -> dst (planes, tiled_plane_size(h//2, w//2)): 2x2 mean on tiled planes."""
     planes = src.numel() // tiled_plane_size(h, w)
     assert src.shape[-1] == tiled_plane_size(h, w) and dst.shape[-1] == tiled_plane_size(h // 2, w // 2) and dst.numel() == planes * dst.shape[-1]
+    if src.dtype == torch.float16:
+        assert dst.dtype == torch.float16 and src.is_cuda and src.is_contiguous() and dst.is_contiguous()
+        _check(lib().bflow_corr_pool2x2_tiled_f16(src.data_ptr(), dst.data_ptr(), planes, h, w, _stream()), "bflow_corr_pool2x2_tiled_f16")
+        return
     _check(lib().bflow_corr_pool2x2_tiled(_dev(src, name="src"), _dev(dst, name="dst"), planes, h, w, _stream()), "bflow_corr_pool2x2_tiled")
 
 
@@ -271,7 +284,7 @@ def make_plane_table(planes: Sequence[dict]):
     arr = (PlaneDesc * len(planes))()
     for k, p in enumerate(planes):
         t = p["tensor"]
-        arr[k].base = _dev(t, name=f"plane{k}")
+        arr[k].base = _dev(t, None, name=f"plane{k}")     # fp32, or fp16 for the tiled fp16 volume
         hw = p.get("hw")
         arr[k].h, arr[k].w = (int(t.shape[-2]), int(t.shape[-1])) if hw is None else (int(hw[0]), int(hw[1]))
         arr[k].level, arr[k].target = int(p["level"]), int(p["target"])
@@ -297,7 +310,8 @@ def corr_lookup_bezier(table, params: torch.Tensor, coef: np.ndarray, out: torch
                                           T, deg, _dev(out, name="out"), B, h1, w1, _stream()), "bflow_corr_lookup_bezier")
 
 
-def corr_lookup_bezier_split(table, params: torch.Tensor, coef: np.ndarray, out_planes: torch.Tensor, tiled: bool = False):
+def corr_lookup_bezier_split(table, params: torch.Tensor, coef: np.ndarray, out_planes: torch.Tensor, tiled: bool = False,
+                             f16_planes: bool = False):
     """out_planes: (2, B, CBk, rows, 32) fp16 (hi, lo), zero-initialised once by the caller (pad channels are never written by the row-major
     kernel).  tiled: the plane table describes tiled planes (bflow_corr_build_split_tiled / bflow_corr_pool2x2_tiled)."""
     B, C2, h1, w1 = params.shape
@@ -306,7 +320,9 @@ def corr_lookup_bezier_split(table, params: torch.Tensor, coef: np.ndarray, out_
     P = len(table)
     assert out_planes.dtype == torch.float16 and out_planes.is_contiguous() and out_planes.shape[0] == 2 and out_planes.shape[1] == B \
         and out_planes.shape[4] == 32 and out_planes.shape[2] * 32 >= P * 81 and out_planes.shape[3] >= h1 * w1
-    fn = lib().bflow_corr_lookup_bezier_split_tiled if tiled else lib().bflow_corr_lookup_bezier_split
+    assert tiled or not f16_planes
+    fn = lib().bflow_corr_lookup_bezier_split_tiled_f16 if f16_planes else lib().bflow_corr_lookup_bezier_split_tiled if tiled \
+        else lib().bflow_corr_lookup_bezier_split
     _check(fn(table, P, _dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
               T, deg, out_planes[0].data_ptr(), out_planes[1].data_ptr(), out_planes.shape[2],
               out_planes.shape[3], B, h1, w1, _stream()), "bflow_corr_lookup_bezier_split" + ("_tiled" if tiled else ""))

@@ -93,6 +93,8 @@ class RAFTSpline(nn.Module):
             times.append(1)
         self.lookup_timestamps = times
         self._coef = None
+        # None = bflow_amd.corr.PRECISION ("split": fp32-class volume); "f16" = fp16 operands and volume (BASELINE configs[4])
+        self.corr_precision: Optional[str] = None
         self._graphs = None
         self.stage_timer: Optional[StageTimer] = None
         self._probe = None            # tools only: callable(name) invoked at stage boundaries inside the captured forward
@@ -252,7 +254,8 @@ class RAFTSpline(nn.Module):
 
         if pr: pr("fnet.end")
         if tm: tm.start("corr computation")
-        corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img, layout="tiled")
+        corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img, layout="tiled",
+                                                  precision=self.corr_precision)
         if tm: tm.stop("corr computation")
         if pr: pr("corr.end")
         cnet_branch.join()

@@ -238,6 +238,18 @@ int bflow_corr_lookup_bezier_split_tiled(const bflow_plane_t* planes, int P, con
                                          bflow_stream_t stream);
 int bflow_corr_pool2x2_tiled(const float* in, float* out, long long planes, int h, int w, bflow_stream_t stream);
 
+/* fp16 correlation (BASELINE configs[4]: "fp16 MFMA correlation ... HBM-bound 4D volume stress").  The same three kernels on an fp16
+ * volume: the build takes the PLAIN fp16 features (the hi planes of the split operands), runs ONE fp16 MFMA pass with fp32 accumulation
+ * and stores fp16 tiled planes (half the bytes, a third of the matrix-core work; accuracy 2^-11 per operand and stored value instead of
+ * 2^-22); pooling and look-up read / write fp16 planes (`base` of the descriptors points at fp16 data), the look-up output is unchanged.
+ *   bflow_corr_build_f16_tiled : f1_hi (B | T*B, D/32, Np, 32), f2_hi (T*B, D/32, Np, 32) fp16 -> out (T, B, N, tiles*32) fp16; D in {128, 256} */
+int bflow_corr_build_f16_tiled(const void* f1_hi, const void* f2_hi, void* out, int T, int B, int D, int h, int w, int Np,
+                               long long f1_target_stride, bflow_stream_t stream);
+int bflow_corr_pool2x2_tiled_f16(const void* in, void* out, long long planes, int h, int w, bflow_stream_t stream);
+int bflow_corr_lookup_bezier_split_tiled_f16(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
+                                             void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
+                                             bflow_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K8  Bezier polynomial coefficients C(deg,i) (1-t)^(deg-i) t^i, i = 1..deg, computed in fp64 on the HOST
  * and rounded to fp32 exactly like BezierCurves._compute_flow_from_timestamps,
