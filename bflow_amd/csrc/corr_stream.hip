@@ -26,6 +26,7 @@
 // Measured on MI355X (round 2, tools/k5_probe.py): C2 (T=4, N=4800) 129-141 us vs 199-211 us for the tile kernel; steady state
 // 7150 cycles per 64 reference rows per CU against a matrix-core floor of 6144 (stores cost ~900 of the difference: with them
 // removed the same loop runs at 6250), 18 k cycles of prologue (first panel), 1.65 GHz sustained.
+#include <cstdlib>
 #include "common.h"
 
 // STREAM_ABL (tools/k5_ablate.sh only; timing builds with WRONG results): 1 no stores, 2 no in-loop DMA, 3 no barrier / DMA wait,
@@ -335,7 +336,10 @@ int launch_kb(const StreamArgs& a, bool pow2, hipStream_t s) {
     const int lds = SLOTS * (F16 ? 2 : 4) * KB * 1024;
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, s, a);
+        // one persistent workgroup per CU (128 KB of LDS, 225 VGPRs); the fp16 variant needs half of both, so two per CU hide each other's
+        // barriers and store bursts (BFLOW_CORR_F16_WGS: 256 | 512, tools A/B)
+        static const int f16_wgs = [] { const char* e = getenv("BFLOW_CORR_F16_WGS"); return e && atoi(e) == 256 ? 256 : 512; }();
+        hipLaunchKernelGGL(kern, dim3(F16 ? f16_wgs : 256), dim3(512), lds, s, a);
     };
     if (pow2) go(corr_stream_kernel<KB, true, F16>);
     else go(corr_stream_kernel<KB, false, F16>);

@@ -10,6 +10,8 @@ dev = "cuda"
 cname, B, H, W, iters = "E_I_LU5_BD10", 1, 1024, 1024, 20
 cfg = O.model_config(cname); sd = O.make_state_dict(cfg, 0)
 m = bflow_amd.RAFTSpline(cfg).eval(); m.load_state_dict(sd); m.to(dev); m.enable_hipgraph()
+if "--f16" in sys.argv:
+    m.corr_precision = "f16"      # BASELINE configs[4]: fp16 MFMA correlation, fp16 volume
 C = cfg["num_bins"]["context"] + cfg["num_bins"]["correlation"] - 1
 vox = torch.from_numpy(synthetic.voxel_grid(B, C, H, W, seed=7))
 a, b = synthetic.image_pair(B, H, W, seed=8); imgs = [torch.from_numpy(a), torch.from_numpy(b)]
@@ -21,7 +23,7 @@ for _ in range(5):
     lo, up = m(voxel_grid=gv, images=gi, iters=iters, test_mode=True)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 f = up.get_flow_from_reference(1.0).cpu()
-print(f"C5 GPU: {dt*1e3:.1f} ms/frame ({1/dt:.1f} frames/s), |flow| mean {float(f.abs().mean()):.3f}, finite {bool(torch.isfinite(f).all())}, "
+print(f"C5 GPU ({'fp16 correlation' if '--f16' in sys.argv else 'split (fp32-class) correlation'}): {dt*1e3:.1f} ms/frame ({1/dt:.1f} frames/s), |flow| mean {float(f.abs().mean()):.3f}, finite {bool(torch.isfinite(f).all())}, "
       f"peak memory {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 if "--no-oracle" not in sys.argv:
     t0 = time.perf_counter()
@@ -30,4 +32,4 @@ if "--no-oracle" not in sys.argv:
     of = O.bezier_flow(oup, 1.0)
     epe = float(torch.sqrt(((f - of) ** 2).sum(1)).mean())
     print(f"C5 oracle: {time.perf_counter()-t0:.0f} s on CPU; EPE GPU vs oracle {epe:.3e} px (|flow| {float(torch.sqrt((of**2).sum(1)).mean()):.2f})")
-    assert epe < 1e-3
+    assert epe < (1e-2 if "--f16" in sys.argv else 1e-3)

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--time-only", action="store_true", help="skip the correctness checks (ablation builds)")
     ap.add_argument("--stamps", action="store_true", help="needs the STREAM_STAMPS build (tools/k5_ablate.sh stamps:-DSTREAM_STAMPS)")
+    ap.add_argument("--f16", action="store_true", help="also time the fp16 tiled volume (bflow_corr_build_f16_tiled)")
     ap.add_argument("--big", action="store_true", help="also time C3 (B=8, T=5) and C5 (N=16384, T=6)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -80,6 +81,21 @@ def main():
     ms, mn = timeit(lambda: hip.corr_build_split(p1, p2, vol, T, B, N, shared_f1=True), args.reps)
     by = 4.0 * ((1 + T) * B * D * N + T * B * N * N)
     print(f"C2 (T=4 B=1 N=4800): median {ms*1e3:.1f} us (min {mn*1e3:.1f})  {by/ms/1e6:.0f} GB/s algorithmic = {by/ms/1e6/8000:.3f} of 8 TB/s", flush=True)
+    if args.f16:
+        for name, B, T, hh, ww, shared in (("C2", 1, 4, 60, 80, True), ("C4 shard", 8, 4, 60, 80, True), ("C5", 1, 6, 128, 128, False)):
+            N = hh * ww
+            f1 = torch.randn(((1 if shared else T) * B, D, N), generator=g).to(dev)
+            f2 = torch.randn((T * B, D, N), generator=g).to(dev)
+            p1, p2 = hip.split_pack(f1), hip.split_pack(f2)
+            for dt, label in ((torch.float32, "split -> fp32 tiled"), (torch.float16, "fp16  -> fp16 tiled")):
+                vol = torch.empty((T, B, N, hip.tiled_plane_size(hh, ww)), dtype=dt, device=dev)
+                ms, mn = timeit(lambda: hip.corr_build_split(p1, p2, vol, T, B, N, shared_f1=shared, tiled_hw=(hh, ww)), max(args.reps // 3, 5))
+                eb = vol.element_size()
+                by = 2.0 * (eb // 2) * (((1 if shared else T) + T) * B * D * N) + eb * T * B * N * N   # fp16: hi planes only
+                print(f"{name} {label}: median {ms*1e3:.1f} us (min {mn*1e3:.1f})  {by/1e6:.0f} MB algorithmic -> {by/ms/1e6:.0f} GB/s = "
+                      f"{by/ms/1e6/8000:.3f} of 8 TB/s", flush=True)
+                del vol
+            del f1, f2, p1, p2
     if args.big:
         for name, B, T, N, shared in (("C4 shard (B=8 T=4)", 8, 4, 4800, True), ("C3 (B=8 T=4+1 M-to-N)", 8, 5, 4800, False),
                                       ("C1 (N=2304 T=5)", 1, 5, 2304, True), ("C5 (N=16384 T=6 M-to-N)", 1, 6, 16384, False)):

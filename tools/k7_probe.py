@@ -71,14 +71,15 @@ def main():
         params[:, :, 0, :4] *= 40.0      # a few far-out-of-plane look-ups (all-zero windows) and border cases
         coef = hip.bezier_coeffs([(i + 1) / Tall for i in range(Tall)], deg)
         outs = {}
-        for layout in ("rows", "tiled"):
-            blk = CorrBlockParallelMultiTarget(corr_computation_events=cc, corr_computation_frames=cimg, layout=layout)
+        for layout in ("rows", "tiled", "tiled-f16"):
+            blk = CorrBlockParallelMultiTarget(corr_computation_events=cc, corr_computation_frames=cimg, layout=layout.split("-")[0],
+                                               precision="f16" if layout.endswith("f16") else None)
             out = blk.new_output_split()
             P = blk.num_planes
-            by = 4.0 * B * N * P * 181
+            by = B * N * P * ((2.0 if layout.endswith("f16") else 4.0) * 100 + 4.0 * 81)
             ms, mn = timeit(lambda: blk.lookup_bezier_split(params, coef, out), args.reps)
             gms = graph_time(lambda: blk.lookup_bezier_split(params, coef, out))
-            print(f"{name} {layout:5s}: B={B} N={N} P={P} deg={deg}: events median {ms*1e3:.1f} us (min {mn*1e3:.1f}), in-graph {gms*1e3:.1f} us; "
+            print(f"{name} {layout:9s}: B={B} N={N} P={P} deg={deg}: events median {ms*1e3:.1f} us (min {mn*1e3:.1f}), in-graph {gms*1e3:.1f} us; "
                   f"{by/1e6:.1f} MB algorithmic -> {by/gms/1e6:.0f} GB/s = {by/gms/1e6/8000:.3f} of 8 TB/s", flush=True)
             outs[layout] = out.float_nhwc()
             del blk, out
