@@ -155,6 +155,33 @@ def test_bezier_container_on_host():
         BezierCurves.create_from_voxel_grid(torch.zeros(1, 9, 60, 96))   # bezier.py:67-68
 
 
+def test_bench_self_launches_its_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a torchrun environment must become the launcher of N ranks (the driver's scaling tier may call
+    it either way), on 127.0.0.1 with a free port, passing its own arguments through."""
+    import importlib
+    import subprocess
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.relaunch(bench.parse_args()) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the global batch of configs[3] splits into micro-batches of 8 for every N of the scaling curve
+    for n in (1, 2, 4, 8):
+        a, b = bdist.shard_range(bench.GLOBAL_BATCH, 0, n)
+        assert (b - a) % min(bench.MICRO_BATCH, b - a) == 0 and (b - a) * n == bench.GLOBAL_BATCH
+
+
 def test_shard_ranges_cover_the_global_batch():
     for G in (1, 7, 8, 64):
         for Wd in (1, 2, 4, 8):
