@@ -112,6 +112,42 @@ class PackedConvWeight:
         return self.planes, self.meta
 
 
+class ThinConvWeight:
+    """fp32 weights of a thin-output convolution laid out tap-major (KH*KW, Cout, Cin) for bflow_conv_thin_acc."""
+
+    def __init__(self):
+        self._key = None
+        self.w = None
+
+    def get(self, weight: torch.Tensor):
+        key = (weight.data_ptr(), weight._version, str(weight.device))
+        if self._key != key:
+            cout, cin, kh, kw = weight.shape
+            with torch.no_grad():
+                self.w = weight.detach().float().permute(2, 3, 0, 1).reshape(kh * kw, cout, cin).contiguous()
+            self._key, self.meta = key, (cout, cin, kh, kw)
+        return self.w, self.meta
+
+
+def conv_thin_acc(x: SplitTensor, packed, bias: Optional[torch.Tensor], acc_nchw: torch.Tensor, out_split: Optional[SplitTensor] = None,
+                  channel_offset: int = 0):
+    """acc_nchw (B, cout, H, W) fp32 += conv(x, w) + bias ("same" zero padding, stride 1, cout <= 32) on the vector ALU in fp32;
+    out_split's 32-channel block at `channel_offset` receives the updated values (see bflow_conv_thin_acc)."""
+    w, (cout, cin, kh, kw) = packed
+    B, H, W, _ = x.shape
+    assert cin == x.channels_padded, f"input has {x.channels_padded} (padded) channels, weight expects {cin}"
+    assert acc_nchw.dtype == torch.float32 and acc_nchw.is_contiguous() and tuple(acc_nchw.shape) == (B, cout, H, W)
+    assert channel_offset % 32 == 0
+    oh = ol = None
+    cbo = rows_o = 0
+    if out_split is not None:
+        assert out_split.planes.shape[1] == B and out_split.H == H and out_split.W == W and channel_offset < out_split.channels_padded
+        oh, ol, cbo, rows_o = out_split.hi.data_ptr(), out_split.lo.data_ptr(), out_split.planes.shape[2], out_split.rows
+    hip._check(hip.lib().bflow_conv_thin_acc(x.hi.data_ptr(), x.lo.data_ptr(), hip._dev(w, name="weight"),
+                                             None if bias is None else hip._dev(bias, name="bias"), acc_nchw.data_ptr(), oh, ol, B, H, W, cin,
+                                             x.rows, cout, kh, kw, cbo, channel_offset // 32, rows_o, hip._stream()), "bflow_conv_thin_acc")
+
+
 def _stats_replicas(stats: Optional[torch.Tensor], B: int, C: int) -> int:
     """Statistics tables are (B, C, 2) or (R, B, C, 2): R replicas that spread the epilogue's fp64 atomics (summed by norm_act)."""
     if stats is None:

@@ -211,8 +211,9 @@ class BasicUpdateBlock(nn.Module):
         bh = self.bezier_head
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
         # bezier += delta (bezier.py:137-139) and the new Bezier channel block of M are produced by the epilogue
-        S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, acc_nchw=bezier, out_split=ws.M,
-               channel_offset=self.motion_dim)
+        # (a 2*deg-channel output: the thin vector-ALU kernel, not a 32-wide MFMA tile)
+        S.conv_thin_acc(d1, self.__dict__.setdefault("_head2_w", S.ThinConvWeight()).get(bh.conv2.weight), bh.conv2.bias, bezier,
+                        out_split=ws.M, channel_offset=self.motion_dim)
         mask_branch.join()
         return mask
 

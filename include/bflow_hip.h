@@ -156,6 +156,20 @@ int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, in
                             int cout_pad, int cin_pad, bflow_stream_t stream);
 int bflow_conv_split(const bflow_conv_desc_t* desc, bflow_stream_t stream);
 
+/* bflow_conv_thin_acc: the thin-output convolution of the Bezier head with its parameter update fused behind it:
+ *     acc[b, co, y, x] += bias[co] + sum_{c, r, q} x[b, y+r-KH/2, x+q-KW/2, c] * w[co, c, r, q]      (zero padding, stride 1)
+ * Replaces BezierHead.conv2 = Conv2d(256, 2*degree, 3, padding=1) (models/raft_spline/update.py:12-18) followed by
+ * BezierCurves.delta_update_params (models/raft_spline/bezier.py:137-139).  Cout <= 32, 3x3 or 1x1 filters, C % 32 == 0, C <= 256.
+ *   x_hi/x_lo : blocked split input (B, C/32, in_rows_per_image, 32);
+ *   w_packed  : fp32 (KH*KW, Cout, C) -- plain fp32 weights, tap-major (no split: the kernel computes in fp32 on the vector ALU,
+ *               the inputs are re-assembled as hi + lo * 2^-11);
+ *   acc_nchw  : (B, Cout, H*W) fp32, updated in place;
+ *   out_hi/lo : NULL, or a split buffer (B, out_channel_blocks, out_rows_per_image, 32) whose block `out_block` receives the
+ *               UPDATED acc values (channels >= Cout of that block: zero) -- the Bezier block of the next GRU input.        */
+int bflow_conv_thin_acc(const void* x_hi, const void* x_lo, const float* w_packed, const float* bias, float* acc_nchw, void* out_hi,
+                        void* out_lo, int B, int H, int W, int C, int in_rows_per_image, int Cout, int KH, int KW,
+                        int out_channel_blocks, int out_block, int out_rows_per_image, bflow_stream_t stream);
+
 /* bflow_plane_stats: stats[p] = (sum, sum of squares) of plane p of an NCHW fp32 tensor (planes = B*C, HW % 4 == 0).
  * bflow_norm_act_split: out = act_out( res + act_a( norm_a(a) ) ) -> split NHWC (and/or fp32 NHWC), where
  *     a     : fp32 NHWC (B, HW, C), or NCHW (B, C, HW) when a_is_nchw (transposed on the fly);

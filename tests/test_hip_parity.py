@@ -658,6 +658,48 @@ def test_conv_split_engine_vs_fp64(cin, cout, k, stride, pad, H, W, B):
     assert (back.cpu().double() - got_s).abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,k,H,W,B,blocks,blk", [
+    (256, 4, 3, 15, 20, 1, 5, 4),       # the Bezier head at degree 2 (update.py:12-18), block 4 of a 5-block GRU input
+    (256, 20, 3, 13, 19, 2, 5, 4),      # degree 10: five passes of four output channels, ragged pixel groups
+    (128, 6, 3, 9, 7, 3, 2, 0),         # fewer than 256 input channels (idle lanes)
+    (64, 3, 1, 11, 5, 2, 1, 0),         # 1x1 filter, Cout not a multiple of 4
+    (256, 4, 3, 48, 64, 8, 5, 4),       # more pixel groups than workgroups (a workgroup walks several groups)
+])
+def test_conv_thin_acc_vs_fp64(cin, cout, k, H, W, B, blocks, blk):
+    """bflow_conv_thin_acc (the vector-ALU Bezier head): acc += conv + bias against fp64, and the emitted split block."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    bias = rs.standard_normal(cout).astype(np.float32)
+    acc0 = (rs.standard_normal((B, cout, H, W)) * 10).astype(np.float32)
+    xs = S.from_nchw(cu(x))
+    xv = xs.float_nhwc().permute(0, 3, 1, 2).cpu().double()       # the value the kernel sees (22-bit split of x)
+    ref = torch.from_numpy(acc0).double() + torch.nn.functional.conv2d(xv, torch.from_numpy(w).double(), torch.from_numpy(bias).double(), padding=k // 2)
+    mag = torch.nn.functional.conv2d(xv.abs(), torch.from_numpy(np.abs(w)).double(), None, padding=k // 2) + torch.from_numpy(np.abs(acc0)).double() + 1.0
+    acc = cu(acc0.copy())
+    out = S.SplitTensor.empty(B, H, W, blocks * 32, DEV)
+    out.planes.fill_(7.0)                                          # sentinel: only block `blk` may change
+    S.conv_thin_acc(xs, S.ThinConvWeight().get(cu(w)), cu(bias), acc, out_split=out, channel_offset=blk * 32)
+    err = float(((acc.cpu().double() - ref).abs() / mag).max())
+    print(f"conv_thin {cin}->{cout} {k}x{k}: err/sum|x||w| {err:.2e}")
+    assert err < 3e-7                                              # fp32 FMA accumulation over <= 2304 products
+    o = out.float_nhwc().permute(0, 3, 1, 2).cpu()
+    got_blk = o[:, blk * 32:blk * 32 + 32]
+    a = acc.cpu()
+    assert float((got_blk[:, :cout] - a).abs().max()) <= float(a.abs().max()) * 2.0 ** -21
+    assert float(got_blk[:, cout:].abs().max()) == 0.0 if cout < 32 else True
+    rest = torch.cat([o[:, :blk * 32], o[:, blk * 32 + 32:]], dim=1)
+    assert rest.numel() == 0 or bool((rest == 7.0 + 7.0 / 2048.0).all())
+    # no output block: only the accumulator is updated
+    acc2 = cu(acc0.copy())
+    S.conv_thin_acc(xs, S.ThinConvWeight().get(cu(w)), None, acc2)
+    ref2 = ref - torch.from_numpy(bias).double().view(1, -1, 1, 1)
+    assert float(((acc2.cpu().double() - ref2).abs() / mag).max()) < 3e-7
+    with pytest.raises(hip.BflowHipError):
+        S.conv_thin_acc(xs, (cu(np.zeros((25, cout, cin), np.float32)), (cout, cin, 5, 5)), None, acc2)
+
+
 # ------------------------------------------------------------------------------------------------- SURVEY 8(f-3): validation harness
 def test_flow_metrics_golden(golden_dir):
     from bflow_amd import metrics as MX
