@@ -5,7 +5,7 @@ import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bflow_amd
 from bflow_amd import configs, synthetic
-from bench import deterministic_state_dict
+from bflow_amd.weights import deterministic_state_dict
 lib = ctypes.CDLL(os.path.join(ROOT, "tools", "stamp", "libstamp.so"))
 lib.stamp.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda:0")
