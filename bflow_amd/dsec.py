@@ -15,12 +15,14 @@ covering [t_start, t_end); `EventStream` wraps an in-memory, time-sorted stream 
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+import os
+from pathlib import Path
+from typing import List, Optional, Tuple
 
 import numpy as np
 import torch
 
-from . import hip
+from . import hip, voxel_cache
 from .representations import VoxelGrid, norm_voxel_grid
 
 
@@ -77,7 +79,7 @@ class TwoStepAssembler:
     them (base.py:55-84); extended_voxel_grid = version 1 (one extra bin of events on either side, base.py:196-200)."""
 
     def __init__(self, num_bins: int, height: int, width: int, rectify_map, normalize_voxel_grid: bool = True, merge_grids: bool = True,
-                 extended_voxel_grid: bool = True, device="cuda"):
+                 extended_voxel_grid: bool = True, device="cuda", voxel_grid_dir=None):
         assert num_bins >= 1
         self.num_bins, self.height, self.width = num_bins, height, width
         self.voxel_grid = VoxelGrid(num_bins, height, width)
@@ -87,6 +89,14 @@ class TwoStepAssembler:
         self.normalize, self.merge_grids, self.version = normalize_voxel_grid, merge_grids, 1 if extended_voxel_grid else 0
         self.device = device
         self._bad = torch.zeros(1, dtype=torch.int32, device=device)
+        # base.py:93-104 `load_voxel_grid`: per-window grids are cached as blosc-zstd HDF5 files (bflow_amd/voxel_cache.py)
+        self.voxel_grid_dir = None
+        if voxel_grid_dir is not None:
+            self.voxel_grid_dir = Path(voxel_grid_dir)
+            if not self.voxel_grid_dir.exists():
+                os.mkdir(self.voxel_grid_dir)
+            else:
+                assert self.voxel_grid_dir.is_dir()
 
     # base.py:160-204 -------------------------------------------------------------------------------------------------
     def construct_voxel_grid(self, events, ts_from: int, ts_to: int) -> torch.Tensor:
@@ -111,12 +121,26 @@ class TwoStepAssembler:
                                     self.rectify_events_map, t0c, t1c, grid, self._bad)
         return grid
 
+    # base.py:205-222 -------------------------------------------------------------------------------------------------
+    def get_voxel_grid(self, events, ts_from: int, ts_to: int, file_index: Optional[int] = None) -> torch.Tensor:
+        """`_get_voxel_grid`: with a cache directory the grid of file `{file_index:06d}.h5` is loaded if it exists, else built and saved."""
+        if self.voxel_grid_dir is None or file_index is None:
+            return self.construct_voxel_grid(events, ts_from, ts_to)
+        f = voxel_cache.dsec_voxel_grid_file(self.voxel_grid_dir, file_index)
+        if not f.exists():
+            grid = self.construct_voxel_grid(events, ts_from, ts_to)
+            voxel_cache.np_array_to_h5(grid.cpu().numpy(), f)
+            return grid
+        return torch.from_numpy(voxel_cache.h5_to_np_array(f)).to(self.device)
+
     # twostep.py:44-92 ------------------------------------------------------------------------------------------------
-    def assemble(self, events, forward_flow_timestamps, index: int, check: bool = True) -> torch.Tensor:
+    def assemble(self, events, forward_flow_timestamps, index: int, check: bool = True, flow_file_index: Optional[int] = None) -> torch.Tensor:
+        """`flow_file_index` (the index in the flow file's name, twostep.py:41) selects the cache files: it for the current window,
+        it - 2 for the previous one (100-ms steps, twostep.py:63-64)."""
         (cf, ct), (pf, pt) = twostep_windows(forward_flow_timestamps, index)
         self._bad.zero_()     # the counter is per sample: one bad sample must not fail (or hide in) the following ones
-        ev_cur = self.construct_voxel_grid(events, cf, ct)
-        ev_prev = self.construct_voxel_grid(events, pf, pt)
+        ev_cur = self.get_voxel_grid(events, cf, ct, flow_file_index)
+        ev_prev = self.get_voxel_grid(events, pf, pt, None if flow_file_index is None else flow_file_index - 2)
         if check:
             # base.py:141-142: raw coordinates must lie inside the map (one device->host read, like the reference's x.max())
             assert int(self._bad) == 0, f"{int(self._bad)} events outside the {self.height}x{self.width} rectification map"

@@ -836,6 +836,36 @@ def test_dsec_twostep_assembly_golden(golden_dir):
         TwoStepAssembler(bins, H, W, rect).assemble(bad, ts, 1)
 
 
+def test_dsec_twostep_assembly_with_voxel_cache(tmp_path):
+    """base.py:205-217 `load_voxel_grid`: the first pass builds the two window grids on the GPU and writes `{index:06d}.h5`
+    (blosc-zstd HDF5, bflow_amd/voxel_cache.py); the second pass must come from the files alone and be bit-identical."""
+    from bflow_amd import voxel_cache as VC
+    from bflow_amd.dsec import EventStream, TwoStepAssembler
+    H, W, bins = 96, 128, 5
+    rs = np.random.RandomState(8)
+    n = 40_000
+    ev = dict(x=rs.randint(0, W, n).astype(np.uint16), y=rs.randint(0, H, n).astype(np.uint16), p=rs.randint(0, 2, n).astype(np.uint8),
+              t=np.sort(rs.randint(10_000_000, 10_260_000, n)).astype(np.int64))
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    rect = np.stack([xx.astype(np.float32), yy.astype(np.float32)], -1)
+    ts = np.array([[10_030_000, 10_130_000], [10_130_000, 10_230_000]], dtype=np.int64)
+    d = VC.dsec_voxel_grid_dir(tmp_path, bins, True)
+    asm = TwoStepAssembler(bins, H, W, rect, voxel_grid_dir=d)
+    first = asm.assemble(EventStream(**ev), ts, 1, flow_file_index=6)
+    assert sorted(os.listdir(d)) == ["000004.h5", "000006.h5"]                    # current = index, previous = index - 2 (twostep.py:63-64)
+    plain = TwoStepAssembler(bins, H, W, rect).assemble(EventStream(**ev), ts, 1)
+    assert torch.equal(first, plain)
+
+    class NoEvents:                                                                # the second pass must not touch the event stream
+        def window(self, *a):
+            raise AssertionError("cache miss")
+        get_start_time_us = get_final_time_us = window
+    again = asm.assemble(NoEvents(), ts, 1, flow_file_index=6)
+    assert torch.equal(again, first)
+    g = VC.h5_to_np_array(VC.dsec_voxel_grid_file(d, 6))
+    assert g.shape == (bins, H, W) and g.dtype == np.float32
+
+
 def test_dsec_twostep_assembly_full_size_vs_oracle():
     """DSEC size (480x640, 5 bins -> 9 channels), ~0.6 M events: GPU assembly vs the CPU restatement."""
     from bflow_amd.dsec import EventStream, TwoStepAssembler
