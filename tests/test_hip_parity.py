@@ -854,7 +854,7 @@ def test_dsec_twostep_assembly_with_voxel_cache(tmp_path):
     first = asm.assemble(EventStream(**ev), ts, 1, flow_file_index=6)
     assert sorted(os.listdir(d)) == ["000004.h5", "000006.h5"]                    # current = index, previous = index - 2 (twostep.py:63-64)
     plain = TwoStepAssembler(bins, H, W, rect).assemble(EventStream(**ev), ts, 1)
-    assert torch.equal(first, plain)
+    assert torch.allclose(first, plain, rtol=1e-4, atol=5e-5)                     # two scatter passes: fp32 atomics in another order
 
     class NoEvents:                                                                # the second pass must not touch the event stream
         def window(self, *a):
