@@ -213,8 +213,12 @@ def main():
         for _ in range(3):
             step6()
         n_it = max(args.steps // 2, 5)
-        t12 = time_steps(step_c2, n_it) / n_it
+        # the difference of two ~4 ms timings: three interleaved rounds, the fastest of each (clock ramps only ever add time)
+        t12 = min(time_steps(step_c2, n_it) / n_it for _ in range(1))
         t6 = time_steps(step6, n_it) / n_it
+        for _ in range(2):
+            t12 = min(t12, time_steps(step_c2, n_it) / n_it)
+            t6 = min(t6, time_steps(step6, n_it) / n_it)
         out["ms_per_gru_iter"] = round((t12 - t6) / (ITERS // 2) * 1e3, 4)
         out["ms_fixed_part"] = round((t12 - ITERS * (t12 - t6) / (ITERS // 2)) * 1e3, 4)
 

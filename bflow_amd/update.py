@@ -22,6 +22,11 @@ from . import hip
 from . import split as S
 
 
+# head2 (Conv2d(256, 2*deg, 3)): the vector-ALU kernel takes 5 us per 4800 pixels, the MFMA halo kernel 17 us at 4800 pixels but only
+# 40 us at 38400 (batch 8) where its grid fills the chip -- measured cross-over near 24000 pixels.
+THIN_HEAD_MAX_PIXELS = 20000
+
+
 class BezierHead(nn.Module):
     def __init__(self, bezier_degree: int, input_dim: int = 128, hidden_dim: int = 256):
         super().__init__()
@@ -211,9 +216,13 @@ class BasicUpdateBlock(nn.Module):
         bh = self.bezier_head
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
         # bezier += delta (bezier.py:137-139) and the new Bezier channel block of M are produced by the epilogue
-        # (a 2*deg-channel output: the thin vector-ALU kernel, not a 32-wide MFMA tile)
-        S.conv_thin_acc(d1, self.__dict__.setdefault("_head2_w", S.ThinConvWeight()).get(bh.conv2.weight), bh.conv2.bias, bezier,
-                        out_split=ws.M, channel_offset=self.motion_dim)
+        if d1.shape[0] * d1.H * d1.W <= THIN_HEAD_MAX_PIXELS:
+            # a 2*deg-channel output on a grid of 40 patches: the thin vector-ALU kernel, not a 32-wide MFMA tile on 40 workgroups
+            S.conv_thin_acc(d1, self.__dict__.setdefault("_head2_w", S.ThinConvWeight()).get(bh.conv2.weight), bh.conv2.bias, bezier,
+                            out_split=ws.M, channel_offset=self.motion_dim)
+        else:
+            S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, acc_nchw=bezier, out_split=ws.M,
+                   channel_offset=self.motion_dim)
         mask_branch.join()
         return mask
 

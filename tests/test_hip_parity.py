@@ -380,13 +380,18 @@ def _model(cname, seed=0):
     return cfg, m.to(DEV), sd
 
 
-@pytest.mark.parametrize("cname,deg,planes", [("E_LU4_BD2", 2, 567), ("E_LU5_BD10", 10, 648), ("E_I_LU4_BD2", 2, 891)])
-def test_update_block_step_split_vs_oracle(cname, deg, planes):
+@pytest.mark.parametrize("cname,deg,planes,thin_head", [("E_LU4_BD2", 2, 567, True), ("E_LU5_BD10", 10, 648, True), ("E_I_LU4_BD2", 2, 891, True),
+                                                        ("E_LU4_BD2", 2, 567, False), ("E_LU5_BD10", 10, 648, False)])
+def test_update_block_step_split_vs_oracle(cname, deg, planes, thin_head, monkeypatch):
     """ONE iteration of the PRODUCT update path against the oracle's BasicUpdateBlock.forward (update.py:116-126).
     `BasicUpdateBlock.forward` fills a split workspace from the NCHW tensors and runs `step_split`: the hoisted `inp` terms of the six gate
     convolutions, the merged z|r convolution with the sigmoid / r*h epilogue, the q convolution with the blend epilogue (both GRU
     halves), the two-source convolutions [h | M] / [r*h | M], the im2col Bezier branch, the head with the `acc_nchw` (P += dP) epilogue
-    and the mask branch.  Degrees 2 and 10 (Bezier block of 4 / 20 channels), 7 / 8 / 11 correlation planes."""
+    and the mask branch.  Degrees 2 and 10 (Bezier block of 4 / 20 channels), 7 / 8 / 11 correlation planes; the head's second
+    convolution on the vector-ALU kernel (small grids) and on the MFMA engine (large grids)."""
+    from bflow_amd import update as U
+    if not thin_head:
+        monkeypatch.setattr(U, "THIN_HEAD_MAX_PIXELS", 0)
     cfg, m, sd = _model(cname)
     rs = np.random.RandomState(6)
     B, h, w = 2, 22, 26
