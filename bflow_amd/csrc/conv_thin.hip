@@ -6,8 +6,8 @@
 // on 256 CUs walking K = 2304 one after the other (17-18 us per GRU iteration, on the critical path).  The work itself is 88 MFLOP: the
 // vector ALU does it exactly in fp32 (inputs are re-assembled as hi + lo * 2^-11, weights stay fp32 -- no split of the weights at all)
 // with ALL pixels in flight at once:
-//   wave = 2 consecutive pixels per group; lane = 4 input channels (lane >> 3 = channel block, lane & 7 = group of 4): 64 lanes x 4 = 256 channels per
-//   pass over the input channels; per (tap, pixel) a lane loads 8 B of hi + 8 B of lo (the 64 lanes read the 8 channel blocks' 64-B rows) and
+//   wave = 2 pixels per group; lane = (pixel, channel block, 8 input channels): 32 lanes x 8 = the 256 input channels of one pixel;
+//   per tap a lane loads 16 B of hi + 16 B of lo (a wave instruction = the 8 channel-block rows of two pixels) and
 //   runs 4 x CO FMAs against weights read from LDS (CO = 4 output channels per pass: 9 taps x 4 x 256 fp32 = 36 KB per workgroup); a butterfly
 //   over the wave finishes the dot products; lanes < Cout add the bias, update the fp32 NCHW accumulator (P += dP) and write the updated
 //   values as ONE 32-channel block of a split tensor (channels >= Cout zero).
@@ -16,9 +16,12 @@
 
 namespace {
 
-typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int CO = 4;          // output channels per pass
-constexpr int PPW = 2;         // pixels per wave and group (4 waves: 8 pixels per group)
+constexpr int GPW = 2;         // pixels per wave and group (lanes 0-31 / 32-63): 8 pixels per group and workgroup
+constexpr int GPB = 1;         // groups per workgroup and pass (2: their loads are all issued together -- measured slower at batch 1:
+                               // 300 workgroups leave some SIMDs with two waves of twice the work)
 
 struct ThinArgs {
     const _Float16 *xh, *xl;   // (B, CB, P_in, 32)
@@ -29,106 +32,145 @@ struct ThinArgs {
     int B, H, W, CB, P_in, Cout, CBo, cb_off, P_out;
 };
 
-// Workgroup = 4 waves; the weights of CO output channels (all taps, 256 input channels, fp32: 36 KB for 3x3) sit in LDS, loaded once per
-// pass; the workgroup then walks groups of 8 pixels.  At batch 1 (2880 pixels) there is less than one wave per SIMD, so nothing hides a
-// load behind another wave: every load of a group (2 x 9 taps x hi/lo, the accumulator values) is issued before the first FMA.
+// Workgroup = 4 waves; the weights of CO output channels (all taps, 256 input channels, fp32: 36 KB for 3x3) sit in LDS, filled once per
+// pass with every load in flight at once.  A wave owns 2 pixels per group: lane = (pixel, channel block, 8 channels) reads 16 B of hi
+// and 16 B of lo per tap.  At batch 1 (4800 pixels, 300 workgroups) there is about one wave per SIMD, so nothing hides a load behind
+// another wave: the loads of BOTH groups of a workgroup (2 x 9 taps x hi/lo, the accumulator values) are issued before the first FMA.
 template <int KH, int KW>
-__global__ __launch_bounds__(256, 2) void conv_thin_kernel(ThinArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_thin_kernel(ThinArgs a) {
     constexpr int NTAPS = KH * KW, ph = KH / 2, pw = KW / 2;
-    __shared__ float4 wl[NTAPS * CO * 64];
+    constexpr int WL = NTAPS * CO * 64;                       // float4 entries: (tap, k, 64 x 4 channels)
+    __shared__ float4 wl[WL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int HW = a.H * a.W, C = a.CB * 32;
     const int b = blockIdx.y;
-    const int n_groups = (HW + 4 * PPW - 1) / (4 * PPW);
-    const int cb = lane >> 3, ch = (lane & 7) * 4;
+    const int n_groups = (HW + 4 * GPW - 1) / (4 * GPW);
+    const int pj = lane >> 5, cb = (lane >> 2) & 7, ch = (lane & 3) * 8;      // pixel of the pair, channel block, first of 8 channels
     const bool lane_on = cb < a.CB;
-    const long long plane = ((long long)b * a.CB + (lane_on ? cb : 0)) * a.P_in;
+    // buffer loads: one 32-bit offset serves the hi and the lo plane, an out-of-image tap is an out-of-range offset (returns zeros)
+    const int plane_bytes = a.CB * a.P_in * 64;
+    const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xh + (long long)b * a.CB * a.P_in * 32), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_l = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xl + (long long)b * a.CB * a.P_in * 32), 0, plane_bytes, 0x00020000);
+    const int lane_off = (cb * a.P_in * 32 + ch) * 2;
+    const int NT_ = KH * KW;
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, NT_ * a.Cout * a.CB * 32 * 4, 0x00020000);
     for (int c0 = 0; c0 < a.Cout; c0 += CO) {
-        if (c0) __syncthreads();
-        // weights -> LDS: entry (t, k, l) = the 4 channels of lane l for output channel c0 + k, tap t
-        for (int e = tid; e < NTAPS * CO * 64; e += 256) {
-            const int l = e & 63, k = (e >> 6) % CO, t = e / (64 * CO);
-            const bool on = (l >> 3) < a.CB && c0 + k < a.Cout;
-            wl[e] = on ? *reinterpret_cast<const float4*>(a.w + ((long long)t * a.Cout + c0 + k) * C + l * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
-            const int n0 = (g * 4 + wave) * PPW;
-            half4v xh[PPW][NTAPS], xl[PPW][NTAPS];
+        const int g_first = blockIdx.x * GPB;
+        half8 xh[GPB][NTAPS], xl[GPB][NTAPS];
+        float old[GPB];
+        bool emit[GPB];
+        float* pa[GPB];
+        // lane e = i * CO + k (< GPW * CO) will own output (pixel i of the wave's pair, channel c0 + k)
+        const int ei = lane / CO, ek = lane % CO;
+        auto load_group = [&](int g0) {
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const int n = min(n0 + i, HW - 1);
+            for (int u = 0; u < GPB; ++u) {
+                const int n0 = ((g0 + u) * 4 + wave) * GPW;
+                const int n = min(n0 + pj, HW - 1);
                 const int py = n / a.W, px = n - py * a.W;
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
                     const int y = py + t / KW - ph, x = px + t % KW - pw;
-                    const bool ok = lane_on && y >= 0 && y < a.H && x >= 0 && x < a.W;
-                    const long long o = (plane + (ok ? y * a.W + x : 0)) * 32 + ch;
-                    const half4v zero = {0, 0, 0, 0};
-                    xh[i][t] = ok ? *reinterpret_cast<const half4v*>(a.xh + o) : zero;
-                    xl[i][t] = ok ? *reinterpret_cast<const half4v*>(a.xl + o) : zero;
+                    const bool ok = lane_on && n0 + pj < HW && y >= 0 && y < a.H && x >= 0 && x < a.W;
+                    const unsigned o = ok ? (unsigned)(lane_off + (y * a.W + x) * 64) : 0x80000000u;
+                    xh[u][t] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r_h, o, 0, 0));
+                    xl[u][t] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r_l, o, 0, 0));
                 }
+                emit[u] = lane < GPW * CO && c0 + ek < a.Cout && n0 + ei < HW;
+                pa[u] = a.acc + ((long long)b * a.Cout + c0 + ek) * HW + n0 + ei;
+                old[u] = emit[u] ? *pa[u] + (a.bias ? a.bias[c0 + ek] : 0.f) : 0.f;
             }
-            // the accumulator value this lane will update: lane = i * CO + k
-            const int ei = lane / CO, ek = lane % CO;
-            const bool emit = lane < PPW * CO && c0 + ek < a.Cout && n0 + ei < HW;
-            float* pa = a.acc + ((long long)b * a.Cout + c0 + ek) * HW + n0 + ei;
-            const float old = emit ? *pa + (a.bias ? a.bias[c0 + ek] : 0.f) : 0.f;
-            float sum[PPW][CO];
+        };
+        if (c0) __syncthreads();
+        if (g_first < n_groups) load_group(g_first);     // in flight under the weight fill: one memory round trip per workgroup, not two
+        {   // weights -> LDS by LDS-DMA (no staging registers next to the 72 input registers): entry (t, k, half, L) = input channels
+            // 8 L + 4 half .. + 3 of output channel c0 + k, tap t (lane L of a pixel reads entries L and 32 + L: consecutive 16-B slots per
+            // lane, no bank conflicts); entry e lands at wl + 16 e = lane-linear per wave instruction; masked entries are out-of-range
+            // offsets (zeros)
+            static_assert(WL % 256 == 0, "whole wave instructions");
 #pragma unroll
-            for (int i = 0; i < PPW; ++i)
+            for (int i = 0; i < WL / 256; ++i) {
+                const int e = tid + i * 256;
+                const int l = e & 63, k = (e >> 6) % CO, t = e / (64 * CO);
+                const int cin = (l & 31) * 8 + (l >> 5) * 4;
+                const bool on = cin < C && c0 + k < a.Cout;
+                const unsigned o = on ? (unsigned)((((t * a.Cout + c0 + k) * C) + cin) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(wl + i * 256 + wave * 64), 16, o, 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int g0 = g_first; g0 < n_groups; g0 += gridDim.x * GPB) {
+            if (g0 != g_first) load_group(g0);
+            // x = hi + lo * 2^-11 re-assembled by ONE mixed-precision FMA per element (fp16 x fp32 + fp16), then packed fp32 FMAs: two
+            // input channels per instruction against the weight pairs, even / odd partial sums per output channel.
+            // One group after the other (the weights are read from LDS once per group).
+            float sum[GPB][CO];
 #pragma unroll
-                for (int k = 0; k < CO; ++k) sum[i][k] = 0.f;
+            for (int u = 0; u < GPB; ++u) {
+                float2v s2[CO];
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                __builtin_amdgcn_sched_barrier(0);          // one tap's LDS reads in flight at a time (the input loads stay up front)
-                float v[PPW][4];
+                for (int k = 0; k < CO; ++k) s2[k] = float2v{0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < PPW; ++i)
+                for (int t = 0; t < NTAPS; ++t) {
+                    __builtin_amdgcn_sched_barrier(0);      // one tap's LDS reads in flight at a time (the input loads stay up front)
+                    float2v x2[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[i][j] = fmaf((float)xl[i][t][j], bflow::SPLIT_LO_INV, (float)xh[i][t][j]);
+                    for (int j = 0; j < 4; ++j)
+                        x2[j] = float2v{fmaf((float)xl[u][t][2 * j], bflow::SPLIT_LO_INV, (float)xh[u][t][2 * j]),
+                                        fmaf((float)xl[u][t][2 * j + 1], bflow::SPLIT_LO_INV, (float)xh[u][t][2 * j + 1])};
 #pragma unroll
-                for (int k = 0; k < CO; ++k) {
-                    const float4 w = wl[(t * CO + k) * 64 + lane];
-#pragma unroll
-                    for (int i = 0; i < PPW; ++i) {
-                        sum[i][k] = fmaf(v[i][0], w.x, sum[i][k]);
-                        sum[i][k] = fmaf(v[i][1], w.y, sum[i][k]);
-                        sum[i][k] = fmaf(v[i][2], w.z, sum[i][k]);
-                        sum[i][k] = fmaf(v[i][3], w.w, sum[i][k]);
+                    for (int k = 0; k < CO; ++k) {
+                        if (k == CO / 2) __builtin_amdgcn_sched_barrier(0);   // the weights of two output channels in registers at a time
+                        const float4 w0 = wl[(t * CO + k) * 64 + (lane & 31)], w1 = wl[(t * CO + k) * 64 + 32 + (lane & 31)];
+                        s2[k] = __builtin_elementwise_fma(x2[0], float2v{w0.x, w0.y}, s2[k]);
+                        s2[k] = __builtin_elementwise_fma(x2[1], float2v{w0.z, w0.w}, s2[k]);
+                        s2[k] = __builtin_elementwise_fma(x2[2], float2v{w1.x, w1.y}, s2[k]);
+                        s2[k] = __builtin_elementwise_fma(x2[3], float2v{w1.z, w1.w}, s2[k]);
+                        asm volatile("" : "+v"(s2[k]));     // pins the FMAs to their tap (LLVM otherwise sinks a group's FMAs below the loop)
                     }
                 }
-            }
-            // finish the dot products over the 64 lanes; lane i * CO + k keeps (pixel i, output channel c0 + k)
-            float mine = 0.f;
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < PPW; ++i)
+                for (int k = 0; k < CO; ++k) sum[u][k] = s2[k][0] + s2[k][1];
+            }
+            // finish the dot products over the 32 lanes of a pixel; lane i * CO + k keeps (pixel i, output channel c0 + k)
+#pragma unroll
+            for (int u = 0; u < GPB; ++u) {
+                float mine = 0.f;
 #pragma unroll
                 for (int k = 0; k < CO; ++k) {
-                    const float s = bflow::wave_sum(sum[i][k]);
-                    if (lane == i * CO + k) mine = s;
-                }
-            if (emit) {
-                const float v = old + mine;                 // bezier.py:137-139: params += delta (+ the conv bias)
-                *pa = v;
-                if (a.oh) {
-                    _Float16 hi, lo;
-                    bflow::split1(v, hi, lo);
-                    const long long o = (((long long)b * a.CBo + a.cb_off) * a.P_out + n0 + ei) * 32 + c0 + ek;
-                    a.oh[o] = hi;
-                    a.ol[o] = lo;
-                }
-            }
-            // channels [Cout, 32) of the emitted block are zero
-            if (c0 == 0 && a.oh && lane >= a.Cout && lane < 32) {
+                    float s = sum[u][k];
 #pragma unroll
-                for (int i = 0; i < PPW; ++i)
-                    if (n0 + i < HW) {
-                        const long long o = (((long long)b * a.CBo + a.cb_off) * a.P_out + n0 + i) * 32 + lane;
-                        a.oh[o] = (_Float16)0.f;
-                        a.ol[o] = (_Float16)0.f;
+                    for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);      // within the 32-lane half
+                    const float other = __shfl_xor(s, 32, 64);                          // the other pixel's total
+                    const float p0 = pj == 0 ? s : other, p1 = pj == 0 ? other : s;
+                    if (lane == k) mine = p0;
+                    if (lane == CO + k) mine = p1;
+                }
+                const int n0 = ((g0 + u) * 4 + wave) * GPW;
+                if (emit[u]) {                                 // (emit implies a valid pixel; a UNIFORM guard here lets the compiler sink group 1's FMAs behind it)
+                    const float v = old[u] + mine;             // bezier.py:137-139: params += delta (+ the conv bias)
+                    *pa[u] = v;
+                    if (a.oh) {
+                        _Float16 hi, lo;
+                        bflow::split1(v, hi, lo);
+                        const long long o = (((long long)b * a.CBo + a.cb_off) * a.P_out + n0 + ei) * 32 + c0 + ek;
+                        a.oh[o] = hi;
+                        a.ol[o] = lo;
                     }
+                }
+                // channels [Cout, 32) of the emitted block are zero
+                if (c0 == 0 && a.oh && lane >= a.Cout && lane < 32) {
+#pragma unroll
+                    for (int i = 0; i < GPW; ++i)
+                        if (n0 + i < HW) {
+                            const long long o = (((long long)b * a.CBo + a.cb_off) * a.P_out + n0 + i) * 32 + lane;
+                            a.oh[o] = (_Float16)0.f;
+                            a.ol[o] = (_Float16)0.f;
+                        }
+                }
             }
         }
     }
@@ -155,8 +197,9 @@ extern "C" int bflow_conv_thin_acc(const void* x_hi, const void* x_lo, const flo
     a.ol = (_Float16*)out_lo;
     a.B = B; a.H = H; a.W = W; a.CB = C / 32; a.P_in = in_rows_per_image; a.Cout = Cout;
     a.CBo = out_channel_blocks; a.cb_off = out_block; a.P_out = out_rows_per_image;
-    const int n_groups = bflow::ceil_div((long long)H * W, 4 * PPW);
-    dim3 grid(std::min(n_groups, std::max(1, 1024 / B)), B);   // beyond ~4 workgroups per CU a workgroup walks several groups on one weight fill
+    const int n_groups = bflow::ceil_div((long long)H * W, 4 * GPW);
+    // one pass over the pixels per workgroup up to ~4 workgroups per CU, beyond that a workgroup walks several group pairs on one weight fill
+    dim3 grid(std::min(bflow::ceil_div(n_groups, GPB), std::max(1, 1024 / B)), B);
     if (KH == 3) hipLaunchKernelGGL((conv_thin_kernel<3, 3>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_thin_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, a);
     return bflow::launch_status("conv_thin_acc");
