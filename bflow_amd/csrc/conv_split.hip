@@ -54,6 +54,7 @@ struct ConvArgs {
     const _Float16 *gh, *gl;   // h planes (B, CBo, P_out, 32)
     const float* gz;           // z (B, CBo, P_out, 32)
     float* acc;                // fp32 (B, Cout, Ho*Wo) accumulated in place, or null
+    int w_sets;                // > 1: image b multiplies weight set b % w_sets (generic kernel only; the weight-gradient GEMMs)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -351,8 +352,9 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
     const rsrc_t r_h2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2h + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
     const rsrc_t r_l2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2l + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
     const int wtile_b = a.cout_pad * 64;                   // bytes of one weight k-tile
-    const rsrc_t r_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, nk * wtile_b, 0x00020000);
-    const rsrc_t r_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.wl, 0, nk * wtile_b, 0x00020000);
+    const long long wset = a.w_sets > 1 ? (long long)(b % a.w_sets) * nk * (wtile_b / 2) : 0;   // halfs
+    const rsrc_t r_wh = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wh + wset), 0, nk * wtile_b, 0x00020000);
+    const rsrc_t r_wl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wl + wset), 0, nk * wtile_b, 0x00020000);
 
     // running (uniform) position of the k-tile to be issued next: tap it, column iq inside the filter row, channel block icb,
     // byte offset of the tap itoff = (r*W + q)*64, flat k-tile index ik.  k-group g takes k-tiles g, g+KG, ...
@@ -1259,6 +1261,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     a.scale = d->scale; a.shift = d->shift; a.act = d->act; a.stats = d->stats;
     a.stats_reps = d->stats_replicas > 0 ? d->stats_replicas : 1; a.stats_rep_stride = (long long)d->B * d->Cout * 2;
     a.acc = d->acc_nchw;
+    a.w_sets = d->weight_sets > 1 ? d->weight_sets : 1;
     a.gate = d->gate; a.gh = (const _Float16*)d->gate_h_hi; a.gl = (const _Float16*)d->gate_h_lo; a.gz = d->gate_z;
     if (d->gate) {
         BFLOW_REQUIRE((d->gate == 1 || d->gate == 2) && d->gate_h_hi && d->gate_h_lo && d->out_hi && d->out_lo && !d->stats && d->act == 0 &&
@@ -1275,7 +1278,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     const char* force = getenv("BFLOW_CONV_KERNEL");           // tests: "generic" forces the generic kernel for every shape
     const bool same = d->stride == 1 && d->pad_w == (d->KW - 1) / 2 && d->pad_h == (d->KH - 1) / 2;
     const int shape = (d->KH == 3 && d->KW == 3) ? 1 : (d->KH == 1 && d->KW == 5) ? 2 : (d->KH == 5 && d->KW == 1) ? 3 : 0;
-    if (same && shape && !(force && strncmp(force, "halo", 4) != 0)) {
+    if (same && shape && a.w_sets == 1 && !(force && strncmp(force, "halo", 4) != 0)) {
         const int patches = bflow::ceil_div(d->H, 8) * bflow::ceil_div(d->W, 16);
         // 64-channel tiles unless that leaves most CUs without a workgroup (batch-1 update block: 40 patches)
         const int nt = ((long long)patches * d->B * bflow::ceil_div(d->Cout, 64) >= 200) ? 2 : 1;

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import split as S
+from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backward run on the HIP conv engine
 
 STATS_R = 8
 
@@ -36,15 +37,15 @@ class ResidualBlock(nn.Module):
 
     def __init__(self, in_planes: int, planes: int, norm_fn: str = "group", stride: int = 1):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.conv1 = Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, padding=1)
         self.norm1 = _make_norm(norm_fn, planes)
         self.norm2 = _make_norm(norm_fn, planes)
         self.downsample = None
         if stride != 1:
             # registered under both names, exactly like the reference (norm3 and downsample.1 share parameters)
             self.norm3 = _make_norm(norm_fn, planes)
-            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+            self.downsample = nn.Sequential(Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = F.relu_(self.norm1(self.conv1(x)))
@@ -64,14 +65,14 @@ class BasicEncoder(nn.Module):
             self.norm1 = nn.GroupNorm(num_groups=8, num_channels=64)
         else:
             self.norm1 = _make_norm(norm_fn, 64)
-        self.conv1 = nn.Conv2d(input_dim, 64, kernel_size=7, stride=2, padding=3)
+        self.conv1 = Conv2d(input_dim, 64, kernel_size=7, stride=2, padding=3)
         planes = [(64, 1), (96, 2), (128, 2)]
         cin = 64
         for idx, (dim, stride) in enumerate(planes, start=1):
             setattr(self, f"layer{idx}", nn.Sequential(ResidualBlock(cin, dim, norm_fn, stride=stride),
                                                        ResidualBlock(dim, dim, norm_fn, stride=1)))
             cin = dim
-        self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
+        self.conv2 = Conv2d(128, output_dim, kernel_size=1)
         for m in self.modules():   # extractor.py:85-92
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")

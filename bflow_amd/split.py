@@ -237,12 +237,13 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
          want_split: bool = True, want_f32: bool = False, out_rows: Optional[int] = None, zero_rows: bool = False,
          x2: Optional[SplitTensor] = None, addend: Optional[torch.Tensor] = None, tile: Optional[int] = None,
          gate: int = GATE_NONE, gate_h: Optional[SplitTensor] = None, gate_z: Optional[torch.Tensor] = None,
-         acc_nchw: Optional[torch.Tensor] = None):
+         acc_nchw: Optional[torch.Tensor] = None, weight_sets: int = 1):
     """Implicit-GEMM convolution.  `packed` = PackedConvWeight.get(weight).  Returns (split_out or None, f32_out or None);
     f32_out is blocked fp32 (B, Cs/32, P_out, 32).  When out_* buffers are given the result is written at channel
     `channel_offset` (a multiple of 32) of their channel dimension (free concatenation).  out_rows > Ho*Wo allocates
     zero-filled tail rows (K5's 128-row operand padding).
     acc_nchw (B, cout, Ho, Wo) fp32: accumulated in place (+= result), outputs receive the updated value.
+    weight_sets S > 1: `packed` holds S filters back to back, image b uses filter b % S (weight-gradient GEMMs, conv_train.py).
     gate = GATE_ZR / GATE_BLEND fuses the SepConvGRU element-wise stage (update.py:38-47) into the epilogue: see bflow_conv_desc_t."""
     planes, (cout, cin_pad, kh, kw, cout_pad) = packed
     B, H, W, _ = x.shape
@@ -297,8 +298,25 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
     if gate != GATE_NONE:
         d.gate, d.gate_h_hi, d.gate_h_lo = gate, gate_h.hi.data_ptr(), gate_h.lo.data_ptr()
         d.gate_z = None if gate_z is None else gate_z.data_ptr()
+    d.weight_sets = weight_sets
     hip._check(hip.lib().bflow_conv_split(ctypes.byref(d), hip._stream()), "bflow_conv_split")
     return out_split, out_f32
+
+
+def wgrad_pack(src: torch.Tensor, out_hw, ksize=(1, 1), stride: int = 1, padding=(0, 0), rows: Optional[int] = None,
+               k_blocks: Optional[int] = None, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NCHW fp32 -> split planes (2, KH*KW, k_blocks, rows, 32) with the pixel index k = (b*Ho + yo)*Wo + xo in the block position
+    (bflow_wgrad_pack): dst[tap, k/32, c, k%32] = scale * src[b, c, yo*stride + r - ph, xo*stride + q - pw]."""
+    B, C, H, W = src.shape
+    Ho, Wo = out_hw
+    kh, kw = ksize
+    ph, pw = padding
+    rows = C if rows is None else rows
+    kb = (B * Ho * Wo + 31) // 32 if k_blocks is None else k_blocks
+    out = torch.empty((2, kh * kw, kb, rows, 32), dtype=torch.float16, device=src.device)
+    hip._check(hip.lib().bflow_wgrad_pack(hip._dev(src, name="src"), out[0].data_ptr(), out[1].data_ptr(), B, C, H, W, Ho, Wo, kh, kw, stride, ph, pw,
+                                          rows, kb, None if scale is None else hip._dev(scale, name="scale"), hip._stream()), "bflow_wgrad_pack")
+    return out
 
 
 def plane_stats(x_nchw: torch.Tensor) -> torch.Tensor:

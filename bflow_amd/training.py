@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import hip
+from . import conv_train, hip
 from .bezier import BezierCurves
 from .corr import CorrBlockParallelMultiTarget, CorrComputation
 from .validation import DataLoading, DataSetType, _get
@@ -221,7 +221,8 @@ def l1_multi_seq_loss_channel_masked(src_list_list: Sequence[Sequence[torch.Tens
 
 # ----------------------------------------------------------------------------------------------- the training forward
 def _update_block_train(ub, net, inp, corr, bezier):
-    """BasicUpdateBlock.forward (update.py:116-126) on torch convolutions; z|r share one launch per GRU half."""
+    """BasicUpdateBlock.forward (update.py:116-126) under autograd; the convolutions (modules = conv_train.Conv2d, the merged z|r filter
+    through conv_train.conv2d) run forward and backward on the HIP conv engine; z|r share one launch per GRU half."""
     enc, gru = ub.encoder, ub.gru
     cor = F.relu(enc.convc2(F.relu(enc.convc1(corr))))
     bez = F.relu(enc.convf2(F.relu(enc.convf1(bezier))))
@@ -230,8 +231,8 @@ def _update_block_train(ub, net, inp, corr, bezier):
     hd = ub.hidden_dim
     for sfx in ("1", "2"):
         cz, cr, cq = (getattr(gru, f"conv{g}{sfx}") for g in "zrq")
-        zr = F.conv2d(torch.cat([net, x], dim=1), torch.cat([cz.weight, cr.weight], dim=0), torch.cat([cz.bias, cr.bias], dim=0),
-                      padding=cz.padding)
+        zr = conv_train.conv2d(torch.cat([net, x], dim=1), torch.cat([cz.weight, cr.weight], dim=0), torch.cat([cz.bias, cr.bias], dim=0),
+                               cz.padding, gru.__dict__.setdefault("_zr_pack" + sfx, conv_train._PackCache()))
         z, r = torch.sigmoid(zr[:, :hd]), torch.sigmoid(zr[:, hd:])
         q = torch.tanh(cq(torch.cat([r * net, x], dim=1)))
         net = (1 - z) * net + z * q

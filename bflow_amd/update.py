@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 from . import hip
 from . import split as S
+from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backward run on the HIP conv engine
 
 
 # head2 (Conv2d(256, 2*deg, 3)): the vector-ALU kernel takes 5 us per 4800 pixels, the MFMA halo kernel 17 us at 4800 pixels but only
@@ -30,8 +31,8 @@ THIN_HEAD_MAX_PIXELS = 20000
 class BezierHead(nn.Module):
     def __init__(self, bezier_degree: int, input_dim: int = 128, hidden_dim: int = 256):
         super().__init__()
-        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
-        self.conv2 = nn.Conv2d(hidden_dim, bezier_degree * 2, 3, padding=1)
+        self.conv1 = Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = Conv2d(hidden_dim, bezier_degree * 2, 3, padding=1)
 
 
 class SepConvGRU(nn.Module):
@@ -40,7 +41,7 @@ class SepConvGRU(nn.Module):
         cin = hidden_dim + input_dim
         for sfx, k, p in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
             for gate in "zrq":
-                setattr(self, f"conv{gate}{sfx}", nn.Conv2d(cin, hidden_dim, k, padding=p))
+                setattr(self, f"conv{gate}{sfx}", Conv2d(cin, hidden_dim, k, padding=p))
 
 
 class BasicMotionEncoder(nn.Module):
@@ -48,11 +49,11 @@ class BasicMotionEncoder(nn.Module):
         super().__init__()
         cor_planes = self._num_cor_planes(model_params["correlation"], model_params["use_boundary_images"], model_params["use_events"])
         bezier_planes = model_params["bezier_degree"] * 2
-        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
-        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
-        self.convf1 = nn.Conv2d(bezier_planes, 128, 7, padding=3)
-        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
-        self.conv = nn.Conv2d(64 + 192, output_dim - bezier_planes, 3, padding=1)
+        self.convc1 = Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = Conv2d(256, 192, 3, padding=1)
+        self.convf1 = Conv2d(bezier_planes, 128, 7, padding=3)
+        self.convf2 = Conv2d(128, 64, 3, padding=1)
+        self.conv = Conv2d(64 + 192, output_dim - bezier_planes, 3, padding=1)
 
     @staticmethod
     def _num_cor_planes(corr_params: Dict[str, Any], use_boundary_images: bool, use_events: bool) -> int:
@@ -94,7 +95,7 @@ class BasicUpdateBlock(nn.Module):
         self.encoder = BasicMotionEncoder(model_params, output_dim=self.motion_dim)
         self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=self.context_dim + self.motion_dim)
         self.bezier_head = BezierHead(model_params["bezier_degree"], input_dim=hidden_dim, hidden_dim=256)
-        self.mask = nn.Sequential(nn.Conv2d(hidden_dim, 256, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(256, 64 * 9, 1, padding=0))
+        self.mask = nn.Sequential(Conv2d(hidden_dim, 256, 3, padding=1), nn.ReLU(inplace=True), Conv2d(256, 64 * 9, 1, padding=0))
 
     def check_engine_support(self):
         """The split-fp16 engine works on 32-channel blocks; the Bezier block must fit one.  Anything else is refused loudly

@@ -125,6 +125,10 @@ typedef struct bflow_conv_desc {
                                          value is what out_f32 / out_hi/lo receive.  Fuses BezierCurves.delta_update_params
                                          (bezier.py:137-139) and the re-emission of the Bezier channel block into the head's last
                                          convolution.                                                                          */
+    int weight_sets;                  /* 0 / 1: one filter for every image.  S > 1: w_hi / w_lo hold S packed filters back to back and image
+                                         b is multiplied with filter b % S (generic kernel).  Used by the weight-gradient GEMMs of the
+                                         training path: "image" = (filter tap, k-chunk), "filter" = the packed output gradient of that
+                                         k-chunk (bflow_wgrad_pack).                                                               */
 } bflow_conv_desc_t;
 /* bflow_conv_stem: the 7x7 stride-2 entry convolution of BasicEncoder (extractor.py:63,110) on a few-channel fp32 NCHW input
  * (5 / 8 / 25 / 41 / 3 channels): im2col in LDS over a TIGHT k = (channel, tap) index instead of 32-channel blocks per tap.
@@ -155,6 +159,17 @@ int bflow_conv_stem(const bflow_stem_desc_t* desc, bflow_stream_t stream);
 int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
                             int cout_pad, int cin_pad, bflow_stream_t stream);
 int bflow_conv_split(const bflow_conv_desc_t* desc, bflow_stream_t stream);
+
+/* bflow_wgrad_pack: re-blocks an NCHW fp32 tensor so that the PIXEL index becomes the contraction index of the conv engine:
+ *     dst[tap, kb, c, j] = scale * src[b, c, yo*stride + r - pad_h, xo*stride + q - pad_w]   (0 outside the image / past the last pixel)
+ *     with k = (b*Ho + yo)*Wo + xo = 32 kb + j, tap = r*KW + q;   dst: split planes (KH*KW, k_blocks, rows, 32), rows >= C (zero rows).
+ * The weight gradient of Conv2d (the adjoint the reference gets from autograd; extractor.py / update.py convolutions) is then
+ *     dW[co, c, r, q] = sum_k dY[k, co] * X_tap[k, c]  =  a 1x1 "convolution" of the engine per (tap, k-chunk):
+ * activations = pack(X) (KH x KW taps, `rows` = C as the pixel rows of the GEMM), filter = pack(dY) (one tap, stride 1, no padding:
+ * exactly the engine's packed-weight layout (k-tile, cout_pad, 32)), see bflow_conv_desc_t.weight_sets.
+ * `scale` (device pointer to one float, or NULL = 1) pre-scales small gradients into fp16's normal range.                       */
+int bflow_wgrad_pack(const float* src, void* dst_hi, void* dst_lo, int B, int C, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
+                     int pad_h, int pad_w, int rows, int k_blocks, const float* scale, bflow_stream_t stream);
 
 /* bflow_conv_thin_acc: the thin-output convolution of the Bezier head with its parameter update fused behind it:
  *     acc[b, co, y, x] += bias[co] + sum_{c, r, q} x[b, y+r-KH/2, x+q-KW/2, c] * w[co, c, r, q]      (zero padding, stride 1)

@@ -705,6 +705,46 @@ def test_conv_thin_acc_vs_fp64(cin, cout, k, H, W, B, blocks, blk):
         S.conv_thin_acc(xs, (cu(np.zeros((25, cout, cin), np.float32)), (cout, cin, 5, 5)), None, acc2)
 
 
+# ------------------------------------------------------------------------------------------------- conv engine backward
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,B,gscale", [
+    (64, 96, (3, 3), 1, (1, 1), 20, 28, 2, 1e-6),       # encoder 3x3; gradients at 1e-6 (the power-of-two pre-scaling must carry them)
+    (64, 96, (3, 3), 2, (1, 1), 20, 28, 2, 1e-3),       # stride-2 entry of a stage: zero-dilated dgrad
+    (64, 96, (1, 1), 2, (0, 0), 21, 27, 1, 1.0),        # 1x1 stride-2 down-sampling branch, odd sizes
+    (5, 64, (7, 7), 2, (3, 3), 32, 48, 2, 1e-2),        # stem: 5 input channels, 49 taps
+    (288, 128, (1, 5), 1, (0, 2), 12, 16, 2, 1e-4),     # GRU horizontal
+    (288, 128, (5, 1), 1, (2, 0), 12, 16, 2, 1e-4),     # GRU vertical
+    (567, 256, (1, 1), 1, (0, 0), 12, 16, 1, 1e-5),     # convc1: Cin not a multiple of 32
+    (4, 128, (7, 7), 1, (3, 3), 12, 16, 2, 1e-3),       # convf1: 7x7 on the Bezier parameters
+    (256, 4, (3, 3), 1, (1, 1), 12, 16, 2, 1e-2),       # head2: 4 output channels
+])
+def test_conv_train_forward_backward_vs_fp64(cin, cout, k, stride, pad, H, W, B, gscale):
+    """conv_train.Conv2d: forward, input gradient, weight gradient (split-K GEMM over pixels on the engine) and bias gradient against
+    torch autograd in fp64."""
+    from bflow_amd import conv_train as CT
+    rs = np.random.RandomState(11)
+    x = rs.standard_normal((B, cin, H, W)).astype(np.float32)
+    m = CT.Conv2d(cin, cout, k, stride=stride, padding=pad).to(DEV)
+    w = (rs.standard_normal((cout, cin, *k)) / np.sqrt(cin * k[0] * k[1])).astype(np.float32)
+    b = rs.standard_normal(cout).astype(np.float32)
+    with torch.no_grad():
+        m.weight.copy_(cu(w)); m.bias.copy_(cu(b))
+    xg = cu(x).requires_grad_(True)
+    y = m(xg)
+    assert y.grad_fn is not None and "ConvFn" in type(y.grad_fn).__name__          # the HIP path ran, not nn.Conv2d.forward
+    gy = (rs.standard_normal(tuple(y.shape)) * gscale).astype(np.float32)
+    y.backward(cu(gy))
+    xd = torch.from_numpy(x).double().requires_grad_(True)
+    wd = torch.from_numpy(w).double().requires_grad_(True)
+    bd = torch.from_numpy(b).double().requires_grad_(True)
+    yd = torch.nn.functional.conv2d(xd, wd, bd, stride=stride, padding=pad)
+    yd.backward(torch.from_numpy(gy).double())
+    def rel(a, r):
+        return float((a.detach().cpu().double() - r).abs().max() / (r.abs().max() + 1e-300))
+    e_y, e_dx, e_dw, e_db = rel(y, yd.detach()), rel(xg.grad, xd.grad), rel(m.weight.grad, wd.grad), rel(m.bias.grad, bd.grad)
+    print(f"conv_train {cin}->{cout} {k} s{stride}: y {e_y:.1e} dx {e_dx:.1e} dw {e_dw:.1e} db {e_db:.1e}")
+    assert e_y < 2e-6 and e_dx < 5e-6 and e_dw < 5e-6 and e_db < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------- SURVEY 8(f-3): validation harness
 def test_flow_metrics_golden(golden_dir):
     from bflow_amd import metrics as MX
