@@ -69,7 +69,9 @@ def _conv_forward(x: torch.Tensor, packed, stride: int, padding: Tuple[int, int]
     B, cb, rows, _ = yf.shape
     kh, kw = packed[1][2], packed[1][3]
     Ho, Wo = (x.shape[2] + 2 * padding[0] - kh) // stride + 1, (x.shape[3] + 2 * padding[1] - kw) // stride + 1
-    return yf[:, :, :Ho * Wo].permute(0, 1, 3, 2).reshape(B, cb * 32, Ho, Wo)[:, :cout].contiguous()
+    out = yf[:, :, :Ho * Wo].permute(0, 1, 3, 2).reshape(B, cb * 32, Ho, Wo)       # a copy (the permuted tensor is not viewable as NCHW)
+    # (never hand autograd a VIEW as a Function output: the in-place ReLUs that follow would be refused)
+    return out if cout == cb * 32 and rows == Ho * Wo else out[:, :cout].clone()
 
 
 class _ConvFn(torch.autograd.Function):
