@@ -34,14 +34,6 @@ ENABLED = True                      # tools / A-B timing: False = torch (MIOpen)
 _TARGET = 8192.0                    # max |dy| after scaling: well inside fp16 (65504), 13 bits of head-room for sums of products
 
 
-def _pow2_scale(t: torch.Tensor) -> torch.Tensor:
-    """2^floor(log2(_TARGET / max|t|)) as a 1-element device tensor (1 for an all-zero / non-finite tensor)."""
-    amax = t.detach().abs().amax().float()
-    e = torch.floor(torch.log2(_TARGET / amax))
-    e = torch.where(torch.isfinite(e), e, torch.zeros_like(e)).clamp(-60.0, 60.0)
-    return torch.exp2(e).reshape(1)
-
-
 class _PackCache:
     """Packed filters keyed on the parameter's storage and in-place version (an optimiser step bumps the version)."""
 
@@ -60,18 +52,14 @@ class _PackCache:
         return self._flip
 
 
-def _conv_forward(x: torch.Tensor, packed, stride: int, padding: Tuple[int, int], bias) -> torch.Tensor:
-    """fp32 NCHW -> engine -> fp32 NCHW.  The result leaves the engine as blocked fp32 (not as a split pair: scaled gradients may
-    exceed the split format's 65504) and is re-ordered by one torch copy."""
-    xs = S.from_nchw(x)
+def _conv_forward(x: torch.Tensor, packed, stride: int, padding: Tuple[int, int], bias, in_scale=None, out_scale=None) -> torch.Tensor:
+    """fp32 NCHW -> engine -> fp32 NCHW (bflow_norm_act_split [x in_scale] -> bflow_conv_split -> bflow_blocked_f32_to_nchw [x out_scale]).
+    The result leaves the engine as blocked fp32, not as a split pair: scaled gradients may exceed the split format's 65504."""
+    xs = S.from_nchw(x, in_scale)
     _, yf = S.conv(xs, packed, stride=stride, padding=padding, shift=bias, want_split=False, want_f32=True)
-    cout = packed[1][0]
-    B, cb, rows, _ = yf.shape
-    kh, kw = packed[1][2], packed[1][3]
+    cout, _, kh, kw, _ = packed[1]
     Ho, Wo = (x.shape[2] + 2 * padding[0] - kh) // stride + 1, (x.shape[3] + 2 * padding[1] - kw) // stride + 1
-    out = yf[:, :, :Ho * Wo].permute(0, 1, 3, 2).reshape(B, cb * 32, Ho, Wo)       # a copy (the permuted tensor is not viewable as NCHW)
-    # (never hand autograd a VIEW as a Function output: the in-place ReLUs that follow would be refused)
-    return out if cout == cb * 32 and rows == Ho * Wo else out[:, :cout].clone()
+    return S.blocked_f32_to_nchw(yf, cout, Ho, Wo, out_scale)
 
 
 class _ConvFn(torch.autograd.Function):
@@ -93,44 +81,63 @@ class _ConvFn(torch.autograd.Function):
         _, _, Ho, Wo = dy.shape
         dx = dw = db = None
         with torch.no_grad():
-            s = _pow2_scale(dy)
-            inv = 1.0 / s
+            sc = S.pow2_scale(dy, _TARGET)                       # {s, 1/s} on the device
+            s, inv = sc[0:1], sc[1:2]
             if ctx.needs_input_grad[0]:
-                dys = dy * s
+                g = dy
                 if stride > 1:                                   # zero-dilated dy: position (yo*stride, xo*stride) of the stride-1 output grid
-                    z = torch.zeros((B, cout, H + 2 * ph - kh + 1, W + 2 * pw - kw + 1), dtype=torch.float32, device=dy.device)
-                    z[:, :, ::stride, ::stride][:, :, :Ho, :Wo] = dys
-                    dys = z
-                dx = _conv_forward(dys, cache.bwd.get(cache.flipped(w)), 1, (kh - 1 - ph, kw - 1 - pw), None) * inv
+                    g = torch.zeros((B, cout, H + 2 * ph - kh + 1, W + 2 * pw - kw + 1), dtype=torch.float32, device=dy.device)
+                    g[:, :, ::stride, ::stride][:, :, :Ho, :Wo] = dy
+                dx = _conv_forward(g, cache.bwd.get(cache.flipped(w)), 1, (kh - 1 - ph, kw - 1 - pw), None, in_scale=s, out_scale=inv)
             if ctx.needs_input_grad[1]:
-                dw = _weight_grad(x, dy, s, (kh, kw), stride, (ph, pw)) * inv
+                dw = _weight_grad(x, dy, s, inv, (kh, kw), stride, (ph, pw))
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = dy.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None
 
 
-def _weight_grad(x: torch.Tensor, dy: torch.Tensor, scale: torch.Tensor, ksize, stride: int, padding) -> torch.Tensor:
-    """dw (Cout, Cin, KH, KW) * scale: one engine launch over (tap, k-chunk) "images" + a sum over the k-chunks."""
+def _pad_ratio(n: int, t: int = 128) -> float:
+    return ((n + t - 1) // t * t) / n
+
+
+def _weight_grad(x: torch.Tensor, dy: torch.Tensor, s: torch.Tensor, inv: torch.Tensor, ksize, stride: int, padding) -> torch.Tensor:
+    """dw (Cout, Cin, KH, KW): engine launches over k-chunk "images" (split-K, to fill the chip) + a sum over the chunks.
+    Two orientations of the same GEMM  dw[co, (tap, ci)] = sum_k dy[k, co] x_tap[k, ci]:
+      A  the GEMM's rows (the engine's 128-row pixel tile) = ci, one image per (tap, chunk), filter = packed dy;
+      B  rows = co, one image per chunk, filter = packed x with all taps as its output channels (small cin: the stem, convf1)."""
     B, cin, H, W = x.shape
     _, cout, Ho, Wo = dy.shape
     kh, kw = ksize
     taps = kh * kw
-    K = B * Ho * Wo
-    kb = (K + 31) // 32
-    cout_pad = (cout + 127) // 128 * 128
-    # split-K: enough (tap, chunk, tile) workgroups for two per CU, chunks of at least 16 k-blocks
-    tiles = ((cin + 127) // 128) * ((cout + 63) // 64) * taps
-    G = max(1, min(kb // 16, (512 + tiles - 1) // tiles))
-    kbg = (kb + G - 1) // G
-    kb_pad = kbg * G
-    xp = S.wgrad_pack(x, (Ho, Wo), ksize, stride, padding, rows=cin, k_blocks=kb_pad)              # (2, taps, kb_pad, cin, 32)
-    gp = S.wgrad_pack(dy, (Ho, Wo), rows=cout_pad, k_blocks=kb_pad, scale=scale)                    # (2, 1, kb_pad, cout_pad, 32)
-    xt = S.SplitTensor(xp.view(2, taps * G, kbg, cin, 32), cin, 1)                                  # image = (tap, chunk): cin "pixels" x kbg*32 "channels"
-    packed = (gp.view(2, kb_pad, cout_pad, 32), (cout, kbg * 32, 1, 1, cout_pad))                   # filter set g = k-tiles [g*kbg, (g+1)*kbg)
-    _, part = S.conv(xt, packed, want_split=False, want_f32=True, weight_sets=G)                    # (taps*G, cout/32 blocks, cin, 32)
-    cb = part.shape[1]
-    dw = part.view(taps, G, cb, cin, 32).sum(dim=1)                                                 # (taps, cb, cin, 32)
-    return dw.permute(1, 3, 2, 0).reshape(cb * 32, cin, kh, kw)[:cout].contiguous()
+    kb = (B * Ho * Wo + 31) // 32
+    use_b = cin < 64 or _pad_ratio(cout) < _pad_ratio(cin)
+    if not use_b:
+        cout_pad = (cout + 127) // 128 * 128
+        tiles = ((cin + 127) // 128) * ((cout + 63) // 64) * taps
+        G = max(1, min(kb // 8, (768 + tiles - 1) // tiles))
+        kbg = (kb + G - 1) // G
+        xp = S.wgrad_pack(x, (Ho, Wo), ksize, stride, padding, rows=cin, k_blocks=kbg * G)                 # (2, taps, kb, cin, 32)
+        gp = S.wgrad_pack(dy, (Ho, Wo), rows=cout_pad, k_blocks=kbg * G, scale=s)                          # (2, 1, kb, cout_pad, 32)
+        xt = S.SplitTensor(xp.view(2, taps * G, kbg, cin, 32), cin, 1)                                     # image = (tap, chunk)
+        packed = (gp.view(2, kbg * G, cout_pad, 32), (cout, kbg * 32, 1, 1, cout_pad))                     # filter set g = k-tiles of chunk g
+        _, part = S.conv(xt, packed, want_split=False, want_f32=True, weight_sets=G)                       # (taps*G, cout blocks, cin, 32)
+        cb = part.shape[1]
+        dw = part.view(taps, G, cb, cin, 32).sum(dim=1)                                                    # (taps, cb, cin, 32)
+        dw = dw.permute(1, 3, 2, 0).reshape(cb * 32, cin, kh, kw)[:cout]
+    else:
+        n = taps * cin
+        n_pad = (n + 127) // 128 * 128
+        tiles = ((cout + 127) // 128) * ((n + 63) // 64)
+        G = max(1, min(kb // 8, (768 + tiles - 1) // tiles))
+        kbg = (kb + G - 1) // G
+        gp = S.wgrad_pack(dy, (Ho, Wo), rows=cout, k_blocks=kbg * G, scale=s)                              # (2, 1, kb, cout, 32)
+        xp = S.wgrad_pack(x, (Ho, Wo), ksize, stride, padding, rows=n_pad, k_blocks=kbg * G, taps_in_rows=True)   # (2, kb, n_pad, 32)
+        gt = S.SplitTensor(gp.view(2, G, kbg, cout, 32), cout, 1)                                          # image = chunk, rows = co
+        packed = (xp, (n, kbg * 32, 1, 1, n_pad))
+        _, part = S.conv(gt, packed, want_split=False, want_f32=True, weight_sets=G)                       # (G, n blocks, cout, 32)
+        nb = part.shape[1]
+        dw = part.sum(dim=0).permute(1, 0, 2).reshape(cout, nb * 32)[:, :n].reshape(cout, taps, cin).permute(0, 2, 1).reshape(cout, cin, kh, kw)
+    return (dw * inv).contiguous()
 
 
 class Conv2d(nn.Conv2d):

@@ -1,0 +1,141 @@
+// Helpers of the training convolutions (bflow_amd/conv_train.py); the MFMA work itself is bflow_conv_split.
+//   bflow_wgrad_pack          operands of the weight-gradient GEMM: NCHW fp32 -> blocked split with the PIXEL index in the block position
+//   bflow_blocked_f32_to_nchw blocked fp32 (B, C/32, P, 32) -> NCHW fp32, optionally times a device scalar (un-scaling of gradients)
+//   bflow_pow2_scale          s = 2^floor(log2(target / max|x|)) and 1/s on the device (no host synchronisation)
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// thread = (k-block, row n, 8 consecutive k): one 16-B store per plane.  layout 0: dst (taps, KB, rows, 32), n = c, tap = blockIdx.y;
+// layout 1: dst (KB, rows, 32) with n = tap * C + c (rows >= taps * C; the rows past that are written as zeros).
+__global__ __launch_bounds__(256) void wgrad_pack_kernel(const float* __restrict__ src, _Float16* __restrict__ dh, _Float16* __restrict__ dl, int B, int C,
+                                                         int H, int W, int Ho, int Wo, int KW, int ntaps, int stride, int pad_h, int pad_w, int rows,
+                                                         int KB, int layout, const float* __restrict__ scale_p) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;          // (kb, n, j8) with j8 fastest: 4 threads per 64-B row
+    if (t >= (long long)KB * rows * 4) return;
+    const int j8 = (int)(t & 3);
+    const long long rc = t >> 2;
+    const int n = (int)(rc % rows);
+    const int kb = (int)(rc / rows);
+    int tap, c;
+    if (layout == 0) { tap = blockIdx.y; c = n; }
+    else { tap = n / C; c = n - tap * C; }
+    const bool row_ok = c < C && tap < ntaps;
+    const float scale = scale_p ? *scale_p : 1.f;
+    const int r = tap / KW, q = tap - r * KW;
+    const int K = B * Ho * Wo;
+    // (b, yo, xo) of the first of the 8 pixels, then incremented
+    int k = kb * 32 + j8 * 8;
+    int b = k / (Ho * Wo), p = k - b * (Ho * Wo);
+    int yo = p / Wo, xo = p - yo * Wo;
+    half8 h8, l8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = 0.f;
+        if (row_ok && k < K) {
+            const int y = yo * stride + r - pad_h, x = xo * stride + q - pad_w;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = src[(((long long)b * C + c) * H + y) * W + x] * scale;
+        }
+        _Float16 hi, lo;
+        bflow::split1(v, hi, lo);
+        h8[i] = hi;
+        l8[i] = lo;
+        ++k;
+        if (++xo == Wo) { xo = 0; if (++yo == Ho) { yo = 0; ++b; } }
+    }
+    const long long o = layout == 0 ? (((long long)tap * KB + kb) * rows + n) * 32 + j8 * 8 : ((long long)kb * rows + n) * 32 + j8 * 8;
+    *reinterpret_cast<half8*>(dh + o) = h8;
+    *reinterpret_cast<half8*>(dl + o) = l8;
+}
+
+// 64 pixels x 32 channels through LDS (coalesced on both sides)
+__global__ __launch_bounds__(256) void blocked_f32_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int CB, int P, int C,
+                                                                  const float* __restrict__ scale_p) {
+    __shared__ float tile[64][33];
+    const int b = blockIdx.z, cb = blockIdx.y, p0 = blockIdx.x * 64;
+    const float scale = scale_p ? *scale_p : 1.f;
+    {
+        const int pl = threadIdx.x >> 2, c8 = (threadIdx.x & 3) * 8;
+        const int pix = p0 + pl;
+        if (pix < HW) {
+            const float4* s4 = reinterpret_cast<const float4*>(x + (((long long)b * CB + cb) * P + pix) * 32 + c8);
+            const float4 a = s4[0], c = s4[1];
+            tile[pl][c8 + 0] = a.x; tile[pl][c8 + 1] = a.y; tile[pl][c8 + 2] = a.z; tile[pl][c8 + 3] = a.w;
+            tile[pl][c8 + 4] = c.x; tile[pl][c8 + 5] = c.y; tile[pl][c8 + 6] = c.z; tile[pl][c8 + 7] = c.w;
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ch = cb * 32 + ty + 4 * i, pix = p0 + tx;
+        if (ch < C && pix < HW) out[((long long)b * C + ch) * HW + pix] = tile[tx][ty + 4 * i] * scale;
+    }
+}
+
+// max |x| over n elements -> out[0] = 2^floor(log2(target / max)), out[1] = 1 / out[0]; work = {max bits, ticket}, zero on entry and
+// left zero on exit (the last workgroup resets it), so one persistent work buffer serves every call on a stream.
+__global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict__ x, long long n, float target, float* __restrict__ out,
+                                                         unsigned* __restrict__ work) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float sm[4];
+    __shared__ bool last;
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        if (!(m == m)) m = __builtin_inff();                        // NaN in the gradient: scale 1 (below)
+        atomicMax(work, __float_as_uint(m));                        // non-negative floats order like their bit patterns
+        __threadfence();
+        last = atomicAdd(work + 1, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const float amax = __uint_as_float(atomicMax(work, 0u));
+        float e = floorf(log2f(target / amax));
+        if (!(amax > 0.f) || !(fabsf(e) <= 60.f)) e = (amax > 0.f && e > 60.f) ? 60.f : (amax > 0.f && e < -60.f ? -60.f : 0.f);
+        out[0] = exp2f(e);
+        out[1] = exp2f(-e);
+        work[0] = 0u;
+        work[1] = 0u;
+    }
+}
+
+}  // namespace
+
+extern "C" int bflow_wgrad_pack(const float* src, void* dst_hi, void* dst_lo, int B, int C, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
+                                int pad_h, int pad_w, int rows, int k_blocks, int taps_in_rows, const float* scale, bflow_stream_t stream) {
+    BFLOW_REQUIRE(src && dst_hi && dst_lo, BFLOW_E_ARG, "wgrad_pack: null pointer");
+    BFLOW_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0 && stride >= 1, BFLOW_E_ARG, "wgrad_pack: bad sizes");
+    BFLOW_REQUIRE(rows >= (taps_in_rows ? KH * KW * C : C), BFLOW_E_ARG, "wgrad_pack: %d rows do not hold the operand", rows);
+    BFLOW_REQUIRE((long long)k_blocks * 32 >= (long long)B * Ho * Wo && KH * KW <= 65535, BFLOW_E_ARG, "wgrad_pack: k_blocks too small");
+    BFLOW_REQUIRE((long long)B * Ho * Wo < (1LL << 31) - 64, BFLOW_E_LIMIT, "wgrad_pack: more than 2^31 pixels");
+    const long long per = (long long)k_blocks * rows * 4;
+    dim3 grid(bflow::ceil_div(per, 256), taps_in_rows ? 1 : KH * KW);
+    hipLaunchKernelGGL(wgrad_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst_hi, (_Float16*)dst_lo, B, C, H, W, Ho, Wo, KW,
+                       KH * KW, stride, pad_h, pad_w, rows, k_blocks, taps_in_rows ? 1 : 0, scale);
+    return bflow::launch_status("wgrad_pack");
+}
+
+extern "C" int bflow_blocked_f32_to_nchw(const float* x, float* out, int B, int HW, int C, int channel_blocks, int rows_per_image, const float* scale,
+                                         bflow_stream_t stream) {
+    BFLOW_REQUIRE(x && out && B > 0 && HW > 0 && C > 0 && channel_blocks * 32 >= C && rows_per_image >= HW && B <= 65535, BFLOW_E_ARG,
+                  "blocked_f32_to_nchw: bad arguments");
+    dim3 grid(bflow::ceil_div(HW, 64), bflow::ceil_div(C, 32), B);
+    hipLaunchKernelGGL(blocked_f32_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, HW, channel_blocks, rows_per_image, C, scale);
+    return bflow::launch_status("blocked_f32_to_nchw");
+}
+
+extern "C" int bflow_pow2_scale(const float* x, long long n, float target, float* out2, void* work8, bflow_stream_t stream) {
+    BFLOW_REQUIRE(x && out2 && work8 && n > 0 && target > 0.f, BFLOW_E_ARG, "pow2_scale: bad arguments");
+    const int blocks = (int)std::min<long long>(256, (n + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, x, n, target, out2, (unsigned*)work8);
+    return bflow::launch_status("pow2_scale");
+}

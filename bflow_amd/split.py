@@ -304,18 +304,42 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
 
 
 def wgrad_pack(src: torch.Tensor, out_hw, ksize=(1, 1), stride: int = 1, padding=(0, 0), rows: Optional[int] = None,
-               k_blocks: Optional[int] = None, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """NCHW fp32 -> split planes (2, KH*KW, k_blocks, rows, 32) with the pixel index k = (b*Ho + yo)*Wo + xo in the block position
-    (bflow_wgrad_pack): dst[tap, k/32, c, k%32] = scale * src[b, c, yo*stride + r - ph, xo*stride + q - pw]."""
+               k_blocks: Optional[int] = None, scale: Optional[torch.Tensor] = None, taps_in_rows: bool = False) -> torch.Tensor:
+    """NCHW fp32 -> split planes with the pixel index k = (b*Ho + yo)*Wo + xo in the block position (bflow_wgrad_pack):
+    (2, KH*KW, k_blocks, rows, 32), or with taps_in_rows (2, k_blocks, rows, 32) where row n = tap*C + c."""
     B, C, H, W = src.shape
     Ho, Wo = out_hw
     kh, kw = ksize
     ph, pw = padding
-    rows = C if rows is None else rows
+    rows = (kh * kw * C if taps_in_rows else C) if rows is None else rows
     kb = (B * Ho * Wo + 31) // 32 if k_blocks is None else k_blocks
-    out = torch.empty((2, kh * kw, kb, rows, 32), dtype=torch.float16, device=src.device)
+    shape = (2, kb, rows, 32) if taps_in_rows else (2, kh * kw, kb, rows, 32)
+    out = torch.empty(shape, dtype=torch.float16, device=src.device)
     hip._check(hip.lib().bflow_wgrad_pack(hip._dev(src, name="src"), out[0].data_ptr(), out[1].data_ptr(), B, C, H, W, Ho, Wo, kh, kw, stride, ph, pw,
-                                          rows, kb, None if scale is None else hip._dev(scale, name="scale"), hip._stream()), "bflow_wgrad_pack")
+                                          rows, kb, int(taps_in_rows), None if scale is None else scale.data_ptr(), hip._stream()), "bflow_wgrad_pack")
+    return out
+
+
+def blocked_f32_to_nchw(x: torch.Tensor, C: int, H: int, W: int, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Blocked fp32 engine output (B, C/32 blocks, rows >= H*W, 32) -> (B, C, H, W) fp32, optionally times a device scalar."""
+    B, cb, rows, _ = x.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    hip._check(hip.lib().bflow_blocked_f32_to_nchw(hip._dev(x, name="x"), out.data_ptr(), B, H * W, C, cb, rows,
+                                                   None if scale is None else scale.data_ptr(), hip._stream()), "bflow_blocked_f32_to_nchw")
+    return out
+
+
+_pow2_work = {}
+
+
+def pow2_scale(x: torch.Tensor, target: float) -> torch.Tensor:
+    """(2,) fp32 device tensor {s, 1/s}, s = 2^floor(log2(target / max|x|)) -- computed on the device (bflow_pow2_scale)."""
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    if key not in _pow2_work:
+        _pow2_work[key] = torch.zeros(2, dtype=torch.int32, device=x.device)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    hip._check(hip.lib().bflow_pow2_scale(hip._dev(x, name="x"), x.numel(), float(target), out.data_ptr(), _pow2_work[key].data_ptr(), hip._stream()),
+               "bflow_pow2_scale")
     return out
 
 
@@ -360,10 +384,15 @@ def norm_act(a: torch.Tensor, shape_bhwc, a_is_nchw: bool = False, stats_a: Opti
     return out, out_f32
 
 
-def from_nchw(x: torch.Tensor) -> SplitTensor:
-    """NCHW fp32 -> blocked split (identity transform); channels are zero-padded to the next multiple of 32."""
+def from_nchw(x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> SplitTensor:
+    """NCHW fp32 -> blocked split (identity transform, or times a 1-element device tensor `scale`); channels are zero-padded to the
+    next multiple of 32."""
     B, C, H, W = x.shape
-    out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True)
+    if scale is None:
+        out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True)
+    else:
+        out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True, scale_a=scale.reshape(1).expand(C).contiguous(),
+                          shift_a=torch.zeros(C, dtype=torch.float32, device=x.device))
     return out
 
 

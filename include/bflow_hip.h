@@ -160,16 +160,24 @@ int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, in
                             int cout_pad, int cin_pad, bflow_stream_t stream);
 int bflow_conv_split(const bflow_conv_desc_t* desc, bflow_stream_t stream);
 
-/* bflow_wgrad_pack: re-blocks an NCHW fp32 tensor so that the PIXEL index becomes the contraction index of the conv engine:
- *     dst[tap, kb, c, j] = scale * src[b, c, yo*stride + r - pad_h, xo*stride + q - pad_w]   (0 outside the image / past the last pixel)
- *     with k = (b*Ho + yo)*Wo + xo = 32 kb + j, tap = r*KW + q;   dst: split planes (KH*KW, k_blocks, rows, 32), rows >= C (zero rows).
- * The weight gradient of Conv2d (the adjoint the reference gets from autograd; extractor.py / update.py convolutions) is then
- *     dW[co, c, r, q] = sum_k dY[k, co] * X_tap[k, c]  =  a 1x1 "convolution" of the engine per (tap, k-chunk):
- * activations = pack(X) (KH x KW taps, `rows` = C as the pixel rows of the GEMM), filter = pack(dY) (one tap, stride 1, no padding:
- * exactly the engine's packed-weight layout (k-tile, cout_pad, 32)), see bflow_conv_desc_t.weight_sets.
- * `scale` (device pointer to one float, or NULL = 1) pre-scales small gradients into fp16's normal range.                       */
+/* Training convolutions (bflow_amd/conv_train.py): the adjoints of Conv2d that the reference gets from autograd over
+ * torch.nn.Conv2d (extractor.py / update.py convolutions) run on bflow_conv_split; these are the helpers around it.
+ * bflow_wgrad_pack: re-blocks an NCHW fp32 tensor so that the PIXEL index becomes the contraction index of the conv engine:
+ *     value(tap, k, c) = scale * src[b, c, yo*stride + r - pad_h, xo*stride + q - pad_w]   (0 outside the image / past the last pixel)
+ *     with k = (b*Ho + yo)*Wo + xo, tap = r*KW + q;  split planes, taps_in_rows == 0: dst (KH*KW, k_blocks, rows, 32) [rows >= C],
+ *     taps_in_rows != 0: dst (k_blocks, rows, 32) with row n = tap*C + c [rows >= KH*KW*C, the rest zeros].
+ *   The weight gradient  dW[co, c, r, q] = sum_k dY[k, co] * X_tap[k, c]  is then a batch of 1x1 "convolutions" of the engine over k-chunks:
+ *   one operand is the activation tensor (its rows = the GEMM's M), the other the packed filter of bflow_conv_desc_t.weight_sets
+ *   ((k-tile, rows, 32) IS the engine's packed-weight layout).  `scale`: device pointer to one float, or NULL = 1.
+ * bflow_blocked_f32_to_nchw: out[b, c, pix] = scale * x[b, c/32, pix, c%32]   (blocked fp32 engine output -> NCHW fp32).
+ * bflow_pow2_scale: out2 = { s, 1/s } with s = 2^floor(log2(target / max|x|)) (1 for an all-zero / non-finite tensor), on the device;
+ *   work8: 8 bytes, zero before the first call (the kernel leaves them zero).  Gradients of 1e-4..1e-9 are pre-scaled by s into fp16's
+ *   normal range before they enter the split format and the results scaled back: exact in binary floating point.                     */
 int bflow_wgrad_pack(const float* src, void* dst_hi, void* dst_lo, int B, int C, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
-                     int pad_h, int pad_w, int rows, int k_blocks, const float* scale, bflow_stream_t stream);
+                     int pad_h, int pad_w, int rows, int k_blocks, int taps_in_rows, const float* scale, bflow_stream_t stream);
+int bflow_blocked_f32_to_nchw(const float* x, float* out, int B, int HW, int C, int channel_blocks, int rows_per_image, const float* scale,
+                              bflow_stream_t stream);
+int bflow_pow2_scale(const float* x, long long n, float target, float* out2, void* work8, bflow_stream_t stream);
 
 /* bflow_conv_thin_acc: the thin-output convolution of the Bezier head with its parameter update fused behind it:
  *     acc[b, co, y, x] += bias[co] + sum_{c, r, q} x[b, y+r-KH/2, x+q-KW/2, c] * w[co, c, r, q]      (zero padding, stride 1)
