@@ -31,6 +31,7 @@ from . import hip
 from . import split as S
 
 ENABLED = True                      # tools / A-B timing: False = torch (MIOpen) convolutions under autograd
+MIN_CHUNK, TARGET_WGS = 8, 768      # split-K of the weight gradient: k-blocks per chunk at least / workgroups aimed at
 _TARGET = 8192.0                    # max |dy| after scaling: well inside fp16 (65504), 13 bits of head-room for sums of products
 
 
@@ -111,33 +112,29 @@ def _weight_grad(x: torch.Tensor, dy: torch.Tensor, s: torch.Tensor, inv: torch.
     taps = kh * kw
     kb = (B * Ho * Wo + 31) // 32
     use_b = cin < 64 or _pad_ratio(cout) < _pad_ratio(cin)
-    if not use_b:
+    if not use_b:                                                                                      # ---- orientation A
         cout_pad = (cout + 127) // 128 * 128
         tiles = ((cin + 127) // 128) * ((cout + 63) // 64) * taps
-        G = max(1, min(kb // 8, (768 + tiles - 1) // tiles))
+        G = max(1, min(kb // MIN_CHUNK, (TARGET_WGS + tiles - 1) // tiles))
         kbg = (kb + G - 1) // G
         xp = S.wgrad_pack(x, (Ho, Wo), ksize, stride, padding, rows=cin, k_blocks=kbg * G)                 # (2, taps, kb, cin, 32)
         gp = S.wgrad_pack(dy, (Ho, Wo), rows=cout_pad, k_blocks=kbg * G, scale=s)                          # (2, 1, kb, cout_pad, 32)
         xt = S.SplitTensor(xp.view(2, taps * G, kbg, cin, 32), cin, 1)                                     # image = (tap, chunk)
         packed = (gp.view(2, kbg * G, cout_pad, 32), (cout, kbg * 32, 1, 1, cout_pad))                     # filter set g = k-tiles of chunk g
         _, part = S.conv(xt, packed, want_split=False, want_f32=True, weight_sets=G)                       # (taps*G, cout blocks, cin, 32)
-        cb = part.shape[1]
-        dw = part.view(taps, G, cb, cin, 32).sum(dim=1)                                                    # (taps, cb, cin, 32)
-        dw = dw.permute(1, 3, 2, 0).reshape(cb * 32, cin, kh, kw)[:cout]
+        return S.wgrad_reduce(part, G, cout, cin, ksize, 0, inv)
     else:
         n = taps * cin
         n_pad = (n + 127) // 128 * 128
         tiles = ((cout + 127) // 128) * ((n + 63) // 64)
-        G = max(1, min(kb // 8, (768 + tiles - 1) // tiles))
+        G = max(1, min(kb // MIN_CHUNK, (TARGET_WGS + tiles - 1) // tiles))
         kbg = (kb + G - 1) // G
         gp = S.wgrad_pack(dy, (Ho, Wo), rows=cout, k_blocks=kbg * G, scale=s)                              # (2, 1, kb, cout, 32)
         xp = S.wgrad_pack(x, (Ho, Wo), ksize, stride, padding, rows=n_pad, k_blocks=kbg * G, taps_in_rows=True)   # (2, kb, n_pad, 32)
         gt = S.SplitTensor(gp.view(2, G, kbg, cout, 32), cout, 1)                                          # image = chunk, rows = co
         packed = (xp, (n, kbg * 32, 1, 1, n_pad))
         _, part = S.conv(gt, packed, want_split=False, want_f32=True, weight_sets=G)                       # (G, n blocks, cout, 32)
-        nb = part.shape[1]
-        dw = part.sum(dim=0).permute(1, 0, 2).reshape(cout, nb * 32)[:, :n].reshape(cout, taps, cin).permute(0, 2, 1).reshape(cout, cin, kh, kw)
-    return (dw * inv).contiguous()
+        return S.wgrad_reduce(part, G, cout, cin, ksize, 1, inv)
 
 
 class Conv2d(nn.Conv2d):

@@ -108,6 +108,27 @@ __global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict
     }
 }
 
+// dw[co, ci, tap] = inv * sum_g part[...]: the engine's blocked fp32 partial results of the k-chunks -> the filter gradient in (Cout, Cin, KH*KW)
+// order.  orientation 0: part (taps, G, CB, rows = Cin, 32) [co = 32 cb + j];  orientation 1: part (G, NB, rows = Cout, 32) [n = 32 nb + j = tap*Cin + ci].
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G, int Cout, int Cin, int taps,
+                                                           int blocks, int rows, int orientation, const float* __restrict__ inv_p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Cout * Cin * taps) return;
+    const int tap = (int)(i % taps);
+    const int ci = (int)((i / taps) % Cin);
+    const int co = (int)(i / ((long long)taps * Cin));
+    float acc = 0.f;
+    if (orientation == 0) {
+        const long long base = ((long long)tap * G * blocks + (co >> 5)) * rows * 32 + (long long)ci * 32 + (co & 31);
+        for (int g = 0; g < G; ++g) acc += part[base + (long long)g * blocks * rows * 32];
+    } else {
+        const int n = tap * Cin + ci;
+        const long long base = ((long long)(n >> 5) * rows + co) * 32 + (n & 31);
+        for (int g = 0; g < G; ++g) acc += part[base + (long long)g * blocks * rows * 32];
+    }
+    dw[i] = acc * (inv_p ? *inv_p : 1.f);
+}
+
 }  // namespace
 
 extern "C" int bflow_wgrad_pack(const float* src, void* dst_hi, void* dst_lo, int B, int C, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
@@ -138,4 +159,15 @@ extern "C" int bflow_pow2_scale(const float* x, long long n, float target, float
     const int blocks = (int)std::min<long long>(256, (n + 256 * 16 - 1) / (256 * 16));
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, x, n, target, out2, (unsigned*)work8);
     return bflow::launch_status("pow2_scale");
+}
+
+extern "C" int bflow_wgrad_reduce(const float* part, float* dw, int G, int Cout, int Cin, int taps, int blocks, int rows, int orientation,
+                                  const float* inv_scale, bflow_stream_t stream) {
+    BFLOW_REQUIRE(part && dw && G > 0 && Cout > 0 && Cin > 0 && taps > 0 && blocks > 0 && rows > 0, BFLOW_E_ARG, "wgrad_reduce: bad arguments");
+    BFLOW_REQUIRE(orientation == 0 ? (blocks * 32 >= Cout && rows >= Cin) : (blocks * 32 >= taps * Cin && rows >= Cout), BFLOW_E_ARG,
+                  "wgrad_reduce: partial results too small");
+    const long long n = (long long)Cout * Cin * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bflow::ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, part, dw, G, Cout, Cin, taps, blocks, rows,
+                       orientation, inv_scale);
+    return bflow::launch_status("wgrad_reduce");
 }

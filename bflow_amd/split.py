@@ -329,6 +329,16 @@ def blocked_f32_to_nchw(x: torch.Tensor, C: int, H: int, W: int, scale: Optional
     return out
 
 
+def wgrad_reduce(part: torch.Tensor, G: int, cout: int, cin: int, ksize, orientation: int, inv: Optional[torch.Tensor]) -> torch.Tensor:
+    """Sum of the k-chunk partial results -> (cout, cin, kh, kw) fp32 times the device scalar `inv` (bflow_wgrad_reduce)."""
+    kh, kw = ksize
+    blocks, rows = part.shape[-3], part.shape[-2]
+    dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=part.device)
+    hip._check(hip.lib().bflow_wgrad_reduce(hip._dev(part, name="part"), dw.data_ptr(), G, cout, cin, kh * kw, blocks, rows, orientation,
+                                            None if inv is None else inv.data_ptr(), hip._stream()), "bflow_wgrad_reduce")
+    return dw
+
+
 _pow2_work = {}
 
 
@@ -384,6 +394,9 @@ def norm_act(a: torch.Tensor, shape_bhwc, a_is_nchw: bool = False, stats_a: Opti
     return out, out_f32
 
 
+_zeros_c = {}
+
+
 def from_nchw(x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> SplitTensor:
     """NCHW fp32 -> blocked split (identity transform, or times a 1-element device tensor `scale`); channels are zero-padded to the
     next multiple of 32."""
@@ -391,8 +404,10 @@ def from_nchw(x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> SplitTen
     if scale is None:
         out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True)
     else:
-        out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True, scale_a=scale.reshape(1).expand(C).contiguous(),
-                          shift_a=torch.zeros(C, dtype=torch.float32, device=x.device))
+        zkey = (C, x.device.index)
+        if zkey not in _zeros_c:
+            _zeros_c[zkey] = torch.zeros(C, dtype=torch.float32, device=x.device)
+        out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True, scale_a=scale.reshape(1).expand(C).contiguous(), shift_a=_zeros_c[zkey])
     return out
 
 

@@ -178,6 +178,11 @@ int bflow_wgrad_pack(const float* src, void* dst_hi, void* dst_lo, int B, int C,
 int bflow_blocked_f32_to_nchw(const float* x, float* out, int B, int HW, int C, int channel_blocks, int rows_per_image, const float* scale,
                               bflow_stream_t stream);
 int bflow_pow2_scale(const float* x, long long n, float target, float* out2, void* work8, bflow_stream_t stream);
+/* bflow_wgrad_reduce: dw (Cout, Cin, KH*KW) = inv_scale * sum over the G k-chunks of the engine's blocked fp32 partial results:
+ *   orientation 0: part (taps, G, blocks, rows >= Cin, 32), output channel = 32*block + lane;  orientation 1: part (G, blocks, rows >= Cout, 32),
+ *   32*block + lane = tap*Cin + ci.                                                                                                  */
+int bflow_wgrad_reduce(const float* part, float* dw, int G, int Cout, int Cin, int taps, int blocks, int rows, int orientation,
+                       const float* inv_scale, bflow_stream_t stream);
 
 /* bflow_conv_thin_acc: the thin-output convolution of the Bezier head with its parameter update fused behind it:
  *     acc[b, co, y, x] += bias[co] + sum_{c, r, q} x[b, y+r-KH/2, x+q-KW/2, c] * w[co, c, r, q]      (zero padding, stride 1)
