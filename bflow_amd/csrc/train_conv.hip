@@ -112,21 +112,28 @@ __global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict
 // order.  orientation 0: part (taps, G, CB, rows = Cin, 32) [co = 32 cb + j];  orientation 1: part (G, NB, rows = Cout, 32) [n = 32 nb + j = tap*Cin + ci].
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G, int Cout, int Cin, int taps,
                                                            int blocks, int rows, int orientation, const float* __restrict__ inv_p) {
+    // thread = one element of a chunk's partial result in ITS order (coalesced reads over the G chunks); the small dw takes the scattered writes
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)Cout * Cin * taps) return;
-    const int tap = (int)(i % taps);
-    const int ci = (int)((i / taps) % Cin);
-    const int co = (int)(i / ((long long)taps * Cin));
+    const long long per_img = (long long)blocks * rows * 32;
+    const int j = (int)(i & 31);
+    const int row = (int)((i >> 5) % rows);
+    const int blk = (int)(((i >> 5) / rows) % blocks);
     float acc = 0.f;
     if (orientation == 0) {
-        const long long base = ((long long)tap * G * blocks + (co >> 5)) * rows * 32 + (long long)ci * 32 + (co & 31);
-        for (int g = 0; g < G; ++g) acc += part[base + (long long)g * blocks * rows * 32];
+        const int tap = (int)(i / per_img);
+        const int co = blk * 32 + j, ci = row;
+        if (tap >= taps || co >= Cout || ci >= Cin) return;
+        const float* p = part + (long long)tap * G * per_img + ((long long)blk * rows + row) * 32 + j;
+        for (int g = 0; g < G; ++g) acc += p[(long long)g * per_img];
+        dw[((long long)co * Cin + ci) * taps + tap] = acc * (inv_p ? *inv_p : 1.f);
     } else {
-        const int n = tap * Cin + ci;
-        const long long base = ((long long)(n >> 5) * rows + co) * 32 + (n & 31);
-        for (int g = 0; g < G; ++g) acc += part[base + (long long)g * blocks * rows * 32];
+        const int n = blk * 32 + j, co = row;
+        if (i >= per_img || n >= taps * Cin || co >= Cout) return;
+        const int tap = n / Cin, ci = n - tap * Cin;
+        const float* p = part + ((long long)blk * rows + row) * 32 + j;
+        for (int g = 0; g < G; ++g) acc += p[(long long)g * per_img];
+        dw[((long long)co * Cin + ci) * taps + tap] = acc * (inv_p ? *inv_p : 1.f);
     }
-    dw[i] = acc * (inv_p ? *inv_p : 1.f);
 }
 
 }  // namespace
@@ -166,7 +173,7 @@ extern "C" int bflow_wgrad_reduce(const float* part, float* dw, int G, int Cout,
     BFLOW_REQUIRE(part && dw && G > 0 && Cout > 0 && Cin > 0 && taps > 0 && blocks > 0 && rows > 0, BFLOW_E_ARG, "wgrad_reduce: bad arguments");
     BFLOW_REQUIRE(orientation == 0 ? (blocks * 32 >= Cout && rows >= Cin) : (blocks * 32 >= taps * Cin && rows >= Cout), BFLOW_E_ARG,
                   "wgrad_reduce: partial results too small");
-    const long long n = (long long)Cout * Cin * taps;
+    const long long n = (long long)blocks * rows * 32 * (orientation == 0 ? taps : 1);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bflow::ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, part, dw, G, Cout, Cin, taps, blocks, rows,
                        orientation, inv_scale);
     return bflow::launch_status("wgrad_reduce");
