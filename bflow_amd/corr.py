@@ -126,7 +126,7 @@ class CorrComputation:
         precision = PRECISION if precision is None else precision
         return (precision == "split" and self.dim in (64, 128, 256)) or (precision == "f16" and self.dim in (128, 256))
 
-    def get_correlation_volume(self, tiled: bool = False, precision: Optional[str] = None) -> torch.Tensor:
+    def get_correlation_volume(self, tiled: bool = False, precision: Optional[str] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(T, B*N, 1, h, w) fp32 -- corr.py:229-272.  One K5 launch per reference group, written straight into its
         slice of the volume (the reference expands fmap1 per target and concatenates, corr.py:254-259).
         tiled=True: (T, B, N, tiled_plane_size(h, w)) with every plane stored as 4 x 8 tiles (the look-up's layout)."""
@@ -140,8 +140,12 @@ class CorrComputation:
         if (tiled or precision == "f16") and not (tiled and self.tiled_supported(precision)):
             raise hip.BflowHipError(f"correlation volume (tiled={tiled}, precision={precision!r}, D={D}): the tiled layout needs 'split' with D in "
                                     "(64, 128, 256) or 'f16' with D in (128, 256); the fp16 volume exists in the tiled layout only")
-        vol = torch.empty((T, B, N, hip.tiled_plane_size(h, w) if tiled else N), dtype=torch.float16 if precision == "f16" else torch.float32,
-                          device=device)
+        vshape, vdtype = (T, B, N, hip.tiled_plane_size(h, w) if tiled else N), torch.float16 if precision == "f16" else torch.float32
+        if out is not None:        # a caller-owned volume (double-buffered frames, bflow_amd/pipeline.py)
+            assert tuple(out.shape) == vshape and out.dtype == vdtype and out.is_contiguous() and out.device == device
+            vol = out
+        else:
+            vol = torch.empty(vshape, dtype=vdtype, device=device)
         thw = (h, w) if tiled else None
         split = precision in ("split", "f16") and D % 64 == 0
         t0 = 0
@@ -167,7 +171,8 @@ class CorrBlockParallelMultiTarget:
                  corr_computation_frames: Optional[CorrComputation] = None,
                  radius: int = 4,
                  layout: str = "rows",
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None,
+                 volume_out: Optional[torch.Tensor] = None):
         """layout = "rows": the reference's (T, B*N, h_L, w_L) planes (any K5 variant; every look-up entry point).
         layout = "tiled": planes stored as 4 x 8 tiles -- the inference product path (lookup_bezier_split); the reference-shaped
         accessors untile on demand.  precision: None = module default (PRECISION); "f16" needs layout = "tiled"."""
@@ -191,8 +196,10 @@ class CorrBlockParallelMultiTarget:
         N = h * w
 
         if self._tiled:
-            base = cc.get_correlation_volume(tiled=True, precision=precision).view(len(levels), B * N, hip.tiled_plane_size(h, w))
+            vout = None if volume_out is None else volume_out.view(len(levels), B, N, hip.tiled_plane_size(h, w))   # a caller-owned level 0
+            base = cc.get_correlation_volume(tiled=True, precision=precision, out=vout).view(len(levels), B * N, hip.tiled_plane_size(h, w))
         else:
+            assert volume_out is None, "volume_out: tiled layout only"
             base = cc.get_correlation_volume(precision=precision).view(len(levels), B * N, h, w)
         self._f16 = base.dtype == torch.float16
         # pyramid: corr.py:297-305 -- level L keeps the targets whose num_levels > L

@@ -81,15 +81,27 @@ class GraphCache:
                self._sig(flow_init), bool(test_mode), getattr(self.model, "corr_precision", None))
         wkey = self._weights_signature()
         if wkey != self._weights_key:
-            self._graphs.clear()                 # destroyed here, outside any capture
+            self.clear()                         # destroyed here, outside any capture
             self._weights_key = wkey
         cap = self._graphs.pop(key, None)
         if cap is None:
             while len(self._graphs) >= self.MAX_GRAPHS:
+                torch.cuda.synchronize()                        # (a graph is only destroyed when its last replay has finished, see clear())
                 self._graphs.pop(next(iter(self._graphs)))      # least recently used first (dict order = recency, see below)
             cap = _Captured(self.model, voxel_grid, images, iters, flow_init, test_mode)
         self._graphs[key] = cap                  # (re-)insert at the end: most recently used
         return cap.replay(voxel_grid, images, flow_init)
 
     def clear(self):
-        self._graphs.clear()
+        """Destroys the captured graphs -- after the device has drained: releasing a hipGraphExec whose last replay is still running is not
+        safe on this runtime (intermittent segmentation fault in a later graph launch)."""
+        if self._graphs:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self._graphs.clear()
+
+    def __del__(self):
+        try:
+            self.clear()
+        except Exception:
+            pass

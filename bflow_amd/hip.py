@@ -460,6 +460,7 @@ def pad_replicate(x: torch.Tensor, pad: Sequence[int]) -> torch.Tensor:
 # (alive until after the join), branch-local temporaries are stream-ordered on the side stream.
 # ----------------------------------------------------------------------------------------------------------------------
 _side_streams = {}
+BRANCHING = True        # tools: False issues every branch on the current stream
 
 
 # ------------------------------------------------------------------------------------------------ training path (f-4)
@@ -544,11 +545,11 @@ class Branch:
     """`with Branch(enabled) as br:` runs the block on the side stream; `br.join()` makes the current stream wait for it."""
 
     def __init__(self, enabled: bool = True):
-        self.enabled = enabled and torch.cuda.is_available()
+        self.enabled = enabled and BRANCHING and torch.cuda.is_available()
         self._ctx = None
         if self.enabled:
             self.main = torch.cuda.current_stream()
-            key = self.main.device_index
+            key = (self.main.device_index, self.main.cuda_stream)      # one side stream per stream that forks: branches nest
             if key not in _side_streams:
                 _side_streams[key] = torch.cuda.Stream(device=self.main.device)
             self.side = _side_streams[key]

@@ -35,6 +35,26 @@ from .update import BasicUpdateBlock
 
 
 
+class EncodedFrame:
+    """What the GRU loop reads of one frame (the output of RAFTSpline._encode): the correlation pyramid, the split workspace with the
+    hidden state / context terms / initial Bezier block, the curve parameters and the look-up's output buffer."""
+
+    def __init__(self, corr_block, ws, bezier, corr_feat):
+        self.corr_block, self.ws, self.bezier, self.corr_feat = corr_block, ws, bezier, corr_feat
+
+    def volume(self) -> torch.Tensor:
+        return self.corr_block._pyramid[0][0]
+
+    def small_tensors(self) -> List[torch.Tensor]:
+        """Everything `_iterate` reads except the level-0 volume (which a double-buffered state receives in place, `volume_out`)."""
+        ws = self.ws
+        out = [t for t, _ in self.corr_block._pyramid[1:]]
+        out += [ws.H.planes, ws.INP.planes, ws.M.planes, self.bezier]
+        for t_zr, t_q in ws.inp_terms:
+            out += [t_zr, t_q]
+        return out
+
+
 class RAFTSpline(nn.Module):
     def __init__(self, model_params: Dict[str, Any]):
         super().__init__()
@@ -186,7 +206,13 @@ class RAFTSpline(nn.Module):
 
     # ---------------------------------------------------------------------------------------- the hot path
     def _forward_impl(self, voxel_grid, images, iters: int, flow_init: Optional[torch.Tensor], test_mode: bool):
-        """raft.py:101-200 on the HIP kernels.  No host<->device synchronisation anywhere (hipGraph-capturable)."""
+        """raft.py:101-200 on the HIP kernels.  No host<->device synchronisation anywhere (hipGraph-capturable).
+        Two phases: `_encode` (raft.py:118-162: encoders, correlation volume + pyramid, context split, initial curve) produces everything
+        the GRU loop reads, `_iterate` (raft.py:164-195) runs the loop.  bflow_amd/pipeline.py overlaps the two phases of consecutive
+        frames."""
+        return self._iterate(self._encode(voxel_grid, images, flow_init), iters, test_mode)
+
+    def _encode(self, voxel_grid, images, flow_init: Optional[torch.Tensor], volume_out: Optional[torch.Tensor] = None) -> "EncodedFrame":
         hdim, cdim = self.hidden_dim, self.context_dim
         tm = self.stage_timer
         pr = self._probe
@@ -226,7 +252,7 @@ class RAFTSpline(nn.Module):
         with hip.Branch(tm is None) as cnet_branch:
             if pr: pr("cnet.begin")
             ws = ub.new_split_workspace(B, h, w, device)
-            ws.overlap = tm is None
+            ws.overlap = tm is None and hip.BRANCHING
             ctx_in = context_input
             if self.fnet_img is None:      # the context bins are the LAST channels of the voxel grid: one window, read in place
                 ctx_in = S.ChannelWindows(voxel_grid, [voxel_grid.shape[1] - self.nbins_context], self.nbins_context)
@@ -255,15 +281,22 @@ class RAFTSpline(nn.Module):
         if pr: pr("fnet.end")
         if tm: tm.start("corr computation")
         corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img, layout="tiled",
-                                                  precision=self.corr_precision)
+                                                  precision=self.corr_precision, volume_out=volume_out)
         if tm: tm.stop("corr computation")
         if pr: pr("corr.end")
         cnet_branch.join()
         if pr: pr("joined")
 
-        coef = self._coefficients()
         corr_feat = corr_block.new_output_split()
         S.bezier_update(bezier, None, ws.M, ub.motion_dim // 32)     # emit the initial Bezier channel block
+        return EncodedFrame(corr_block, ws, bezier, corr_feat)
+
+    def _iterate(self, fr: "EncodedFrame", iters: int, test_mode: bool):
+        tm = self.stage_timer
+        pr = self._probe
+        ub = self.update_block
+        corr_block, ws, bezier, corr_feat = fr.corr_block, fr.ws, fr.bezier, fr.corr_feat
+        coef = self._coefficients()
         ups: List[torch.Tensor] = []
         if tm: tm.start("all iters")
         for itr in range(iters):

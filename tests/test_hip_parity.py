@@ -705,6 +705,36 @@ def test_conv_thin_acc_vs_fp64(cin, cout, k, H, W, B, blocks, blk):
         S.conv_thin_acc(xs, (cu(np.zeros((25, cout, cin), np.float32)), (cout, cin, 5, 5)), None, acc2)
 
 
+def test_concurrent_runner_matches_sequential():
+    """bflow_amd/pipeline.py: two independent forwards as parallel branches of one hipGraph must reproduce the sequential forward bit for
+    bit, replay after replay, and re-capture when the weights change."""
+    from bflow_amd.pipeline import ConcurrentRunner
+    cfg, m, sd = _model("E_LU4_BD2")
+    frames = [torch.from_numpy(synthetic.voxel_grid(1, 9, 96, 128, seed=40 + i)).to(DEV) for i in range(6)]
+    with torch.no_grad():
+        ref = [m(voxel_grid=f, iters=4, test_mode=True) for f in frames]
+        ref = [(lo.get_params().clone(), up.get_params().clone()) for lo, up in ref]
+        run = ConcurrentRunner(m, iters=4, streams=2)
+        for rep in range(2):
+            for k in range(0, 6, 2):
+                outs = run(frames[k:k + 2])
+                for j, (lo, up) in enumerate(outs):
+                    assert torch.equal(lo.get_params(), ref[k + j][0]) and torch.equal(up.get_params(), ref[k + j][1])
+        run.close()
+        with pytest.raises(ValueError):
+            ConcurrentRunner(m, iters=4, streams=3)
+        # new weights -> new capture
+        sd2 = {k_: v * 1.01 if v.dtype.is_floating_point and "running" not in k_ else v for k_, v in m.state_dict().items()}
+        m.load_state_dict(sd2)
+        run2 = ConcurrentRunner(m, iters=4, streams=2)
+        a = run2(frames[:2])
+        lo0 = a[0][0].get_params().clone()
+        lo_seq, _ = m(voxel_grid=frames[0], iters=4, test_mode=True)
+        assert torch.equal(lo0, lo_seq.get_params()) and not torch.equal(lo0, ref[0][0])
+    with pytest.raises(hip.BflowHipError):
+        ConcurrentRunner(m, 4, 2)([frames[0].cpu(), frames[1].cpu()])
+
+
 # ------------------------------------------------------------------------------------------------- SURVEY 8(f-4): conv engine backward
 @pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,B,gscale", [
     (64, 96, (3, 3), 1, (1, 1), 20, 28, 2, 1e-6),       # encoder 3x3; gradients at 1e-6 (the power-of-two pre-scaling must carry them)
