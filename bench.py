@@ -14,6 +14,9 @@ Metric (BASELINE.json): frames/s of the whole job + ms per GRU iteration, raft-s
           micro-batches of 8 = C4's per-GPU batch at N = 8): strong scaling, no data-path collective; `c2_weak` (batch 1 per GPU,
           the N = 1 workload on every rank) is measured in the same run and reported next to it.  At N = 1 the same global-64
           workload is reported as `c4_strong`, so that both curves have their N = 1 point.
+          A rank's micro-batches are independent: they run two at a time as parallel branches of one captured graph
+          (bflow_amd/pipeline.py; same frames, bit-identical outputs).  `c2_two_in_flight` (N = 1 extras) is the same mechanism on two
+          batch-1 frames: a frame-stream throughput, reported next to `value`, never as `value`.
 After the timed regions the per-rank EPE state is all-gathered once over RCCL (the path's single exchange step).
 
 One "step" = one forward (voxel grids resident in HBM -> full-resolution Bezier flow) over the rank's frames of that step,
