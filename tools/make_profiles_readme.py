@@ -28,7 +28,8 @@ sources still hash to the same value.
 | frames/s, 1 GPU, hipGraph replay | **{b["value"]:.1f}** ({b["ms_per_step"]:.2f} ms/frame) | 236.8 (4.22 ms) |
 | ms per GRU iteration (marginal, under replay) | **{b["ms_per_gru_iter"]:.3f}** | 0.181–0.186 |
 | fixed part (encoders + volume + pyramid + up-sampling) | {b["ms_fixed_part"]:.2f} ms | 1.94–2.1 ms |
-| configs[3] global batch 64 on ONE GPU (8 micro-batches of 8) | {b["c4_strong"]["value"]:.1f} frames/s | (batch 8: 300–314) |
+| configs[3] global batch 64 on ONE GPU (8 micro-batches of 8, two at a time as parallel branches of one graph) | {b["c4_strong"]["value"]:.1f} frames/s | (batch 8: 300–314) |
+| two batch-1 frames in flight (`c2_two_in_flight`, next to `value`, never `value`) | {b["c2_two_in_flight"]["value"]:.1f} frames/s | — |
 | CPU baseline (oracle = op-for-op port, torch CPU fp32, {cb["cores"]} threads) | {cb["value"]:.2f} frames/s ({cb["ms_per_frame"]:.0f} ms/frame) | 0.75 |
 
 | Kernel (as `bench.py` launches it) | bound | achieved | peak | frac | launch | PMC traffic vs algorithmic |
