@@ -148,7 +148,9 @@ def main():
     # ---- workload B: C4, global batch 64 -> contiguous shard of this rank, micro-batches of 8 (one captured graph, replayed per micro-batch)
     assert GLOBAL_BATCH % (world * MICRO_BATCH) == 0 or world * MICRO_BATCH > GLOBAL_BATCH, "global batch 64 must split into micro-batches of 8"
     s0, s1 = bdist.shard_range(GLOBAL_BATCH, rank, world)
-    micro = min(MICRO_BATCH, s1 - s0)
+    # micro-batches of 8 (C4's per-GPU batch), but always at least two per rank: two forwards in flight fill the chip better than one
+    # (8 frames at N = 8: two concurrent micro-batches of 4 = 358 frames/s, one of 8 = 332; tools/two_frame_probe.py)
+    micro = min(MICRO_BATCH, max(1, (s1 - s0) // 2)) if not args.no_graph else min(MICRO_BATCH, s1 - s0)
     n_micro = (s1 - s0) // micro
     vox8 = None
 
