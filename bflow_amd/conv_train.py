@@ -36,21 +36,24 @@ _TARGET = 8192.0                    # max |dy| after scaling: well inside fp16 (
 
 
 class _PackCache:
-    """Packed filters keyed on the parameter's storage and in-place version (an optimiser step bumps the version)."""
+    """Packed filters of one convolution (forward: the filter itself; backward: flipped in space, transposed in (cin, cout)), keyed on
+    the storage and in-place version of the SOURCE parameters (an optimiser step bumps the version).  The tensor a pack was made from
+    is kept alive next to it: a derived filter (torch.cat of two gate filters, the flipped copy) is a fresh tensor on every call, and a
+    key on ITS address could match a freed predecessor's."""
 
     def __init__(self):
-        self.fwd = S.PackedConvWeight()
-        self.bwd = S.PackedConvWeight()
-        self._flip_key = None
-        self._flip = None
+        self._key = {"fwd": None, "bwd": None}
+        self._store = {"fwd": None, "bwd": None}
 
-    def flipped(self, w: torch.Tensor) -> torch.Tensor:
-        key = (w.data_ptr(), w._version)
-        if self._flip_key != key:
+    def get(self, which: str, weight: torch.Tensor, srcs):
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in srcs)
+        if self._key[which] != key:
             with torch.no_grad():
-                self._flip = w.detach().flip(2, 3).transpose(0, 1).contiguous()
-            self._flip_key = key
-        return self._flip
+                w = weight.detach().float()
+                w = w.flip(2, 3).transpose(0, 1).contiguous() if which == "bwd" else w.contiguous()
+                packed = S.PackedConvWeight().get(w)              # a fresh packer: nothing to mistake for
+            self._store[which], self._key[which] = (w, packed), key
+        return self._store[which][1]
 
 
 def _conv_forward(x: torch.Tensor, packed, stride: int, padding: Tuple[int, int], bias, in_scale=None, out_scale=None) -> torch.Tensor:
@@ -65,12 +68,12 @@ def _conv_forward(x: torch.Tensor, packed, stride: int, padding: Tuple[int, int]
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, cache):
+    def forward(ctx, x, weight, bias, stride, padding, cache, srcs):
         x = x.float().contiguous()
         ctx.save_for_backward(x, weight)
-        ctx.stride, ctx.padding, ctx.cache, ctx.has_bias = stride, padding, cache, bias is not None
+        ctx.stride, ctx.padding, ctx.cache, ctx.srcs, ctx.has_bias = stride, padding, cache, srcs, bias is not None
         with torch.no_grad():
-            return _conv_forward(x, cache.fwd.get(weight), stride, padding, None if bias is None else bias.detach().float().contiguous())
+            return _conv_forward(x, cache.get("fwd", weight, srcs), stride, padding, None if bias is None else bias.detach().float().contiguous())
 
     @staticmethod
     def backward(ctx, dy):
@@ -89,12 +92,12 @@ class _ConvFn(torch.autograd.Function):
                 if stride > 1:                                   # zero-dilated dy: position (yo*stride, xo*stride) of the stride-1 output grid
                     g = torch.zeros((B, cout, H + 2 * ph - kh + 1, W + 2 * pw - kw + 1), dtype=torch.float32, device=dy.device)
                     g[:, :, ::stride, ::stride][:, :, :Ho, :Wo] = dy
-                dx = _conv_forward(g, cache.bwd.get(cache.flipped(w)), 1, (kh - 1 - ph, kw - 1 - pw), None, in_scale=s, out_scale=inv)
+                dx = _conv_forward(g, cache.get("bwd", w, ctx.srcs), 1, (kh - 1 - ph, kw - 1 - pw), None, in_scale=s, out_scale=inv)
             if ctx.needs_input_grad[1]:
                 dw = _weight_grad(x, dy, s, inv, (kh, kw), stride, (ph, pw))
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = dy.sum(dim=(0, 2, 3))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def _pad_ratio(n: int, t: int = 128) -> float:
@@ -145,12 +148,13 @@ class Conv2d(nn.Conv2d):
                 and self.dilation == (1, 1) and self.stride[0] == self.stride[1] and self.stride[0] in (1, 2) and self.padding_mode == "zeros"
                 and not isinstance(self.padding, str)):
             cache = self.__dict__.setdefault("_hip_pack", _PackCache())
-            return _ConvFn.apply(x, self.weight, self.bias, self.stride[0], tuple(self.padding), cache)
+            return _ConvFn.apply(x, self.weight, self.bias, self.stride[0], tuple(self.padding), cache, (self.weight,))
         return super().forward(x)
 
 
-def conv2d(x: torch.Tensor, weight: torch.Tensor, bias, padding, cache: _PackCache, stride: int = 1) -> torch.Tensor:
-    """Functional form for derived filters (the merged z|r convolution of the training forward)."""
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias, padding, cache: _PackCache, srcs, stride: int = 1) -> torch.Tensor:
+    """Functional form for derived filters (the merged z|r convolution of the training forward); `srcs` = the parameters `weight` was
+    built from (the cache key)."""
     if ENABLED and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        return _ConvFn.apply(x, weight, bias, stride, tuple(padding), cache)
+        return _ConvFn.apply(x, weight, bias, stride, tuple(padding), cache, tuple(srcs))
     return torch.nn.functional.conv2d(x, weight, bias, stride=stride, padding=padding)

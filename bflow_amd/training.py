@@ -232,7 +232,7 @@ def _update_block_train(ub, net, inp, corr, bezier):
     for sfx in ("1", "2"):
         cz, cr, cq = (getattr(gru, f"conv{g}{sfx}") for g in "zrq")
         zr = conv_train.conv2d(torch.cat([net, x], dim=1), torch.cat([cz.weight, cr.weight], dim=0), torch.cat([cz.bias, cr.bias], dim=0),
-                               cz.padding, gru.__dict__.setdefault("_zr_pack" + sfx, conv_train._PackCache()))
+                               cz.padding, gru.__dict__.setdefault("_zr_pack" + sfx, conv_train._PackCache()), (cz.weight, cr.weight))
         z, r = torch.sigmoid(zr[:, :hd]), torch.sigmoid(zr[:, hd:])
         q = torch.tanh(cq(torch.cat([r * net, x], dim=1)))
         net = (1 - z) * net + z * q

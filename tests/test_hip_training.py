@@ -209,6 +209,55 @@ def test_train_step_and_optimizer():
     assert out["pred"].shape == (B, 2, H, W) and out["bezier_prediction"].get_params().requires_grad is False
 
 
+def test_engine_gradients_follow_the_weights_across_optimizer_steps():
+    """The packed (forward) and flipped (backward) filters of conv_train are cached per parameter version: after optimiser steps the
+    gradients on the conv engine must still equal the ones torch convolutions compute from the SAME updated weights."""
+    import copy
+    from bflow_amd import conv_train as CT
+    cfg = O.model_config("E_LU4_BD2")
+    model = _product_model(cfg)
+    B, H, W = 1, 96, 128
+    vox, _ = TC.inputs(cfg, B, H, W)
+    gts, valids, _ = TC.train_targets(B, H, W, "dsec")
+    batch = {DataLoading.FLOW: cu(gts[0]), DataLoading.FLOW_VALID: cu(valids[0]), DataLoading.EV_REPR: vox.to(DEV),
+             DataLoading.DATASET_TYPE: [DataSetType.DSEC]}
+    step = training.TrainStep(model, num_iter_train=3)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    for _ in range(3):                                       # three updates through the engine's own gradients
+        opt.zero_grad(set_to_none=True)
+        step(batch)["loss"].backward()
+        opt.step()
+    opt.zero_grad(set_to_none=True)
+    loss_hip = step(batch)["loss"]
+    loss_hip.backward()
+    g_hip = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    ref = copy.deepcopy(model)                               # same weights / BatchNorm state, torch (MIOpen) convolutions
+    # the deep copy shares nothing; undo the BatchNorm statistics update of the step just taken on `model` by copying BEFORE it is irrelevant:
+    # gradients in train mode use batch statistics, not the running ones
+    ref.zero_grad(set_to_none=True)
+    try:
+        CT.ENABLED = False
+        loss_ref = training.TrainStep(ref, num_iter_train=3)(batch)["loss"]
+        loss_ref.backward()
+    finally:
+        CT.ENABLED = True
+    assert abs(float(loss_hip) - float(loss_ref)) < 1e-4 * abs(float(loss_ref))
+    worst = 0.0
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for k, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        # (the bias of a convolution in front of a normalisation layer has an exactly zero gradient: what both paths return there is
+        #  round-off at 1e-8 -- scale floors at 1e-5 of the largest gradient)
+        scale = max(float(p.grad.abs().max()), 1e-5 * gmax)
+        e = float((g_hip[k] - p.grad).abs().max()) / scale
+        if e > 2e-3:
+            print(f"   {k}: {e:.2e} (scale {scale:.2e})")
+        worst = max(worst, e)
+    print(f"engine vs torch convolutions after 3 optimiser steps: worst scaled gradient difference {worst:.2e}")
+    assert worst < 2e-3
+
+
 def test_adjoint_identities_at_dsec_size():
     """Size-independent property at BASELINE C2 size (60x80 grid, 4 targets, 7 pyramid planes, 368.6 MB volume): look-up, pooling and
     up-sampling are LINEAR in the volume / the Bezier parameters, so <L x, y> == <x, L^T y> must hold for the adjoint kernels
