@@ -433,7 +433,11 @@ def _parse_filters(msg: bytes):
 
 def read_h5_dataset(path: Union[str, Path], name: str = DATASET_NAME) -> np.ndarray:
     with open(path, "rb") as f:
-        return _H5File(f.read()).read_dataset(name)
+        buf = f.read()
+    try:
+        return _H5File(buf).read_dataset(name)
+    except (struct.error, IndexError, ValueError, zlib.error, OverflowError, MemoryError, RecursionError) as e:   # a corrupt structure: h5py reports OSError
+        raise VoxelCacheError(f"{path}: damaged HDF5 structure ({type(e).__name__}: {e})")
 
 
 def h5_to_np_array(inpath: Union[str, Path]) -> Optional[np.ndarray]:
