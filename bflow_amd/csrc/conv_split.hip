@@ -865,6 +865,9 @@ struct StemArgs {
     int win[8];
 };
 
+#ifndef STEM_ABL
+#define STEM_ABL 0      // tools/stem_ablate.sh: 1 no epilogue, 2 no tile build, 4 no patch load, 8 no MFMA
+#endif
 template <int KS, int STRIDE>
 __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs sa) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
                 const int gy = gy0 + pr, gx = gx0 + pc;
                 const bool ok = i < total && gy >= 0 && gy < sa.H && gx >= 0 && gx < sa.W;
                 const unsigned off = ok ? (unsigned)(((c * sa.H + gy) * sa.W + gx) * 4) : 0x80000000u;
-                pv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_x, off, 0, 0));
+                pv[j] = (STEM_ABL & 4) ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_x, off, 0, 0));
             }
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
@@ -996,12 +999,12 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
             koff[k] = c < nch ? (c * PR + r) * PC + q : -1;
         }
         __syncthreads();
-        build_tile(0, kb & 1);
+        if (!(STEM_ABL & 2)) build_tile(0, kb & 1);
         for (int kbl = 0; kbl < sa.kblocks_per_chunk; ++kbl, ++kb) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // weight tile kb landed
             __syncthreads();                                                  // ... everywhere; activation tile kb is complete
             STEM_ISSUE_W(kb + 1, (kb + 1) & 1)
-            if (kbl + 1 < sa.kblocks_per_chunk) build_tile(kbl + 1, (kb + 1) & 1);   // VALU work under this block's MFMAs
+            if (kbl + 1 < sa.kblocks_per_chunk && !(STEM_ABL & 2)) build_tile(kbl + 1, (kb + 1) & 1);   // VALU work under this block's MFMAs
             const char* at = lds + O_A + (kb & 1) * A_TILE;
             const char* wt = lds + O_W + (kb & 1) * W_TILE;
 #pragma unroll
@@ -1014,9 +1017,11 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
                     const int wo = (n * 32 + l31) * 64 + co;
                     const half8 wh = *reinterpret_cast<const half8*>(wt + wo);
                     const half8 wl = *reinterpret_cast<const half8*>(wt + NT * 2048 + wo);
+                    if (!(STEM_ABL & 8)) {
                     hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh[n], 0, 0, 0);
                     xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, xx[n], 0, 0, 0);
                     xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, xx[n], 0, 0, 0);
+                    } else { hh[n][0] += (float)wh[0] * (float)xh[0] + (float)wl[1] * (float)xl[1]; }
                 }
             }
         }
@@ -1026,6 +1031,15 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
     __syncthreads();
 
     const int Wo = a.Wo, Ho = a.Ho, yw = y0 + wave * 2;
+    if (STEM_ABL & 1) {
+        float acc_ = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_ += hh[n][r] + xx[n][r];
+        if (acc_ == 12345.678f) a.out_f32[tid] = acc_;
+        return;
+    }
     conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
         const int y = yw + (row >> 4), x = x0 + (row & 15);
         return (y < Ho && x < Wo) ? y * Wo + x : -1; }, n0, lane, wave, tid, true, reinterpret_cast<float*>(lds));
