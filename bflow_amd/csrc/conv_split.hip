@@ -97,9 +97,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
     constexpr int RS = CONV_STG_STRIDE;
     constexpr int NIT = 4 / GROUPS;                       // row groups of 8 pixels per wave on the read side
     const int it0 = grp * NIT;
-    const int wave_all = wave + 4 * grp;                  // statistics scratch is per wave of the whole workgroup
+    constexpr int SLABS = NW / GROUPS;                    // pixel slabs (waves per k-group): 4, or 5 in the 10-wave kernel
+    const int wave_all = wave + SLABS * grp;              // statistics scratch is per wave of the whole workgroup
     float* const stg0 = red + 2 * NW * BN + wave * NT * (32 * RS);   // the NT slabs of pixel slab `wave` (group 0's partial sums),
-    constexpr int GSTRIDE = 4 * NT * (32 * RS);                      // group 1's set lies GSTRIDE floats further; behind the statistics scratch
+    constexpr int GSTRIDE = SLABS * NT * (32 * RS);                  // group 1's set lies GSTRIDE floats further; behind the statistics scratch
     const int kh = lane >> 5, l31 = lane & 31;
     const int rr = lane >> 3, ch = (lane & 7) * 4;        // read side: rows rr + 8*it, channels ch .. ch+3 of the block
     if (writer || GROUPS > 1) {
@@ -842,6 +843,169 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 10-wave variant of the small-grid kernel: a 10 x 16 pixel patch = 5 pixel slabs x 2 k-groups.  On the DSEC-size grid (60 x 80) the 8 x 16
+// patches of conv_halo8_kernel leave the last patch row half empty (60 = 7.5 x 8) and a 256-channel convolution (z|r of the GRU, the first
+// head convolution) becomes 40 x 8 = 320 workgroups on 256 CUs: 64 CUs carry two and set the launch time (22 us against 15.6 us for
+// the 160-workgroup q convolution of the same depth).  10 x 16 patches tile 60 x 80 exactly: 30 x 8 = 240 workgroups, one per CU, 25 %
+// more pixels each at the same weight traffic.  Same stages, rings and epilogue as above; the LDS-DMA pieces are dealt over 5 waves
+// per plane with dummy pieces so that every wave issues the same count.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KH, int KW>
+__global__ __launch_bounds__(640, 1) void conv_halo10_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NSL = 5;                                          // pixel slabs of 2 x 16 pixels: waves per k-group
+    constexpr int TH = 2 * NSL, TW = 16;
+    constexpr int HWD = TW + KW - 1, HR = HWD * (TH + KH - 1);
+    constexpr int A_UNITS = (HR + 15) / 16;
+    constexpr int A_PLANE = A_UNITS * 1024, A_BUF = 2 * A_PLANE;
+    constexpr int NTAPS = KH * KW;
+    constexpr int TPS = 3;                                          // taps per step (the last step of a 5-tap filter has 2)
+    constexpr int NST = (NTAPS + TPS - 1) / TPS;                    // steps per channel block (3 or 2)
+    constexpr int B_TAP = 4096, B_SLOT = TPS * B_TAP;               // per tap: 32 weight rows x 64 B x 2 planes
+    constexpr int O_B = 2 * A_BUF;
+    // wave (q, plane): plane = wave_all & 1 (hi / lo), q = wave_all >> 1 (0 .. 4).  Per plane a halo buffer is A_UNITS 1-KB pieces and a
+    // weight slot 2*TPS; wave q takes pieces q + 5 i.  Every wave issues the SAME number of LDS-DMA instructions (the counted vmcnt
+    // waits are compile-time): indices past the end are dummy pieces -- out-of-range source offsets (nothing fetched) into a scratch KB.
+    constexpr int NIA = (A_UNITS + NSL - 1) / NSL;                  // halo load instructions per wave per channel block
+    constexpr int O_SCR = O_B + 2 * B_SLOT;                         // 1 KB scratch behind the weight slots
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave_all >= NSL ? 1 : 0, wave = wave_all - grp * NSL;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.z;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    int y0, x0, n0;
+    {
+        const int ntn = a.n_tiles;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int mt = (slot / ntn) * 8 + xcd;
+        if (mt >= tiles_x * tiles_y) return;
+        n0 = (slot - (slot / ntn) * ntn) * 32;
+        const int ty = mt / tiles_x;
+        y0 = ty * TH;
+        x0 = (mt - ty * tiles_x) * TW;
+    }
+
+    // ---- LDS-DMA sources ------------------------------------------------------------------------------------------
+    const int urow = lane >> 2;
+    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    const int q = wave_all >> 1;
+    const bool lo_p = wave_all & 1;
+    unsigned aoff[NIA];
+    int a_unit[NIA];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int unit = q + NSL * i;
+        a_unit[i] = unit;
+        const int row = unit * 16 + urow;
+        const int hy = row / HWD, hx = row - hy * HWD;
+        const int py = y0 - a.pad_h + hy, px = x0 - a.pad_w + hx;
+        const bool ok = unit < A_UNITS && row < HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
+        aoff[i] = ok ? (unsigned)(((py * a.W + px) * 32 + uchunk) * 2) : 0x80000000u;
+    }
+    const unsigned wvo0 = (unsigned)(((n0 + urow) * 32 + uchunk) * 2), wvo1 = wvo0 + 16 * 64;   // weight rows of unit 0 / 1
+    const int CB2 = a.CB - a.CB1;
+    const int plane_b = a.P_in * 64;
+    const rsrc_t r_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_p ? a.xl : a.xh) + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_p ? a.x2l : a.x2h) + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const int wtile_b = a.cout_pad * 64;
+    const rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(lo_p ? a.wl : a.wh), 0, NTAPS * a.CB * wtile_b, 0x00020000);
+    char* const a_dst = lds + (lo_p ? A_PLANE : 0);
+    char* const w_dst = lds + O_B + (lo_p ? 2048 : 0);
+
+#define H8_ISSUE_A(CBI, BUF)                                                                                             \
+    {                                                                                                                    \
+        const int cbi_ = (CBI) < a.CB ? (CBI) : a.CB - 1;                                                                \
+        const bool first_ = cbi_ < a.CB1;                                                                                \
+        const rsrc_t ra_ = first_ ? r_a1 : r_a2;                                                                         \
+        const int so_ = (first_ ? cbi_ : cbi_ - a.CB1) * plane_b;                                                        \
+        _Pragma("unroll") for (int i = 0; i < NIA; ++i)                                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lptr_t)(a_unit[i] < A_UNITS ? a_dst + (BUF) * A_BUF + a_unit[i] * 1024 : lds + O_SCR), 16, \
+                                                     aoff[i], so_, 0, 0);                                                \
+    }
+    // weight slot for step (CBI, ST): taps ST*TPS .. ; piece idx -> tap idx / 2, unit idx & 1.  ST is a compile-time constant.
+#define H8_ISSUE_B(CBI, ST, SLOT)                                                                                        \
+    {                                                                                                                    \
+        constexpr int ntp_ = (NTAPS - (ST) * TPS) < TPS ? (NTAPS - (ST) * TPS) : TPS;      /* taps of this step */       \
+        constexpr int nib_ = (2 * ntp_ + NSL - 1) / NSL;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < nib_; ++i) {                                                               \
+            const int idx_ = q + NSL * i;                                                                                \
+            const bool real_ = idx_ < 2 * ntp_;                                                                          \
+            const int so_ = (((ST) * TPS + (idx_ >> 1)) * a.CB + (CBI)) * wtile_b;   /* past the end: out of range, never consumed */ \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(real_ ? w_dst + (SLOT) * B_SLOT + (idx_ >> 1) * B_TAP + (idx_ & 1) * 1024 : lds + O_SCR), 16, \
+                                                     real_ ? ((idx_ & 1) ? wvo1 : wvo0) : 0x80000000u, so_, 0, 0);       \
+        }                                                                                                                \
+    }
+
+    f32x16 hh[1], x1, x2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        hh[0][r] = 0.f;
+        x1[r] = 0.f;
+        x2[r] = 0.f;
+    }
+
+    H8_ISSUE_A(0, 0)
+    H8_ISSUE_B(0, 0, 0)
+
+    const int R0 = (wave * 2 + slab_row(l31)) * HWD + slab_col(l31);
+    const int kq = grp * 2 + kh;                                    // this lane's 16-B k-chunk of the 64-B row
+    const int wro = l31 * 64 + ((kq ^ ((l31 >> 2) & 3)) * 16);      // weight fragment offset inside a (tap, plane) tile
+    int cur = 0;
+    for (int cb = 0; cb < a.CB; ++cb) {
+        const char* abuf = lds + (cb & 1) * A_BUF;
+        static_for<0, NTAPS>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int st = t / TPS, j = t % TPS;
+            if (j == 0) {                          // ---- step boundary
+                // in flight, oldest first: [halo of block cb+1 (issued at st 0, AFTER that step's weights)], weights of this step
+                if (NST > 1 && st == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    constexpr int stn = (st + 1) % NST;
+                    const int cbn = cb + (st + 1) / NST;
+                    H8_ISSUE_B(cbn, stn, cur ^ 1)
+                }
+                if (st == 0) H8_ISSUE_A(cb + 1, (cb + 1) & 1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const char* wcur = lds + O_B + cur * B_SLOT;
+            const int R = R0 + (t / KW) * HWD + (t % KW);
+            const int ao = R * 64 + ((kq ^ ((R >> 2) & 3)) * 16);
+            const half8 xh = *reinterpret_cast<const half8*>(abuf + ao);
+            const half8 xl = *reinterpret_cast<const half8*>(abuf + A_PLANE + ao);
+            const half8 wh = *reinterpret_cast<const half8*>(wcur + j * B_TAP + wro);
+            const half8 wl = *reinterpret_cast<const half8*>(wcur + j * B_TAP + 2048 + wro);
+            hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh[0], 0, 0, 0);   // D[channel][pixel]
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, x1, 0, 0, 0);
+            x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, x2, 0, 0, 0);
+            if (j == TPS - 1 || t == NTAPS - 1) {
+                __builtin_amdgcn_sched_barrier(0);   // fragment reads complete before the next barrier releases the refill
+                cur ^= 1;
+            }
+        });
+    }
+#undef H8_ISSUE_A
+#undef H8_ISSUE_B
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- the two k-halves are combined on the read side of the shared epilogue (each group stages its partial sums)
+    f32x16 xx[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xx[0][r] = x1[r] + x2[r];
+    const int W = a.W, H = a.H, yw = y0 + wave * 2;
+    conv_epilogue<1, 2 * NSL, 2>(a, hh, xx, b, [=](int row) {
+        const int y = yw + slab_row(row), x = x0 + slab_col(row);
+        return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, grp == 0, reinterpret_cast<float*>(lds), grp);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Stem kernel: KS x KS stride-2 convolution of a FEW-channel fp32 NCHW tensor (the 7x7/2 entry convolution of BasicEncoder,
 // extractor.py:63,110: 5 / 8 / 25 / 41 / 3 input channels -> 64).  With so few channels a 32-channel k-block per tap would be
 // 85-97 % padding, and an im2col tensor in HBM would be 8x the input.  Instead the k index runs over (channel, tap) TIGHTLY
@@ -1305,6 +1469,13 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<N, KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((conv_halo_kernel<N, KHH, KWW>), hgrid, dim3(CT), lds, s, a);                               \
     }
+#define LAUNCH_HALO10(KHH, KWW)                                                                                        \
+    {                                                                                                                  \
+        const int lds = 2 * 2 * (((16 + (KWW) - 1) * (10 + (KHH) - 1) + 15) / 16) * 1024 + 2 * 3 * 4096 + 1024;          \
+        dim3 grid10((patches10 + 7) / 8 * 8 * a.n_tiles, 1, d->B);                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo10_kernel<KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((conv_halo10_kernel<KHH, KWW>), grid10, dim3(640), lds, s, a);                              \
+    }
 #define LAUNCH_HALO8(KHH, KWW)                                                                                         \
     {                                                                                                                  \
         const int lds = 2 * 2 * (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16) * 1024 + 2 * 3 * 4096;                   \
@@ -1312,11 +1483,16 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         hipLaunchKernelGGL((conv_halo8_kernel<KHH, KWW>), hgrid, dim3(2 * CT), lds, s, a);                             \
     }
         const bool small8 = nt == 1 && !(force && strcmp(force, "halo4") == 0);   // small grids: the 8-wave split-k variant
-        if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }
-        else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else if (small8) LAUNCH_HALO8(1, 5) else LAUNCH_HALO(1, 1, 5) }
-        else { if (nt == 2) LAUNCH_HALO(2, 5, 1) else if (small8) LAUNCH_HALO8(5, 1) else LAUNCH_HALO(1, 5, 1) }
+        // 10 x 16 patches when the 8 x 16 grid needs a second workgroup on some CUs and the 10 x 16 grid does not
+        const int patches10 = bflow::ceil_div(d->H, 10) * bflow::ceil_div(d->W, 16);
+        const long long wg8 = (long long)patches * d->B * a.n_tiles, wg10 = (long long)patches10 * d->B * a.n_tiles;
+        const bool ten = small8 && ((force && strncmp(force, "halo", 4) == 0 && force[4]) ? strcmp(force, "halo10") == 0 : (wg8 > 256 && wg10 <= 256));
+        if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (ten) LAUNCH_HALO10(3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }
+        else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else if (ten) LAUNCH_HALO10(1, 5) else if (small8) LAUNCH_HALO8(1, 5) else LAUNCH_HALO(1, 1, 5) }
+        else { if (nt == 2) LAUNCH_HALO(2, 5, 1) else if (ten) LAUNCH_HALO10(5, 1) else if (small8) LAUNCH_HALO8(5, 1) else LAUNCH_HALO(1, 5, 1) }
 #undef LAUNCH_HALO
 #undef LAUNCH_HALO8
+#undef LAUNCH_HALO10
         return bflow::launch_status("conv_split(halo)");
     }
     const bool deep = nblocks <= 320;   // at most ~1 workgroup per CU: spend the LDS on prefetch depth instead of co-residency

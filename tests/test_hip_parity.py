@@ -663,6 +663,41 @@ def test_conv_split_engine_vs_fp64(cin, cout, k, stride, pad, H, W, B):
     assert (back.cpu().double() - got_s).abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,k,pad,H,W,B,force", [
+    (288, 256, (1, 5), (0, 2), 60, 80, 1, None),      # z|r of the GRU at DSEC size: 320 workgroups of 8x16 patches -> 240 of 10x16 (auto)
+    (288, 256, (5, 1), (2, 0), 60, 80, 1, None),
+    (128, 256, (3, 3), (1, 1), 60, 80, 1, None),      # first head convolution
+    (96, 126, (3, 3), (1, 1), 33, 47, 1, "halo10"),   # forced: ragged patches in both directions, Cout not a multiple of 32
+    (64, 64, (1, 5), (0, 2), 10, 16, 2, "halo10"),    # exactly one patch per image
+    (160, 96, (5, 1), (2, 0), 21, 50, 1, "halo10"),
+])
+def test_conv_halo10_vs_fp64_and_8x16(cin, cout, k, pad, H, W, B, force, monkeypatch):
+    """The 10-wave / 10x16-patch small-grid kernel against fp64 and, bit for bit, against the 8x16 kernel (same accumulation order)."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, *k)) / np.sqrt(cin * k[0] * k[1])).astype(np.float32)
+    bias = rs.standard_normal(cout).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(bias).double(), padding=pad)
+    mag = torch.nn.functional.conv2d(torch.from_numpy(np.abs(x)).double(), torch.from_numpy(np.abs(w)).double(), None, padding=pad) + 1.0
+    xs = S.from_nchw(cu(x))
+    pk = S.PackedConvWeight().get(cu(w))
+    if force:
+        monkeypatch.setenv("BFLOW_CONV_KERNEL", force)
+    stats = torch.zeros((B, cout, 2), dtype=torch.float64, device=DEV)
+    o_split, o_f32 = S.conv(xs, pk, padding=pad, shift=cu(bias), act=S.ACT_RELU, want_f32=True, stats=stats)
+    refr = torch.relu(ref)
+    got = S.blocked_f32_to_nhwc(o_f32, H, W, cout).permute(0, 3, 1, 2).cpu().double()
+    got_s = o_split.float_nhwc().permute(0, 3, 1, 2).cpu().double()
+    err, err_s = float(((got - refr).abs() / mag).max()), float(((got_s - refr).abs() / mag).max())
+    print(f"halo10 {cin}->{cout} {k}: err/sum|x||w| fp32-out {err:.2e} split-out {err_s:.2e}")
+    assert err < 5e-7 and err_s < 1e-6
+    np.testing.assert_allclose(stats[..., 0].cpu().numpy(), refr.sum(dim=(2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    monkeypatch.setenv("BFLOW_CONV_KERNEL", "halo8x16")
+    _, o2 = S.conv(xs, pk, padding=pad, shift=cu(bias), act=S.ACT_RELU, want_f32=True)
+    assert float((S.blocked_f32_to_nhwc(o2, H, W, cout) - S.blocked_f32_to_nhwc(o_f32, H, W, cout)).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cin,cout,k,H,W,B,blocks,blk", [
     (256, 4, 3, 15, 20, 1, 5, 4),       # the Bezier head at degree 2 (update.py:12-18), block 4 of a 5-block GRU input
     (256, 20, 3, 13, 19, 2, 5, 4),      # degree 10: five passes of four output channels, ragged pixel groups
