@@ -850,10 +850,9 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
 // more pixels each at the same weight traffic.  Same stages, rings and epilogue as above; the LDS-DMA pieces are dealt over 5 waves
 // per plane with dummy pieces so that every wave issues the same count.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KH, int KW>
-__global__ __launch_bounds__(640, 1) void conv_halo10_kernel(ConvArgs a) {
+template <int KH, int KW, int NSL>                                  // NSL = pixel slabs of 2 x 16 pixels = waves per k-group: 5 (or 3, see the dispatch)
+__global__ __launch_bounds__(128 * NSL, 1) void conv_halo10_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NSL = 5;                                          // pixel slabs of 2 x 16 pixels: waves per k-group
     constexpr int TH = 2 * NSL, TW = 16;
     constexpr int HWD = TW + KW - 1, HR = HWD * (TH + KH - 1);
     constexpr int A_UNITS = (HR + 15) / 16;
@@ -1469,13 +1468,14 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<N, KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((conv_halo_kernel<N, KHH, KWW>), hgrid, dim3(CT), lds, s, a);                               \
     }
-#define LAUNCH_HALO10(KHH, KWW)                                                                                        \
+#define LAUNCH_HALO_NSL(KHH, KWW, NSLL, PATCHES)                                                                       \
     {                                                                                                                  \
-        const int lds = 2 * 2 * (((16 + (KWW) - 1) * (10 + (KHH) - 1) + 15) / 16) * 1024 + 2 * 3 * 4096 + 1024;          \
-        dim3 grid10((patches10 + 7) / 8 * 8 * a.n_tiles, 1, d->B);                                                     \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo10_kernel<KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((conv_halo10_kernel<KHH, KWW>), grid10, dim3(640), lds, s, a);                              \
+        const int lds = 2 * 2 * (((16 + (KWW) - 1) * (2 * (NSLL) + (KHH) - 1) + 15) / 16) * 1024 + 2 * 3 * 4096 + 1024;  \
+        dim3 gridn(((PATCHES) + 7) / 8 * 8 * a.n_tiles, 1, d->B);                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo10_kernel<KHH, KWW, NSLL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((conv_halo10_kernel<KHH, KWW, NSLL>), gridn, dim3(128 * (NSLL)), lds, s, a);                \
     }
+#define LAUNCH_HALO10(KHH, KWW) LAUNCH_HALO_NSL(KHH, KWW, 5, patches10)
 #define LAUNCH_HALO8(KHH, KWW)                                                                                         \
     {                                                                                                                  \
         const int lds = 2 * 2 * (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16) * 1024 + 2 * 3 * 4096;                   \
@@ -1486,6 +1486,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         // 10 x 16 patches when the 8 x 16 grid needs a second workgroup on some CUs and the 10 x 16 grid does not
         const int patches10 = bflow::ceil_div(d->H, 10) * bflow::ceil_div(d->W, 16);
         const long long wg8 = (long long)patches * d->B * a.n_tiles, wg10 = (long long)patches10 * d->B * a.n_tiles;
+        // (6 x 16 patches = 3 slabs, for the 128-channel convolutions that leave 96 CUs idle, were measured: q 12.2 vs 11.9 us -- not built)
         const bool ten = small8 && ((force && strncmp(force, "halo", 4) == 0 && force[4]) ? strcmp(force, "halo10") == 0 : (wg8 > 256 && wg10 <= 256));
         if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (ten) LAUNCH_HALO10(3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }
         else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else if (ten) LAUNCH_HALO10(1, 5) else if (small8) LAUNCH_HALO8(1, 5) else LAUNCH_HALO(1, 1, 5) }
@@ -1493,6 +1494,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
 #undef LAUNCH_HALO
 #undef LAUNCH_HALO8
 #undef LAUNCH_HALO10
+#undef LAUNCH_HALO_NSL
         return bflow::launch_status("conv_split(halo)");
     }
     const bool deep = nblocks <= 320;   // at most ~1 workgroup per CU: spend the LDS on prefetch depth instead of co-residency
