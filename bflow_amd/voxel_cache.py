@@ -10,7 +10,7 @@ Reference call sites:
                                 load if the file exists, else construct and save
   data/multiflow2d/sample.py:100-103             file `voxel_grid_v{version}_{num_bins_total}_bins[_downsampled].h5`
 
-The arithmetic behind that boundary lives in third-party code that is NOT under /root/reference and not installed in this image:
+The arithmetic behind that boundary lives in third-party code that is NOT under /root/reference and not importable from the image's Python:
 libhdf5 (through h5py; the reference pins no version: environment created from `conda install h5py blosc-hdf5-plugin`, README.md:24-29),
 the hdf5-blosc filter plugin (filter revision 2) and c-blosc 1.x with its bundled Zstandard.  This module restates the published
 formats:
@@ -21,9 +21,13 @@ formats:
   * Blosc 1 frame: 16-byte header (version, versionlz, flags, typesize, nbytes, blocksize, cbytes), `bstarts`, per block either one
     stream or `typesize` split streams, each prefixed by its int32 compressed size (== the raw size: stored), byte un-shuffle per block;
   * Zstandard frames through the system's libzstd.so.1 (ctypes); LZ4 blocks through liblz4.so.1; zlib through Python's zlib.
-PARITY UNPINNED: neither h5py nor blosc exist in the build image, so no file written by the reference itself could be captured as a
-fixture; the tests pin the reader against byte streams assembled by hand from the specifications above (tests/test_voxel_cache.py)
-and against this module's own writer.  Host-side I/O only: nothing here is on the GPU hot path.
+PARITY PINNED in both directions (tests/test_voxel_cache.py): the system Python of the build image has neither h5py nor blosc, but its
+conda interpreter has h5py 3.3.0 / HDF5 1.10.6 and PyTables 3.6.1, which registers the Blosc filter (c-blosc 1.20.1) with libhdf5.
+tests/golden/make_voxel_cache_golden.py runs the REFERENCE's own `np_array_to_h5` there and commits the files it writes
+(tests/golden/voxel_cache/*.h5): this reader decodes them bit-exactly (also a full-size 15x480x640 file with libhdf5's own two-level
+chunk B-tree, checked by hand); and files written by this module are read back by h5py on the real libhdf5 (a test that runs
+wherever that interpreter exists).  On top of that the reader is checked against byte streams assembled by hand from the
+specifications above (layouts neither writer produces).  Host-side I/O only: nothing here is on the GPU hot path.
 """
 from __future__ import annotations
 

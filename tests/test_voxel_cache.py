@@ -1,9 +1,14 @@
 """the voxel-grid cache wire format (HDF5 + Blosc filter 32001, blosc:zstd, byte shuffle) -- host-side I/O, CPU tests.
-The reader is pinned against byte streams assembled here BY HAND from the published formats (independent of the module's writer),
-then writer -> reader round trips.  (No file written by the reference's own h5py / blosc stack exists in the build image: see the
-module header, "parity unpinned".)"""
+PINNED against the reference: tests/golden/voxel_cache/*.h5 were written by the reference's own `np_array_to_h5`
+(data/utils/generic.py:49-55) on real libhdf5 1.10.6 / h5py 3.3.0 / hdf5-blosc / c-blosc 1.20.1 (tests/golden/make_voxel_cache_golden.py, run
+with the build image's conda interpreter); where that interpreter exists the module's WRITER is also read back by libhdf5 itself.
+In addition the reader is checked against byte streams assembled here by hand from the published formats (layouts neither writer
+produces), and writer -> reader round trips."""
+import json
 import os
 import struct
+import subprocess
+import sys
 import zlib
 
 import numpy as np
@@ -18,6 +23,59 @@ def _sparse_grid(shape, seed, dtype=np.float32):
     rs = np.random.RandomState(seed)
     g = rs.standard_normal(shape) * (rs.uniform(size=shape) < 0.3)
     return g.astype(dtype)
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voxel_cache")
+CONDA_PY = "/opt/conda/bin/python3.9"            # the build image's interpreter with h5py + PyTables (Blosc filter); absent on the GPU box
+
+
+def golden_array(shape, seed):
+    """The arrays of tests/golden/make_voxel_cache_golden.py (same code)."""
+    rs = np.random.RandomState(seed)
+    return (rs.standard_normal(shape) * (rs.uniform(size=shape) < 0.3)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------------------------ the reference's own files
+def test_reader_on_files_written_by_the_reference():
+    """Files produced by the reference's np_array_to_h5 (real libhdf5 + hdf5-blosc + c-blosc/zstd): bit-exact through this module's reader."""
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
+    assert meta["hdf5"].startswith("1.") and len(meta["cases"]) == 3
+    for name, c in meta["cases"].items():
+        assert c["filters"] == {"32001": [2, 2, 4, int(np.prod(c["chunks"])) * 4, 1, 1, 5]}     # hdf5-blosc's cd_values (module header)
+        a = VC.h5_to_np_array(os.path.join(GOLDEN, name + ".h5"))
+        assert a.dtype == np.float32 and a.shape == tuple(c["shape"])
+        assert np.array_equal(a, golden_array(tuple(c["shape"]), c["seed"]))
+        with pytest.raises(KeyError):
+            VC.read_h5_dataset(os.path.join(GOLDEN, name + ".h5"), "flow")
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="needs the build image's conda interpreter (h5py + PyTables' Blosc filter)")
+def test_writer_output_is_read_by_libhdf5(tmp_path):
+    """The other direction: files written by this module, read by h5py on the real libhdf5 with the real Blosc filter."""
+    probe = subprocess.run([CONDA_PY, "-c", "import numpy; numpy.typeDict = numpy.sctypeDict; import tables, h5py; assert h5py.h5z.filter_avail(32001)"],
+                           capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("h5py / PyTables not importable in the conda interpreter")
+    cases = {"a": golden_array((15, 60, 80), 21), "b": golden_array((5, 33, 47), 22), "c": golden_array((9, 480, 640), 23)[:, ::3, ::5].copy()}
+    for k, arr in cases.items():
+        VC.np_array_to_h5(arr, tmp_path / f"{k}.h5")
+        np.save(tmp_path / f"{k}.npy", arr)
+    VC.write_h5_dataset(tmp_path / "d.h5", cases["a"], chunks=(1, 8, 8))                     # 600 chunks: a two-level chunk B-tree
+    np.save(tmp_path / "d.npy", cases["a"])
+    script = (
+        "import sys, numpy\n"
+        "numpy.typeDict = numpy.sctypeDict\n"
+        "import tables, h5py\n"
+        "for k in 'abcd':\n"
+        "    with h5py.File(sys.argv[1] + '/' + k + '.h5', 'r') as f:\n"
+        "        d = f['voxel_grid']\n"
+        "        assert list(f.keys()) == ['voxel_grid'] and '32001' in d._filters, d._filters\n"
+        "        b = d[...]\n"
+        "    a = numpy.load(sys.argv[1] + '/' + k + '.npy')\n"
+        "    assert b.dtype == a.dtype and b.shape == a.shape and (a == b).all(), k\n"
+        "print('OK')\n")
+    r = subprocess.run([CONDA_PY, "-c", script, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
 
 # ------------------------------------------------------------------------------------------------------------------ Blosc frames
