@@ -6,12 +6,16 @@ modules/raft_spline.py:63-188).  Here a convolution module routes GPU tensors un
   forward   y = conv(x, w) + b                      bflow_conv_split (blocked split tensors, fp16 MFMA x 3, fp32 accumulation)
   dgrad     dx = conv_transpose(dy, w)              the SAME engine: a stride-1 convolution of dy (zero-dilated for stride 2) with
                                                     the filter flipped in space and transposed in (cin, cout)
-  wgrad     dw[co, ci, r, q] = sum_k dy[k, co] x[k + (r, q), ci]
-                                                    the SAME engine as a batch of 1x1 "convolutions" whose contraction index is the
-                                                    PIXEL index: bflow_wgrad_pack re-blocks x (one shifted copy per filter tap) and
-                                                    dy so that pixels sit in the 32-wide block position; "image" = (tap, k-chunk),
-                                                    "filter" = the packed dy of that k-chunk (bflow_conv_desc_t.weight_sets); the
-                                                    k-chunks (split-K, to fill the chip) are summed afterwards
+  wgrad     dw[co, ci, r, q] = sum_k dy[k, co] x[k + (r, q), ci]      (the contraction index is the PIXEL)
+                                                    stride-1 3x3 / 1x5 / 5x1 / 1x1: bflow_conv_wgrad_halo, a dedicated MFMA kernel on the SAME
+                                                    blocked split tensors the forward (x) and the input-gradient pass (dy) staged --
+                                                    nothing is re-packed; pixel-contiguous fragments come from the row-major
+                                                    [pixel][channel] LDS tiles through ds_read_b64_tr_b16 (hardware transpose read);
+                                                    every other shape (stride 2, 7x7): the engine's 1x1 "convolution" as a GEMM:
+                                                    bflow_wgrad_pack re-blocks x (one shifted copy per filter tap) and dy so that
+                                                    pixels sit in the 32-wide block position; "image" = (tap, k-chunk), "filter" =
+                                                    the packed operand of that k-chunk (bflow_conv_desc_t.weight_sets); the k-chunks
+                                                    (split-K, to fill the chip) are summed by bflow_wgrad_reduce
   dbias     sum of dy over (batch, y, x)            torch reduction
 
 Gradients are tiny (1e-4 .. 1e-9) and the split format keeps 22 bits only inside fp16's normal range, so dy is pre-scaled by a
@@ -32,6 +36,8 @@ from . import split as S
 
 ENABLED = True                      # tools / A-B timing: False = torch (MIOpen) convolutions under autograd
 MIN_CHUNK, TARGET_WGS = 8, 768      # split-K of the weight gradient: k-blocks per chunk at least / workgroups aimed at
+HALO_WGRAD = True                   # stride-1 3x3 / 1x5 / 5x1 / 1x1: bflow_conv_wgrad_halo (no re-packing); False = the pack + GEMM path everywhere
+_DEBUG_CMP = None                    # tools: a list collects (relative difference halo vs pack-GEMM weight gradient, shape, scale) per call
 _TARGET = 8192.0                    # max |dy| after scaling: well inside fp16 (65504), 13 bits of head-room for sums of products
 
 
@@ -66,35 +72,68 @@ def _conv_forward(x: torch.Tensor, packed, stride: int, padding: Tuple[int, int]
     return S.blocked_f32_to_nchw(yf, cout, Ho, Wo, out_scale)
 
 
+def _halo_wgrad_ok(stride: int, padding, ksize) -> bool:
+    """bflow_conv_wgrad_halo: stride 1, "same" padding, 3x3 / 1x5 / 5x1 / 1x1."""
+    kh, kw = ksize
+    return HALO_WGRAD and stride == 1 and tuple(padding) == (kh // 2, kw // 2) and (kh, kw) in ((3, 3), (1, 5), (5, 1), (1, 1))
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, cache, srcs):
         x = x.float().contiguous()
-        ctx.save_for_backward(x, weight)
+        cout, cin, kh, kw = weight.shape
         ctx.stride, ctx.padding, ctx.cache, ctx.srcs, ctx.has_bias = stride, padding, cache, srcs, bias is not None
+        ctx.xshape = tuple(x.shape)
         with torch.no_grad():
-            return _conv_forward(x, cache.get("fwd", weight, srcs), stride, padding, None if bias is None else bias.detach().float().contiguous())
+            packed = cache.get("fwd", weight, srcs)
+            xs = S.from_nchw(x)
+            _, yf = S.conv(xs, packed, stride=stride, padding=padding, shift=None if bias is None else bias.detach().float().contiguous(),
+                           want_split=False, want_f32=True)
+            Ho, Wo = (x.shape[2] + 2 * padding[0] - kh) // stride + 1, (x.shape[3] + 2 * padding[1] - kw) // stride + 1
+            y = S.blocked_f32_to_nchw(yf, cout, Ho, Wo)
+        ctx.halo = _halo_wgrad_ok(stride, padding, (kh, kw))
+        # the weight gradient reads X: in the engine's own layout (as staged for the forward) where bflow_conv_wgrad_halo takes it
+        ctx.save_for_backward(xs.planes if ctx.halo else x, weight)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        xsaved, w = ctx.saved_tensors
         stride, (ph, pw), cache = ctx.stride, ctx.padding, ctx.cache
         cout, cin, kh, kw = w.shape
-        B, _, H, W = x.shape
+        B, _, H, W = ctx.xshape
         dy = dy.float().contiguous()
         _, _, Ho, Wo = dy.shape
         dx = dw = db = None
         with torch.no_grad():
             sc = S.pow2_scale(dy, _TARGET)                       # {s, 1/s} on the device
             s, inv = sc[0:1], sc[1:2]
+            gs = None
+            if stride == 1 and (ctx.needs_input_grad[0] or (ctx.halo and ctx.needs_input_grad[1])):
+                gs = S.from_nchw(dy, s)                          # dY in the engine's layout, pre-scaled: shared by dgrad and wgrad
             if ctx.needs_input_grad[0]:
-                g = dy
-                if stride > 1:                                   # zero-dilated dy: position (yo*stride, xo*stride) of the stride-1 output grid
+                packed = cache.get("bwd", w, ctx.srcs)
+                if stride == 1:
+                    g_in = gs
+                else:                                            # zero-dilated dy: position (yo*stride, xo*stride) of the stride-1 output grid
                     g = torch.zeros((B, cout, H + 2 * ph - kh + 1, W + 2 * pw - kw + 1), dtype=torch.float32, device=dy.device)
                     g[:, :, ::stride, ::stride][:, :, :Ho, :Wo] = dy
-                dx = _conv_forward(g, cache.get("bwd", w, ctx.srcs), 1, (kh - 1 - ph, kw - 1 - pw), None, in_scale=s, out_scale=inv)
+                    g_in = S.from_nchw(g, s)
+                _, xf = S.conv(g_in, packed, stride=1, padding=(kh - 1 - ph, kw - 1 - pw), want_split=False, want_f32=True)
+                dx = S.blocked_f32_to_nchw(xf, cin, H, W, inv)
             if ctx.needs_input_grad[1]:
-                dw = _weight_grad(x, dy, s, inv, (kh, kw), stride, (ph, pw))
+                if ctx.halo:
+                    xs = S.SplitTensor(xsaved, H, W, cin)
+                    acc = S.conv_wgrad_halo(xs, gs, cout, (kh, kw))                       # (taps, cout_pad, cin_pad)
+                    dw = (acc[:, :cout, :cin] * inv).permute(1, 2, 0).reshape(cout, cin, kh, kw)
+                    if _DEBUG_CMP is not None:
+                        xr = xs.to_nchw()[:, :cin]
+                        ref = _weight_grad(xr.contiguous(), dy, s, inv, (kh, kw), stride, (ph, pw))
+                        e = float((dw - ref).abs().max() / (ref.abs().max() + 1e-30))
+                        _DEBUG_CMP.append((e, (B, cin, cout, H, W, kh, kw), float(ref.abs().max())))
+                else:
+                    dw = _weight_grad(xsaved, dy, s, inv, (kh, kw), stride, (ph, pw))
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = dy.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None, None

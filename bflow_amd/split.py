@@ -339,6 +339,17 @@ def wgrad_reduce(part: torch.Tensor, G: int, cout: int, cin: int, ksize, orienta
     return dw
 
 
+def conv_wgrad_halo(xs: "SplitTensor", gs: "SplitTensor", cout: int, ksize) -> torch.Tensor:
+    """(KH*KW, cout_pad64, cin_pad) fp32 = sum over pixels of dY (gs, blocked split, cout channels) x shifted X (xs): bflow_conv_wgrad_halo."""
+    kh, kw = ksize
+    B, H, W, _ = xs.shape
+    assert gs.shape[:3] == (B, H, W) and xs.rows == gs.rows
+    acc = torch.zeros((kh * kw, (cout + 63) // 64 * 64, xs.channels_padded), dtype=torch.float32, device=xs.planes.device)
+    hip._check(hip.lib().bflow_conv_wgrad_halo(xs.hi.data_ptr(), xs.lo.data_ptr(), gs.hi.data_ptr(), gs.lo.data_ptr(), acc.data_ptr(), B, H, W,
+                                               xs.channels_padded, cout, xs.rows, kh, kw, hip._stream()), "bflow_conv_wgrad_halo")
+    return acc
+
+
 _pow2_work = {}
 
 

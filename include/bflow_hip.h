@@ -183,6 +183,14 @@ int bflow_pow2_scale(const float* x, long long n, float target, float* out2, voi
  *   32*block + lane = tap*Cin + ci.                                                                                                  */
 int bflow_wgrad_reduce(const float* part, float* dw, int G, int Cout, int Cin, int taps, int blocks, int rows, int orientation,
                        const float* inv_scale, bflow_stream_t stream);
+/* bflow_conv_wgrad_halo: weight gradient of a stride-1 "same" convolution (3x3, 1x5, 5x1, 1x1) straight from the engine's blocked split
+ * tensors -- X as the forward staged it, dY (pre-scaled) as the input-gradient pass staged it; nothing is re-packed:
+ *     dw_acc[tap, co, ci] += sum_{b, y, x} dY[b, y, x, co] * X[b, y + r - KH/2, x + q - KW/2, ci]      (tap = r*KW + q)
+ *   dw_acc: fp32 (KH*KW, ceil(Cout/64)*64, Cin_pad), zero before the call (fp32 atomics across the k-split workgroups);
+ *   x_*: (B, Cin_pad/32, rows_per_image, 32), dy_*: (B, ceil(Cout/32), rows_per_image, 32).  The pixel contraction is fed by
+ *   ds_read_b64_tr_b16 (transposed fragments from the row-major [pixel][channel] LDS tiles).                                        */
+int bflow_conv_wgrad_halo(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw_acc, int B, int H, int W, int Cin_pad,
+                          int Cout, int rows_per_image, int KH, int KW, bflow_stream_t stream);
 
 /* bflow_conv_thin_acc: the thin-output convolution of the Bezier head with its parameter update fused behind it:
  *     acc[b, co, y, x] += bias[co] + sum_{c, r, q} x[b, y+r-KH/2, x+q-KW/2, c] * w[co, c, r, q]      (zero padding, stride 1)

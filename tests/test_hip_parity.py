@@ -810,6 +810,47 @@ def test_conv_train_forward_backward_vs_fp64(cin, cout, k, stride, pad, H, W, B,
     assert e_y < 2e-6 and e_dx < 5e-6 and e_dw < 5e-6 and e_db < 1e-5
 
 
+def test_conv_train_filter_caches_follow_in_place_updates():
+    """The packed forward filter and the flipped / transposed backward filter are cached per parameter version: after an in-place
+    update (what an optimiser step is) forward, input and weight gradient must use the NEW filter -- module and functional form
+    (derived filter = torch.cat of two parameters, a fresh tensor on every call)."""
+    from bflow_amd import conv_train as CT
+    rs = np.random.RandomState(12)
+    x = rs.standard_normal((2, 64, 12, 16)).astype(np.float32)
+    m = CT.Conv2d(64, 96, 3, padding=1).to(DEV)
+    za, zb = torch.nn.Parameter(cu(rs.standard_normal((32, 64, 1, 5)).astype(np.float32) * 0.1)), torch.nn.Parameter(cu(rs.standard_normal((32, 64, 1, 5)).astype(np.float32) * 0.1))
+    cache = CT._PackCache()
+
+    def check():
+        xg = cu(x).requires_grad_(True)
+        y = m(xg)
+        z = CT.conv2d(xg, torch.cat([za, zb], dim=0), None, (0, 2), cache, (za, zb))
+        (y.square().sum() + z.square().sum()).backward()
+        xd = torch.from_numpy(x).double().requires_grad_(True)
+        wd, bd = m.weight.detach().cpu().double().requires_grad_(True), m.bias.detach().cpu().double()
+        ad, bd2 = za.detach().cpu().double().requires_grad_(True), zb.detach().cpu().double().requires_grad_(True)
+        yd = torch.nn.functional.conv2d(xd, wd, bd, padding=1)
+        zd = torch.nn.functional.conv2d(xd, torch.cat([ad, bd2], dim=0), None, padding=(0, 2))
+        (yd.square().sum() + zd.square().sum()).backward()
+        rel = lambda a, r: float((a.detach().cpu().double() - r).abs().max() / r.abs().max())
+        errs = (rel(y, yd.detach()), rel(z, zd.detach()), rel(xg.grad, xd.grad), rel(m.weight.grad, wd.grad), rel(za.grad, ad.grad), rel(zb.grad, bd2.grad))
+        for p_ in (m.weight, m.bias, za, zb):
+            p_.grad = None
+        return errs
+
+    e0 = check()
+    with torch.no_grad():                                     # "optimiser steps": in-place, the version counter moves, the storage stays
+        m.weight.mul_(-1.7).add_(0.01)
+        za.mul_(2.5)
+        zb.add_(0.3)
+    e1 = check()
+    with torch.no_grad():
+        m.weight.copy_(cu(rs.standard_normal((96, 64, 3, 3)).astype(np.float32) * 0.05))
+    e2 = check()
+    print("filter-cache test: worst relative errors", max(e0), max(e1), max(e2))
+    assert max(e0) < 5e-6 and max(e1) < 5e-6 and max(e2) < 5e-6
+
+
 # ------------------------------------------------------------------------------------------------- SURVEY 8(f-3): validation harness
 def test_flow_metrics_golden(golden_dir):
     from bflow_amd import metrics as MX
