@@ -148,5 +148,5 @@ class BezierCurves:
         if self._params.is_cuda and not (torch.is_grad_enabled() and self._params.requires_grad):
             flows = hip.bezier_eval(self._params.contiguous().float(), coef, add_coords0=False)
         else:  # host-resident container (see module docstring)
-            flows = torch.einsum("bdphw,tp->tbdhw", pv, torch.from_numpy(coef).to(pv.device))
+            flows = torch.einsum("bdphw,tp->tbdhw", pv, hip.const_tensor(coef, pv.device) if pv.is_cuda else torch.from_numpy(coef))
         return flows[0] if scalar else flows

@@ -16,7 +16,7 @@ modules/raft_spline.py:63-188).  Here a convolution module routes GPU tensors un
                                                     pixels sit in the 32-wide block position; "image" = (tap, k-chunk), "filter" =
                                                     the packed operand of that k-chunk (bflow_conv_desc_t.weight_sets); the k-chunks
                                                     (split-K, to fill the chip) are summed by bflow_wgrad_reduce
-  dbias     sum of dy over (batch, y, x)            torch reduction
+  dbias     sum of dy over (batch, y, x)            bflow_grad_stats: the same pass over dy that finds the scale below
 
 Gradients are tiny (1e-4 .. 1e-9) and the split format keeps 22 bits only inside fp16's normal range, so dy is pre-scaled by a
 power of two chosen on the device from max|dy| (no host synchronisation) and the results are scaled back -- exact in binary
@@ -38,6 +38,7 @@ ENABLED = True                      # tools / A-B timing: False = torch (MIOpen)
 MIN_CHUNK, TARGET_WGS = 8, 768      # split-K of the weight gradient: k-blocks per chunk at least / workgroups aimed at
 HALO_WGRAD = True                   # stride-1 3x3 / 1x5 / 5x1 / 1x1: bflow_conv_wgrad_halo (no re-packing); False = the pack + GEMM path everywhere
 _DEBUG_CMP = None                    # tools: a list collects (relative difference halo vs pack-GEMM weight gradient, shape, scale) per call
+CAPTURING = False                   # set by training.GraphedTrainStep around its capture: every filter pack is recorded into the graph
 _TARGET = 8192.0                    # max |dy| after scaling: well inside fp16 (65504), 13 bits of head-room for sums of products
 
 
@@ -53,7 +54,7 @@ class _PackCache:
 
     def get(self, which: str, weight: torch.Tensor, srcs):
         key = tuple((t.data_ptr(), t._version, str(t.device)) for t in srcs)
-        if self._key[which] != key:
+        if self._key[which] != key or CAPTURING:
             with torch.no_grad():
                 w = weight.detach().float()
                 w = w.flip(2, 3).transpose(0, 1).contiguous() if which == "bwd" else w.contiguous()
@@ -107,7 +108,10 @@ class _ConvFn(torch.autograd.Function):
         _, _, Ho, Wo = dy.shape
         dx = dw = db = None
         with torch.no_grad():
-            sc = S.pow2_scale(dy, _TARGET)                       # {s, 1/s} on the device
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                sc, db = S.grad_stats(dy, _TARGET)               # {s, 1/s} on the device and the bias gradient, one pass over dy
+            else:
+                sc = S.pow2_scale(dy, _TARGET)
             s, inv = sc[0:1], sc[1:2]
             gs = None
             if stride == 1 and (ctx.needs_input_grad[0] or (ctx.halo and ctx.needs_input_grad[1])):
@@ -134,8 +138,6 @@ class _ConvFn(torch.autograd.Function):
                         _DEBUG_CMP.append((e, (B, cin, cout, H, W, kh, kw), float(ref.abs().max())))
                 else:
                     dw = _weight_grad(xsaved, dy, s, inv, (kh, kw), stride, (ph, pw))
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = dy.sum(dim=(0, 2, 3))
         return dx, dw, db, None, None, None, None
 
 

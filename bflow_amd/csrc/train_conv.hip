@@ -2,6 +2,7 @@
 //   bflow_wgrad_pack          operands of the weight-gradient GEMM: NCHW fp32 -> blocked split with the PIXEL index in the block position
 //   bflow_blocked_f32_to_nchw blocked fp32 (B, C/32, P, 32) -> NCHW fp32, optionally times a device scalar (un-scaling of gradients)
 //   bflow_pow2_scale          s = 2^floor(log2(target / max|x|)) and 1/s on the device (no host synchronisation)
+//   bflow_grad_stats          the same scale AND the bias gradient (per-channel sum) in one pass over an NCHW gradient
 #include "common.h"
 #include <algorithm>
 
@@ -81,7 +82,12 @@ __global__ __launch_bounds__(256) void blocked_f32_to_nchw_kernel(const float* _
 __global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict__ x, long long n, float target, float* __restrict__ out,
                                                          unsigned* __restrict__ work) {
     float m = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    const long long n4 = ((reinterpret_cast<size_t>(x) & 15) == 0) ? n >> 2 : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     __shared__ float sm[4];
@@ -105,6 +111,83 @@ __global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict
         out[1] = exp2f(-e);
         work[0] = 0u;
         work[1] = 0u;
+    }
+}
+
+// bflow_grad_stats: ONE pass over an NCHW gradient for both things the backward of a convolution needs from all of it: the power-of-two
+// scale (as pow2_scale_kernel) and the bias gradient db[c] = sum over (b, y, x).  Two launches instead of tickets and fences (a release
+// fence is an L2 write-back on this chip): grad_stats_kernel -- one WAVE per item = (plane, segment of GS_SEG elements), four independent
+// 16-B loads per lane, per-item sums to `partial`, per-workgroup max to `partial + items` --, grad_stats_final_kernel -- one workgroup adds
+// them per channel in a fixed order (deterministic, nothing to zero beforehand).
+constexpr int GS_SEG = 1024;
+__global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict__ x, int planes, int HW, int segs, float* __restrict__ partial) {
+    __shared__ float sm[4];
+    const int items = planes * segs;
+    const bool vec = (HW & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float m = 0.f;
+    for (int item = blockIdx.x * 4 + wave; item < items; item += gridDim.x * 4) {
+        const int plane = item / segs, seg = item - plane * segs;
+        const float* base = x + (long long)plane * HW;
+        float s = 0.f;
+        if (vec) {
+            const int n4 = HW >> 2, j0 = seg * (GS_SEG / 4) + lane;
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const float4*>(base)[min(j0 + 64 * k, n4 - 1)];   // clamped: no branch around a load
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = j0 + 64 * k < n4;
+                const float sk = (v[k].x + v[k].y) + (v[k].z + v[k].w);
+                const float mk = fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+                s += in ? sk : 0.f;
+                m = fmaxf(m, in ? mk : 0.f);
+            }
+        } else {
+            const int i0 = seg * GS_SEG + lane;
+#pragma unroll 4
+            for (int k = 0; k < GS_SEG / 64; ++k) {
+                const float v = base[min(i0 + 64 * k, HW - 1)];
+                const bool in = i0 + 64 * k < HW;
+                s += in ? v : 0.f;
+                m = fmaxf(m, in ? fabsf(v) : 0.f);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) partial[item] = s;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) sm[wave] = (m == m) ? m : __builtin_inff();      // NaN in the gradient: scale 1 (below)
+    __syncthreads();
+    if (threadIdx.x == 0) partial[items + blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+__global__ __launch_bounds__(256) void grad_stats_final_kernel(const float* __restrict__ partial, int B, int C, int segs, int blocks, float target,
+                                                               float* __restrict__ out, float* __restrict__ db) {
+    __shared__ float sm[4];
+    const int items = B * C * segs;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < blocks; i += 256) m = fmaxf(m, partial[items + i]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float amax = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        float e = floorf(log2f(target / amax));
+        if (!(amax > 0.f) || !(fabsf(e) <= 60.f)) e = (amax > 0.f && e > 60.f) ? 60.f : (amax > 0.f && e < -60.f ? -60.f : 0.f);
+        out[0] = exp2f(e);
+        out[1] = exp2f(-e);
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float* p = partial + (long long)(b * C + c) * segs;
+            for (int sg = 0; sg < segs; ++sg) acc += p[sg];
+        }
+        db[c] = acc;
     }
 }
 
@@ -138,6 +221,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 }  // namespace
 
+static int bflow_grad_stats_blocks(int B, int C, int HW) {
+    const long long items = (long long)B * C * bflow::ceil_div(HW, GS_SEG);
+    return (int)std::max<long long>(1, std::min<long long>((items + 3) / 4, 1024));
+}
+
 extern "C" int bflow_wgrad_pack(const float* src, void* dst_hi, void* dst_lo, int B, int C, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
                                 int pad_h, int pad_w, int rows, int k_blocks, int taps_in_rows, const float* scale, bflow_stream_t stream) {
     BFLOW_REQUIRE(src && dst_hi && dst_lo, BFLOW_E_ARG, "wgrad_pack: null pointer");
@@ -163,9 +251,19 @@ extern "C" int bflow_blocked_f32_to_nchw(const float* x, float* out, int B, int 
 
 extern "C" int bflow_pow2_scale(const float* x, long long n, float target, float* out2, void* work8, bflow_stream_t stream) {
     BFLOW_REQUIRE(x && out2 && work8 && n > 0 && target > 0.f, BFLOW_E_ARG, "pow2_scale: bad arguments");
-    const int blocks = (int)std::min<long long>(256, (n + 256 * 16 - 1) / (256 * 16));
+    const int blocks = (int)std::min<long long>(512, (n + 16383) / 16384);
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, x, n, target, out2, (unsigned*)work8);
     return bflow::launch_status("pow2_scale");
+}
+
+extern "C" int bflow_grad_stats(const float* x, int B, int C, int HW, float target, float* out2, float* partial, float* dbias, bflow_stream_t stream) {
+    BFLOW_REQUIRE(x && out2 && partial && dbias && B > 0 && C > 0 && HW > 0 && target > 0.f, BFLOW_E_ARG, "grad_stats: bad arguments");
+    const int segs = bflow::ceil_div(HW, GS_SEG);
+    BFLOW_REQUIRE((long long)B * C * segs < (1LL << 30), BFLOW_E_LIMIT, "grad_stats: too many planes");
+    const int blocks = bflow_grad_stats_blocks(B, C, HW);
+    hipLaunchKernelGGL(grad_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B * C, HW, segs, partial);
+    hipLaunchKernelGGL(grad_stats_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, B, C, segs, blocks, target, out2, dbias);
+    return bflow::launch_status("grad_stats");
 }
 
 extern "C" int bflow_wgrad_reduce(const float* part, float* dw, int G, int Cout, int Cin, int taps, int blocks, int rows, int orientation,

@@ -24,7 +24,7 @@ MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -118,6 +118,7 @@ def lib() -> ctypes.CDLL:
         "bflow_wgrad_pack": [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, vp],
         "bflow_blocked_f32_to_nchw": [vp, vp, i, i, i, i, i, vp, vp],
         "bflow_pow2_scale": [vp, ll, f, vp, vp, vp],
+        "bflow_grad_stats": [vp, i, i, i, f, vp, vp, vp, vp],
         "bflow_wgrad_reduce": [vp, vp, i, i, i, i, i, i, i, vp, vp],
         "bflow_conv_wgrad_halo": [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp],
         "bflow_plane_stats": [vp, vp, ll, i, vp],
@@ -465,6 +466,23 @@ BRANCHING = True        # tools: False issues every branch on the current stream
 
 
 # ------------------------------------------------------------------------------------------------ training path (f-4)
+_const_cache: dict = {}
+
+
+def const_tensor(arr, device) -> torch.Tensor:
+    """Device copy of a small host constant (Bezier coefficient tables), cached by value: no host-to-device copy after the first
+    use -- a pageable copy is not allowed inside a stream capture (training.GraphedTrainStep warms the cache before it captures)."""
+    import numpy as np
+    a = np.ascontiguousarray(arr)
+    key = (a.dtype.str, a.shape, a.tobytes(), str(device))
+    t = _const_cache.get(key)
+    if t is None:
+        if len(_const_cache) > 256:
+            _const_cache.clear()
+        t = _const_cache[key] = torch.from_numpy(a.copy()).to(device)
+    return t
+
+
 def make_grad_table(tensors: Sequence[torch.Tensor]):
     """HOST array of device pointers to the per-plane gradient slabs (same order as make_plane_table)."""
     arr = (ctypes.c_void_p * len(tensors))()

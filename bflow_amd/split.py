@@ -364,6 +364,17 @@ def pow2_scale(x: torch.Tensor, target: float) -> torch.Tensor:
     return out
 
 
+def grad_stats(dy: torch.Tensor, target: float):
+    """({s, 1/s}, dbias): the power-of-two scale of `pow2_scale` and the per-channel sum of an NCHW gradient in one pass (bflow_grad_stats)."""
+    B, C, H, W = dy.shape
+    out = torch.empty(2, dtype=torch.float32, device=dy.device)
+    db = torch.empty(C, dtype=torch.float32, device=dy.device)
+    partial = torch.empty(B * C * ((H * W + 1023) // 1024) + 1024, dtype=torch.float32, device=dy.device)
+    hip._check(hip.lib().bflow_grad_stats(hip._dev(dy, name="dy"), B, C, H * W, float(target), out.data_ptr(), partial.data_ptr(), db.data_ptr(),
+                                          hip._stream()), "bflow_grad_stats")
+    return out, db
+
+
 def plane_stats(x_nchw: torch.Tensor) -> torch.Tensor:
     """(B, C, 2) fp64 (sum, sum of squares) per plane of an NCHW fp32 tensor."""
     B, C, H, W = x_nchw.shape

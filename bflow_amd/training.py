@@ -4,8 +4,10 @@ What runs where:
     K5 correlation volume, K6 pyramid, K7 look-up, K13 convex up-sampling, masked L1   forward AND backward on the HIP kernels
                                                                                        (csrc/backward.hip: hand-written adjoints)
     K5 backward (two plain GEMMs per target, K = N)                                     rocBLAS through torch.matmul
-    convolutions / norms / GRU gates                                                    torch (MIOpen) under autograd -- the split-fp16
-                                                                                       conv engine is an inference engine (no backward)
+    convolutions (forward, input and weight gradient)                                   the split-fp16 conv engine + bflow_conv_wgrad_halo
+                                                                                       (conv_train.py: custom autograd Function)
+    norms / activations / GRU gate arithmetic                                           torch element-wise ops under autograd
+    the whole step (forward + loss + backward + AdamW)                                  optionally ONE hipGraph (GraphedTrainStep)
 
 Reference: RAFTSpline.forward with test_mode=False (models/raft_spline/raft.py:101-200), utils/losses.py:6-62,
 RAFTSplineModule.training_step / configure_optimizers (modules/raft_spline.py:64-188,321-356).
@@ -141,7 +143,7 @@ class _LookupBezierFn(torch.autograd.Function):
         gt = torch.zeros((T, B, 2, h, w), dtype=torch.float32, device=p.device)
         for k, t in enumerate(block._plane_targets):          # planes of one target (its pyramid levels), fixed order
             gt[t] += gc[k]
-        cf = torch.from_numpy(coef).to(p.device)
+        cf = hip.const_tensor(coef, p.device)
         gp = torch.einsum("tbdhw,tp->bdphw", gt, cf).reshape(B, 2 * deg, h, w)
         return None, None, gp, torch.zeros(1, dtype=torch.float32, device=p.device)
 
@@ -285,9 +287,13 @@ def forward_train(model, voxel_grid: Optional[torch.Tensor], images: Optional[Li
 
 
 # ----------------------------------------------------------------------------------------------- the training step
-def configure_optimizers(model: torch.nn.Module, train_params: Dict[str, Any]):
-    """modules/raft_spline.py:321-356: AdamW (+ linear OneCycleLR stepped per optimiser step)."""
-    opt = torch.optim.AdamW(model.parameters(), lr=train_params["learning_rate"], weight_decay=train_params["weight_decay"])
+def configure_optimizers(model: torch.nn.Module, train_params: Dict[str, Any], capturable: bool = False):
+    """modules/raft_spline.py:321-356: AdamW (+ linear OneCycleLR stepped per optimiser step).  capturable: the step counters and the
+    learning rate live on the device, so that `GraphedTrainStep` can record the optimiser step into its hipGraph."""
+    lr = train_params["learning_rate"]
+    if capturable:
+        lr = torch.tensor(float(lr), dtype=torch.float32, device=next(model.parameters()).device)
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=train_params["weight_decay"], capturable=capturable)
     sch_p = train_params["lr_scheduler"]
     if not sch_p["use"]:
         return opt, None
@@ -336,3 +342,93 @@ class TrainStep:
             out.update(loss=loss, pred=flows[-1][-1], gt=gt)
             return out
         raise NotImplementedError(ds)
+
+
+class GraphedTrainStep:
+    """forward + loss + backward + AdamW step of one batch signature as ONE hipGraph (torch.cuda.CUDAGraph == hipGraph on ROCm).
+
+    A training step at the reference's DSEC shape is ~6000 small launches; eagerly the HOST is the bound (tools/train_probe.py: the time
+    to enqueue a step equals the step time, on the library convolutions as well as on the engine).  Captured once and replayed, the step
+    runs at the speed of its kernels.  The optimiser must be built with `configure_optimizers(..., capturable=True)`; the scheduler (if
+    any) is stepped on the host after every replay -- it only fills the learning-rate tensor the recorded AdamW kernels read.
+    The batch tensors are copied into the graph's static inputs; the returned loss / prediction are the graph's static outputs
+    (overwritten by the next call)."""
+
+    def __init__(self, step: TrainStep, optimizer: torch.optim.Optimizer, scheduler=None, warmup: int = 2):
+        self.step, self.opt, self.sch, self.warmup = step, optimizer, scheduler, int(warmup)
+        self._sig = None
+        self._graph = None
+
+    @staticmethod
+    def _signature(batch) -> Tuple:
+        sig = []
+        for k in sorted(batch, key=str):
+            v = batch[k]
+            sig.append((str(k), (tuple(v.shape), str(v.dtype)) if torch.is_tensor(v) else repr(v)))
+        return tuple(sig)
+
+    def _run(self, batch):
+        out = self.step(batch)
+        out["loss"].backward()
+        self.opt.step()
+        return out
+
+    def _capture(self, batch):
+        import gc
+        self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        # warm-up on a side stream (lazy state: AdamW moments -- created INSIDE a capture they would be re-zeroed by every replay --,
+        # device constants, allocator growth), then undone: parameters, buffers and optimiser state are put back, so neither the
+        # warm-up nor the capture counts as a training step
+        model = self.step.model
+        params = [p for g in self.opt.param_groups for p in g["params"]]
+        snap_p = [p.detach().clone() for p in params]
+        snap_b = [b.detach().clone() for b in model.buffers()]
+        snap_s = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in self.opt.state[p].items()} for p in params if p in self.opt.state}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, self.warmup)):
+                self.opt.zero_grad(set_to_none=True)
+                self._run(self._static)
+            with torch.no_grad():
+                for p, q in zip(params, snap_p):
+                    p.copy_(q)
+                for b, q in zip(model.buffers(), snap_b):
+                    b.copy_(q)
+                for p in params:
+                    for k, v in self.opt.state.get(p, {}).items():
+                        if torch.is_tensor(v):
+                            old = snap_s.get(id(p), {}).get(k)
+                            v.copy_(old) if old is not None else v.zero_()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.opt.zero_grad(set_to_none=True)                # .grad tensors are allocated from the graph's pool and overwritten by every replay
+        self._graph = torch.cuda.CUDAGraph()
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()                                        # see graph.py: no finaliser of an older graph inside the capture
+        conv_train.CAPTURING = True                         # filter packs are RE-BUILT inside the graph: a warm cache would freeze stale packs into it
+        try:
+            with torch.cuda.graph(self._graph):
+                self._out = self._run(self._static)
+        finally:
+            conv_train.CAPTURING = False
+            if gc_was_on:
+                gc.enable()
+
+    def __call__(self, batch: Dict[Any, Any]) -> Dict[str, Any]:
+        sig = self._signature(batch)
+        first = self._sig != sig
+        if first:
+            if self._graph is not None:
+                torch.cuda.synchronize()
+                self._graph = None
+            self._sig = sig
+            self._capture(batch)                            # warm-up steps + the capture itself do NOT count as training steps of `batch` ...
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                self._static[k].copy_(v)
+        self._graph.replay()                                # ... this replay does
+        if self.sch is not None:
+            self.sch.step()
+        return self._out

@@ -172,12 +172,16 @@ int bflow_conv_split(const bflow_conv_desc_t* desc, bflow_stream_t stream);
  * bflow_blocked_f32_to_nchw: out[b, c, pix] = scale * x[b, c/32, pix, c%32]   (blocked fp32 engine output -> NCHW fp32).
  * bflow_pow2_scale: out2 = { s, 1/s } with s = 2^floor(log2(target / max|x|)) (1 for an all-zero / non-finite tensor), on the device;
  *   work8: 8 bytes, zero before the first call (the kernel leaves them zero).  Gradients of 1e-4..1e-9 are pre-scaled by s into fp16's
- *   normal range before they enter the split format and the results scaled back: exact in binary floating point.                     */
+ *   normal range before they enter the split format and the results scaled back: exact in binary floating point.
+ * bflow_grad_stats: the same {s, 1/s} for an NCHW gradient (B, C, HW) AND dbias[c] = sum over (b, pixel) -- the bias gradient autograd
+ *   derives for torch.nn.Conv2d -- in one pass over x; partial: scratch of B*C*ceil(HW/1024) + 1024 floats (per-segment sums and
+ *   per-workgroup maxima, combined in a fixed order by a second, one-workgroup launch: deterministic, no atomics).                 */
 int bflow_wgrad_pack(const float* src, void* dst_hi, void* dst_lo, int B, int C, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
                      int pad_h, int pad_w, int rows, int k_blocks, int taps_in_rows, const float* scale, bflow_stream_t stream);
 int bflow_blocked_f32_to_nchw(const float* x, float* out, int B, int HW, int C, int channel_blocks, int rows_per_image, const float* scale,
                               bflow_stream_t stream);
 int bflow_pow2_scale(const float* x, long long n, float target, float* out2, void* work8, bflow_stream_t stream);
+int bflow_grad_stats(const float* x, int B, int C, int HW, float target, float* out2, float* partial, float* dbias, bflow_stream_t stream);
 /* bflow_wgrad_reduce: dw (Cout, Cin, KH*KW) = inv_scale * sum over the G k-chunks of the engine's blocked fp32 partial results:
  *   orientation 0: part (taps, G, blocks, rows >= Cin, 32), output channel = 32*block + lane;  orientation 1: part (G, blocks, rows >= Cout, 32),
  *   32*block + lane = tap*Cin + ci.                                                                                                  */

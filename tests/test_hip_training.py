@@ -261,6 +261,56 @@ def test_engine_gradients_follow_the_weights_across_optimizer_steps():
     assert worst < 2e-2
 
 
+def test_graphed_train_step_matches_eager_steps():
+    """training.GraphedTrainStep: forward + loss + backward + AdamW recorded as ONE hipGraph and replayed must train like the eager
+    step -- same losses step by step (the filter packs are re-built INSIDE the graph from the weights AdamW just wrote, the learning
+    rate is read from the tensor the scheduler fills), and different batches of one signature go through the same graph."""
+    from bflow_amd import configs, synthetic
+    from bflow_amd.weights import deterministic_state_dict
+    cfg = configs.model_config("E_LU4_BD2")
+    B, H, W = 2, 64, 96
+    tp = dict(learning_rate=2e-4, weight_decay=1e-4, lr_scheduler=dict(use=True, total_steps=50, pct_start=0.3))
+
+    def batch(seed):
+        rs = np.random.RandomState(seed)
+        return {DataLoading.EV_REPR: cu(synthetic.voxel_grid(B, 9, H, W, seed=seed)),
+                DataLoading.FLOW: cu(rs.standard_normal((B, 2, H, W)).astype(np.float32) * 4),
+                DataLoading.FLOW_VALID: cu(rs.rand(B, H, W) > 0.2), DataLoading.DATASET_TYPE: [DataSetType.DSEC] * B}
+
+    batches = [batch(5), batch(6), batch(5), batch(7)]
+
+    def make(capturable):
+        m = bflow_amd.RAFTSpline(cfg)
+        m.load_state_dict(deterministic_state_dict(m, seed=0))
+        m.to(DEV).train()
+        opt, sch = training.configure_optimizers(m, tp, capturable=capturable)
+        return m, opt, sch, training.TrainStep(m, num_iter_train=3)
+
+    m1, opt1, sch1, step1 = make(False)
+    eager = []
+    for b in batches:
+        opt1.zero_grad(set_to_none=True)
+        out = step1(b)
+        out["loss"].backward()
+        opt1.step()
+        sch1.step()
+        eager.append(float(out["loss"]))
+    m2, opt2, sch2, step2 = make(True)
+    gstep = training.GraphedTrainStep(step2, opt2, sch2)                 # its warm-up and capture are undone: the run starts from the same weights
+    graphed = [float(gstep(b)["loss"]) for b in batches]
+    print("losses eager", eager, "graphed", graphed)
+    assert eager[0] != eager[2]                                          # the weights moved between the two visits of batch 5
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) < 2e-3 * abs(a), (eager, graphed)              # fp32 atomics order + three steps of drift; a frozen pack or lr is far off
+    worst = 0.0
+    for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
+        worst = max(worst, float((p - q).abs().max() / (p.abs().max() + 1e-12)))
+    print("worst relative parameter difference after 4 steps", worst)
+    assert worst < 5e-2
+    torch.cuda.synchronize()
+    del gstep
+
+
 def test_adjoint_identities_at_dsec_size():
     """Size-independent property at BASELINE C2 size (60x80 grid, 4 targets, 7 pyramid planes, 368.6 MB volume): look-up, pooling and
     up-sampling are LINEAR in the volume / the Bezier parameters, so <L x, y> == <x, L^T y> must hold for the adjoint kernels
