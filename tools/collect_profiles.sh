@@ -29,8 +29,8 @@ for key, rx in (("roofline", "conv_halo_kernel"), ("roofline_corr_build", "corr_
             w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep)
         os.remove(p)
 PY
-# training path: step time at the reference's DSEC training shape + its kernel breakdown
-python "$REPO/tools/train_probe.py" 10 2>/dev/null | tail -1 > "$OUT/r02_train_probe.txt"
-rm -rf /tmp/ktt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktt -o train -- python "$REPO/tools/train_probe.py" 5 > /tmp/ktt.log 2>&1
-f=$(find /tmp/ktt -name "*kernel_stats.csv" | head -1); head -31 "$f" > "$OUT/r02_train_rocprofv3_kernel_stats.csv"
+# training path: step time at the reference's DSEC training shape (eager = host-bound, and as one hipGraph) + the kernel breakdown of the graphed step
+BFLOW_TRAIN_PROBE_GRAPH=1 python "$REPO/tools/train_probe.py" 10 2>/dev/null | grep -E "train step|hipGraph" > "$OUT/r02_train_probe.txt"
+rm -rf /tmp/ktt; BFLOW_TRAIN_PROBE_GRAPH=engine rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktt -o train -- python "$REPO/tools/train_probe.py" 5 > /tmp/ktt.log 2>&1
+f=$(find /tmp/ktt -name "*kernel_stats.csv" | head -1); head -41 "$f" > "$OUT/r02_train_rocprofv3_kernel_stats.csv"
 ls -la "$OUT"

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 b = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
 p = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))["kernels"]
 r, rk, rl, cb = b["roofline"], b["roofline_corr_build"], b["roofline_lookup"], b["cpu_baseline"]
-train = open(os.path.join(ROOT, "profiles", "r02_train_probe.txt")).read().strip().replace("train step ", "")
+train = " / ".join(l.strip() for l in open(os.path.join(ROOT, "profiles", "r02_train_probe.txt")).read().strip().replace("train step ", "").splitlines())
 txt = f'''# profiles/ — measured evidence, MI355X (gfx950)
 
 Round-2 files (`r02_*`) were produced on a `gpurun` MI355X box by `tools/collect_profiles.sh` (the only writer of these files) and this
@@ -19,7 +19,7 @@ sources still hash to the same value.
 | `r02_rocprofv3_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline` (top 45 rows) | per-kernel totals/averages over the same command (both workloads of the bench: batch 1 and batch 8, so the averages mix the two): every row is a kernel of this repository or torch's copy / fill plumbing — no library convolution or GEMM |
 | `r02_pmc_{{FETCH,WRITE}}_SIZE_<key>.csv` | `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) on `tools/roofline_probe.py --key <key>` — the same launchers `bench.py` times (`tools/roofline_kernels.py`); last 5 launches of the kernel | fabric-side traffic per launch of the three roofline kernels |
 | `r02_pmc.json` | `tools/pmc_to_json.py` on the six CSVs | bytes per launch incl. the gfx950 ×2 FETCH_SIZE correction for wide coalesced streams (MI355X_MICROARCH.md §HBM) + the kernel-source hash |
-| `r02_train_probe.txt`, `r02_train_rocprofv3_kernel_stats.csv` | `python tools/train_probe.py 10`; `rocprofv3 --kernel-trace --stats -- python tools/train_probe.py 5` | training path (SURVEY §8 f-4) with the convolutions (forward, dgrad, wgrad) on the conv engine (round 2; 52.8 ms/step with torch / MIOpen convolutions, `conv_train.ENABLED = False`): {train} |
+| `r02_train_probe.txt`, `r02_train_rocprofv3_kernel_stats.csv` | `BFLOW_TRAIN_PROBE_GRAPH=1 python tools/train_probe.py 10`; `BFLOW_TRAIN_PROBE_GRAPH=engine rocprofv3 --kernel-trace --stats -- python tools/train_probe.py 5` | training path (SURVEY §8 f-4) with the convolutions (forward, dgrad, wgrad) on the conv engine, eagerly (host-bound) and as one hipGraph per step (`training.GraphedTrainStep`), the latter also on torch / MIOpen convolutions (`conv_train.ENABLED = False`): {train} |
 
 ## Round-2 numbers (C2 = E_LU4_BD2 events-only, DSEC 640×480, batch 1, 12 iterations)
 

@@ -34,6 +34,8 @@ print(f"train step B={B} {H}x{W} iters={ITERS}: {dt*1e3:.1f} ms/step = {B/dt:.1f
       f"loss {float(recs[0][1]):.4f} -> {float(recs[-1][1]):.4f}; peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB; host enqueue {t_host*1e3:.1f} ms/step")
 if os.environ.get("BFLOW_TRAIN_PROBE_GRAPH"):        # the same step as ONE hipGraph (training.GraphedTrainStep)
     for tag, on in (("engine", True), ("torch convolutions", False)):
+        if os.environ["BFLOW_TRAIN_PROBE_GRAPH"] in ("engine", "torch") and (os.environ["BFLOW_TRAIN_PROBE_GRAPH"] == "engine") != on:
+            continue
         from bflow_amd import conv_train
         conv_train.ENABLED = on
         m2 = bflow_amd.RAFTSpline(configs.model_config("E_LU4_BD2"))
