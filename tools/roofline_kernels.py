@@ -23,9 +23,12 @@ def build(model, vox, cfg, low_params=None):
         x5 = torch.cat(grids, dim=0)
         # (1) dominant kernel by time: the split-fp16 halo convolution.  Largest single launch: encoder layer1 conv, 64->64 3x3 on the
         #     5 stacked half-resolution maps (5B x 240 x 320), InstanceNorm statistics accumulated by the epilogue.
-        y = torch.nn.functional.conv2d(x5, model.fnet_ev.conv1.weight, None, stride=2, padding=3)
-        n5, c0, h0, w0 = y.shape
-        cur, _ = S.norm_act(y, (n5, h0, w0, c0), a_is_nchw=True, stats_a=S.plane_stats(y), act_a=S.ACT_RELU)
+        #     Its input is produced the way the product produces it: the engine's own 7x7/2 stem + the fused normalise / ReLU kernel.
+        n5, c0 = x5.shape[0], model.fnet_ev.conv1.out_channels
+        h0, w0 = (x5.shape[2] - 1) // 2 + 1, (x5.shape[3] - 1) // 2 + 1
+        st0 = torch.zeros((n5, c0, 2), dtype=torch.float64, device=dev)
+        _, f0 = S.conv_stem(x5.contiguous(), S.PackedStemWeight().get(model.fnet_ev.conv1.weight), stats=st0, want_split=False, want_f32=True)
+        cur, _ = S.norm_act(f0, (n5, h0, w0, c0), stats_a=st0, act_a=S.ACT_RELU)
         pk = S.PackedConvWeight().get(model.fnet_ev.layer1[0].conv1.weight)
         st = torch.zeros((8, n5, 64, 2), dtype=torch.float64, device=dev)      # 8 replicas, as the encoder uses them
         o32 = torch.empty((n5, 2, h0 * w0, 32), dtype=torch.float32, device=dev)
