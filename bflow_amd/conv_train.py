@@ -56,9 +56,9 @@ class _PackCache:
         key = tuple((t.data_ptr(), t._version, str(t.device)) for t in srcs)
         if self._key[which] != key or CAPTURING:
             with torch.no_grad():
-                w = weight.detach().float()
-                w = w.flip(2, 3).transpose(0, 1).contiguous() if which == "bwd" else w.contiguous()
-                packed = S.PackedConvWeight().get(w)              # a fresh packer: nothing to mistake for
+                w = weight.detach().float().contiguous()
+                # "bwd": flipped in space, transposed in (cin, cout) -- by the pack kernel itself (bflow_conv_pack_weights_adjoint)
+                packed = S.PackedConvWeight().get(w, adjoint=which == "bwd")    # a fresh packer: nothing to mistake for
             self._store[which], self._key[which] = (w, packed), key
         return self._store[which][1]
 
@@ -129,8 +129,7 @@ class _ConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 if ctx.halo:
                     xs = S.SplitTensor(xsaved, H, W, cin)
-                    acc = S.conv_wgrad_halo(xs, gs, cout, (kh, kw))                       # (taps, cout_pad, cin_pad)
-                    dw = (acc[:, :cout, :cin] * inv).permute(1, 2, 0).reshape(cout, cin, kh, kw)
+                    dw = S.conv_wgrad_halo(xs, gs, cout, cin, (kh, kw), inv)
                     if _DEBUG_CMP is not None:
                         xr = xs.to_nchw()[:, :cin]
                         ref = _weight_grad(xr.contiguous(), dy, s, inv, (kh, kw), stride, (ph, pw))

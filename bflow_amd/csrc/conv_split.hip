@@ -1212,8 +1212,10 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
 // ---------------------------------------------------------------------------------------------------------------------
 // weights (Cout, Cin, KH, KW) fp32 -> split (KH*KW*CB, Cout_pad, 32), zero padded (k-tile-major)
 // ---------------------------------------------------------------------------------------------------------------------
+// adjoint != 0: the filter of the INPUT-GRADIENT convolution, read from the forward weight w (Cin, Cout, KH, KW) [the roles swap: this
+// pack's "Cout" rows are the forward's input channels]: w'[co][c][tap] = w[c][co][ntaps - 1 - tap]  (flipped in space, transposed in channels)
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ wh, _Float16* __restrict__ wl,
-                                                           int Cout, int Cin, int ntaps, int Cout_pad, int CB) {
+                                                           int Cout, int Cin, int ntaps, int Cout_pad, int CB, int adjoint) {
     const long long total = (long long)ntaps * CB * Cout_pad * 32;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c32 = (int)(i & 31);
@@ -1222,7 +1224,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         const int kt = (int)(t1 / Cout_pad);
         const int tap = kt / CB, c = (kt - tap * CB) * 32 + c32;
         float v = 0.f;
-        if (co < Cout && c < Cin) v = w[((long long)co * Cin + c) * ntaps + tap];
+        if (co < Cout && c < Cin) v = adjoint ? w[((long long)c * Cout + co) * ntaps + (ntaps - 1 - tap)] : w[((long long)co * Cin + c) * ntaps + tap];
         _Float16 h, l;
         split1(v, h, l);
         wh[i] = h;
@@ -1517,8 +1519,18 @@ extern "C" int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, i
                   BFLOW_E_ARG, "conv_pack_weights: bad arguments");
     const long long total = (long long)cout_pad * KH * KW * cin_pad;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)w_hi,
-                       (_Float16*)w_lo, Cout, Cin, KH * KW, cout_pad, cin_pad / 32);
+                       (_Float16*)w_lo, Cout, Cin, KH * KW, cout_pad, cin_pad / 32, 0);
     return bflow::launch_status("conv_pack_weights");
+}
+
+extern "C" int bflow_conv_pack_weights_adjoint(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW, int cout_pad, int cin_pad,
+                                               bflow_stream_t stream) {
+    BFLOW_REQUIRE(w && w_hi && w_lo && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && cout_pad >= Cout && cin_pad >= Cin && cin_pad % 32 == 0,
+                  BFLOW_E_ARG, "conv_pack_weights_adjoint: bad arguments");
+    const long long total = (long long)cout_pad * KH * KW * cin_pad;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)w_hi,
+                       (_Float16*)w_lo, Cout, Cin, KH * KW, cout_pad, cin_pad / 32, 1);
+    return bflow::launch_status("conv_pack_weights_adjoint");
 }
 
 extern "C" int bflow_plane_stats(const float* x, double* stats, long long planes, int HW, bflow_stream_t stream) {

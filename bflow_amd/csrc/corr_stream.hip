@@ -382,7 +382,8 @@ int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, 
     a.CH2 = ceil_div(N, 2 * CHUNK);
     a.n_pan = T * B * a.JP;
     a.RX = 1;   // row slice of one XCD: CH2 / RX pairs x 2 chunks x (D/32 * 4 KB) <= 2.5 MB
-    while (a.RX < 8 && (long long)ceil_div(a.CH2, a.RX) * 2 * (D / 32) * 4096 > (5LL << 19)) a.RX *= 2;
+    static const long long slice_limit = [] { const char* e = getenv("BFLOW_CORR_SLICE_KB"); return e && atoi(e) > 0 ? (long long)atoi(e) << 10 : (5LL << 19); }();
+    while (a.RX < 8 && (long long)ceil_div(a.CH2, a.RX) * 2 * (D / 32) * 4096 > slice_limit) a.RX *= 2;
 #ifdef STREAM_STAMPS
     a.stamps = g_stamp_buf;
 #else

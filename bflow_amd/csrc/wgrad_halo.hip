@@ -225,6 +225,21 @@ __global__ __launch_bounds__(256, 1) void wgrad_halo_kernel(WgradArgs a) {
     }
 }
 
+// dw[co][ci][tap] = inv * acc[tap][co][ci]; acc is left ZERO (the accumulator is a persistent buffer: the next call adds into zeros again)
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ acc, float* __restrict__ dw, int taps, int Cout, int Cin, int cout_pad,
+                                                           int cin_pad, const float* __restrict__ inv_p) {
+    const long long total = (long long)taps * cout_pad * cin_pad;
+    const float inv = inv_p ? *inv_p : 1.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ci = (int)(i % cin_pad);
+        const long long t1 = i / cin_pad;
+        const int co = (int)(t1 % cout_pad), tap = (int)(t1 / cout_pad);
+        const float v = acc[i];
+        acc[i] = 0.f;
+        if (co < Cout && ci < Cin) dw[((long long)co * Cin + ci) * taps + tap] = v * inv;
+    }
+}
+
 template <int KH, int KW, int CIB>
 void launch(const WgradArgs& a, int items, hipStream_t s) {
     constexpr int HR = (16 + KW - 1) * (8 + KH - 1), XU = 4 * ((HR + 63) / 64);
@@ -237,6 +252,15 @@ void launch(const WgradArgs& a, int items, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int bflow_conv_wgrad_finish(float* dw_acc, float* dw, int taps, int Cout, int Cin, int cin_pad, const float* inv_scale, bflow_stream_t stream) {
+    BFLOW_REQUIRE(dw_acc && dw && taps > 0 && Cout > 0 && Cin > 0 && cin_pad >= Cin && cin_pad % 32 == 0, BFLOW_E_ARG, "conv_wgrad_finish: bad arguments");
+    const int cout_pad = (Cout + 63) / 64 * 64;
+    const long long total = (long long)taps * cout_pad * cin_pad;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dw_acc, dw, taps, Cout, Cin, cout_pad,
+                       cin_pad, inv_scale);
+    return bflow::launch_status("conv_wgrad_finish");
+}
 
 extern "C" int bflow_conv_wgrad_halo(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw_acc, int B, int H, int W, int Cin_pad,
                                      int Cout, int rows_per_image, int KH, int KW, bflow_stream_t stream) {

@@ -98,16 +98,21 @@ class PackedConvWeight:
         self._key = None
         self.planes = None
 
-    def get(self, weight: torch.Tensor, cin_pad: Optional[int] = None):
+    def get(self, weight: torch.Tensor, cin_pad: Optional[int] = None, adjoint: bool = False):
+        """adjoint: pack the filter of the input-gradient convolution (flipped in space, transposed in channels) straight from the forward
+        weight (bflow_conv_pack_weights_adjoint): its "cout" is the forward's cin."""
         cout, cin, kh, kw = weight.shape
+        if adjoint:
+            cout, cin = cin, cout
         cin_pad = (cin + 31) // 32 * 32 if cin_pad is None else cin_pad
         cout_pad = (cout + 127) // 128 * 128   # any channel tile (64/96/128) may read up to 128 rows from its first row
-        key = (weight.data_ptr(), weight._version, cin_pad, str(weight.device))
+        key = (weight.data_ptr(), weight._version, cin_pad, str(weight.device), adjoint)
         if self._key != key:
             w = weight.detach().float().contiguous()
             planes = torch.empty((2, kh * kw * (cin_pad // 32), cout_pad, 32), dtype=torch.float16, device=w.device)
-            hip._check(hip.lib().bflow_conv_pack_weights(hip._dev(w, name="weight"), planes[0].data_ptr(), planes[1].data_ptr(), cout, cin,
-                                                         kh, kw, cout_pad, cin_pad, hip._stream()), "bflow_conv_pack_weights")
+            fn = hip.lib().bflow_conv_pack_weights_adjoint if adjoint else hip.lib().bflow_conv_pack_weights
+            hip._check(fn(hip._dev(w, name="weight"), planes[0].data_ptr(), planes[1].data_ptr(), cout, cin,
+                          kh, kw, cout_pad, cin_pad, hip._stream()), "bflow_conv_pack_weights")
             self._key, self.planes, self.meta = key, planes, (cout, cin_pad, kh, kw, cout_pad)
         return self.planes, self.meta
 
@@ -339,15 +344,28 @@ def wgrad_reduce(part: torch.Tensor, G: int, cout: int, cin: int, ksize, orienta
     return dw
 
 
-def conv_wgrad_halo(xs: "SplitTensor", gs: "SplitTensor", cout: int, ksize) -> torch.Tensor:
-    """(KH*KW, cout_pad64, cin_pad) fp32 = sum over pixels of dY (gs, blocked split, cout channels) x shifted X (xs): bflow_conv_wgrad_halo."""
+_wgrad_acc = {}
+
+
+def conv_wgrad_halo(xs: "SplitTensor", gs: "SplitTensor", cout: int, cin: int, ksize, inv_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dw (cout, cin, KH, KW) fp32 = inv_scale * sum over pixels of dY (gs, blocked split, pre-scaled) x shifted X (xs): bflow_conv_wgrad_halo
+    into a persistent fp32 accumulator (one per shape, device and stream; zero between calls) + bflow_conv_wgrad_finish (scale, re-order
+    to the filter layout, re-zero the accumulator)."""
     kh, kw = ksize
     B, H, W, _ = xs.shape
     assert gs.shape[:3] == (B, H, W) and xs.rows == gs.rows
-    acc = torch.zeros((kh * kw, (cout + 63) // 64 * 64, xs.channels_padded), dtype=torch.float32, device=xs.planes.device)
+    dev = xs.planes.device
+    key = (kh * kw, (cout + 63) // 64 * 64, xs.channels_padded, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    acc = _wgrad_acc.pop(key, None)              # popped while in use: an exception in between does not leave a dirty accumulator behind
+    if acc is None:
+        acc = torch.zeros(key[:3], dtype=torch.float32, device=dev)
+    dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=dev)
     hip._check(hip.lib().bflow_conv_wgrad_halo(xs.hi.data_ptr(), xs.lo.data_ptr(), gs.hi.data_ptr(), gs.lo.data_ptr(), acc.data_ptr(), B, H, W,
                                                xs.channels_padded, cout, xs.rows, kh, kw, hip._stream()), "bflow_conv_wgrad_halo")
-    return acc
+    hip._check(hip.lib().bflow_conv_wgrad_finish(acc.data_ptr(), dw.data_ptr(), kh * kw, cout, cin, xs.channels_padded,
+                                                 None if inv_scale is None else inv_scale.data_ptr(), hip._stream()), "bflow_conv_wgrad_finish")
+    _wgrad_acc[key] = acc
+    return dw
 
 
 _pow2_work = {}

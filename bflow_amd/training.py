@@ -354,8 +354,11 @@ class GraphedTrainStep:
     The batch tensors are copied into the graph's static inputs; the returned loss / prediction are the graph's static outputs
     (overwritten by the next call)."""
 
-    def __init__(self, step: TrainStep, optimizer: torch.optim.Optimizer, scheduler=None, warmup: int = 2):
-        self.step, self.opt, self.sch, self.warmup = step, optimizer, scheduler, int(warmup)
+    def __init__(self, step: TrainStep, optimizer: torch.optim.Optimizer, scheduler=None, warmup: int = 2, grad_sync=None):
+        """grad_sync: a `dist.GradientBuckets` of the model (data-parallel training, one process per GPU): its bucketed RCCL all-reduces are
+        launched by the gradient hooks during the backward pass and finished before the optimiser step -- recorded into the graph like
+        every other node (stream-ordered collectives are capturable).  On one rank it is a no-op."""
+        self.step, self.opt, self.sch, self.warmup, self.grad_sync = step, optimizer, scheduler, int(warmup), grad_sync
         self._sig = None
         self._graph = None
 
@@ -370,6 +373,8 @@ class GraphedTrainStep:
     def _run(self, batch):
         out = self.step(batch)
         out["loss"].backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
         self.opt.step()
         return out
 

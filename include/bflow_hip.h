@@ -158,6 +158,10 @@ typedef struct bflow_stem_desc {
 int bflow_conv_stem(const bflow_stem_desc_t* desc, bflow_stream_t stream);
 int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
                             int cout_pad, int cin_pad, bflow_stream_t stream);
+/* The filter of the input-gradient convolution packed straight from the FORWARD weight w (Cin, Cout, KH, KW) -- flipped in space, transposed in
+ * channels: what autograd's conv_transpose of torch.nn.Conv2d uses -- (Cout, Cin = the roles of THIS convolution, i.e. the forward's Cin, Cout). */
+int bflow_conv_pack_weights_adjoint(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
+                            int cout_pad, int cin_pad, bflow_stream_t stream);
 int bflow_conv_split(const bflow_conv_desc_t* desc, bflow_stream_t stream);
 
 /* Training convolutions (bflow_amd/conv_train.py): the adjoints of Conv2d that the reference gets from autograd over
@@ -192,7 +196,9 @@ int bflow_wgrad_reduce(const float* part, float* dw, int G, int Cout, int Cin, i
  *     dw_acc[tap, co, ci] += sum_{b, y, x} dY[b, y, x, co] * X[b, y + r - KH/2, x + q - KW/2, ci]      (tap = r*KW + q)
  *   dw_acc: fp32 (KH*KW, ceil(Cout/64)*64, Cin_pad), zero before the call (fp32 atomics across the k-split workgroups);
  *   x_*: (B, Cin_pad/32, rows_per_image, 32), dy_*: (B, ceil(Cout/32), rows_per_image, 32).  The pixel contraction is fed by
- *   ds_read_b64_tr_b16 (transposed fragments from the row-major [pixel][channel] LDS tiles).                                        */
+ *   ds_read_b64_tr_b16 (transposed fragments from the row-major [pixel][channel] LDS tiles).
+ * bflow_conv_wgrad_finish: dw (Cout, Cin, KH*KW) = inv_scale * dw_acc, and dw_acc is left ZERO (a persistent accumulator needs no memset). */
+int bflow_conv_wgrad_finish(float* dw_acc, float* dw, int taps, int Cout, int Cin, int cin_pad, const float* inv_scale, bflow_stream_t stream);
 int bflow_conv_wgrad_halo(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw_acc, int B, int H, int W, int Cin_pad,
                           int Cout, int rows_per_image, int KH, int KW, bflow_stream_t stream);
 
