@@ -38,7 +38,8 @@ ENABLED = True                      # tools / A-B timing: False = torch (MIOpen)
 MIN_CHUNK, TARGET_WGS = 8, 768      # split-K of the weight gradient: k-blocks per chunk at least / workgroups aimed at
 HALO_WGRAD = True                   # stride-1 3x3 / 1x5 / 5x1 / 1x1: bflow_conv_wgrad_halo (no re-packing); False = the pack + GEMM path everywhere
 _DEBUG_CMP = None                    # tools: a list collects (relative difference halo vs pack-GEMM weight gradient, shape, scale) per call
-CAPTURING = False                   # set by training.GraphedTrainStep around its capture: every filter pack is recorded into the graph
+CAPTURE_EPOCH = 0                   # != 0 while training.GraphedTrainStep captures: every filter is packed ONCE inside that capture (recorded into
+                                    # the graph, so that replays re-pack the weights AdamW just wrote), whatever the caches held before
 _TARGET = 8192.0                    # max |dy| after scaling: well inside fp16 (65504), 13 bits of head-room for sums of products
 
 
@@ -51,15 +52,16 @@ class _PackCache:
     def __init__(self):
         self._key = {"fwd": None, "bwd": None}
         self._store = {"fwd": None, "bwd": None}
+        self._epoch = {"fwd": 0, "bwd": 0}
 
     def get(self, which: str, weight: torch.Tensor, srcs):
         key = tuple((t.data_ptr(), t._version, str(t.device)) for t in srcs)
-        if self._key[which] != key or CAPTURING:
+        if self._key[which] != key or (CAPTURE_EPOCH and self._epoch[which] != CAPTURE_EPOCH):
             with torch.no_grad():
                 w = weight.detach().float().contiguous()
                 # "bwd": flipped in space, transposed in (cin, cout) -- by the pack kernel itself (bflow_conv_pack_weights_adjoint)
                 packed = S.PackedConvWeight().get(w, adjoint=which == "bwd")    # a fresh packer: nothing to mistake for
-            self._store[which], self._key[which] = (w, packed), key
+            self._store[which], self._key[which], self._epoch[which] = (w, packed), key, CAPTURE_EPOCH
         return self._store[which][1]
 
 

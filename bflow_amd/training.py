@@ -354,6 +354,8 @@ class GraphedTrainStep:
     The batch tensors are copied into the graph's static inputs; the returned loss / prediction are the graph's static outputs
     (overwritten by the next call)."""
 
+    _epochs = 0
+
     def __init__(self, step: TrainStep, optimizer: torch.optim.Optimizer, scheduler=None, warmup: int = 2, grad_sync=None):
         """grad_sync: a `dist.GradientBuckets` of the model (data-parallel training, one process per GPU): its bucketed RCCL all-reduces are
         launched by the gradient hooks during the backward pass and finished before the optimiser step -- recorded into the graph like
@@ -408,16 +410,18 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.opt.zero_grad(set_to_none=True)                # .grad tensors are allocated from the graph's pool and overwritten by every replay
+        self._mutated = list(params) + list(model.buffers())
         self._graph = torch.cuda.CUDAGraph()
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()                                        # see graph.py: no finaliser of an older graph inside the capture
-        conv_train.CAPTURING = True                         # filter packs are RE-BUILT inside the graph: a warm cache would freeze stale packs into it
+        GraphedTrainStep._epochs += 1
+        conv_train.CAPTURE_EPOCH = GraphedTrainStep._epochs  # filter packs are RE-BUILT (once each) inside the graph: a warm cache would freeze stale packs into it
         try:
             with torch.cuda.graph(self._graph):
                 self._out = self._run(self._static)
         finally:
-            conv_train.CAPTURING = False
+            conv_train.CAPTURE_EPOCH = 0
             if gc_was_on:
                 gc.enable()
 
@@ -434,6 +438,9 @@ class GraphedTrainStep:
             if torch.is_tensor(v):
                 self._static[k].copy_(v)
         self._graph.replay()                                # ... this replay does
+        # the replay rewrote parameters, BatchNorm buffers and optimiser state behind autograd's back: bump their version counters (no
+        # launch), every cache keyed on them -- packed filters of the inference engine, captured inference graphs -- then sees the change
+        torch.autograd.graph.increment_version(self._mutated)
         if self.sch is not None:
             self.sch.step()
         return self._out

@@ -294,10 +294,26 @@ def test_graphed_train_step_matches_eager_steps():
         out["loss"].backward()
         opt1.step()
         sch1.step()
-        eager.append(float(out["loss"]))
+        eager.append(float(out["loss"].detach()))
     m2, opt2, sch2, step2 = make(True)
+    vox_inf = batches[0][DataLoading.EV_REPR]
+    with torch.no_grad():                                                # warm the INFERENCE engine's filter caches on the initial weights
+        m2.eval()
+        before = m2(voxel_grid=vox_inf, iters=3, test_mode=True)[1].get_params().clone()
+        m2.train()
     gstep = training.GraphedTrainStep(step2, opt2, sch2)                 # its warm-up and capture are undone: the run starts from the same weights
-    graphed = [float(gstep(b)["loss"]) for b in batches]
+    graphed = [float(gstep(b)["loss"].detach()) for b in batches]
+    # replays rewrite the weights behind autograd's back: the inference path (packed filters keyed on parameter versions) must see them
+    with torch.no_grad():
+        m2.eval()
+        after = m2(voxel_grid=vox_inf, iters=3, test_mode=True)[1].get_params().clone()
+        m3 = bflow_amd.RAFTSpline(cfg)
+        m3.load_state_dict(m2.state_dict())
+        m3.to(DEV).eval()
+        fresh = m3(voxel_grid=vox_inf, iters=3, test_mode=True)[1].get_params()
+        m2.train()
+    assert not torch.equal(before, after)
+    assert torch.equal(after, fresh), float((after - fresh).abs().max())
     print("losses eager", eager, "graphed", graphed)
     assert eager[0] != eager[2]                                          # the weights moved between the two visits of batch 5
     for a, b in zip(eager, graphed):

@@ -31,7 +31,7 @@ t_host = (time.perf_counter() - t0) / steps          # time the host needs to EN
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
 f = sum(e[0].elapsed_time(e[1]) for e, _ in recs) / steps; b = sum(e[1].elapsed_time(e[2]) for e, _ in recs) / steps; o = sum(e[2].elapsed_time(e[3]) for e, _ in recs) / steps
 print(f"train step B={B} {H}x{W} iters={ITERS}: {dt*1e3:.1f} ms/step = {B/dt:.1f} samples/s  (forward+loss {f:.1f} ms, backward {b:.1f} ms, AdamW {o:.1f} ms); "
-      f"loss {float(recs[0][1]):.4f} -> {float(recs[-1][1]):.4f}; peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB; host enqueue {t_host*1e3:.1f} ms/step")
+      f"loss {float(recs[0][1].detach()):.4f} -> {float(recs[-1][1].detach()):.4f}; peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB; host enqueue {t_host*1e3:.1f} ms/step")
 if os.environ.get("BFLOW_TRAIN_PROBE_GRAPH"):        # the same step as ONE hipGraph (training.GraphedTrainStep)
     for tag, on in (("engine", True), ("torch convolutions", False)):
         if os.environ["BFLOW_TRAIN_PROBE_GRAPH"] in ("engine", "torch") and (os.environ["BFLOW_TRAIN_PROBE_GRAPH"] == "engine") != on:
@@ -42,11 +42,11 @@ if os.environ.get("BFLOW_TRAIN_PROBE_GRAPH"):        # the same step as ONE hipG
         m2.load_state_dict(deterministic_state_dict(m2, seed=0)); m2.to(dev).train()
         o2, s2 = training.configure_optimizers(m2, dict(learning_rate=1e-4, weight_decay=1e-4, lr_scheduler=dict(use=True, total_steps=1000, pct_start=0.01)), capturable=True)
         g = training.GraphedTrainStep(training.TrainStep(m2, num_iter_train=ITERS), o2, s2)
-        l0 = float(g(batch)["loss"])
+        l0 = float(g(batch)["loss"].detach())
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps): out = g(batch)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-        print(f"  one hipGraph per step, {tag}: {dt*1e3:.1f} ms/step = {B/dt:.1f} samples/s; loss {l0:.4f} -> {float(out['loss']):.4f}")
+        print(f"  one hipGraph per step, {tag}: {dt*1e3:.1f} ms/step = {B/dt:.1f} samples/s; loss {l0:.4f} -> {float(out["loss"].detach()):.4f}")
         del g, m2, o2, s2
     conv_train.ENABLED = True
 if os.environ.get("BFLOW_TRAIN_PROBE_AB"):           # the same step on torch / MIOpen convolutions
