@@ -46,7 +46,7 @@ if os.environ.get("BFLOW_TRAIN_PROBE_GRAPH"):        # the same step as ONE hipG
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps): out = g(batch)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-        print(f"  one hipGraph per step, {tag}: {dt*1e3:.1f} ms/step = {B/dt:.1f} samples/s; loss {l0:.4f} -> {float(out["loss"].detach()):.4f}")
+        print(f"  one hipGraph per step, {tag}: {dt*1e3:.1f} ms/step = {B/dt:.1f} samples/s; loss {l0:.4f} -> {float(out['loss'].detach()):.4f}")
         del g, m2, o2, s2
     conv_train.ENABLED = True
 if os.environ.get("BFLOW_TRAIN_PROBE_AB"):           # the same step on torch / MIOpen convolutions
