@@ -24,7 +24,7 @@ MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -123,6 +123,10 @@ def lib() -> ctypes.CDLL:
         "bflow_wgrad_reduce": [vp, vp, i, i, i, i, i, i, i, vp, vp],
         "bflow_conv_wgrad_halo": [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp],
         "bflow_conv_wgrad_finish": [vp, vp, i, i, i, i, vp, vp],
+        "bflow_gru_zr_fwd": [vp, vp, vp, vp, vp, i, i, ll, vp],
+        "bflow_gru_zr_bwd": [vp, vp, vp, vp, vp, vp, vp, i, i, ll, vp],
+        "bflow_gru_blend_fwd": [vp, vp, vp, vp, vp, i, i, ll, vp],
+        "bflow_gru_blend_bwd": [vp, vp, vp, vp, vp, vp, vp, i, i, ll, vp],
         "bflow_plane_stats": [vp, vp, ll, i, vp],
         "bflow_norm_act_split": [ctypes.POINTER(NormDesc), vp],
         "bflow_split_to_nchw": [vp, vp, vp, i, i, i, i, i, ll, vp],
@@ -590,3 +594,50 @@ class Branch:
     def join(self):
         if self.enabled:
             self.main.wait_stream(self.side)
+
+
+# ------------------------------------------------------------------------------------------------- SepConvGRU gates of the training path
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().float().contiguous()
+
+
+def gru_zr_fwd(zr_pre: torch.Tensor, h: torch.Tensor):
+    """(z, r, r*h) from the merged z | r pre-activations (B, 2C, H, W) and the hidden state (B, C, H, W): bflow_gru_zr_fwd."""
+    zr_pre, h = _f32c(zr_pre), _f32c(h)
+    B, C, H, W = h.shape
+    assert zr_pre.shape == (B, 2 * C, H, W)
+    z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+    _check(lib().bflow_gru_zr_fwd(_dev(zr_pre, name="zr_pre"), _dev(h, name="h"), _dev(z), _dev(r), _dev(rh), B, C, H * W, _stream()), "bflow_gru_zr_fwd")
+    return z, r, rh
+
+
+def gru_zr_bwd(dz: Optional[torch.Tensor], drh: torch.Tensor, z: torch.Tensor, r: torch.Tensor, h: torch.Tensor):
+    """-> (d zr_pre (B, 2C, H, W), dh through r*h): bflow_gru_zr_bwd."""
+    B, C, H, W = h.shape
+    drh = _f32c(drh)
+    dz = None if dz is None else _f32c(dz)
+    dzr = torch.empty((B, 2 * C, H, W), dtype=torch.float32, device=h.device)
+    dh = torch.empty_like(h)
+    _check(lib().bflow_gru_zr_bwd(None if dz is None else _dev(dz, name="dz"), _dev(drh, name="drh"), _dev(z), _dev(r), _dev(h), _dev(dzr), _dev(dh),
+                                  B, C, H * W, _stream()), "bflow_gru_zr_bwd")
+    return dzr, dh
+
+
+def gru_blend_fwd(q_pre: torch.Tensor, z: torch.Tensor, h: torch.Tensor):
+    """(q = tanh(q_pre), h_new = (1 - z) h + z q): bflow_gru_blend_fwd."""
+    q_pre, z, h = _f32c(q_pre), _f32c(z), _f32c(h)
+    B, C, H, W = h.shape
+    q, hn = torch.empty_like(h), torch.empty_like(h)
+    _check(lib().bflow_gru_blend_fwd(_dev(q_pre, name="q_pre"), _dev(z, name="z"), _dev(h, name="h"), _dev(q), _dev(hn), B, C, H * W, _stream()),
+           "bflow_gru_blend_fwd")
+    return q, hn
+
+
+def gru_blend_bwd(dhn: torch.Tensor, q: torch.Tensor, z: torch.Tensor, h: torch.Tensor):
+    """-> (d q_pre, dz, dh through the blend): bflow_gru_blend_bwd."""
+    dhn = _f32c(dhn)
+    B, C, H, W = h.shape
+    dq, dz, dh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+    _check(lib().bflow_gru_blend_bwd(_dev(dhn, name="dh_new"), _dev(q), _dev(z), _dev(h), _dev(dq), _dev(dz), _dev(dh), B, C, H * W, _stream()),
+           "bflow_gru_blend_bwd")
+    return dq, dz, dh

@@ -222,22 +222,69 @@ def l1_multi_seq_loss_channel_masked(src_list_list: Sequence[Sequence[torch.Tens
 
 
 # ----------------------------------------------------------------------------------------------- the training forward
-def _update_block_train(ub, net, inp, corr, bezier):
+class _GruZRFn(torch.autograd.Function):
+    """(z, r*h) = (sigmoid(zr[:, :C]), sigmoid(zr[:, C:]) * h): bflow_gru_zr_fwd / bflow_gru_zr_bwd (update.py:38-44 under autograd)."""
+
+    @staticmethod
+    def forward(ctx, zr_pre, h):
+        z, r, rh = hip.gru_zr_fwd(zr_pre, h)
+        hs = h.detach().float().contiguous()
+        ctx.save_for_backward(z, r, hs)
+        return z, rh
+
+    @staticmethod
+    def backward(ctx, dz, drh):
+        z, r, h = ctx.saved_tensors
+        if drh is None:
+            drh = torch.zeros_like(h)
+        dzr, dh = hip.gru_zr_bwd(dz, drh, z, r, h)
+        return dzr, dh
+
+
+class _GruBlendFn(torch.autograd.Function):
+    """h' = (1 - z) h + z tanh(q_pre): bflow_gru_blend_fwd / bflow_gru_blend_bwd (update.py:45-47 under autograd)."""
+
+    @staticmethod
+    def forward(ctx, q_pre, z, h):
+        q, hn = hip.gru_blend_fwd(q_pre, z, h)
+        ctx.save_for_backward(q, z.detach().float().contiguous(), h.detach().float().contiguous())
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        q, z, h = ctx.saved_tensors
+        return hip.gru_blend_bwd(dhn, q, z, h)
+
+
+FUSED_GATES = True                  # tools / A-B: False = the reference's chain of element-wise torch ops under autograd
+
+
+def _update_block_train(ub, net, inp, corr, bezier, merged=None):
     """BasicUpdateBlock.forward (update.py:116-126) under autograd; the convolutions (modules = conv_train.Conv2d, the merged z|r filter
-    through conv_train.conv2d) run forward and backward on the HIP conv engine; z|r share one launch per GRU half."""
+    through conv_train.conv2d) run forward and backward on the HIP conv engine; z|r share one launch per GRU half; the gate arithmetic of
+    a half is two fused launches (csrc/gru_gates.hip).  `merged`: dict the caller keeps for ONE forward -- the z|r filters / biases are
+    concatenated once per forward, not once per iteration."""
     enc, gru = ub.encoder, ub.gru
     cor = F.relu(enc.convc2(F.relu(enc.convc1(corr))))
     bez = F.relu(enc.convf2(F.relu(enc.convf1(bezier))))
     motion = torch.cat([F.relu(enc.conv(torch.cat([cor, bez], dim=1))), bezier], dim=1)
     x = torch.cat([inp, motion], dim=1)
     hd = ub.hidden_dim
+    merged = {} if merged is None else merged
     for sfx in ("1", "2"):
         cz, cr, cq = (getattr(gru, f"conv{g}{sfx}") for g in "zrq")
-        zr = conv_train.conv2d(torch.cat([net, x], dim=1), torch.cat([cz.weight, cr.weight], dim=0), torch.cat([cz.bias, cr.bias], dim=0),
-                               cz.padding, gru.__dict__.setdefault("_zr_pack" + sfx, conv_train._PackCache()), (cz.weight, cr.weight))
-        z, r = torch.sigmoid(zr[:, :hd]), torch.sigmoid(zr[:, hd:])
-        q = torch.tanh(cq(torch.cat([r * net, x], dim=1)))
-        net = (1 - z) * net + z * q
+        if sfx not in merged:
+            merged[sfx] = (torch.cat([cz.weight, cr.weight], dim=0), torch.cat([cz.bias, cr.bias], dim=0))
+        wzr, bzr = merged[sfx]
+        zr = conv_train.conv2d(torch.cat([net, x], dim=1), wzr, bzr, cz.padding,
+                               gru.__dict__.setdefault("_zr_pack" + sfx, conv_train._PackCache()), (cz.weight, cr.weight))
+        if FUSED_GATES and zr.is_cuda and (hd * net.shape[2] * net.shape[3]) % 4 == 0:
+            z, rh = _GruZRFn.apply(zr, net)
+            net = _GruBlendFn.apply(cq(torch.cat([rh, x], dim=1)), z, net)
+        else:
+            z, r = torch.sigmoid(zr[:, :hd]), torch.sigmoid(zr[:, hd:])
+            q = torch.tanh(cq(torch.cat([r * net, x], dim=1)))
+            net = (1 - z) * net + z * q
     delta = ub.bezier_head.conv2(F.relu(ub.bezier_head.conv1(net)))
     mask = 0.25 * ub.mask(net)
     return net, mask, delta
@@ -276,11 +323,12 @@ def forward_train(model, voxel_grid: Optional[torch.Tensor], images: Optional[Li
         params = params + flow_init
     coef = model._coefficients()
     ups: List[BezierCurves] = []
+    merged: Dict[str, Any] = {}                                  # z|r filters of the two GRU halves, concatenated once per forward
     for _ in range(iters):
         if model.detach_bezier:                                  # raft.py:167-168
             params = params.detach()
         corr = block.lookup_bezier(params, coef)
-        net, mask, delta = _update_block_train(model.update_block, net, inp, corr, params)
+        net, mask, delta = _update_block_train(model.update_block, net, inp, corr, params, merged)
         params = params + delta                                  # bezier.py:137-139
         ups.append(BezierCurves(cvx_upsample(params, mask)))
     return params, ups

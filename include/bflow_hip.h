@@ -186,6 +186,18 @@ int bflow_blocked_f32_to_nchw(const float* x, float* out, int B, int HW, int C, 
                               bflow_stream_t stream);
 int bflow_pow2_scale(const float* x, long long n, float target, float* out2, void* work8, bflow_stream_t stream);
 int bflow_grad_stats(const float* x, int B, int C, int HW, float target, float* out2, float* partial, float* dbias, bflow_stream_t stream);
+/* SepConvGRU gate arithmetic of the training path, forward and backward (update.py:33-48 under autograd; csrc/gru_gates.hip): fp32 NCHW,
+ * C*HW % 4 == 0, 16-B aligned.  zr_pre (B, 2C, HW) = the z | r pre-activations of one merged convolution.
+ *   bflow_gru_zr_fwd:    z = sigmoid(zr_pre[:, :C]), r = sigmoid(zr_pre[:, C:]), rh = r * h
+ *   bflow_gru_zr_bwd:    dzr_pre = [dz * z(1-z) | drh * h * r(1-r)], dh = drh * r          (dz may be NULL = zeros)
+ *   bflow_gru_blend_fwd: q = tanh(q_pre), h_new = (1 - z) * h + z * q
+ *   bflow_gru_blend_bwd: dq_pre = dh_new * z * (1 - q^2), dz = dh_new * (q - h), dh = dh_new * (1 - z)                                  */
+int bflow_gru_zr_fwd(const float* zr_pre, const float* h, float* z, float* r, float* rh, int B, int C, long long HW, bflow_stream_t stream);
+int bflow_gru_zr_bwd(const float* dz, const float* drh, const float* z, const float* r, const float* h, float* dzr_pre, float* dh, int B, int C,
+                     long long HW, bflow_stream_t stream);
+int bflow_gru_blend_fwd(const float* q_pre, const float* z, const float* h, float* q, float* h_new, int B, int C, long long HW, bflow_stream_t stream);
+int bflow_gru_blend_bwd(const float* dh_new, const float* q, const float* z, const float* h, float* dq_pre, float* dz, float* dh, int B, int C,
+                        long long HW, bflow_stream_t stream);
 /* bflow_wgrad_reduce: dw (Cout, Cin, KH*KW) = inv_scale * sum over the G k-chunks of the engine's blocked fp32 partial results:
  *   orientation 0: part (taps, G, blocks, rows >= Cin, 32), output channel = 32*block + lane;  orientation 1: part (G, blocks, rows >= Cout, 32),
  *   32*block + lane = tap*Cin + ci.                                                                                                  */

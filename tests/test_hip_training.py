@@ -261,6 +261,31 @@ def test_engine_gradients_follow_the_weights_across_optimizer_steps():
     assert worst < 2e-2
 
 
+def test_gru_gate_kernels_match_autograd_fp64():
+    """csrc/gru_gates.hip (bflow_gru_zr_fwd / _bwd, bflow_gru_blend_fwd / _bwd) through their autograd Functions against the reference's
+    chain of element-wise ops (update.py:38-47) under fp64 autograd: values to 2e-6, gradients to 2e-6 of their largest entry."""
+    torch.manual_seed(3)
+    B, C, H, W = 2, 128, 9, 14
+    zr = (torch.randn(B, 2 * C, H, W, device=DEV) * 2).requires_grad_()
+    h = torch.randn(B, C, H, W, device=DEV).requires_grad_()
+    qp = (torch.randn(B, C, H, W, device=DEV) * 2).requires_grad_()
+    w1, w2 = torch.randn(B, C, H, W, device=DEV), torch.randn(B, C, H, W, device=DEV)
+    z, rh = training._GruZRFn.apply(zr, h)
+    hn = training._GruBlendFn.apply(qp + 0.5 * rh, z, h)           # q_pre depends on r*h as in the GRU (through a convolution there)
+    ((hn * w1).sum() + (rh * w2).sum()).backward()
+    zr64, h64, qp64 = (t.detach().double().requires_grad_() for t in (zr, h, qp))
+    z_ref, r_ref = torch.sigmoid(zr64[:, :C]), torch.sigmoid(zr64[:, C:])
+    rh_ref = r_ref * h64
+    q_ref = torch.tanh(qp64 + 0.5 * rh_ref)
+    hn_ref = (1 - z_ref) * h64 + z_ref * q_ref
+    ((hn_ref * w1.double()).sum() + (rh_ref * w2.double()).sum()).backward()
+    assert float((z.double() - z_ref).abs().max()) < 2e-6 and float((rh.double() - rh_ref).abs().max()) < 2e-6
+    assert float((hn.double() - hn_ref).abs().max()) < 2e-6
+    for got, ref, name in ((zr.grad, zr64.grad, "zr_pre"), (h.grad, h64.grad, "h"), (qp.grad, qp64.grad, "q_pre")):
+        e = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert e < 2e-6, (name, e)
+
+
 def test_graphed_train_step_matches_eager_steps():
     """training.GraphedTrainStep: forward + loss + backward + AdamW recorded as ONE hipGraph and replayed must train like the eager
     step -- same losses step by step (the filter packs are re-built INSIDE the graph from the weights AdamW just wrote, the learning
