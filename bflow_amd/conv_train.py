@@ -110,14 +110,13 @@ class _ConvFn(torch.autograd.Function):
         _, _, Ho, Wo = dy.shape
         dx = dw = db = None
         with torch.no_grad():
+            sc, dbs = S.grad_stats(dy, _TARGET)                  # {s, 1/s, s per channel} on the device and the bias gradient, one pass over dy
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                sc, db = S.grad_stats(dy, _TARGET)               # {s, 1/s} on the device and the bias gradient, one pass over dy
-            else:
-                sc = S.pow2_scale(dy, _TARGET)
-            s, inv = sc[0:1], sc[1:2]
+                db = dbs
+            s, inv, svec = sc[0:1], sc[1:2], sc[2:]
             gs = None
             if stride == 1 and (ctx.needs_input_grad[0] or (ctx.halo and ctx.needs_input_grad[1])):
-                gs = S.from_nchw(dy, s)                          # dY in the engine's layout, pre-scaled: shared by dgrad and wgrad
+                gs = S.from_nchw(dy, scale_vec=svec)             # dY in the engine's layout, pre-scaled: shared by dgrad and wgrad
             if ctx.needs_input_grad[0]:
                 packed = cache.get("bwd", w, ctx.srcs)
                 if stride == 1:
@@ -125,7 +124,7 @@ class _ConvFn(torch.autograd.Function):
                 else:                                            # zero-dilated dy: position (yo*stride, xo*stride) of the stride-1 output grid
                     g = torch.zeros((B, cout, H + 2 * ph - kh + 1, W + 2 * pw - kw + 1), dtype=torch.float32, device=dy.device)
                     g[:, :, ::stride, ::stride][:, :, :Ho, :Wo] = dy
-                    g_in = S.from_nchw(g, s)
+                    g_in = S.from_nchw(g, scale_vec=svec)
                 _, xf = S.conv(g_in, packed, stride=1, padding=(kh - 1 - ph, kw - 1 - pw), want_split=False, want_f32=True)
                 dx = S.blocked_f32_to_nchw(xf, cin, H, W, inv)
             if ctx.needs_input_grad[1]:

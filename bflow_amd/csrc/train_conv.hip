@@ -174,13 +174,16 @@ __global__ __launch_bounds__(256) void grad_stats_final_kernel(const float* __re
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
+    __shared__ float s_scale;
     if (threadIdx.x == 0) {
         const float amax = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
         float e = floorf(log2f(target / amax));
         if (!(amax > 0.f) || !(fabsf(e) <= 60.f)) e = (amax > 0.f && e > 60.f) ? 60.f : (amax > 0.f && e < -60.f ? -60.f : 0.f);
-        out[0] = exp2f(e);
+        out[0] = s_scale = exp2f(e);
         out[1] = exp2f(-e);
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) out[2 + c] = s_scale;       // the scale once per channel: bflow_norm_act_split's scale_a of the staging pass
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = 0.f;
         for (int b = 0; b < B; ++b) {

@@ -383,9 +383,10 @@ def pow2_scale(x: torch.Tensor, target: float) -> torch.Tensor:
 
 
 def grad_stats(dy: torch.Tensor, target: float):
-    """({s, 1/s}, dbias): the power-of-two scale of `pow2_scale` and the per-channel sum of an NCHW gradient in one pass (bflow_grad_stats)."""
+    """({s, 1/s, s x C}, dbias): the power-of-two scale of `pow2_scale` (and C copies of it: `from_nchw(dy, scale_vec=out[2:])`) and the
+    per-channel sum of an NCHW gradient in one pass (bflow_grad_stats)."""
     B, C, H, W = dy.shape
-    out = torch.empty(2, dtype=torch.float32, device=dy.device)
+    out = torch.empty(2 + C, dtype=torch.float32, device=dy.device)
     db = torch.empty(C, dtype=torch.float32, device=dy.device)
     partial = torch.empty(B * C * ((H * W + 1023) // 1024) + 1024, dtype=torch.float32, device=dy.device)
     hip._check(hip.lib().bflow_grad_stats(hip._dev(dy, name="dy"), B, C, H * W, float(target), out.data_ptr(), partial.data_ptr(), db.data_ptr(),
@@ -437,17 +438,20 @@ def norm_act(a: torch.Tensor, shape_bhwc, a_is_nchw: bool = False, stats_a: Opti
 _zeros_c = {}
 
 
-def from_nchw(x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> SplitTensor:
-    """NCHW fp32 -> blocked split (identity transform, or times a 1-element device tensor `scale`); channels are zero-padded to the
-    next multiple of 32."""
+def from_nchw(x: torch.Tensor, scale: Optional[torch.Tensor] = None, scale_vec: Optional[torch.Tensor] = None) -> SplitTensor:
+    """NCHW fp32 -> blocked split (identity transform, or times a 1-element device tensor `scale`, or times the (C,) device vector
+    `scale_vec`); channels are zero-padded to the next multiple of 32."""
     B, C, H, W = x.shape
-    if scale is None:
+    if scale is None and scale_vec is None:
         out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True)
     else:
         zkey = (C, x.device.index)
         if zkey not in _zeros_c:
             _zeros_c[zkey] = torch.zeros(C, dtype=torch.float32, device=x.device)
-        out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True, scale_a=scale.reshape(1).expand(C).contiguous(), shift_a=_zeros_c[zkey])
+        if scale_vec is None:
+            scale_vec = scale.reshape(1).expand(C).contiguous()
+        assert scale_vec.shape == (C,) and scale_vec.is_contiguous()
+        out, _ = norm_act(x.float().contiguous(), (B, H, W, C), a_is_nchw=True, scale_a=scale_vec, shift_a=_zeros_c[zkey])
     return out
 
 

@@ -177,7 +177,8 @@ int bflow_conv_split(const bflow_conv_desc_t* desc, bflow_stream_t stream);
  * bflow_pow2_scale: out2 = { s, 1/s } with s = 2^floor(log2(target / max|x|)) (1 for an all-zero / non-finite tensor), on the device;
  *   work8: 8 bytes, zero before the first call (the kernel leaves them zero).  Gradients of 1e-4..1e-9 are pre-scaled by s into fp16's
  *   normal range before they enter the split format and the results scaled back: exact in binary floating point.
- * bflow_grad_stats: the same {s, 1/s} for an NCHW gradient (B, C, HW) AND dbias[c] = sum over (b, pixel) -- the bias gradient autograd
+ * bflow_grad_stats: out2 = {s, 1/s, s x C} (2 + C floats: the scale again once per channel, = scale_a of the bflow_norm_act_split pass that
+ *   stages the gradient) for an NCHW gradient (B, C, HW) AND dbias[c] = sum over (b, pixel) -- the bias gradient autograd
  *   derives for torch.nn.Conv2d -- in one pass over x; partial: scratch of B*C*ceil(HW/1024) + 1024 floats (per-segment sums and
  *   per-workgroup maxima, combined in a fixed order by a second, one-workgroup launch: deterministic, no atomics).                 */
 int bflow_wgrad_pack(const float* src, void* dst_hi, void* dst_lo, int B, int C, int H, int W, int Ho, int Wo, int KH, int KW, int stride,
