@@ -362,7 +362,22 @@ class TrainStep:
         self.model, self.iters = model, int(num_iter_train)
         self.use_events, self.use_images, self.multi_loss = use_events, use_images, multi_loss
 
-    def __call__(self, batch: Dict[Any, Any]) -> Dict[str, Any]:
+    @staticmethod
+    def timestamps(batch: Dict[Any, Any]) -> Optional[List[float]]:
+        """MultiFlow: the GT timestamps as host floats (one per GT, equal along the batch: modules/raft_spline.py:135-139) -- a device
+        synchronisation; DSEC: None."""
+        tss = _get(batch, DataLoading.FLOW_TIMESTAMPS)
+        if tss is None:
+            return None
+        times = []
+        for ts in tss:
+            if ts.numel() > 1:
+                assert 0 <= (ts[1:] - ts[:-1]).abs().mean().item() < 0.001
+            times.append(float(ts[0].item()))
+        return times
+
+    def __call__(self, batch: Dict[Any, Any], times: Optional[List[float]] = None) -> Dict[str, Any]:
+        """times: the result of `timestamps(batch)` when the caller already has it (GraphedTrainStep reads it outside its capture)."""
         gt = _get(batch, DataLoading.FLOW)
         valid = _get(batch, DataLoading.FLOW_VALID)
         ev = _get(batch, DataLoading.EV_REPR)
@@ -380,11 +395,7 @@ class TrainStep:
             out.update(loss=l1_seq_loss_channel_masked(flows, gt, valid), pred=flows[-1], gt=gt, gt_valid=valid)
             return out
         if ds == DataSetType.MULTIFLOW2D.name:
-            times = []
-            for ts in _get(batch, DataLoading.FLOW_TIMESTAMPS):   # one (N,) tensor per GT: equal along the batch (:135-139)
-                if ts.numel() > 1:
-                    assert 0 <= (ts[1:] - ts[:-1]).abs().mean().item() < 0.001
-                times.append(float(ts[0].item()))
+            times = self.timestamps(batch) if times is None else times
             flows = [[p.get_flow_from_reference(t) for t in times] for p in preds]
             loss = l1_multi_seq_loss_channel_masked(flows, gt) if self.multi_loss else l1_seq_loss_channel_masked(flows[-1], gt[-1])
             out.update(loss=loss, pred=flows[-1][-1], gt=gt)
@@ -410,18 +421,38 @@ class GraphedTrainStep:
         every other node (stream-ordered collectives are capturable).  On one rank it is a no-op."""
         self.step, self.opt, self.sch, self.warmup, self.grad_sync = step, optimizer, scheduler, int(warmup), grad_sync
         self._sig = None
+        self._times = None
         self._graph = None
 
     @staticmethod
-    def _signature(batch) -> Tuple:
-        sig = []
-        for k in sorted(batch, key=str):
-            v = batch[k]
-            sig.append((str(k), (tuple(v.shape), str(v.dtype)) if torch.is_tensor(v) else repr(v)))
-        return tuple(sig)
+    def _sig_of(v):
+        if torch.is_tensor(v):
+            return (tuple(v.shape), str(v.dtype), str(v.device))
+        if isinstance(v, (list, tuple)):
+            return tuple(GraphedTrainStep._sig_of(x) for x in v)
+        return repr(v)
+
+    @staticmethod
+    def _clone(v):
+        if torch.is_tensor(v):
+            return v.clone()
+        if isinstance(v, (list, tuple)):
+            return type(v)(GraphedTrainStep._clone(x) for x in v)
+        return v
+
+    @staticmethod
+    def _copy_into(dst, src):
+        if torch.is_tensor(dst):
+            dst.copy_(src)
+        elif isinstance(dst, (list, tuple)):
+            for d, s_ in zip(dst, src):
+                GraphedTrainStep._copy_into(d, s_)
+
+    def _signature(self, batch, times) -> Tuple:
+        return tuple((str(k), self._sig_of(batch[k])) for k in sorted(batch, key=str)) + (("times", tuple(times) if times else None),)
 
     def _run(self, batch):
-        out = self.step(batch)
+        out = self.step(batch, times=self._times)
         out["loss"].backward()
         if self.grad_sync is not None:
             self.grad_sync.finish()
@@ -430,7 +461,7 @@ class GraphedTrainStep:
 
     def _capture(self, batch):
         import gc
-        self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        self._static = {k: self._clone(v) for k, v in batch.items()}
         # warm-up on a side stream (lazy state: AdamW moments -- created INSIDE a capture they would be re-zeroed by every replay --,
         # device constants, allocator growth), then undone: parameters, buffers and optimiser state are put back, so neither the
         # warm-up nor the capture counts as a training step
@@ -474,17 +505,17 @@ class GraphedTrainStep:
                 gc.enable()
 
     def __call__(self, batch: Dict[Any, Any]) -> Dict[str, Any]:
-        sig = self._signature(batch)
+        times = self.step.timestamps(batch)                 # MultiFlow: host floats frozen into the graph (Bezier coefficient tables) -> part of the signature
+        sig = self._signature(batch, times)
         first = self._sig != sig
         if first:
             if self._graph is not None:
                 torch.cuda.synchronize()
                 self._graph = None
-            self._sig = sig
+            self._sig, self._times = sig, times
             self._capture(batch)                            # warm-up steps + the capture itself do NOT count as training steps of `batch` ...
         for k, v in batch.items():
-            if torch.is_tensor(v):
-                self._static[k].copy_(v)
+            self._copy_into(self._static[k], v)
         self._graph.replay()                                # ... this replay does
         # the replay rewrote parameters, BatchNorm buffers and optimiser state behind autograd's back: bump their version counters (no
         # launch), every cache keyed on them -- packed filters of the inference engine, captured inference graphs -- then sees the change
