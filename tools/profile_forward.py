@@ -12,7 +12,11 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--iters", type=int, default=12)
 ap.add_argument("--graph", action="store_true")
+ap.add_argument("--no-branch", action="store_true", help="every side-stream branch on the main stream (hip.BRANCHING = False)")
 args = ap.parse_args()
+if args.no_branch:
+    from bflow_amd import hip as _hip
+    _hip.BRANCHING = False
 dev = torch.device("cuda:0")
 torch.backends.cudnn.benchmark = True
 cfg = configs.model_config("E_LU4_BD2")
