@@ -257,6 +257,7 @@ class _GruBlendFn(torch.autograd.Function):
 
 
 FUSED_GATES = True                  # tools / A-B: False = the reference's chain of element-wise torch ops under autograd
+HOIST_INP = True                    # the context features' share of the GRU gate convolutions once per forward instead of once per iteration
 
 
 def _update_block_train(ub, net, inp, corr, bezier, merged=None):
@@ -268,23 +269,43 @@ def _update_block_train(ub, net, inp, corr, bezier, merged=None):
     cor = F.relu(enc.convc2(F.relu(enc.convc1(corr))))
     bez = F.relu(enc.convf2(F.relu(enc.convf1(bezier))))
     motion = torch.cat([F.relu(enc.conv(torch.cat([cor, bez], dim=1))), bezier], dim=1)
-    x = torch.cat([inp, motion], dim=1)
     hd = ub.hidden_dim
+    cd = inp.shape[1]
     merged = {} if merged is None else merged
+    hoist = HOIST_INP and inp.is_cuda
+    x = None if hoist else torch.cat([inp, motion], dim=1)
     for sfx in ("1", "2"):
         cz, cr, cq = (getattr(gru, f"conv{g}{sfx}") for g in "zrq")
+        pad = cz.padding
         if sfx not in merged:
-            merged[sfx] = (torch.cat([cz.weight, cr.weight], dim=0), torch.cat([cz.bias, cr.bias], dim=0))
-        wzr, bzr = merged[sfx]
-        zr = conv_train.conv2d(torch.cat([net, x], dim=1), wzr, bzr, cz.padding,
-                               gru.__dict__.setdefault("_zr_pack" + sfx, conv_train._PackCache()), (cz.weight, cr.weight))
-        if FUSED_GATES and zr.is_cuda and (hd * net.shape[2] * net.shape[3]) % 4 == 0:
+            wzr, bzr = torch.cat([cz.weight, cr.weight], dim=0), torch.cat([cz.bias, cr.bias], dim=0)
+            if hoist:
+                # the GRU input is cat(h, inp, motion) and `inp` does not change over the iterations (raft.py:145-147): its share of every
+                # gate convolution is computed ONCE per forward (as the inference path does, update.py prepare_inp) and added per iteration
+                pc = lambda tag: gru.__dict__.setdefault("_pack_" + tag + sfx, conv_train._PackCache())
+                srcs_zr, srcs_q = (cz.weight, cr.weight), (cq.weight,)
+                t_zr = conv_train.conv2d(inp, wzr[:, hd:hd + cd].contiguous(), bzr, pad, pc("zr_inp"), srcs_zr)
+                t_q = conv_train.conv2d(inp, cq.weight[:, hd:hd + cd].contiguous(), cq.bias, pad, pc("q_inp"), srcs_q)
+                w_zr = torch.cat([wzr[:, :hd], wzr[:, hd + cd:]], dim=1)
+                w_q = torch.cat([cq.weight[:, :hd], cq.weight[:, hd + cd:]], dim=1)
+                merged[sfx] = (w_zr, t_zr, w_q, t_q, pc("zr_hm"), pc("q_hm"), srcs_zr, srcs_q)
+            else:
+                merged[sfx] = (wzr, bzr)
+        if hoist:
+            w_zr, t_zr, w_q, t_q, pk_zr, pk_q, srcs_zr, srcs_q = merged[sfx]
+            zr = conv_train.conv2d(torch.cat([net, motion], dim=1), w_zr, None, pad, pk_zr, srcs_zr) + t_zr
+        else:
+            wzr, bzr = merged[sfx]
+            zr = conv_train.conv2d(torch.cat([net, x], dim=1), wzr, bzr, pad,
+                                   gru.__dict__.setdefault("_zr_pack" + sfx, conv_train._PackCache()), (cz.weight, cr.weight))
+        fused = FUSED_GATES and zr.is_cuda and (hd * net.shape[2] * net.shape[3]) % 4 == 0
+        if fused:
             z, rh = _GruZRFn.apply(zr, net)
-            net = _GruBlendFn.apply(cq(torch.cat([rh, x], dim=1)), z, net)
         else:
             z, r = torch.sigmoid(zr[:, :hd]), torch.sigmoid(zr[:, hd:])
-            q = torch.tanh(cq(torch.cat([r * net, x], dim=1)))
-            net = (1 - z) * net + z * q
+            rh = r * net
+        q_pre = (conv_train.conv2d(torch.cat([rh, motion], dim=1), w_q, None, pad, pk_q, srcs_q) + t_q) if hoist else cq(torch.cat([rh, x], dim=1))
+        net = _GruBlendFn.apply(q_pre, z, net) if fused else (1 - z) * net + z * torch.tanh(q_pre)
     delta = ub.bezier_head.conv2(F.relu(ub.bezier_head.conv1(net)))
     mask = 0.25 * ub.mask(net)
     return net, mask, delta
