@@ -83,7 +83,7 @@ def _halo_wgrad_ok(stride: int, padding, ksize) -> bool:
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, cache, srcs):
+    def forward(ctx, x, weight, bias, stride, padding, cache, srcs, relu=False):
         x = x.float().contiguous()
         cout, cin, kh, kw = weight.shape
         ctx.stride, ctx.padding, ctx.cache, ctx.srcs, ctx.has_bias = stride, padding, cache, srcs, bias is not None
@@ -92,17 +92,20 @@ class _ConvFn(torch.autograd.Function):
             packed = cache.get("fwd", weight, srcs)
             xs = S.from_nchw(x)
             _, yf = S.conv(xs, packed, stride=stride, padding=padding, shift=None if bias is None else bias.detach().float().contiguous(),
-                           want_split=False, want_f32=True)
+                           act=S.ACT_RELU if relu else S.ACT_NONE, want_split=False, want_f32=True)
             Ho, Wo = (x.shape[2] + 2 * padding[0] - kh) // stride + 1, (x.shape[3] + 2 * padding[1] - kw) // stride + 1
             y = S.blocked_f32_to_nchw(yf, cout, Ho, Wo)
         ctx.halo = _halo_wgrad_ok(stride, padding, (kh, kw))
         # the weight gradient reads X: in the engine's own layout (as staged for the forward) where bflow_conv_wgrad_halo takes it
-        ctx.save_for_backward(xs.planes if ctx.halo else x, weight)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(xs.planes if ctx.halo else x, weight, *((y,) if relu else ()))      # ReLU in the conv epilogue: its mask is y > 0
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xsaved, w = ctx.saved_tensors
+        xsaved, w = ctx.saved_tensors[:2]
+        if ctx.relu:
+            dy = torch.ops.aten.threshold_backward(dy.float(), ctx.saved_tensors[2], 0.0)
         stride, (ph, pw), cache = ctx.stride, ctx.padding, ctx.cache
         cout, cin, kh, kw = w.shape
         B, _, H, W = ctx.xshape
@@ -138,7 +141,7 @@ class _ConvFn(torch.autograd.Function):
                         _DEBUG_CMP.append((e, (B, cin, cout, H, W, kh, kw), float(ref.abs().max())))
                 else:
                     dw = _weight_grad(xsaved, dy, s, inv, (kh, kw), stride, (ph, pw))
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def _pad_ratio(n: int, t: int = 128) -> float:
@@ -184,13 +187,18 @@ def _weight_grad(x: torch.Tensor, dy: torch.Tensor, s: torch.Tensor, inv: torch.
 class Conv2d(nn.Conv2d):
     """nn.Conv2d whose GPU forward under autograd runs (and differentiates) on the HIP conv engine.  State-dict compatible."""
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
         if (ENABLED and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad) and self.groups == 1
                 and self.dilation == (1, 1) and self.stride[0] == self.stride[1] and self.stride[0] in (1, 2) and self.padding_mode == "zeros"
                 and not isinstance(self.padding, str)):
             cache = self.__dict__.setdefault("_hip_pack", _PackCache())
-            return _ConvFn.apply(x, self.weight, self.bias, self.stride[0], tuple(self.padding), cache, (self.weight,))
-        return super().forward(x)
+            return _ConvFn.apply(x, self.weight, self.bias, self.stride[0], tuple(self.padding), cache, (self.weight,), relu)
+        y = super().forward(x)
+        return torch.relu(y) if relu else y
+
+    def relu(self, x: torch.Tensor) -> torch.Tensor:
+        """relu(conv(x)): the activation runs in the convolution's epilogue on the engine path (one launch less, forward)."""
+        return self.forward(x, relu=True)
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias, padding, cache: _PackCache, srcs, stride: int = 1) -> torch.Tensor:

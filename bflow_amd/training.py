@@ -266,9 +266,9 @@ def _update_block_train(ub, net, inp, corr, bezier, merged=None):
     a half is two fused launches (csrc/gru_gates.hip).  `merged`: dict the caller keeps for ONE forward -- the z|r filters / biases are
     concatenated once per forward, not once per iteration."""
     enc, gru = ub.encoder, ub.gru
-    cor = F.relu(enc.convc2(F.relu(enc.convc1(corr))))
-    bez = F.relu(enc.convf2(F.relu(enc.convf1(bezier))))
-    motion = torch.cat([F.relu(enc.conv(torch.cat([cor, bez], dim=1))), bezier], dim=1)
+    cor = enc.convc2.relu(enc.convc1.relu(corr))                 # relu(conv(.)): the activation is the convolution's epilogue
+    bez = enc.convf2.relu(enc.convf1.relu(bezier))
+    motion = torch.cat([enc.conv.relu(torch.cat([cor, bez], dim=1)), bezier], dim=1)
     hd = ub.hidden_dim
     cd = inp.shape[1]
     merged = {} if merged is None else merged
@@ -306,8 +306,8 @@ def _update_block_train(ub, net, inp, corr, bezier, merged=None):
             rh = r * net
         q_pre = (conv_train.conv2d(torch.cat([rh, motion], dim=1), w_q, None, pad, pk_q, srcs_q) + t_q) if hoist else cq(torch.cat([rh, x], dim=1))
         net = _GruBlendFn.apply(q_pre, z, net) if fused else (1 - z) * net + z * torch.tanh(q_pre)
-    delta = ub.bezier_head.conv2(F.relu(ub.bezier_head.conv1(net)))
-    mask = 0.25 * ub.mask(net)
+    delta = ub.bezier_head.conv2(ub.bezier_head.conv1.relu(net))
+    mask = 0.25 * ub.mask[2](ub.mask[0].relu(net))               # nn.Sequential(conv, ReLU, conv) (update.py:111-114)
     return net, mask, delta
 
 

@@ -810,6 +810,27 @@ def test_conv_train_forward_backward_vs_fp64(cin, cout, k, stride, pad, H, W, B,
     assert e_y < 2e-6 and e_dx < 5e-6 and e_dw < 5e-6 and e_db < 1e-5
 
 
+def test_conv_train_relu_epilogue_vs_fp64():
+    """conv_train.Conv2d.relu (the activation in the conv epilogue; its mask = y > 0 in the backward) against relu(conv) under fp64 autograd."""
+    from bflow_amd import conv_train as CT
+    torch.manual_seed(2)
+    for (cin, cout, k, pad, H, W, B) in ((64, 96, 3, 1, 19, 23, 2), (128, 64, 1, 0, 12, 16, 1)):
+        m = CT.Conv2d(cin, cout, k, padding=pad).to(DEV)
+        x = torch.randn(B, cin, H, W, device=DEV, requires_grad=True)
+        wgt = torch.randn(B, cout, H, W, device=DEV)
+        y = m.relu(x)
+        (y * wgt).sum().backward()
+        x64 = x.detach().double().requires_grad_()
+        w64, b64 = m.weight.detach().double().requires_grad_(), m.bias.detach().double().requires_grad_()
+        y64 = torch.relu(torch.nn.functional.conv2d(x64, w64, b64, padding=pad))
+        (y64 * wgt.double()).sum().backward()
+        assert float((y.double() - y64).abs().max()) < 5e-6
+        assert float((y == 0).float().mean()) > 0.2                                 # the mask is exercised
+        for got, ref, name in ((x.grad, x64.grad, "dx"), (m.weight.grad, w64.grad, "dw"), (m.bias.grad, b64.grad, "db")):
+            e = float((got.double() - ref).abs().max() / ref.abs().max())
+            assert e < 5e-6, (name, e)
+
+
 def test_conv_train_filter_caches_follow_in_place_updates():
     """The packed forward filter and the flipped / transposed backward filter are cached per parameter version: after an in-place
     update (what an optimiser step is) forward, input and weight gradient must use the NEW filter -- module and functional form
