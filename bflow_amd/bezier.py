@@ -148,5 +148,7 @@ class BezierCurves:
         if self._params.is_cuda and not (torch.is_grad_enabled() and self._params.requires_grad):
             flows = hip.bezier_eval(self._params.contiguous().float(), coef, add_coords0=False)
         else:  # host-resident container (see module docstring)
-            flows = torch.einsum("bdphw,tp->tbdhw", pv, hip.const_tensor(coef, pv.device) if pv.is_cuda else torch.from_numpy(coef))
+            cf = (hip.const_tensor(coef, pv.device) if pv.is_cuda else torch.from_numpy(coef)).to(pv.dtype)
+            # sum_p pv[b, d, p] * cf[t, p] as a broadcast product (identical to the reference's einsum up to summation order; no library GEMM)
+            flows = (pv.unsqueeze(0) * cf.view(cf.shape[0], 1, 1, degree, 1, 1)).sum(dim=3)
         return flows[0] if scalar else flows

@@ -114,6 +114,43 @@ __global__ __launch_bounds__(256) void pow2_scale_kernel(const float* __restrict
     }
 }
 
+// x (R, P, C) fp32 row-major [pixel][channel] -> blocked split (R, CB, P, 32), value * scale, channels >= C zero: the activation operand of the
+// conv engine from a ROW-major matrix (bflow_norm_act_split stages the column-major / NCHW case).  thread = 8 channels of one pixel.
+__global__ __launch_bounds__(256) void rows_to_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int R,
+                                                            int P, int C, int CB, const float* __restrict__ scale_p) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const float scale = scale_p ? *scale_p : 1.f;
+    const long long total = (long long)R * CB * P * 4;
+    const bool vec = (C & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int chunk = (int)(i & 3);
+        const long long t1 = i >> 2;
+        const int p = (int)(t1 % P);
+        const long long t2 = t1 / P;
+        const int cb = (int)(t2 % CB), r = (int)(t2 / CB);
+        const int c0 = cb * 32 + chunk * 8;
+        const float* src = x + ((long long)r * P + p) * C + c0;
+        float v[8];
+        if (vec && c0 + 8 <= C) {
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = c0 + j < C ? src[j] : 0.f;
+        }
+        half8 h8, l8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 hh, ll;
+            bflow::split1(v[j] * scale, hh, ll);
+            h8[j] = hh;
+            l8[j] = ll;
+        }
+        *reinterpret_cast<half8*>(hi + i * 8) = h8;      // (((r * CB + cb) * P + p) * 4 + chunk) * 8 == i * 8
+        *reinterpret_cast<half8*>(lo + i * 8) = l8;
+    }
+}
+
 // bflow_grad_stats: ONE pass over an NCHW gradient for both things the backward of a convolution needs from all of it: the power-of-two
 // scale (as pow2_scale_kernel) and the bias gradient db[c] = sum over (b, y, x).  Two launches instead of tickets and fences (a release
 // fence is an L2 write-back on this chip): grad_stats_kernel -- one WAVE per item = (plane, segment of GS_SEG elements), four independent
@@ -257,6 +294,15 @@ extern "C" int bflow_pow2_scale(const float* x, long long n, float target, float
     const int blocks = (int)std::min<long long>(512, (n + 16383) / 16384);
     hipLaunchKernelGGL(pow2_scale_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, x, n, target, out2, (unsigned*)work8);
     return bflow::launch_status("pow2_scale");
+}
+
+extern "C" int bflow_rows_to_split(const float* x, void* out_hi, void* out_lo, int R, int P, int C, const float* scale, bflow_stream_t stream) {
+    BFLOW_REQUIRE(x && out_hi && out_lo && R > 0 && P > 0 && C > 0, BFLOW_E_ARG, "rows_to_split: bad arguments");
+    const int CB = (C + 31) / 32;
+    const long long total = (long long)R * CB * P * 4;
+    hipLaunchKernelGGL(rows_to_split_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)out_hi, (_Float16*)out_lo,
+                       R, P, C, CB, scale);
+    return bflow::launch_status("rows_to_split");
 }
 
 extern "C" int bflow_grad_stats(const float* x, int B, int C, int HW, float target, float* out2, float* partial, float* dbias, bflow_stream_t stream) {

@@ -455,6 +455,17 @@ def from_nchw(x: torch.Tensor, scale: Optional[torch.Tensor] = None, scale_vec: 
     return out
 
 
+def from_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> SplitTensor:
+    """(R, P, C) fp32 row-major [pixel][channel] -> SplitTensor of R images with P pixel rows (H = 1, W = P) and C channels, times the
+    1-element device tensor `scale` (bflow_rows_to_split)."""
+    R, P, C = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = SplitTensor.empty(R, 1, P, C, x.device)
+    hip._check(hip.lib().bflow_rows_to_split(hip._dev(x, name="x"), out.hi.data_ptr(), out.lo.data_ptr(), R, P, C,
+                                             None if scale is None else scale.data_ptr(), hip._stream()), "bflow_rows_to_split")
+    return out
+
+
 def bezier_update(params: torch.Tensor, delta: Optional[torch.Tensor], dst: SplitTensor, dst_block: int,
                   dst2: Optional[SplitTensor] = None, dst2_block: int = 0):
     """params (B, 2deg, h, w) fp32 += delta (blocked fp32, first 2deg channels); re-emit as split channel block(s)."""

@@ -3,7 +3,8 @@
 What runs where:
     K5 correlation volume, K6 pyramid, K7 look-up, K13 convex up-sampling, masked L1   forward AND backward on the HIP kernels
                                                                                        (csrc/backward.hip: hand-written adjoints)
-    K5 backward (two plain GEMMs per target, K = N)                                     rocBLAS through torch.matmul
+    K5 backward (two GEMMs per target, K = N)                                           the conv engine as a batch of 1x1 convolutions with one
+                                                                                       filter per image (_volume_adjoint_engine)
     convolutions (forward, input and weight gradient)                                   the split-fp16 conv engine + bflow_conv_wgrad_halo
                                                                                        (conv_train.py: custom autograd Function)
     norms / activations / GRU gate arithmetic                                           torch element-wise ops under autograd
@@ -27,6 +28,7 @@ import torch
 import torch.nn.functional as F
 
 from . import conv_train, hip
+from . import split as S
 from .bezier import BezierCurves
 from .corr import CorrBlockParallelMultiTarget, CorrComputation
 from .validation import DataLoading, DataSetType, _get
@@ -95,8 +97,11 @@ class TrainCorrBlock:
             a = f1.float().reshape(B, D, N)
             b = f2.float().reshape(tg, B, D, N)
             s = 1.0 / math.sqrt(D)
-            gf1 = torch.matmul(b, dC.transpose(-1, -2)).sum(dim=0).mul_(s)      # (B, D, N): sum_t f2[t] @ dC[t]^T
-            gf2 = torch.matmul(a.unsqueeze(0), dC).mul_(s)                     # (tg, B, D, N): f1 @ dC[t]
+            if NATIVE_VOLUME_ADJOINT and dC.is_cuda and D % 32 == 0:
+                gf1, gf2 = _volume_adjoint_engine(dC, a, b, s)
+            else:
+                gf1 = torch.matmul(b, dC.transpose(-1, -2)).sum(dim=0).mul_(s)      # (B, D, N): sum_t f2[t] @ dC[t]^T
+                gf2 = torch.matmul(a.unsqueeze(0), dC).mul_(s)                     # (tg, B, D, N): f1 @ dC[t]
             out += [gf1.view(B, D, h, w).to(f1.dtype), gf2.view(tg, B, D, h, w).to(f2.dtype)]
             t0 += tg
         assert t0 == T
@@ -107,6 +112,47 @@ class TrainCorrBlock:
     def lookup_bezier(self, params: torch.Tensor, coef: np.ndarray) -> torch.Tensor:
         """(B, 2*deg, h, w) Bezier parameters -> (B, P*81, h, w) correlation features, differentiable in params and the volume."""
         return _LookupBezierFn.apply(self, coef, params, self.token)
+
+
+NATIVE_VOLUME_ADJOINT = True        # tools / A-B: False = the two GEMMs per target through torch.matmul (rocBLAS)
+
+
+def _stacked_filters(w: torch.Tensor, n_pad: int):
+    """w (S, D, N): S filters of a 1x1 "convolution" with N input channels -> packed for bflow_conv_desc_t.weight_sets = S (filter set s =
+    k-tiles [s * n_pad / 32, (s + 1) * n_pad / 32))."""
+    S_, D, N = w.shape
+    if N == n_pad:
+        flat = w.permute(1, 0, 2).reshape(D, S_ * N, 1, 1)
+    else:
+        flat = torch.zeros((D, S_, n_pad), dtype=torch.float32, device=w.device)
+        flat[:, :, :N] = w.permute(1, 0, 2)
+        flat = flat.reshape(D, S_ * n_pad, 1, 1)
+    planes, (cout, _, _, _, cout_pad) = S.PackedConvWeight().get(flat.contiguous())
+    return planes, (cout, n_pad, 1, 1, cout_pad)
+
+
+def _volume_adjoint_engine(dC: torch.Tensor, f1: torch.Tensor, f2: torch.Tensor, s: float):
+    """The adjoint of CorrComputation._corr_dot_prod_util (corr.py:264-272) on the split-fp16 conv engine instead of rocBLAS:
+        d f1[b, d, n] = s * sum_t sum_m f2[t, b, d, m] dC[t, b, n, m]        d f2[t, b, d, m] = s * sum_n f1[b, d, n] dC[t, b, n, m]
+    Both are 1x1 "convolutions" over N pixels with N input channels and one filter per image (weight_sets): for d f2 the pixel index is m and
+    dC[t, b] (n-major) IS the NCHW operand; for d f1 the pixel index is n and the row-major dC is staged by bflow_rows_to_split.  dC (values
+    of 1e-6 ... 1e-9) is pre-scaled by a device-side power of two, as in conv_train."""
+    tg, B, N, _ = dC.shape
+    D = f1.shape[1]
+    n_pad = (N + 31) // 32 * 32
+    dCf = dC.reshape(tg * B, N, N).contiguous()
+    sc = S.pow2_scale(dCf, conv_train._TARGET)
+    sc_s = sc * s                                                   # {s_pow2 * s (unused), s / s_pow2}: the un-scaling also applies 1 / sqrt(D)
+    inv = sc_s[1:2]
+    # d f2: image (t, b), pixel m, channel n; filter of image (t, b) = f1[b]  (image index % B == b)
+    x2 = S.from_nchw(dCf.view(tg * B, N, 1, N), sc[0:1])
+    _, o2 = S.conv(x2, _stacked_filters(f1, n_pad), want_split=False, want_f32=True, weight_sets=B, tile=128)
+    gf2 = S.blocked_f32_to_nchw(o2, D, 1, N, inv).view(tg, B, D, N)
+    # d f1: image (t, b), pixel n, channel m; filter of image (t, b) = f2[t, b]; summed over t
+    x1 = S.from_rows(dCf, sc[0:1])
+    _, o1 = S.conv(x1, _stacked_filters(f2.reshape(tg * B, D, N), n_pad), want_split=False, want_f32=True, weight_sets=tg * B, tile=128)
+    gf1 = S.blocked_f32_to_nchw(o1, D, 1, N, inv).view(tg, B, D, N).sum(dim=0)
+    return gf1, gf2
 
 
 class _CorrBlockFn(torch.autograd.Function):
@@ -144,7 +190,8 @@ class _LookupBezierFn(torch.autograd.Function):
         for k, t in enumerate(block._plane_targets):          # planes of one target (its pyramid levels), fixed order
             gt[t] += gc[k]
         cf = hip.const_tensor(coef, p.device)
-        gp = torch.einsum("tbdhw,tp->bdphw", gt, cf).reshape(B, 2 * deg, h, w)
+        # sum_t gt[t, b, d] * cf[t, p] as a broadcast product (T, deg <= 16: an einsum would go through a library GEMM)
+        gp = (gt.unsqueeze(3) * cf.view(T, 1, 1, deg, 1, 1).to(gt.dtype)).sum(dim=0).reshape(B, 2 * deg, h, w)
         return None, None, gp, torch.zeros(1, dtype=torch.float32, device=p.device)
 
 

@@ -186,6 +186,10 @@ int bflow_wgrad_pack(const float* src, void* dst_hi, void* dst_lo, int B, int C,
 int bflow_blocked_f32_to_nchw(const float* x, float* out, int B, int HW, int C, int channel_blocks, int rows_per_image, const float* scale,
                               bflow_stream_t stream);
 int bflow_pow2_scale(const float* x, long long n, float target, float* out2, void* work8, bflow_stream_t stream);
+/* bflow_rows_to_split: x (R, P, C) fp32 row-major [pixel][channel] -> blocked split (R, ceil(C/32), P, 32) = scale * x (pad channels zero): the
+ *   engine's activation operand from a row-major matrix -- the adjoint of CorrComputation._corr_dot_prod_util (corr.py:264-272) contracts the
+ *   volume gradient dC[n, m] over m for d f1 and over n for d f2; bflow_norm_act_split stages the second (NCHW-like) case, this the first.        */
+int bflow_rows_to_split(const float* x, void* out_hi, void* out_lo, int R, int P, int C, const float* scale, bflow_stream_t stream);
 int bflow_grad_stats(const float* x, int B, int C, int HW, float target, float* out2, float* partial, float* dbias, bflow_stream_t stream);
 /* SepConvGRU gate arithmetic of the training path, forward and backward (update.py:33-48 under autograd; csrc/gru_gates.hip): fp32 NCHW,
  * C*HW % 4 == 0, 16-B aligned.  zr_pre (B, 2C, HW) = the z | r pre-activations of one merged convolution.

@@ -261,6 +261,26 @@ def test_engine_gradients_follow_the_weights_across_optimizer_steps():
     assert worst < 2e-2
 
 
+@pytest.mark.parametrize("tg,B,D,h,w", [(3, 2, 64, 9, 12), (1, 1, 256, 7, 11), (4, 3, 256, 36, 48)])
+def test_volume_adjoint_on_the_engine_vs_fp64(tg, B, D, h, w):
+    """training._volume_adjoint_engine (the adjoint of corr.py:264-272 as batched 1x1 convolutions with one filter per image, volume gradient
+    pre-scaled by a device-side power of two) against the two fp64 GEMMs per target; N = h*w not a multiple of 32 in the small cases; the
+    volume gradient has the magnitude it has in training (1e-7)."""
+    torch.manual_seed(4)
+    N = h * w
+    dC = torch.randn(tg, B, N, N, device=DEV) * 1e-7
+    f1, f2 = torch.randn(B, D, N, device=DEV), torch.randn(tg, B, D, N, device=DEV)
+    s = 1.0 / np.sqrt(D)
+    g1, g2 = training._volume_adjoint_engine(dC, f1, f2, s)
+    r1 = (torch.matmul(f2.double(), dC.double().transpose(-1, -2)).sum(dim=0) * s)
+    r2 = torch.matmul(f1.double().unsqueeze(0), dC.double()) * s
+    e1 = float((g1.double() - r1).abs().max() / r1.abs().max())
+    e2 = float((g2.double() - r2).abs().max() / r2.abs().max())
+    print(f"volume adjoint tg={tg} B={B} D={D} N={N}: relative errors {e1:.2e} {e2:.2e}")
+    assert g1.shape == (B, D, N) and g2.shape == (tg, B, D, N)
+    assert e1 < 2e-6 and e2 < 2e-6
+
+
 def test_gru_gate_kernels_match_autograd_fp64():
     """csrc/gru_gates.hip (bflow_gru_zr_fwd / _bwd, bflow_gru_blend_fwd / _bwd) through their autograd Functions against the reference's
     chain of element-wise ops (update.py:38-47) under fp64 autograd: values to 2e-6, gradients to 2e-6 of their largest entry."""
