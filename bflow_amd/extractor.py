@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from . import split as S
 from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backward run on the HIP conv engine
+from .norm_train import norm_act  # [relu](norm(x)): hand-written forward / backward in GPU training mode
 
 STATS_R = 8
 
@@ -48,10 +49,10 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = F.relu_(self.norm1(self.conv1(x)))
-        y = F.relu_(self.norm2(self.conv2(y)))
+        y = norm_act(self.norm1, self.conv1(x), True)        # relu(norm(conv)): csrc/norm_train.hip in GPU training mode, else the modules
+        y = norm_act(self.norm2, self.conv2(y), True)
         if self.downsample is not None:
-            x = self.downsample(x)
+            x = norm_act(self.norm3, self.downsample[0](x), False)
         return F.relu_(x + y)
 
 
@@ -202,7 +203,7 @@ class BasicEncoder(nn.Module):
         if as_list:
             nb, count = x[0].shape[0], len(x)
             x = torch.cat(list(x), dim=0)
-        x = F.relu_(self.norm1(self.conv1(x)))
+        x = norm_act(self.norm1, self.conv1(x), True)
         x = self.layer3(self.layer2(self.layer1(x)))
         if project:
             x = self.conv2(x)

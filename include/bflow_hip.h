@@ -191,6 +191,23 @@ int bflow_pow2_scale(const float* x, long long n, float target, float* out2, voi
  *   volume gradient dC[n, m] over m for d f1 and over n for d f2; bflow_norm_act_split stages the second (NCHW-like) case, this the first.        */
 int bflow_rows_to_split(const float* x, void* out_hi, void* out_lo, int R, int P, int C, const float* scale, bflow_stream_t stream);
 int bflow_grad_stats(const float* x, int B, int C, int HW, float target, float* out2, float* partial, float* dbias, bflow_stream_t stream);
+/* InstanceNorm2d / BatchNorm2d (+ ReLU) of the training path, forward and backward (extractor.py norm layers under autograd; csrc/norm_train.hip).
+ * NCHW fp32; a "plane" is one (image, channel); mode 0 = instance (statistics per plane), 1 = batch (per channel over the batch, training mode).
+ *   forward : bflow_plane_stats -> bflow_norm_train_finalize (mean, rstd, scale = gamma*rstd, shift = beta - mean*scale per plane; mode 1 also
+ *             updates running_mean / running_var [unbiased] with `momentum` when they are given) -> bflow_norm_train_apply (y = [relu](x*scale+shift))
+ *   backward: g = dy * [x*scale + shift > 0] (relu) | dy;  bflow_norm_train_bwd_stats (per plane sum g, sum g*xhat, fp64) ->
+ *             bflow_norm_train_bwd_finalize (k1, k2 = their means over the normalisation set; mode 1: dgamma = sum g*xhat, dbeta = sum g) ->
+ *             bflow_norm_train_bwd_apply (dx = scale * (g - k1 - xhat*k2)).                                                                 */
+int bflow_norm_train_finalize(const double* stats, int mode, int B, int C, int HW, float eps, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float* mean, float* rstd, float* scale, float* shift,
+                              bflow_stream_t stream);
+int bflow_norm_train_apply(const float* x, const float* scale, const float* shift, float* y, long long planes, int HW, int relu, bflow_stream_t stream);
+int bflow_norm_train_bwd_stats(const float* dy, const float* x, const float* mean, const float* rstd, const float* scale, const float* shift,
+                               double* sums, long long planes, int HW, int relu, bflow_stream_t stream);
+int bflow_norm_train_bwd_finalize(const double* sums, int mode, int B, int C, int HW, float* k1, float* k2, float* dgamma, float* dbeta,
+                                  bflow_stream_t stream);
+int bflow_norm_train_bwd_apply(const float* dy, const float* x, const float* mean, const float* rstd, const float* scale, const float* shift,
+                               const float* k1, const float* k2, float* dx, long long planes, int HW, int relu, bflow_stream_t stream);
 /* SepConvGRU gate arithmetic of the training path, forward and backward (update.py:33-48 under autograd; csrc/gru_gates.hip): fp32 NCHW,
  * C*HW % 4 == 0, 16-B aligned.  zr_pre (B, 2C, HW) = the z | r pre-activations of one merged convolution.
  *   bflow_gru_zr_fwd:    z = sigmoid(zr_pre[:, :C]), r = sigmoid(zr_pre[:, C:]), rh = r * h

@@ -281,6 +281,49 @@ def test_volume_adjoint_on_the_engine_vs_fp64(tg, B, D, h, w):
     assert e1 < 2e-6 and e2 < 2e-6
 
 
+@pytest.mark.parametrize("kind,relu", [("instance", True), ("instance", False), ("batch", True), ("batch", False)])
+def test_norm_train_kernels_match_torch_autograd_fp64(kind, relu):
+    """norm_train.norm_act (csrc/norm_train.hip: InstanceNorm2d / training-mode BatchNorm2d, optional ReLU, forward + two-pass backward, running
+    statistics) against the torch modules under fp64 autograd: values, input / affine gradients, running mean / variance, batch counter."""
+    from bflow_amd import norm_train as NT
+    torch.manual_seed(7)
+    B, C, H, W = 3, 48, 10, 14
+    x = (torch.randn(B, C, H, W, device=DEV) * 2 + 0.5).requires_grad_()
+    wgt = torch.randn(B, C, H, W, device=DEV)
+    mk = (lambda: torch.nn.InstanceNorm2d(C)) if kind == "instance" else (lambda: torch.nn.BatchNorm2d(C))
+    m, ref = mk().to(DEV).train(), mk().to(DEV).double().train()
+    if kind == "batch":
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(C) + 0.5)
+            m.bias.copy_(torch.randn(C) * 0.3)
+            ref.weight.copy_(m.weight.double())
+            ref.bias.copy_(m.bias.double())
+    assert NT._supported(m, x) is not None
+    for _ in range(2):                                            # two steps: the running statistics are updated twice
+        y = NT.norm_act(m, x, relu)
+    x.grad = None
+    m.zero_grad()
+    y = NT.norm_act(m, x, relu)
+    (y * wgt).sum().backward()
+    x64 = x.detach().double().requires_grad_()
+    for _ in range(2):
+        y64 = ref(x64)
+        y64 = torch.relu(y64) if relu else y64
+    x64.grad = None
+    ref.zero_grad()
+    y64 = ref(x64)
+    y64 = torch.relu(y64) if relu else y64
+    (y64 * wgt.double()).sum().backward()
+    assert float((y.double() - y64).abs().max()) < 5e-6
+    e = float((x.grad.double() - x64.grad).abs().max() / x64.grad.abs().max())
+    assert e < 5e-6, e
+    if kind == "batch":
+        for a, b, name in ((m.weight.grad, ref.weight.grad, "dgamma"), (m.bias.grad, ref.bias.grad, "dbeta"), (m.running_mean, ref.running_mean, "running_mean"),
+                           (m.running_var, ref.running_var, "running_var")):
+            assert float((a.double() - b).abs().max() / b.abs().max()) < 5e-6, name
+        assert int(m.num_batches_tracked) == int(ref.num_batches_tracked) == 3
+
+
 def test_gru_gate_kernels_match_autograd_fp64():
     """csrc/gru_gates.hip (bflow_gru_zr_fwd / _bwd, bflow_gru_blend_fwd / _bwd) through their autograd Functions against the reference's
     chain of element-wise ops (update.py:38-47) under fp64 autograd: values to 2e-6, gradients to 2e-6 of their largest entry."""
