@@ -225,7 +225,7 @@ def main():
             "value": prim["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "strong" if primary_is_c4 else "weak",
             "vs_baseline": None, "dtype": "f32 (split-fp16 pairs)",
-            "arithmetic": "fp32 values carried as split fp16 pairs (hi + lo*2^-11) on the fp16 matrix cores, fp32 accumulation; parity 1e-5 px EPE vs the fp32 CPU reference",
+            "arithmetic": "fp32 values carried as split fp16 pairs (hi + lo*2^-11) on the fp16 matrix cores, fp32 accumulation; correlation cross terms (hi*lo + lo*hi) on the fp8 matrix rate; parity 2e-5 px EPE vs the fp32 CPU reference",
             "data": "synthetic",
             "config": {"workload": wl_c4 if primary_is_c4 else wl_c2, "global_batch": GLOBAL_BATCH if primary_is_c4 else world,
                        "frames_per_rank_per_step": (s1 - s0) if primary_is_c4 else 1, "iters": ITERS, "hipgraph": not args.no_graph},
@@ -295,6 +295,9 @@ def main():
                 if k["flops"]:
                     r["flop_per_launch"] = k["flops"]
                     r["tflops_equivalent"] = round(k["flops"] / (ms * 1e-3) / 1e12, 1)
+                    if k.get("mfma_peak"):     # the kernel's second roof: matrix cores (fp32-equivalent peak of its arithmetic)
+                        r["mfma_peak_tflops_equivalent"] = round(k["mfma_peak"], 1)
+                        r["frac_mfma"] = round(k["flops"] / (ms * 1e-3) / 1e12 / k["mfma_peak"], 4)
             if k.get("note"):
                 r["note"] = k["note"]
             # HBM traffic per launch cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the SAME launches

@@ -24,7 +24,28 @@ from . import hip
 #   "f32"   : exact fp32 MFMA, fp32 volume (row-major planes only)
 #   "f16"   : plain fp16 operands, fp16 tiled volume (BASELINE configs[4]: "fp16 MFMA correlation"): half the volume bytes, a third of the
 #             matrix-core work, fp16 accuracy (2^-11 per operand and stored value) -- measured EPE vs the fp32 oracle: tests/, DESIGN.md
+#   "split8": hi*hi on the fp16 rate + BOTH cross terms (hi*lo + lo*hi) of a 32-channel block in one fp8 (e4m3) K = 64 MFMA, fp32 tiled volume:
+#             two matrix-pipe units per product instead of three and a higher sustained clock (the matrix cores are power-limited on real
+#             data); the cross terms carry 2^-11 of a product, so their 2^-4 operand rounding leaves ~2^-16 per product
+#   "split/h", "split8/h", "f16/w": the same arithmetics with the other storage type (fp16 / fp16 / fp32 volume) -- the decomposition of the
+#             fp16 variant's error into operand and storage rounding (tests/test_hip_parity.py), not product defaults
+# name -> (bflow_corr_build_tiled arithmetic, fp16 volume)
+PRECISIONS = {"split": (hip.ARITH_SPLIT, False), "f32": (None, False), "f16": (hip.ARITH_F16, True), "split8": (hip.ARITH_SPLIT8, False),
+              "split/h": (hip.ARITH_SPLIT, True), "split8/h": (hip.ARITH_SPLIT8, True), "f16/w": (hip.ARITH_F16, False)}
+TILED_ONLY = frozenset(("f16", "split8", "split/h", "split8/h", "f16/w"))      # written by bflow_corr_build_tiled only
 PRECISION = os.environ.get("BFLOW_CORR_PRECISION", "split")
+
+
+def _x8_planes(p1: torch.Tensor, p2: torch.Tensor):
+    """x8 planes of the two packed operands of one reference group; one launch when they are neighbouring slices of one tensor."""
+    n1 = p1[0].numel()
+    if (p1[0].data_ptr() + 2 * n1 == p2[0].data_ptr() and p1[1].data_ptr() + 2 * n1 == p2[1].data_ptr()
+            and p1._base is not None and p1._base is p2._base and p1.shape[2:] == p2.shape[2:]):
+        both = torch.empty((p1.shape[1] + p2.shape[1],) + tuple(p1.shape[2:-1]) + (64,), dtype=torch.uint8, device=p1.device)
+        hip._check(hip.lib().bflow_split_to_x8(p1[0].data_ptr(), p1[1].data_ptr(), both.data_ptr(), (n1 + p2[0].numel()) // 32, hip._stream()),
+                   "bflow_split_to_x8")
+        return both[:p1.shape[1]], both[p1.shape[1]:]
+    return hip.split_to_x8(p1), hip.split_to_x8(p2)
 
 _LIST_TYPES: Tuple[type, ...] = (list, tuple)
 try:  # omegaconf is optional (the reference passes ListConfig objects when driven by Hydra, corr.py:8,147)
@@ -124,7 +145,7 @@ class CorrComputation:
         """The tiled-plane volume is written by the streaming K5 kernel only: split operands with D in {64, 128, 256}, fp16 with D in
         {128, 256}."""
         precision = PRECISION if precision is None else precision
-        return (precision == "split" and self.dim in (64, 128, 256)) or (precision == "f16" and self.dim in (128, 256))
+        return (precision == "split" and self.dim in (64, 128, 256)) or (precision in TILED_ONLY and self.dim in (128, 256))
 
     def get_correlation_volume(self, tiled: bool = False, precision: Optional[str] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(T, B*N, 1, h, w) fp32 -- corr.py:229-272.  One K5 launch per reference group, written straight into its
@@ -135,30 +156,41 @@ class CorrComputation:
         T = self.num_targets_overall
         device = self._packed[0][0].device if self._packed[0] is not None else self._fmap1[0].device
         precision = PRECISION if precision is None else precision
-        if precision not in ("split", "f32", "f16"):
-            raise ValueError(f"correlation precision {precision!r}: expected 'split', 'f32' or 'f16'")
-        if (tiled or precision == "f16") and not (tiled and self.tiled_supported(precision)):
+        if precision not in PRECISIONS:
+            raise ValueError(f"correlation precision {precision!r}: expected one of {sorted(PRECISIONS)}")
+        if (tiled or precision in TILED_ONLY) and not (tiled and self.tiled_supported(precision)):
             raise hip.BflowHipError(f"correlation volume (tiled={tiled}, precision={precision!r}, D={D}): the tiled layout needs 'split' with D in "
-                                    "(64, 128, 256) or 'f16' with D in (128, 256); the fp16 volume exists in the tiled layout only")
-        vshape, vdtype = (T, B, N, hip.tiled_plane_size(h, w) if tiled else N), torch.float16 if precision == "f16" else torch.float32
+                                    f"(64, 128, 256) or one of {sorted(TILED_ONLY)} with D in (128, 256), which exist in the tiled layout only")
+        arithmetic, st16 = PRECISIONS[precision]
+        vshape, vdtype = (T, B, N, hip.tiled_plane_size(h, w) if tiled else N), torch.float16 if st16 else torch.float32
         if out is not None:        # a caller-owned volume (double-buffered frames, bflow_amd/pipeline.py)
             assert tuple(out.shape) == vshape and out.dtype == vdtype and out.is_contiguous() and out.device == device
             vol = out
         else:
             vol = torch.empty(vshape, dtype=vdtype, device=device)
         thw = (h, w) if tiled else None
-        split = precision in ("split", "f16") and D % 64 == 0
+        split = precision != "f32" and D % 64 == 0
+
+        def build(p1, p2, dst, tg):
+            if precision in TILED_ONLY:
+                x8 = None
+                if arithmetic == hip.ARITH_SPLIT8:   # ONE conversion launch when the two operands are neighbours in one tensor (the encoder's output)
+                    x8 = _x8_planes(p1, p2)
+                hip.corr_build_tiled(p1, p2, dst, tg, B, N, shared_f1=True, tiled_hw=thw, arithmetic=arithmetic, x8=x8)
+            else:
+                hip.corr_build_split(p1, p2, dst, tg, B, N, shared_f1=True, tiled_hw=thw)
+
         t0 = 0
         for f1, f2, packed in zip(self._fmap1, self._fmap2, self._packed):
             tg = f2.shape[0]
             if packed is not None:
-                hip.corr_build_split(packed[0], packed[1], vol[t0:t0 + tg], tg, B, N, shared_f1=True, tiled_hw=thw)
+                build(packed[0], packed[1], vol[t0:t0 + tg], tg)
                 t0 += tg
                 continue
             f1 = f1.float().contiguous().view(B, D, N)
             f2 = f2.float().contiguous().view(tg * B, D, N)
             if split:   # split-fp16 MFMA engine
-                hip.corr_build_split(hip.split_pack(f1), hip.split_pack(f2), vol[t0:t0 + tg], tg, B, N, shared_f1=True, tiled_hw=thw)
+                build(hip.split_pack(f1), hip.split_pack(f2), vol[t0:t0 + tg], tg)
             else:       # exact-fp32 MFMA
                 hip.corr_build_f32(f1, f2.view(tg, B, D, N), vol[t0:t0 + tg])
             t0 += tg

@@ -14,10 +14,10 @@
 //     accumulators are scaled and stored, one register (two full 128-B lines) per k-step, between the MFMAs; the fragments of the
 //     next k-step (and, across the chunk boundary, of the next chunk) are read ahead.  The two waves of a SIMD keep its matrix
 //     pipe busy for each other; one s_barrier per chunk is the only synchronisation.  A workgroup writes 32 rows x 1 KB per chunk.
-// Work = (panel, chunk) items in panel-major order on an RX x PX grid of XCDs: an XCD owns one row slice of the reference (<= 2.5
-// MB, so that it stays in the XCD's L2 while 32 workgroups re-read it) for a contiguous range of panels; its workgroups take
-// contiguous, equally long ranges of that list.  A panel switch inside a range reloads the 128 registers (~25 k cycles: 256 KB per
-// CU at the ~10 B/clk a CU sustains on L2 misses); the grid keeps that to <= 1 per workgroup at DSEC size.
+// Work = segments (panel, chunk range): an XCD owns a contiguous range of the panel list and its workgroups walk the reference rows in
+// LOCKSTEP, each on its own panel (round 3; see the comment at the segment arithmetic), so that a 32-KB row chunk is fetched from the
+// fabric once per XCD and served to the other 31 workgroups by the L2 whatever the write stream evicts; the volume stores are
+// non-temporal for the same reason.  A workgroup changes its panel (128 registers, 256 KB) only between rounds.
 //
 // vmcnt bookkeeping (gfx9 counts loads AND stores in vmcnt and retires them in order): per chunk a wave issues PW = KB/2 DMA pieces
 // and exactly 16 buffer stores (out-of-range ones are dropped by the buffer bounds check, not skipped), so "my pieces of chunk i+1
@@ -33,6 +33,10 @@
 // 4 no MFMA, 5 no fragment reads
 #ifndef STREAM_ABL
 #define STREAM_ABL 0
+#endif
+// STREAM_STORE_AUX (tools A/B): cache-policy bits of the volume stores (gfx950 buffer aux: 1 sc0, 2 nt, 16 sc1)
+#ifndef STREAM_STORE_AUX
+#define STREAM_STORE_AUX 2   // nt: the write stream must not evict the reference rows the XCD re-reads (C5, fp8 cross terms: 2242 -> 1653 us)
 #endif
 #ifdef STREAM_STAMPS   // tools/k5_ablate.sh "stamps" build: s_memtime stamps of wave 0 of every workgroup (64 x u64 per workgroup)
 static unsigned long long* g_stamp_buf = nullptr;
@@ -68,31 +72,45 @@ struct StreamArgs {
     int JP;                 // column panels per target matrix = ceil(N / 256)
     int CH2;                // pairs of 32-row chunks = ceil(N / 64)
     int n_pan;              // panels = T * B * JP
-    int RX;                 // XCD grid: RX row slices x (8 / RX) panel ranges
     int ph, pw;             // > 0: tiled planes (bflow_hip.h: 4x8 tiles); 0: row-major (N, N) slabs
     int PS;                 // elements of one plane of the volume: N (row-major) or tiles * 32
     unsigned long long* stamps;   // STREAM_STAMPS builds only
 };
 
 struct Item {   // wave-uniform description of one (panel, chunk): 32 reference rows i0.. against the 256 columns of panel (t, b, jp)
-    int pan, t, b, jp, c, i0;
+    int pan, t, b, jp, c, cend, i0;   // cend: end of the chunk range of the segment the item belongs to
 };
 
-struct Cursor {   // position in the workgroup's item list; advanced without divisions
-    int pan, t, b, jp, c;
+struct Cursor {   // position in the workgroup's item list (divisions only at a segment change)
+    int seg, pan, t, b, jp, c, cend;
 };
 
-// F16 = true (bflow_corr_build_f16_tiled; BASELINE configs[4] "fp16 MFMA correlation"): plain fp16 operands (the hi planes alone), ONE
-// MFMA per k-step, fp16 volume: a third of the matrix-core work and half of the bytes; the lo planes are neither loaded nor staged.
-template <int KB, bool POW2, bool F16>
+// MODE (arithmetic of the contraction):
+//   M_SPLIT  three fp16 MFMA passes per k-step on (hi, lo) pairs: hi*hi + (hi*lo + lo*hi) 2^-11 -- fp32-class products (the default);
+//   M_F16    (BASELINE configs[4] "fp16 MFMA correlation") plain fp16 operands (the hi planes alone), ONE MFMA per k-step: a third of the
+//            matrix-core work; the second planes are neither loaded nor staged;
+//   M_X8     hi*hi on the fp16 rate + BOTH cross terms of a 32-channel block in ONE v_mfma_f32_32x32x64_f8f6f4 (e4m3, unit scales, twice the
+//            fp16 rate): the second plane of an operand is its "x8" plane -- per (row, 32-channel block) 64 B = [hi8 x 32 | lo8 x 32],
+//            bflow_split_to_x8 -- so that the K = 64 of the instruction is [A_hi8 | A_lo8] . [B_lo8 | B_hi8]: lanes 0-31 (first k half) hold
+//            hi8 of the streamed row / lo8 of the stationary column, lanes 32-63 the opposite.  Two matrix-pipe units per block instead
+//            of three (1024 instead of 1536 cycles per chunk and wave) and less power per product (tools/micro/fp8_cross.hip: the 3-pass
+//            stream runs at 1.41-1.65 GHz on random data, this one at 1.79 GHz: 1.64x in wall time).  The cross terms only carry 2^-11 of
+//            the product, so their 2^-4 operand rounding leaves ~2^-16 per product (measured in tests/test_hip_parity.py).
+// ST16: the volume is stored as fp16 (half the bytes) instead of fp32.
+enum { M_SPLIT = 0, M_F16 = 1, M_X8 = 2 };
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int KB, bool POW2, int MODE, bool ST16>
 __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // SLOTS x (4*KB KB) ring; the only shared object
+    constexpr bool F16 = MODE == M_F16, X8 = MODE == M_X8;
     constexpr int NS = 2 * KB;                 // k16 steps per chunk
     constexpr int NPL = F16 ? 1 : 2;           // operand planes
     constexpr int PW = NPL * KB / 4;           // DMA pieces (1 KB) per wave per chunk
     constexpr int SLOT_BYTES = NPL * 2 * KB * 1024;  // 32 rows x D x planes fp16
     constexpr int PLANE_BYTES = 2 * KB * 1024;
-    constexpr int OB = F16 ? 2 : 4;            // bytes per volume element
+    constexpr int OB = ST16 ? 2 : 4;           // bytes per volume element
     static_assert(PW >= 1, "F16 needs D >= 128");
     constexpr int ST_PER_STEP = 16 / NS > 0 ? 16 / NS : 1;
     static_assert(16 % NS == 0 || NS % 16 == 0, "k-steps and accumulator registers must divide");
@@ -103,30 +121,50 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     const int l31 = lane & 31, kh = lane >> 5;
     const int D = KB * 32;
 
-    // ---- this workgroup's item range.  Items are 32-row chunks, handed out in PAIRS (64 rows) so that every workgroup runs an even
-    // number of chunks per panel (the two accumulator sets alternate roles).  The 8 XCDs form an RX x PX grid: XCD (rx, px) owns row
-    // slice rx of the reference (small enough to stay in its 4-MB L2 while 32 workgroups re-read it) for the contiguous range px of
-    // the panel list (panel-major = target-major, so XCD mates stream the same reference matrix and share panel loads through L2);
-    // its workgroups split that panel-major item list evenly.
+    // ---- this workgroup's work: SEGMENTS (panel, chunk range), chunks handed out in PAIRS (64 rows: the two accumulator sets alternate
+    // roles).  XCD x owns a contiguous range of the panel list (panel-major = target-major: XCD mates stream the same reference matrix).
+    // Its workgroups run in LOCKSTEP over the reference rows: in a full round workgroup i takes panel (round * per_x + i) and walks ALL
+    // chunks; the P mod per_x panels of the last round are shared out 2-D -- panel j gets floor or ceil(per_x / R) workgroups which split its
+    // chunks evenly.  Workgroups that stream the same rows at the same time share them through the XCD's L2 whatever the write stream does
+    // to its contents (with equal contiguous ranges of a panel-major list, as in round 2, the mates of an XCD are spread over the whole row
+    // slice, which the kernel's own stores keep evicting: 276 MB of fabric reads for 24.6 MB of operands at DSEC size), and a workgroup
+    // changes its panel only between rounds.
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, per_x = gridDim.x >> 3;
-    const int rx = xcd % a.RX, px = xcd / a.RX, PX = 8 / a.RX;
-    const int c_lo = 2 * (int)((long long)rx * a.CH2 / a.RX), c_hi = 2 * (int)((long long)(rx + 1) * a.CH2 / a.RX);
-    const int p_lo = (int)((long long)px * a.n_pan / PX), p_hi = (int)((long long)(px + 1) * a.n_pan / PX);
-    const int len = c_hi - c_lo;   // even
-    const long long pairs = (long long)(p_hi - p_lo) * (len >> 1);
-    const int start = 2 * (int)(pairs * idx / per_x), end = 2 * (int)(pairs * (idx + 1) / per_x);
-    const int n = end - start;     // even
+    const int p_lo = (int)((long long)xcd * a.n_pan / 8), p_hi = (int)((long long)(xcd + 1) * a.n_pan / 8);
+    const int P = p_hi - p_lo, full = P / per_x, R = P - full * per_x;
+    int t_pan = 0, t_c0 = 0, t_c1 = 0;      // this workgroup's share of the last (partial) round
+    if (R > 0) {
+        const int base = per_x / R, extra = per_x - base * R;      // the first `extra` panels get base + 1 workgroups
+        int j, k, S;
+        if (idx < extra * (base + 1)) {
+            j = idx / (base + 1);
+            k = idx - j * (base + 1);
+            S = base + 1;
+        } else {
+            const int i2 = idx - extra * (base + 1);
+            j = extra + i2 / base;
+            k = i2 - (i2 / base) * base;
+            S = base;
+        }
+        t_pan = p_lo + full * per_x + j;
+        t_c0 = 2 * (int)((long long)k * a.CH2 / S);
+        t_c1 = 2 * (int)((long long)(k + 1) * a.CH2 / S);
+    }
+    const int n = full * 2 * a.CH2 + (t_c1 - t_c0);     // chunks of this workgroup: even
     if (n <= 0) return;
 
     Cursor cur;
-    {
-        const int pan = p_lo + start / len;
-        cur.pan = pan;
-        cur.t = pan / (a.B * a.JP);
-        cur.b = (pan / a.JP) % a.B;
-        cur.jp = pan % a.JP;
-        cur.c = c_lo + start % len;
-    }
+    auto set_segment = [&](Cursor& k, int seg) {
+        k.seg = seg;
+        const int pan = seg < full ? p_lo + seg * per_x + idx : t_pan;
+        k.pan = pan;
+        k.t = pan / (a.B * a.JP);
+        k.b = (pan / a.JP) % a.B;
+        k.jp = pan % a.JP;
+        k.c = seg < full ? 0 : t_c0;
+        k.cend = seg < full ? 2 * a.CH2 : t_c1;
+    };
+    set_segment(cur, 0);
     auto item_of = [&](const Cursor& k) -> Item {
         Item r;
         r.pan = k.pan;
@@ -134,21 +172,12 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
         r.b = k.b;
         r.jp = k.jp;
         r.c = k.c;
+        r.cend = k.cend;
         r.i0 = k.c * CHUNK;
         return r;
     };
     auto advance = [&](Cursor& k) {
-        if (++k.c == c_hi) {   // next panel, first chunk of this XCD's range
-            k.c = c_lo;
-            ++k.pan;
-            if (++k.jp == a.JP) {
-                k.jp = 0;
-                if (++k.b == a.B) {
-                    k.b = 0;
-                    ++k.t;
-                }
-            }
-        }
+        if (++k.c == k.cend) set_segment(k, k.seg + 1);   // next round (never called past the last item)
     };
     int fetched = 0;   // items handed out by next_item(); past the end the LAST item is repeated (its slot is never read)
     auto next_item = [&]() -> Item {
@@ -183,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     };
 
     // ---- target panel -> registers: lane holds column (wave*32 + l31) of the panel, 8 consecutive k per k16 step
-    half8 Bh[NS], Bl[NS];
+    half8 Bh[NS], Bl[NS];                      // M_X8: Bl[2 kb], Bl[2 kb + 1] = the 32 x8 bytes of block kb (lo8 for lanes 0-31, hi8 for 32-63)
     auto load_panel = [&](int tb, int jp) {
         int col = jp * COLS_WG + wave * 32 + l31;   // row-major planes: 32 consecutive target pixels per wave
         if (a.pw > 0) {
@@ -196,18 +225,22 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
         }
         col = col < a.Np ? col : a.Np - 1;   // columns >= N (row-major) / tiles past the plane are never stored
         const unsigned vo = (unsigned)col * 64u + (unsigned)kh * 16u;
+        const unsigned vo8 = (unsigned)col * 64u + (unsigned)(1 - kh) * 32u;   // stationary side: first k half = lo8 (bytes 32..63), second = hi8
         const unsigned mat = (unsigned)(((long long)tb * a.Np * D) * 2);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const unsigned so = mat + (unsigned)(s >> 1) * kb_bytes;
             Bh[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r2h, vo + (s & 1) * 32, so, 0));
-            if (!F16) Bl[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r2l, vo + (s & 1) * 32, so, 0));
+            if (X8) Bl[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r2l, vo8 + (s & 1) * 16, so, 0));
+            else if (!F16) Bl[s] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r2l, vo + (s & 1) * 32, so, 0));
         }
     };
 
     // fragment read offsets inside a slot (bytes): row l31, logical chunk (s&1)*2 + kh
     const int sw = (l31 >> 2) & 3;
     const int fo_even = l31 * 64 + ((kh ^ sw) << 4), fo_odd = l31 * 64 + (((2 + kh) ^ sw) << 4);
+    // second plane: lo fragments of the same k-step, or (M_X8) the streamed row's x8 bytes: chunks 2 kh, 2 kh + 1 (hi8 for lanes 0-31, lo8 for 32-63)
+    const int fo2_even = X8 ? l31 * 64 + (((2 * kh) ^ sw) << 4) : fo_even, fo2_odd = X8 ? l31 * 64 + (((2 * kh + 1) ^ sw) << 4) : fo_odd;
 
     // ---- store side: one accumulator register = rows (r&3) + 8*(r>>2) + 4*kh of the wave's 32, 32 consecutive columns
     auto store_base = [&](const Item& im, __amdgpu_buffer_rsrc_t& rs) -> unsigned {
@@ -223,11 +256,11 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
         v = POW2 ? v * a.scale : v / a.scale;
         if (STREAM_ABL == 1) {
             asm volatile("" ::"v"(v), "v"(off));
-        } else if (F16) {
+        } else if (ST16) {
             const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rs, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rs, off, 0, STREAM_STORE_AUX);
         } else {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, STREAM_STORE_AUX);
         }
     };
 
@@ -255,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     constexpr int DMA_S0 = NS >= 8 ? 2 : 1;
     constexpr int VMCNT_TOP = (NS - (DMA_S0 + PW)) * ST_PER_STEP + 16 + PW;
     static_assert(DMA_S0 + PW <= NS && VMCNT_TOP < 64, "DMA schedule");
-    half8 fh[2], fl[2];
+    half8 fh[2], fl[2], ale;
 #define STREAM_STEP(CH_, CX_, PH_, PX_)                                                                                     \
     {                                                                                                                       \
         if (STREAM_ABL != 3) {                                                                                              \
@@ -269,16 +302,25 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
         _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                                    \
             {   /* fragments of the next k-step (the next chunk's step 0 behind the last one) */                           \
                 const int sn_ = (s + 1) % NS;                                                                               \
-                const char* fp = (s + 1 < NS ? sb : sn) + (sn_ >> 1) * 2048 + ((sn_ & 1) ? fo_odd : fo_even);               \
+                const char* fb = (s + 1 < NS ? sb : sn) + (sn_ >> 1) * 2048;                                                \
                 if (STREAM_ABL != 5) {                                                                                      \
-                    fh[(s + 1) & 1] = *reinterpret_cast<const half8*>(fp);                                                  \
-                    if (!F16) fl[(s + 1) & 1] = *reinterpret_cast<const half8*>(fp + PLANE_BYTES);                          \
+                    fh[(s + 1) & 1] = *reinterpret_cast<const half8*>(fb + ((sn_ & 1) ? fo_odd : fo_even));                \
+                    if (!F16) fl[(s + 1) & 1] = *reinterpret_cast<const half8*>(fb + PLANE_BYTES + ((sn_ & 1) ? fo2_odd : fo2_even)); \
                 }                                                                                                           \
             }                                                                                                               \
             const half8 ah = fh[s & 1], al = fl[s & 1];                                                                     \
+            if (X8 && !(s & 1)) ale = al;                                                                                   \
             if (STREAM_ABL != 4) {                                                                                          \
                 CH_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[s], CH_, 0, 0, 0);                                      \
-                if (!F16) {                                                                                                 \
+                if (X8) {                                                                                                   \
+                    if (s & 1) {                                                                                            \
+                        const i32x4 a0 = __builtin_bit_cast(i32x4, ale), a1 = __builtin_bit_cast(i32x4, al);                \
+                        const i32x4 b0 = __builtin_bit_cast(i32x4, Bl[s - 1]), b1 = __builtin_bit_cast(i32x4, Bl[s]);       \
+                        const i32x8 a8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};                          \
+                        const i32x8 b8 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};                          \
+                        CX_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, CX_, 0, 0, 0, 0, 0, 0);               \
+                    }                                                                                                       \
+                } else if (!F16) {                                                                                          \
                     CX_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[s], CX_, 0, 0, 0);                                  \
                     CX_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[s], CX_, 0, 0, 0);                                  \
                 }                                                                                                           \
@@ -309,10 +351,10 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
         if (it == 0) {   // first chunk: nobody prefetched its k-step-0 fragments
             __builtin_amdgcn_s_barrier();
             fh[0] = *reinterpret_cast<const half8*>(lds + fo_even);
-            if (!F16) fl[0] = *reinterpret_cast<const half8*>(lds + PLANE_BYTES + fo_even);
+            if (!F16) fl[0] = *reinterpret_cast<const half8*>(lds + PLANE_BYTES + fo2_even);
         }
         STAMP(1 + it)
-        const int stop = min(n, it + (c_hi - q0.c));   // chunks of this panel in the workgroup's range: even
+        const int stop = it + (q0.cend - q0.c);        // chunks left in this segment (one panel): even
         do {
             STREAM_STEP(X_hh, X_xx, Y_hh, Y_xx)
             STREAM_STEP(Y_hh, Y_xx, X_hh, X_xx)
@@ -331,8 +373,9 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     STAMP_RT(63)
 }
 
-template <int KB, bool F16>
+template <int KB, int MODE, bool ST16>
 int launch_kb(const StreamArgs& a, bool pow2, hipStream_t s) {
+    constexpr bool F16 = MODE == M_F16;
     const int lds = SLOTS * (F16 ? 2 : 4) * KB * 1024;
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -341,9 +384,17 @@ int launch_kb(const StreamArgs& a, bool pow2, hipStream_t s) {
         static const int f16_wgs = [] { const char* e = getenv("BFLOW_CORR_F16_WGS"); return e && atoi(e) == 256 ? 256 : 512; }();
         hipLaunchKernelGGL(kern, dim3(F16 ? f16_wgs : 256), dim3(512), lds, s, a);
     };
-    if (pow2) go(corr_stream_kernel<KB, true, F16>);
-    else go(corr_stream_kernel<KB, false, F16>);
-    return bflow::launch_status(F16 ? "corr_build_f16_tiled(stream)" : "corr_build_split(stream)");
+    if (pow2) go(corr_stream_kernel<KB, true, MODE, ST16>);
+    else go(corr_stream_kernel<KB, false, MODE, ST16>);
+    return bflow::launch_status(MODE == M_F16 ? "corr_build(stream, fp16 operands)" : MODE == M_X8 ? "corr_build(stream, fp8 cross terms)" : "corr_build_split(stream)");
+}
+
+template <int MODE, bool ST16>
+int launch_mode(const StreamArgs& a, int D, bool pow2, hipStream_t s) {
+    if (D == 256) return launch_kb<8, MODE, ST16>(a, pow2, s);
+    if (D == 128) return launch_kb<4, MODE, ST16>(a, pow2, s);
+    if constexpr (MODE == M_SPLIT && !ST16) return launch_kb<2, MODE, ST16>(a, pow2, s);   // D = 64: the fp32 split volume only
+    return BFLOW_E_ARG;
 }
 
 }  // namespace
@@ -357,9 +408,10 @@ bool corr_stream_supported(int T, int B, int D, int N, int Np) {
 }
 
 // plane_h x plane_w > 0 (= N): the volume is written as TILED planes (see bflow_corr_build_split_tiled); 0, 0: row-major (T, B, N, N)
-// f16 = true: f1_lo / f2_lo are ignored (may be null), `out` is an fp16 volume (D in {128, 256})
+// arithmetic: 0 split (f*_lo = lo planes), 1 fp16 operands (f*_lo ignored, may be null), 2 fp8 cross terms (f*_lo = x8 planes, bflow_split_to_x8);
+// out_fp16: `out` is an fp16 volume.  Everything but (split, fp32) needs D in {128, 256}.
 int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, void* out, int T, int B, int D, int N, int Np,
-                       long long f1_target_stride, int plane_h, int plane_w, bool f16, hipStream_t stream) {
+                       long long f1_target_stride, int plane_h, int plane_w, int arithmetic, bool out_fp16, hipStream_t stream) {
     StreamArgs a;
     a.f1h = (const _Float16*)f1_hi;
     a.f1l = (const _Float16*)f1_lo;
@@ -381,19 +433,19 @@ int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, 
     a.JP = ceil_div(a.PS, COLS_WG);
     a.CH2 = ceil_div(N, 2 * CHUNK);
     a.n_pan = T * B * a.JP;
-    a.RX = 1;   // row slice of one XCD: CH2 / RX pairs x 2 chunks x (D/32 * 4 KB) <= 2.5 MB
-    static const long long slice_limit = [] { const char* e = getenv("BFLOW_CORR_SLICE_KB"); return e && atoi(e) > 0 ? (long long)atoi(e) << 10 : (5LL << 19); }();
-    while (a.RX < 8 && (long long)ceil_div(a.CH2, a.RX) * 2 * (D / 32) * 4096 > slice_limit) a.RX *= 2;
 #ifdef STREAM_STAMPS
     a.stamps = g_stamp_buf;
 #else
     a.stamps = nullptr;
 #endif
-    if (f16) return D == 128 ? launch_kb<4, true>(a, pow2, stream) : launch_kb<8, true>(a, pow2, stream);
-    switch (D) {
-        case 64: return launch_kb<2, false>(a, pow2, stream);
-        case 128: return launch_kb<4, false>(a, pow2, stream);
-        default: return launch_kb<8, false>(a, pow2, stream);
+    switch (arithmetic * 2 + (out_fp16 ? 1 : 0)) {
+        case 0: return launch_mode<M_SPLIT, false>(a, D, pow2, stream);
+        case 1: return launch_mode<M_SPLIT, true>(a, D, pow2, stream);
+        case 2: return launch_mode<M_F16, false>(a, D, pow2, stream);
+        case 3: return launch_mode<M_F16, true>(a, D, pow2, stream);
+        case 4: return launch_mode<M_X8, false>(a, D, pow2, stream);
+        case 5: return launch_mode<M_X8, true>(a, D, pow2, stream);
+        default: return BFLOW_E_ARG;
     }
 }
 

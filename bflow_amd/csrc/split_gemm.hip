@@ -234,7 +234,7 @@ __global__ __launch_bounds__(V2_T, 2) void corr_build_split_v2_kernel(const _Flo
 namespace bflow {
 bool corr_stream_supported(int T, int B, int D, int N, int Np);
 int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, void* out, int T, int B, int D, int N, int Np,
-                       long long f1_target_stride, int plane_h, int plane_w, bool f16, hipStream_t stream);
+                       long long f1_target_stride, int plane_h, int plane_w, int arithmetic, bool out_fp16, hipStream_t stream);
 }
 
 extern "C" int bflow_split_pack(const float* src, void* hi, void* lo, int R, int D, int N, int Np, bflow_stream_t stream) {
@@ -253,7 +253,7 @@ extern "C" int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, cons
     // D in {64, 128, 256}: the A-stationary streaming kernel (corr_stream.hip); anything else: the 256x128 tile kernel below
     static const bool force_tile = getenv("BFLOW_CORR_TILE_KERNEL") != nullptr;   // A/B timing only (tools/)
     if (!force_tile && bflow::corr_stream_supported(T, B, D, N, Np))
-        return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, 0, 0, false, (hipStream_t)stream);
+        return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, 0, 0, 0, false, (hipStream_t)stream);
     BFLOW_REQUIRE((long long)T * B <= 65535, BFLOW_E_LIMIT, "corr_build_split: T*B too large");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_build_split_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               V2_STAGES * V2_STAGE);   // 144 KB of dynamic LDS; idempotent, per device
@@ -276,7 +276,7 @@ extern "C" int bflow_corr_build_split_tiled(const void* f1_hi, const void* f1_lo
                   B, h, w, Np);
     BFLOW_REQUIRE(bflow::corr_stream_supported(T, B, D, N, Np), BFLOW_E_ARG, "corr_build_split_tiled: needs D in {64, 128, 256} and < 2 GiB slabs (D=%d N=%d)",
                   D, N);
-    return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, h, w, false, (hipStream_t)stream);
+    return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, h, w, 0, false, (hipStream_t)stream);
 }
 
 // BASELINE configs[4] ("fp16 MFMA correlation ... HBM-bound 4D volume stress"): the volume from PLAIN fp16 operands (the hi planes of the
@@ -291,5 +291,54 @@ extern "C" int bflow_corr_build_f16_tiled(const void* f1_hi, const void* f2_hi, 
                   h, w, Np);
     BFLOW_REQUIRE((D == 128 || D == 256) && bflow::corr_stream_supported(T, B, D, N, Np), BFLOW_E_ARG,
                   "corr_build_f16_tiled: needs D in {128, 256} and < 2 GiB slabs (D=%d N=%d)", D, N);
-    return bflow::corr_stream_launch(f1_hi, nullptr, f2_hi, nullptr, out, T, B, D, N, Np, f1_target_stride, h, w, true, (hipStream_t)stream);
+    return bflow::corr_stream_launch(f1_hi, nullptr, f2_hi, nullptr, out, T, B, D, N, Np, f1_target_stride, h, w, 1, true, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// x8 planes for the fp8 cross terms of bflow_corr_build_tiled (arithmetic = 2): per (row, 32-channel block) the 64 bytes
+// [e4m3(hi) x 32 | e4m3(lo) x 32] of the split pair (OCP e4m3, round to nearest even, saturating).  One thread = 8 channels.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void split_to_x8_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, unsigned char* __restrict__ x8,
+                                                           long long rows) {
+    const long long i = blockIdx.x * 256LL + threadIdx.x;          // (row, 8-channel group)
+    if (i >= rows * 4) return;
+    const long long row = i >> 2;
+    const int g = (int)(i & 3);
+    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+    const half8v h = *reinterpret_cast<const half8v*>(hi + row * 32 + g * 8), l = *reinterpret_cast<const half8v*>(lo + row * 32 + g * 8);
+    auto pack4 = [](float a, float b, float c, float d) {
+        int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+        return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    };
+    const int2 ph = make_int2(pack4((float)h[0], (float)h[1], (float)h[2], (float)h[3]), pack4((float)h[4], (float)h[5], (float)h[6], (float)h[7]));
+    const int2 pl = make_int2(pack4((float)l[0], (float)l[1], (float)l[2], (float)l[3]), pack4((float)l[4], (float)l[5], (float)l[6], (float)l[7]));
+    *reinterpret_cast<int2*>(x8 + row * 64 + g * 8) = ph;
+    *reinterpret_cast<int2*>(x8 + row * 64 + 32 + g * 8) = pl;
+}
+}  // namespace
+
+extern "C" int bflow_split_to_x8(const void* hi, const void* lo, void* x8, long long rows, bflow_stream_t stream) {
+    BFLOW_REQUIRE(hi && lo && x8 && rows > 0, BFLOW_E_ARG, "split_to_x8: bad arguments");
+    hipLaunchKernelGGL(split_to_x8_kernel, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)hi,
+                       (const _Float16*)lo, (unsigned char*)x8, rows);
+    return bflow::launch_status("split_to_x8");
+}
+
+// The tiled volume with every arithmetic / storage combination of the streaming kernel (csrc/corr_stream.hip):
+//   arithmetic 0: split pairs, three fp16 MFMA passes (f*_second = lo planes)       = bflow_corr_build_split_tiled when out_fp16 = 0
+//              1: plain fp16 operands, one pass (f*_second ignored, may be null)     = bflow_corr_build_f16_tiled when out_fp16 = 1
+//              2: hi*hi on fp16 + both cross terms on the fp8 rate (f*_second = x8 planes written by bflow_split_to_x8)
+//   out_fp16    : the volume is stored as fp16 tiled planes instead of fp32.
+// D in {128, 256} (and 64 for arithmetic 0 with an fp32 volume).
+extern "C" int bflow_corr_build_tiled(const void* f1_hi, const void* f1_second, const void* f2_hi, const void* f2_second, void* out, int T, int B,
+                                      int D, int h, int w, int Np, long long f1_target_stride, int arithmetic, int out_fp16, bflow_stream_t stream) {
+    BFLOW_REQUIRE(f1_hi && f2_hi && out && arithmetic >= 0 && arithmetic <= 2, BFLOW_E_ARG, "corr_build_tiled: bad arguments");
+    BFLOW_REQUIRE(arithmetic == 1 || (f1_second && f2_second), BFLOW_E_ARG, "corr_build_tiled: arithmetic %d needs the second operand planes", arithmetic);
+    const int N = h * w;
+    BFLOW_REQUIRE(T > 0 && B > 0 && h > 0 && w > 0 && Np >= N && Np % 128 == 0, BFLOW_E_ARG, "corr_build_tiled: bad sizes T=%d B=%d h=%d w=%d Np=%d", T, B, h, w, Np);
+    BFLOW_REQUIRE(bflow::corr_stream_supported(T, B, D, N, Np) && (D != 64 || (arithmetic == 0 && !out_fp16)), BFLOW_E_ARG,
+                  "corr_build_tiled: needs D in {128, 256} (64: split / fp32 only) and < 2 GiB slabs (D=%d N=%d)", D, N);
+    return bflow::corr_stream_launch(f1_hi, f1_second, f2_hi, f2_second, out, T, B, D, N, Np, f1_target_stride, h, w, arithmetic, out_fp16 != 0,
+                                     (hipStream_t)stream);
 }

@@ -78,7 +78,7 @@ class GraphCache:
 
     def run(self, voxel_grid, images, iters: int, flow_init, test_mode: bool):
         key = (self._sig(voxel_grid), None if images is None else tuple(self._sig(x) for x in images), int(iters),
-               self._sig(flow_init), bool(test_mode), getattr(self.model, "corr_precision", None))
+               self._sig(flow_init), bool(test_mode), self.model.resolved_corr_precision())
         wkey = self._weights_signature()
         if wkey != self._weights_key:
             self.clear()                         # destroyed here, outside any capture

@@ -24,7 +24,7 @@ MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_rows_to_split", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_norm_train_finalize", "bflow_norm_train_apply", "bflow_norm_train_bwd_stats", "bflow_norm_train_bwd_finalize", "bflow_norm_train_bwd_apply", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_build_tiled", "bflow_split_to_x8", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_rows_to_split", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_norm_train_finalize", "bflow_norm_train_apply", "bflow_norm_train_bwd_stats", "bflow_norm_train_bwd_finalize", "bflow_norm_train_bwd_apply", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -109,6 +109,8 @@ def lib() -> ctypes.CDLL:
         "bflow_corr_pool2x2_tiled": [vp, vp, ll, i, i, vp],
         "bflow_corr_pool2x2_tiled_f16": [vp, vp, ll, i, i, vp],
         "bflow_corr_build_f16_tiled": [vp, vp, vp, i, i, i, i, i, i, ll, vp],
+        "bflow_corr_build_tiled": [vp, vp, vp, vp, vp, i, i, i, i, i, i, ll, i, i, vp],
+        "bflow_split_to_x8": [vp, vp, vp, ll, vp],
         "bflow_corr_lookup_bezier_split_tiled_f16": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_corr_lookup_bezier_split_tiled": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_conv_pack_weights": [vp, vp, vp, i, i, i, i, i, i, vp],
@@ -250,6 +252,40 @@ def untile_planes(t: torch.Tensor, h: int, w: int) -> torch.Tensor:
     lead = t.shape[:-1]
     v = t.reshape(*lead, th, tw, TILE_H, TILE_W).transpose(-3, -2).reshape(*lead, th * TILE_H, tw * TILE_W)
     return v[..., :h, :w].contiguous()
+
+
+ARITH_SPLIT, ARITH_F16, ARITH_SPLIT8 = 0, 1, 2    # bflow_corr_build_tiled `arithmetic`
+
+
+def split_to_x8(p: torch.Tensor) -> torch.Tensor:
+    """p (2, R, KB, Np, 32) fp16 split planes -> (R, KB, Np, 64) uint8 "x8" plane: per (row, 32-channel block) [e4m3(hi) x 32 | e4m3(lo) x 32],
+    the second operand plane of the fp8-cross-term correlation (bflow_corr_build_tiled, arithmetic = 2)."""
+    assert p.dtype == torch.float16 and p.is_cuda and p.shape[0] == 2 and p.shape[-1] == 32 and p[0].is_contiguous() and p[1].is_contiguous()
+    out = torch.empty(tuple(p.shape[1:-1]) + (64,), dtype=torch.uint8, device=p.device)
+    _check(lib().bflow_split_to_x8(p[0].data_ptr(), p[1].data_ptr(), out.data_ptr(), p[0].numel() // 32, _stream()), "bflow_split_to_x8")
+    return out
+
+
+def corr_build_tiled(p1: torch.Tensor, p2: torch.Tensor, out: torch.Tensor, T: int, B: int, N: int, shared_f1: bool, tiled_hw: Sequence[int],
+                     arithmetic: int = ARITH_SPLIT, x8: Optional[Sequence[torch.Tensor]] = None):
+    """The tiled volume with any arithmetic (ARITH_*) and fp32 or fp16 storage (out.dtype).  ARITH_SPLIT8 takes the x8 planes of both
+    operands (`x8 = (split_to_x8(p1), split_to_x8(p2))`; computed here when omitted)."""
+    _, R2, KB, Np, _32 = p2.shape
+    D = KB * 32
+    h, w = int(tiled_hw[0]), int(tiled_hw[1])
+    assert R2 == T * B and p1.shape[1] == (B if shared_f1 else T * B) and h * w == N
+    assert p1.dtype == torch.float16 and p2.dtype == torch.float16 and p1.is_cuda and p2.is_cuda
+    assert p1[0].is_contiguous() and p1[1].is_contiguous() and p2[0].is_contiguous() and p2[1].is_contiguous()
+    assert out.shape == (T, B, N, tiled_plane_size(h, w)) and out.is_cuda and out.is_contiguous() and out.dtype in (torch.float16, torch.float32)
+    if arithmetic == ARITH_SPLIT8:
+        if x8 is None:
+            x8 = (split_to_x8(p1), split_to_x8(p2))
+        s1, s2 = x8[0].data_ptr(), x8[1].data_ptr()
+    else:
+        s1, s2 = p1[1].data_ptr(), p2[1].data_ptr()
+    _check(lib().bflow_corr_build_tiled(p1[0].data_ptr(), s1, p2[0].data_ptr(), s2, out.data_ptr(), T, B, D, h, w, Np,
+                                        0 if shared_f1 else B * Np * D, int(arithmetic), 1 if out.dtype == torch.float16 else 0, _stream()),
+           "bflow_corr_build_tiled")
 
 
 def corr_build_split(p1: torch.Tensor, p2: torch.Tensor, out: torch.Tensor, T: int, B: int, N: int, shared_f1: bool,

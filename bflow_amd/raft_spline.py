@@ -19,6 +19,8 @@ Inputs must live on the GPU: there is no CPU fallback (the CPU restatement lives
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -113,11 +115,23 @@ class RAFTSpline(nn.Module):
             times.append(1)
         self.lookup_timestamps = times
         self._coef = None
-        # None = bflow_amd.corr.PRECISION ("split": fp32-class volume); "f16" = fp16 operands and volume (BASELINE configs[4])
+        # Correlation arithmetic (bflow_amd/corr.py PRECISIONS).  None = the model default: BFLOW_CORR_PRECISION when set, else "split8"
+        # (hi*hi on the fp16 matrix rate, both cross terms on the fp8 rate, fp32 volume: 2.2e-5 px against the fp32 oracle at C2 / C5 where
+        # the three-pass "split" measures 1.3e-5, K5 142 -> 95 us) for feature dims 128 / 256, "split" otherwise.
+        # "f16" = fp16 operands AND fp16 volume (BASELINE configs[4]; 2.3-2.7e-3 px: outside the 1e-3 bar, opt-in).
         self.corr_precision: Optional[str] = None
         self._graphs = None
         self.stage_timer: Optional[StageTimer] = None
         self._probe = None            # tools only: callable(name) invoked at stage boundaries inside the captured forward
+
+    def resolved_corr_precision(self) -> str:
+        """The correlation arithmetic a forward will use (see `corr_precision`)."""
+        if self.corr_precision is not None:
+            return self.corr_precision
+        if "BFLOW_CORR_PRECISION" in os.environ:
+            return os.environ["BFLOW_CORR_PRECISION"]
+        enc = self.fnet_ev if self.fnet_ev is not None else self.fnet_img
+        return "split8" if enc.conv2.out_channels in (128, 256) else "split"
 
     # ---------------------------------------------------------------------------------------- reference API
     def freeze_bn(self):
@@ -281,7 +295,7 @@ class RAFTSpline(nn.Module):
         if pr: pr("fnet.end")
         if tm: tm.start("corr computation")
         corr_block = CorrBlockParallelMultiTarget(corr_computation_events=corr_ev, corr_computation_frames=corr_img, layout="tiled",
-                                                  precision=self.corr_precision, volume_out=volume_out)
+                                                  precision=self.resolved_corr_precision(), volume_out=volume_out)
         if tm: tm.stop("corr computation")
         if pr: pr("corr.end")
         cnet_branch.join()

@@ -340,6 +340,21 @@ int bflow_corr_pool2x2_tiled(const float* in, float* out, long long planes, int 
 int bflow_corr_build_f16_tiled(const void* f1_hi, const void* f2_hi, void* out, int T, int B, int D, int h, int w, int Np,
                                long long f1_target_stride, bflow_stream_t stream);
 int bflow_corr_pool2x2_tiled_f16(const void* in, void* out, long long planes, int h, int w, bflow_stream_t stream);
+
+/* K5 with every arithmetic / storage combination of the streaming kernel (csrc/corr_stream.hip); replaces the same reference lines as
+ * bflow_corr_build_split (models/raft_utils/corr.py:237-272).  Operands as bflow_corr_build_split_tiled; `out` (T, B, N, tiles*32).
+ *   arithmetic 0: split pairs, three fp16 MFMA passes; f*_second = lo planes              (= bflow_corr_build_split_tiled when out_fp16 = 0)
+ *              1: plain fp16 operands, one pass; f*_second ignored (may be null)           (= bflow_corr_build_f16_tiled when out_fp16 = 1)
+ *              2: hi*hi on the fp16 rate + both cross terms of a 32-channel block in ONE v_mfma_f32_32x32x64_f8f6f4 (e4m3, unit scales);
+ *                 f*_second = "x8" planes (rows, D/32, Np, 64 bytes) written by bflow_split_to_x8.  Two matrix-pipe units per product
+ *                 instead of three; the cross terms carry 2^-11 of a product, their 2^-4 operand rounding leaves ~2^-16 per product.
+ *   out_fp16    : the volume is stored as fp16 tiled planes (half the bytes) instead of fp32.
+ * D in {128, 256}; 64 for (arithmetic 0, fp32 volume) only.
+ * bflow_split_to_x8: hi, lo (rows, 32) fp16 planes of a split tensor -> x8 (rows, 64): [e4m3(hi) x 32 | e4m3(lo) x 32] per row (OCP e4m3,
+ * round to nearest even, saturating at +-448; |x| < 2^-10 becomes 0: such elements keep fp16 accuracy in the product).                      */
+int bflow_split_to_x8(const void* hi, const void* lo, void* x8, long long rows, bflow_stream_t stream);
+int bflow_corr_build_tiled(const void* f1_hi, const void* f1_second, const void* f2_hi, const void* f2_second, void* out, int T, int B, int D,
+                           int h, int w, int Np, long long f1_target_stride, int arithmetic, int out_fp16, bflow_stream_t stream);
 int bflow_corr_lookup_bezier_split_tiled_f16(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
                                              void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
                                              bflow_stream_t stream);

@@ -275,29 +275,85 @@ def test_corr_f16_volume_pyramid_and_lookup(B, D, h, w, levels, shared):
     assert (got - want).abs().max().item() <= 4e-7 * float(want.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("cname,B,H,W,iters", [("E_LU4_BD2", 1, 480, 640, 12), ("E_I_LU5_BD10", 1, 1024, 1024, 20)])
-def test_e2e_f16_correlation_vs_oracle(cname, B, H, W, iters):
-    """BASELINE configs[4] (and C2 for comparison) with the fp16 correlation: the flow against the fp32 CPU oracle.  The reference has no
-    fp16 path (raft.py:122 forces .float()), so this is NOT a parity claim at the 1e-3 px bar of the default (split) precision: the
-    tolerance below is the measured effect of rounding features and volume to fp16 (2^-11 relative) with margin, stated here and in
-    DESIGN.md; the same models pass the 1e-3 bar in test_e2e_baseline_configs_full_size_vs_oracle with the default precision."""
+@pytest.mark.parametrize("B,D,h,w,T,shared", [(1, 256, 60, 80, 4, True), (2, 128, 15, 20, 3, True), (2, 256, 17, 24, 2, False)])
+def test_corr_split8_volume_vs_fp64(B, D, h, w, T, shared):
+    """"split8" (the model default): hi*hi on the fp16 matrix rate, both cross terms of a 32-channel block in one fp8 (e4m3) K = 64 MFMA.
+    (1) the x8 planes are torch's e4m3 rounding of the hi and lo planes; (2) the volume against an fp64 GEMM: every cross product carries
+    <= (1 + 2^-4)^2 - 1 < 2^-3 relative error and is <= 2^-11 |a||b| in magnitude, two of them per product => analytic worst case
+    2^-13 = 1.22e-4 of sum|a||b| (measured max 2.7-6.7e-5, rms error / rms value 1.0e-5; "split": 2e-7 / 1.3e-7); (3) operands that are
+    exactly representable in fp16 have zero lo planes, hence zero cross terms: the volume must then equal the three-pass "split" volume
+    BIT FOR BIT (same hi*hi MFMA sequence) -- the fp8 instruction, its operand halves and the x8 layout are exercised on real data in (2)."""
+    N = h * w
+    rs = np.random.RandomState(17)
+    f1 = cu(rs.standard_normal(((1 if shared else T) * B, D, N)).astype(np.float32))
+    f2 = cu(rs.standard_normal((T * B, D, N)).astype(np.float32))
+    f2[0, :, 0] *= 3e-3
+    f2[0, :, 1] *= 30.0          # (stays inside e4m3's +-448: torch's conversion has no saturation)
+    p1, p2 = hip.split_pack(f1), hip.split_pack(f2)
+    x8 = hip.split_to_x8(p2)
+    assert x8.shape == tuple(p2.shape[1:-1]) + (64,)
+    want = torch.cat([p2[0].float().cpu().to(torch.float8_e4m3fn).view(torch.uint8), p2[1].float().cpu().to(torch.float8_e4m3fn).view(torch.uint8)], dim=-1)
+    assert torch.equal(x8.cpu(), want)
+    th = (h, w)
+
+    def volume(q1, q2, ar):
+        v = torch.full((T, B, N, hip.tiled_plane_size(h, w)), float("nan"), device=DEV)
+        hip.corr_build_tiled(q1, q2, v, T, B, N, shared_f1=shared, tiled_hw=th, arithmetic=ar)
+        return v
+
+    v8 = volume(p1, p2, hip.ARITH_SPLIT8)
+    out = hip.untile_planes(v8, h, w).reshape(T, B, N, N).double().cpu()
+    a = f1.double().cpu().view(-1, B, D, N)
+    a = a.expand(T, B, D, N) if shared else a
+    b = f2.double().cpu().view(T, B, D, N)
+    ref = a.transpose(2, 3) @ b / np.sqrt(D)
+    mag = a.abs().transpose(2, 3) @ b.abs() / np.sqrt(D)
+    err = (out - ref).abs()
+    worst, rms = float((err / mag).max()), float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"split8 volume B={B} D={D} {h}x{w} T={T}: max err / sum|a||b| = {worst:.2e}, rms err / rms value = {rms:.2e}")
+    assert torch.isfinite(v8[..., :1]).all() and worst < 1.25e-4 and rms < 3e-5
+    def exact16(f):   # fp16-representable, fp16-NORMAL values (the format keeps fp16 subnormals in the lo plane): lo planes are zero
+        f = f.half().float()
+        return torch.where(f.abs() < 2.0 ** -13, torch.full_like(f, 2.0 ** -10), f)
+
+    g1, g2 = hip.split_pack(exact16(f1)), hip.split_pack(exact16(f2))
+    assert not bool(g1[1].any()) and not bool(g2[1].any())
+    assert torch.equal(hip.untile_planes(volume(g1, g2, hip.ARITH_SPLIT8), h, w), hip.untile_planes(volume(g1, g2, hip.ARITH_SPLIT), h, w))
+
+
+@pytest.mark.parametrize("cname,H,W,iters,cases", [
+    ("E_LU4_BD2", 480, 640, 12, [("split", 1e-4), ("split8", 2e-4), ("f16/w", 1e-3), ("split/h", 5e-3), ("f16", 5e-3)]),
+    ("E_I_LU5_BD10", 1024, 1024, 20, [("split8", 2e-4), ("f16", 5e-3)])])
+def test_e2e_correlation_precisions_vs_oracle(cname, H, W, iters, cases):
+    """The full forward against the fp32 CPU oracle per correlation arithmetic (C2, and BASELINE configs[4] = C5 at its own size).
+      "split"   three fp16 MFMA passes on split pairs, fp32 volume                    1.3e-5 px   (bar: the north star's 1e-3)
+      "split8"  hi*hi fp16 + cross terms on the fp8 rate, fp32 volume: THE DEFAULT    2.2e-5 px (C2), 1.7e-5 (C5)
+      "f16/w"   plain fp16 operands (one pass), fp32 volume                            6.0e-4 px: inside the bar, little margin
+      "split/h" fp32-class products, fp16 volume                                       2.5e-3 px: the STORAGE rounding is what breaks the bar
+      "f16"     BASELINE configs[4] "fp16 MFMA correlation": fp16 operands and volume  2.6e-3 px (C2), 2.3e-3 (C5)
+    The reference has no fp16 path (raft.py:122 forces .float()); an fp16 VOLUME cannot meet the 1e-3 px bar of the north star whatever the
+    products are (the 2^-11 rounding of every stored value, not of the operands, dominates), so "f16" / "split/h" are opt-in variants whose
+    measured effect is pinned here at 5e-3 px (include/bflow_hip.h says the same)."""
     cfg, m, sd = _model(cname)
-    m.corr_precision = "f16"
     m.enable_hipgraph()
     C = cfg["num_bins"]["context"] + cfg["num_bins"]["correlation"] - 1
-    vox = torch.from_numpy(synthetic.voxel_grid(B, C, H, W, seed=7))
+    vox = torch.from_numpy(synthetic.voxel_grid(1, C, H, W, seed=7))
     imgs = None
     if cfg["use_boundary_images"]:
-        a, b = synthetic.image_pair(B, H, W, seed=8)
+        a, b = synthetic.image_pair(1, H, W, seed=8)
         imgs = [torch.from_numpy(a), torch.from_numpy(b)]
-    low, up = m(voxel_grid=vox.to(DEV), images=None if imgs is None else [i.to(DEV) for i in imgs], iters=iters, test_mode=True)
-    flow = up.get_flow_from_reference(1.0).cpu()
     with torch.inference_mode():
         _, rup = O.forward(sd, cfg, vox, imgs, iters=iters, test_mode=True)
     rflow = O.bezier_flow(rup, 1.0)
-    e = float(O.epe_masked(flow, rflow))
-    print(f"{cname} {H}x{W} fp16 correlation: EPE vs fp32 oracle = {e:.3e} px at mean |flow| = {float(rflow.abs().mean()):.2f} px")
-    assert torch.isfinite(flow).all() and e < 1e-2      # measured 2.3e-3 (C5) / 2.6e-3 (C2) px at |flow| ~ 20 px
+    for prec, tol in cases:
+        m.corr_precision = prec
+        low, up = m(voxel_grid=vox.to(DEV), images=None if imgs is None else [i.to(DEV) for i in imgs], iters=iters, test_mode=True)
+        flow = up.get_flow_from_reference(1.0).cpu()
+        e = float(O.epe_masked(flow, rflow))
+        print(f"{cname} {H}x{W} corr_precision={prec}: EPE vs fp32 oracle = {e:.3e} px at mean |flow| = {float(rflow.abs().mean()):.2f} px")
+        assert torch.isfinite(flow).all() and e < tol, (prec, e, tol)
+    m.corr_precision = None
+    assert m.resolved_corr_precision() == "split8"
 
 
 # ------------------------------------------------------------------------------------------------- K8 / K13

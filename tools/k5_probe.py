@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--stamps", action="store_true", help="needs the STREAM_STAMPS build (tools/k5_ablate.sh stamps:-DSTREAM_STAMPS)")
     ap.add_argument("--f16", action="store_true", help="also time the fp16 tiled volume (bflow_corr_build_f16_tiled)")
     ap.add_argument("--big", action="store_true", help="also time C3 (B=8, T=5) and C5 (N=16384, T=6)")
+    ap.add_argument("--stamp-mode", default="split", help="arithmetic of the stamped launch: split | split8 | f16/w (tiled volume)")
+    ap.add_argument("--stamp-shape", default="C2", help="C2 | C5")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     print("kernel:", "tile (256x128)" if os.environ.get("BFLOW_CORR_TILE_KERNEL") else "stream", flush=True)
@@ -112,14 +114,18 @@ def main():
         import ctypes
         st = torch.zeros((256, 64), dtype=torch.int64, device=dev)
         hip.lib().bflow_k5_set_stamp_buffer(ctypes.c_void_p(st.data_ptr()))
-        B, D, N, T = 1, 256, 4800, 4
-        f1 = torch.randn((B, D, N), generator=g).to(dev)
+        B, D, hh, ww, T, shared = (1, 256, 60, 80, 4, True) if args.stamp_shape == "C2" else (1, 256, 128, 128, 6, False)
+        N = hh * ww
+        f1 = torch.randn(((1 if shared else T) * B, D, N), generator=g).to(dev)
         f2 = torch.randn((T * B, D, N), generator=g).to(dev)
         p1, p2 = hip.split_pack(f1), hip.split_pack(f2)
-        vol = torch.empty((T, B, N, N), device=dev)
+        ar = {"split": hip.ARITH_SPLIT, "split8": hip.ARITH_SPLIT8, "f16/w": hip.ARITH_F16}[args.stamp_mode]
+        vol = torch.empty((T, B, N, hip.tiled_plane_size(hh, ww)), device=dev)
+        x8 = (hip.split_to_x8(p1), hip.split_to_x8(p2))
         for _ in range(3):
-            hip.corr_build_split(p1, p2, vol, T, B, N, shared_f1=True)
+            hip.corr_build_tiled(p1, p2, vol, T, B, N, shared_f1=shared, tiled_hw=(hh, ww), arithmetic=ar, x8=x8)
         torch.cuda.synchronize()
+        print(f"stamped launch: {args.stamp_shape} {args.stamp_mode} (tiled volume)")
         s = st.cpu().numpy()
         print("cycle stamps = s_memtime (shader clock); real-time stamps = s_memrealtime (100 MHz)")
         for wg in (0, 1, 8, 9, 100, 255):

@@ -10,7 +10,7 @@ from bflow_amd import hip, split as S
 from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
 
 CONV_NAME = "conv_halo_kernel<2,3,3> (encoder layer1 3x3 64->64, 5x240x320)"
-K5_NAME = "corr_stream_kernel<8, true> (bflow_corr_build_split, D = 256)"
+K5_NAME = "corr_stream_kernel<8, true, 2, false> (bflow_corr_build_tiled: split8 arithmetic, fp32 tiled volume, D = 256 -- the product launch)"
 LOOKUP_NAME = "corr_lookup_tile_kernel<float, 2, 256> (fused bezier, tiled planes, split out)"
 
 
@@ -43,10 +43,20 @@ def build(model, vox, cfg, low_params=None):
         N = h8 * w8
         T = len(grids) - 1
         planes = model.fnet_ev.forward_split(x5, out_rows=hip.padded_rows(N)).planes
-        vol = torch.empty((T, B, N, N), device=dev)
-        out.append(dict(key="roofline_corr_build", name=K5_NAME, regex="corr_stream_kernel", bound="hbm",
-                        launch=lambda: hip.corr_build_split(planes[:, :B], planes[:, B:], vol, T, B, N, shared_f1=True),
-                        flops=2.0 * T * B * D * N * N, bytes=4.0 * ((1 + T) * B * D * N + T * B * N * N)))
+        # the launch of the product path (bflow_amd/corr.py): TILED planes, the model's default arithmetic ("split8": hi*hi on the fp16 rate +
+        # both cross terms on the fp8 rate); the x8 operand planes come from one 3-us conversion launch in front of it (not timed here)
+        prec = model.resolved_corr_precision()
+        arith = {"split": hip.ARITH_SPLIT, "split8": hip.ARITH_SPLIT8}[prec]
+        vol = torch.empty((T, B, N, hip.tiled_plane_size(h8, w8)), device=dev)
+        p1, p2 = planes[:, :B], planes[:, B:]
+        x8 = (hip.split_to_x8(p1), hip.split_to_x8(p2)) if arith == hip.ARITH_SPLIT8 else None
+        out.append(dict(key="roofline_corr_build", name=K5_NAME if arith == hip.ARITH_SPLIT8 else K5_NAME.replace("2, false", "0, false").replace("split8", "split"),
+                        regex="corr_stream_kernel", bound="hbm",
+                        launch=lambda: hip.corr_build_tiled(p1, p2, vol, T, B, N, shared_f1=True, tiled_hw=(h8, w8), arithmetic=arith, x8=x8),
+                        flops=2.0 * T * B * D * N * N, bytes=4.0 * ((1 + T) * B * D * N + T * B * N * N),
+                        # second roof: matrix cores.  Matrix-pipe cost per fp32-class product: 3 fp16 units ("split") or
+                        # 1 fp16 + 2 x 1/2 (fp8 runs at twice the fp16 rate) = 2 units ("split8")
+                        mfma_peak=2500.0 / (2 if arith == hip.ARITH_SPLIT8 else 3)))
         # (3) the look-up gather (HBM-bound), 24.33 MB algorithmic per sample-iteration at C2: 100 taps read + 81 values written
         #     (4 B each; the split output is also 4 B per value) per (pixel, plane)
         cc = CorrComputation.from_packed(planes[:, :B], planes[:, B:], B, D, h8, w8, cfg["correlation"]["ev"]["levels"])
@@ -56,5 +66,5 @@ def build(model, vox, cfg, low_params=None):
         coef = model._coefficients()
         out.append(dict(key="roofline_lookup", name=LOOKUP_NAME, regex="corr_lookup_tile_kernel", bound="hbm",
                         launch=lambda: cblk.lookup_bezier_split(params, coef, feat),
-                        flops=None, bytes=4.0 * B * N * cblk.num_planes * (100 + 81), keep=(cblk, vol, planes)))
+                        flops=None, bytes=4.0 * B * N * cblk.num_planes * (100 + 81), keep=(cblk, vol, planes, x8)))
     return out
