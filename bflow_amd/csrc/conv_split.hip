@@ -274,6 +274,77 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Direct epilogue of the TRANSPOSED halo kernel (TR = true: activation fragment as the A operand, weight fragment as B, so an
+// accumulator tile is D[pixel][channel]): lane = output channel (lane & 31), and register r of a lane is pixel column x0 + r of the
+// wave's 2 x 16 slab, patch row (popcount(r >> 2) + (lane >> 5)) & 1 (slab_row / slab_col of pixel (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
+// One accumulator register of a wave is therefore TWO COMPLETE 128-B pixel rows of the blocked fp32 output (32 channels x 4 B each):
+// it is stored as it is -- no LDS transpose, no slab round trip, no wave barrier (the store stream shape K5 uses: 4.7-5.0 TB/s alone,
+// tools/micro/store_patterns.hip) -- the per-channel scale / shift is ONE value per lane and the InstanceNorm sums are plain register
+// adds over the 16 registers plus one half swap.  Used for the convolutions that write pre-normalisation fp32 (+ statistics): every
+// 3 x 3 of the InstanceNorm feature encoder (extractor.py:27-31,47-55).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, int NW = 4>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, int yw, int x0, int n0, int lane,
+                                                     int wave, int tid, float* red) {
+    constexpr int BN = 32 * NT;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const long long plane = (long long)a.P_out * 32;                 // floats of one channel block of one image
+    // rows yw + kh ("same") and yw + 1 - kh ("other") of the slab; a row outside the image is an out-of-range offset (dropped)
+    const int y_same = yw + kh, y_other = yw + 1 - kh;
+    const unsigned off_same = y_same < a.H ? (unsigned)(((y_same * a.W + x0) * 32 + l31) * 4) : 0x80000000u;
+    const unsigned off_other = y_other < a.H ? (unsigned)(((y_other * a.W + x0) * 32 + l31) * 4) : 0x80000000u;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int cbase = n0 + n * 32;
+        if (cbase >= a.Cout) break;
+        const int c = cbase + l31;
+        const bool cok = c < a.Cout;
+        const float sc = (a.scale && cok) ? a.scale[c] : 1.f, sh = (a.shift && cok) ? a.shift[c] : 0.f;
+        float* ob = a.out_f32 + ((long long)b * a.CBo + a.cb_off + (n0 >> 5) + n) * plane;
+        const rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)(plane * 4), 0x00020000);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool other = (__builtin_popcount((unsigned)(r >> 2)) & 1) != 0;
+            float v = (hh[n][r] + xx[n][r] * LO_INV) * sc + sh;
+            if (a.act == 1) v = fmaxf(v, 0.f);
+            else if (a.act == 2) v = tanhf(v);
+            if (!cok) v = 0.f;                                   // padded channels of the last block are written as zeros
+            const unsigned base = other ? off_other : off_same;
+            const bool ok = x0 + r < a.W && base != 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, ok ? base + (unsigned)r * 128u : 0x80000000u, 0, 0);
+            if (ok) { s1 += v; s2 += v * v; }
+        }
+        if (a.stats) {                                           // the other 16 pixels of this channel sit in the other half of the wave
+            float x = s1, y = s1;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+            s1 = x + y;
+            x = s2; y = s2;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+            s2 = x + y;
+            if (lane < 32) {
+                red[(0 * NW + wave) * BN + n * 32 + l31] = s1;
+                red[(1 * NW + wave) * BN + n * 32 + l31] = s2;
+            }
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid - which * BN;
+            const int col = n0 + c;
+            if (col < a.Cout) {
+                const float* p = red + which * NW * BN + c;
+                double sum = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += (double)p[w * BN];
+                atomicAdd(a.stats + (long long)(blockIdx.x % a.stats_reps) * a.stats_rep_stride + ((long long)b * a.Cout + col) * 2 + which, sum);
+            }
+        }
+    }
+}
+
 // NT = output-channel tile / 32;  S = depth of the LDS ring (k-tiles in flight = S - 1): 3 for grids that fill the chip
 // (2 workgroups per CU hide each other's latency), deeper for small grids (batch-1 update block: <= 1 workgroup per CU, so
 // the whole 160 KB of LDS can go into prefetch depth).
@@ -488,7 +559,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (A 16 x 16 patch / 8-wave / up-to-128-channel variant -- half the weight bytes per MFMA -- was measured 10-25 % SLOWER on
 // every encoder and batch-8 shape: eight waves that meet at one barrier per tap serialise more than two independent 4-wave
 // workgroups per CU do.  NW stays a constant so that the index arithmetic below reads generally.)
-template <int NT, int KH, int KW>
+template <int NT, int KH, int KW, bool TR = false>    // TR: transposed accumulators D[pixel][channel] + the direct epilogue (fp32 output only)
 __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = 4;
@@ -638,12 +709,21 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
             else if (!last_cb) HALO_READ(nxh, nxl, nwh, nwl, abuf_next, wnext, 0)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (TR) {        // D[pixel][channel]
 #pragma unroll
-                for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh[ks][n], cxh[ks], hh[n], 0, 0, 0);   // D[channel][pixel]
+                    for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxh[ks], cwh[ks][n], hh[n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwl[ks][n], cxh[ks], xx[n], 0, 0, 0);
+                    for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxh[ks], cwl[ks][n], xx[n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh[ks][n], cxl[ks], xx[n], 0, 0, 0);
+                    for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxl[ks], cwh[ks][n], xx[n], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh[ks][n], cxh[ks], hh[n], 0, 0, 0);   // D[channel][pixel]
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwl[ks][n], cxh[ks], xx[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cwh[ks][n], cxl[ks], xx[n], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -664,9 +744,13 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
     __builtin_amdgcn_s_barrier();
 
     const int W = a.W, H = a.H, yw = y0 + wave * 2;
-    conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
-        const int y = yw + slab_row(row), x = x0 + slab_col(row);
-        return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, true, reinterpret_cast<float*>(lds));
+    if constexpr (TR) {
+        conv_epilogue_direct<NT>(a, hh, xx, b, yw, x0, n0, lane, wave, tid, reinterpret_cast<float*>(lds));
+    } else {
+        conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
+            const int y = yw + slab_row(row), x = x0 + slab_col(row);
+            return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, true, reinterpret_cast<float*>(lds));
+    }
 #endif
 }
 
@@ -1467,8 +1551,13 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     {                                                                                                                  \
         constexpr int units_ = (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16 + 1) / 2 * 2;                           \
         const int lds = 2 * 2 * units_ * 1024 + 4 * (N) * 4096;                                                        \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<N, KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((conv_halo_kernel<N, KHH, KWW>), hgrid, dim3(CT), lds, s, a);                               \
+        if ((N) == 2 && (KHH) == 3 && direct) {   /* fp32 (+ statistics) output: transposed accumulators, stores without an LDS transpose */ \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 3, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((conv_halo_kernel<2, 3, 3, true>), hgrid, dim3(CT), lds, s, a);                         \
+        } else {                                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<N, KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((conv_halo_kernel<N, KHH, KWW>), hgrid, dim3(CT), lds, s, a);                           \
+        }                                                                                                              \
     }
 #define LAUNCH_HALO_NSL(KHH, KWW, NSLL, PATCHES)                                                                       \
     {                                                                                                                  \
@@ -1484,6 +1573,8 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo8_kernel<KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((conv_halo8_kernel<KHH, KWW>), hgrid, dim3(2 * CT), lds, s, a);                             \
     }
+        static const bool no_direct = getenv("BFLOW_CONV_NO_DIRECT") != nullptr;      // A/B timing (tools/)
+        const bool direct = !no_direct && a.out_f32 && !a.oh && !a.addend && !a.gate && !a.acc;
         const bool small8 = nt == 1 && !(force && strcmp(force, "halo4") == 0);   // small grids: the 8-wave split-k variant
         // 10 x 16 patches when the 8 x 16 grid needs a second workgroup on some CUs and the 10 x 16 grid does not
         const int patches10 = bflow::ceil_div(d->H, 10) * bflow::ceil_div(d->W, 16);
