@@ -284,16 +284,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
 // adds over the 16 registers plus one half swap.  Used for the convolutions that write pre-normalisation fp32 (+ statistics): every
 // 3 x 3 of the InstanceNorm feature encoder (extractor.py:27-31,47-55).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, int NW = 4>
-__device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, int yw, int x0, int n0, int lane,
+// `offset_of(r)`: byte offset of (the pixel of accumulator register r of this lane, channel lane & 31) inside one channel block of the
+// output image, or 0x80000000 (out of range: the store is dropped by the buffer bounds check) for pixels outside the image.
+template <int NT, int NW = 4, typename OffsetOf>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, OffsetOf offset_of, int n0, int lane,
                                                      int wave, int tid, float* red) {
     constexpr int BN = 32 * NT;
-    const int kh = lane >> 5, l31 = lane & 31;
+    const int l31 = lane & 31;
     const long long plane = (long long)a.P_out * 32;                 // floats of one channel block of one image
-    // rows yw + kh ("same") and yw + 1 - kh ("other") of the slab; a row outside the image is an out-of-range offset (dropped)
-    const int y_same = yw + kh, y_other = yw + 1 - kh;
-    const unsigned off_same = y_same < a.H ? (unsigned)(((y_same * a.W + x0) * 32 + l31) * 4) : 0x80000000u;
-    const unsigned off_other = y_other < a.H ? (unsigned)(((y_other * a.W + x0) * 32 + l31) * 4) : 0x80000000u;
+    unsigned offs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) offs[r] = offset_of(r);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int cbase = n0 + n * 32;
@@ -306,15 +307,12 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool other = (__builtin_popcount((unsigned)(r >> 2)) & 1) != 0;
             float v = (hh[n][r] + xx[n][r] * LO_INV) * sc + sh;
             if (a.act == 1) v = fmaxf(v, 0.f);
             else if (a.act == 2) v = tanhf(v);
             if (!cok) v = 0.f;                                   // padded channels of the last block are written as zeros
-            const unsigned base = other ? off_other : off_same;
-            const bool ok = x0 + r < a.W && base != 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, ok ? base + (unsigned)r * 128u : 0x80000000u, 0, 0);
-            if (ok) { s1 += v; s2 += v * v; }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, offs[r], 0, 0);
+            if (offs[r] != 0x80000000u) { s1 += v; s2 += v * v; }
         }
         if (a.stats) {                                           // the other 16 pixels of this channel sit in the other half of the wave
             float x = s1, y = s1;
@@ -745,7 +743,11 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 
     const int W = a.W, H = a.H, yw = y0 + wave * 2;
     if constexpr (TR) {
-        conv_epilogue_direct<NT>(a, hh, xx, b, yw, x0, n0, lane, wave, tid, reinterpret_cast<float*>(lds));
+        // register r of lane (channel, kh): pixel column x0 + r, patch row (popcount(r >> 2) + kh) & 1 of the wave's 2 x 16 slab
+        const int kh_ = lane >> 5, c4 = (lane & 31) * 4;
+        conv_epilogue_direct<NT>(a, hh, xx, b, [=](int r) {
+            const int y = yw + ((__builtin_popcount((unsigned)(r >> 2)) + kh_) & 1), x = x0 + r;
+            return (y < H && x < W) ? (unsigned)((y * W + x) * 128 + c4) : 0x80000000u; }, n0, lane, wave, tid, reinterpret_cast<float*>(lds));
     } else {
         conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
             const int y = yw + slab_row(row), x = x0 + slab_col(row);
@@ -1115,7 +1117,7 @@ struct StemArgs {
 #ifndef STEM_ABL
 #define STEM_ABL 0      // tools/stem_ablate.sh: 1 no epilogue, 2 no tile build, 4 no patch load, 8 no MFMA
 #endif
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, bool TR = false>   // TR: transposed accumulators + direct fp32 epilogue, as in conv_halo_kernel
 __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs sa) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 2, TH = 8, TW = 16;
@@ -1265,9 +1267,15 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
                     const half8 wh = *reinterpret_cast<const half8*>(wt + wo);
                     const half8 wl = *reinterpret_cast<const half8*>(wt + NT * 2048 + wo);
                     if (!(STEM_ABL & 8)) {
+                    if constexpr (TR) {
+                    hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, hh[n], 0, 0, 0);
+                    xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, xx[n], 0, 0, 0);
+                    xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, xx[n], 0, 0, 0);
+                    } else {
                     hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh[n], 0, 0, 0);
                     xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, xx[n], 0, 0, 0);
                     xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, xx[n], 0, 0, 0);
+                    }
                     } else { hh[n][0] += (float)wh[0] * (float)xh[0] + (float)wl[1] * (float)xl[1]; }
                 }
             }
@@ -1287,9 +1295,17 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
         if (acc_ == 12345.678f) a.out_f32[tid] = acc_;
         return;
     }
-    conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
-        const int y = yw + (row >> 4), x = x0 + (row & 15);
-        return (y < Ho && x < Wo) ? y * Wo + x : -1; }, n0, lane, wave, tid, true, reinterpret_cast<float*>(lds));
+    if constexpr (TR) {
+        // register r of lane (channel, kh): pixel (r & 3) + 8 (r >> 2) + 4 kh of the wave's 2 x 16 row-major slab
+        const int kh_ = lane >> 5, c4 = (lane & 31) * 4;
+        conv_epilogue_direct<NT>(a, hh, xx, b, [=](int r) {
+            const int y = yw + (r >> 3), x = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh_;
+            return (y < Ho && x < Wo) ? (unsigned)((y * Wo + x) * 128 + c4) : 0x80000000u; }, n0, lane, wave, tid, reinterpret_cast<float*>(lds));
+    } else {
+        conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
+            const int y = yw + (row >> 4), x = x0 + (row & 15);
+            return (y < Ho && x < Wo) ? y * Wo + x : -1; }, n0, lane, wave, tid, true, reinterpret_cast<float*>(lds));
+    }
 #endif
 }
 
@@ -1698,7 +1714,13 @@ extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream
     const int patches = bflow::ceil_div(Ho, 8) * bflow::ceil_div(Wo, 16);
     dim3 grid((patches + 7) / 8 * 8 * a.n_tiles, 1, d->B);
     const int lds = 2 * (2 * CBM * 64) + 2 * (2 * 2 * 2048) + 8 * 21 * 37 * 4 + sa.kblocks_per_chunk * 32 * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel<7, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((conv_stem_kernel<7, 2>), grid, dim3(CT), lds, (hipStream_t)stream, a, sa);
+    static const bool no_direct = getenv("BFLOW_CONV_NO_DIRECT") != nullptr;      // A/B timing (tools/)
+    if (!no_direct && a.out_f32 && !a.oh) {     // fp32 (+ statistics) output: transposed accumulators, direct stores (see conv_epilogue_direct)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel<7, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((conv_stem_kernel<7, 2, true>), grid, dim3(CT), lds, (hipStream_t)stream, a, sa);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel<7, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((conv_stem_kernel<7, 2>), grid, dim3(CT), lds, (hipStream_t)stream, a, sa);
+    }
     return bflow::launch_status("conv_stem");
 }
