@@ -343,6 +343,14 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (
     }
 }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 // NT = output-channel tile / 32;  S = depth of the LDS ring (k-tiles in flight = S - 1): 3 for grids that fill the chip
 // (2 workgroups per CU hide each other's latency), deeper for small grids (batch-1 update block: <= 1 workgroup per CU, so
 // the whole 160 KB of LDS can go into prefetch depth).
@@ -528,6 +536,181 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Direct-activation variant of the generic kernel (round 3) for the shapes the halo kernels do not take -- 1x1 and stride-2 filters:
+// the generic kernel stages the 128-pixel activation tile of EVERY (tap, channel block) through LDS next to the weight tile (16 + 4 NT KB
+// per k-tile) and is bound by the ~25 B/clk a CU moves global -> LDS (the stride-2 3x3 of encoder layer2 ran 98 us for 13 us of
+// matrix work; the 1x1 convc1 of the update block 15 us for 3.4).  But the activation fragment of a lane is PRIVATE to its wave (a wave
+// owns 32 pixels): here it never touches LDS.  Lane (pixel, k half) loads its four 16-B fragments (hi / lo x two 16-deep steps) of a
+// k-tile straight from global memory into registers -- consecutive pixels are consecutive 64-B rows, so a wave instruction reads
+// 32 rows x 32 B; padding / out-of-image taps are out-of-range buffer offsets (zeros) -- two k-tiles ahead; only the weight tile
+// (shared by the waves) goes through a 3-stage LDS-DMA ring.  One counted vmcnt + one barrier per k-tile cover both streams.
+//   KG = 2: 8 waves, the two groups alternate k-tiles and are combined in the shared epilogue (small grids: two waves per SIMD).
+//   TR: transposed accumulators D[pixel][channel] + the direct fp32 epilogue (fp32 + statistics outputs; KG = 1 only).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, int KG, bool TR, int NSTG>   // NSTG: k-tiles in flight + 1 (3 .. 6)
+__global__ __launch_bounds__(CT * KG, 2) void conv_direct_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!(TR && KG > 1), "the direct epilogue has no k-group combine");
+    constexpr int BN = 32 * NT;
+    constexpr int STAGE = 2 * NT * 2048;                  // weight tile: BN rows x 64 B x (hi, lo)
+    constexpr int NLW = NT;                               // weight DMA pieces (1 KB) per wave per k-tile: 4 NT pieces over 4 waves
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3, grp = wave_all >> 2;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.z;
+    const int HoWo = a.Ho * a.Wo;
+    int m0, n0;
+    {
+        const int ntn = a.n_tiles;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int mt = (slot / ntn) * 8 + xcd;
+        m0 = mt * CBM;
+        n0 = (slot - (slot / ntn) * ntn) * BN;
+        if (m0 >= HoWo) return;
+    }
+    const int ntaps = a.KH * a.KW;
+    const int nk = ntaps * a.CB;
+    char* const ring = lds + grp * (NSTG * STAGE);
+
+    // ---- activation side: this lane's pixel, its byte offset for tap (0, 0) of channel block 0 and the mask of valid taps
+    int aoffb;
+    unsigned long long vmask = 0;
+    {
+        const int m = m0 + wave * 32 + l31;
+        const bool rok = m < HoWo;
+        const int ho = m / a.Wo, wo = m - ho * a.Wo;
+        const int hb = ho * a.stride - a.pad_h, wb = wo * a.stride - a.pad_w;
+        aoffb = ((hb * a.W + wb) * 32 + kh * 8) * 2;
+        for (int t = 0; t < ntaps; ++t) {
+            const int r = t / a.KW, q = t - r * a.KW;
+            const int hi_ = hb + r, wi_ = wb + q;
+            if (rok && hi_ >= 0 && hi_ < a.H && wi_ >= 0 && wi_ < a.W) vmask |= 1ull << t;
+        }
+    }
+    // ---- weight side: piece j of this wave: plane (wave * NLW + j) / (2 NT), unit (16 rows) (wave * NLW + j) % (2 NT)
+    const int urow = lane >> 2;
+    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    unsigned wvo[NLW];
+#pragma unroll
+    for (int j = 0; j < NLW; ++j) {
+        int r = n0 + ((wave * NLW + j) % (2 * NT)) * 16 + urow;
+        r = r < a.cout_pad ? r : a.cout_pad - 1;
+        wvo[j] = (unsigned)((r * 32 + uchunk) * 2);
+    }
+    const int CB2 = a.CB - a.CB1;
+    const int plane_b = a.P_in * 64;
+    const rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xh + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_l1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xl + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_h2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2h + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const rsrc_t r_l2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2l + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const int wtile_b = a.cout_pad * 64;
+    const rsrc_t r_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, nk * wtile_b, 0x00020000);
+    const rsrc_t r_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.wl, 0, nk * wtile_b, 0x00020000);
+
+    // running (uniform) position of the k-tile to be issued next (as in conv_split_kernel)
+    int it = 0, iq = 0, icb = grp, itoff = 0, ik = grp;
+    bool ivalid = true;
+    auto settle = [&]() {
+        while (icb >= a.CB) {
+            icb -= a.CB; ++it; ++iq; itoff += 64;
+            if (iq == a.KW) { iq = 0; itoff += (a.W - a.KW) * 64; }
+        }
+        if (it >= ntaps) { ivalid = false; it = 0; iq = 0; icb = 0; itoff = 0; ik = 0; }
+    };
+    settle();
+    auto advance = [&]() { icb += KG; ik += KG; if (ivalid) settle(); else { icb = 0; ik = 0; } };
+
+    half8 xh[NSTG][2], xl[NSTG][2];       // activation fragments of three k-tiles (consumed / landing / just requested)
+#define DIRECT_ISSUE(SLOT)                                                                                               \
+    {                                                                                                                    \
+        char* sb = ring + (SLOT) * STAGE;                                                                                \
+        const int wso_ = ik * wtile_b;                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < NLW; ++j) {                                                                \
+            const int pc_ = wave * NLW + j;                                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pc_ / (2 * NT) ? r_wl : r_wh, (lptr_t)(sb + pc_ * 1024), 16, wvo[j], wso_, 0, 0); \
+        }                                                                                                                \
+        const bool first_ = icb < a.CB1;                                                                                 \
+        const rsrc_t rh_ = first_ ? r_h1 : r_h2;                                                                         \
+        const rsrc_t rl_ = first_ ? r_l1 : r_l2;                                                                         \
+        const bool ok_ = ivalid && ((vmask >> it) & 1ull);                                                               \
+        const unsigned vo_ = ok_ ? (unsigned)(aoffb + (first_ ? icb : icb - a.CB1) * plane_b + itoff) : 0x80000000u;     \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                               \
+            xh[SLOT][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rh_, ok_ ? vo_ + ks * 32 : vo_, 0, 0)); \
+            xl[SLOT][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rl_, ok_ ? vo_ + ks * 32 : vo_, 0, 0)); \
+        }                                                                                                                \
+        advance();                                                                                                       \
+    }
+
+    f32x16 hh[NT], xx[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            hh[n][r] = 0.f;
+            xx[n][r] = 0.f;
+        }
+
+    static_for<0, NSTG - 1>([&](auto u) __attribute__((always_inline)) { DIRECT_ISSUE(decltype(u)::value) });
+    const int sw = (l31 >> 2) & 3;
+    const int nsteps = (nk + KG - 1) / KG;
+    // one k-tile: everything of the issue group NSTG - 1 steps back (its weight pieces AND its activation fragments) has landed when at
+    // most NSTG - 2 groups (NLW + 4 operations each) are still in flight; the barrier publishes the weight tile and frees the stage read
+    // one step ago
+#define DIRECT_STEP(U)                                                                                                   \
+    if (kt0 + (U) < nsteps) {                                                                                            \
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((NSTG - 2) * (NLW + 4)) : "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        DIRECT_ISSUE(((U) + NSTG - 1) % NSTG)                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        const char* wt = ring + (U) * STAGE;                                                                             \
+        half8 wh[2][NT], wl[2][NT];                                                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                               \
+            const int co = ((ks * 2 + kh) ^ sw) * 16;                                                                    \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                             \
+                const int wo = (n * 32 + l31) * 64 + co;                                                                 \
+                wh[ks][n] = *reinterpret_cast<const half8*>(wt + wo);                                                    \
+                wl[ks][n] = *reinterpret_cast<const half8*>(wt + NT * 2048 + wo);                                        \
+            }                                                                                                            \
+        }                                                                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                               \
+            if constexpr (TR) {                                                                                          \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[U][ks], wh[ks][n], hh[n], 0, 0, 0); \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[U][ks], wl[ks][n], xx[n], 0, 0, 0); \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[U][ks], wh[ks][n], xx[n], 0, 0, 0); \
+            } else {                                                                                                     \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][n], xh[U][ks], hh[n], 0, 0, 0); \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks][n], xh[U][ks], xx[n], 0, 0, 0); \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][n], xl[U][ks], xx[n], 0, 0, 0); \
+            }                                                                                                            \
+        }                                                                                                                \
+    }
+    for (int kt0 = 0; kt0 < nsteps; kt0 += NSTG) {
+        static_for<0, NSTG>([&](auto u) __attribute__((always_inline)) { DIRECT_STEP(decltype(u)::value) });
+    }
+#undef DIRECT_STEP
+#undef DIRECT_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // all LDS-DMA traffic has landed: the ring can be reused by the epilogue
+
+    const int mw = m0 + wave * 32;
+    if constexpr (TR) {
+        const int kh_ = lane >> 5, c4 = (lane & 31) * 4;
+        conv_epilogue_direct<NT>(a, hh, xx, b, [=](int r) {
+            const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * kh_;
+            return m < HoWo ? (unsigned)(m * 128 + c4) : 0x80000000u; }, n0, lane, wave, tid, reinterpret_cast<float*>(lds));
+    } else {
+        conv_epilogue<NT, 4 * KG, KG>(a, hh, xx, b, [=](int row) { return mw + row < HoWo ? mw + row : -1; }, n0, lane, wave, tid, grp == 0,
+                                      reinterpret_cast<float*>(lds), grp);
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Halo variant for stride-1 "same" convolutions (3x3, 1x5, 5x1): the kernels above are bound by the global->LDS fill rate of
 // a CU (~25 B/clk measured, L2-resident data), not by the matrix cores, and the generic kernel re-stages the activation tile
 // for EVERY tap.  Here a workgroup owns an 8 x 16 pixel patch; per 32-channel block its (8+KH-1) x (16+KW-1) halo patch is
@@ -546,13 +729,6 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
 __device__ __forceinline__ int slab_row(int n) { return __builtin_popcount((unsigned)(n >> 2) & 7u) & 1; }
 __device__ __forceinline__ int slab_col(int n) { return ((n >> 3) & 3) * 4 + (n & 3); }
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 // (A 16 x 16 patch / 8-wave / up-to-128-channel variant -- half the weight bytes per MFMA -- was measured 10-25 % SLOWER on
 // every encoder and batch-8 shape: eight waves that meet at one barrier per tap serialise more than two independent 4-wave
@@ -1605,6 +1781,40 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
 #undef LAUNCH_HALO10
 #undef LAUNCH_HALO_NSL
         return bflow::launch_status("conv_split(halo)");
+    }
+    // every other inference shape (1x1, stride 2): the direct-activation kernel; the generic kernel keeps the weight-set GEMMs of the
+    // training path (and BFLOW_CONV_KERNEL=generic for tests / A-B timing)
+    static const bool no_directk = getenv("BFLOW_CONV_NO_DIRECT_KERNEL") != nullptr;   // A/B timing (tools/)
+    // (grids that fill the chip several times only: on the <= 320-workgroup grids of the batch-1 update block a 32-channel, two-k-group variant of it
+    // measured 17-19 us for convc1 against 16.4 us for the generic split-k kernel -- there the chain of dependent L2 round trips, not
+    // the LDS fill rate, sets the time -- so those stay on the generic kernel)
+    const long long mt_ = bflow::ceil_div((long long)Ho * Wo, CBM) * d->B;
+    if (a.w_sets == 1 && !force && !no_directk && mt_ * bflow::ceil_div(d->Cout, 64) >= 600) {   // (376-workgroup grids of layer3: 39.7 vs 34.0 us, generic)
+        static const bool no_direct = getenv("BFLOW_CONV_NO_DIRECT") != nullptr;
+        const int nt = (d->Cout > 64 && d->Cout <= 96) ? 3 : 2;     // 64-channel tiles; 96 when that is the whole layer
+        a.n_tiles = bflow::ceil_div(d->Cout, 32 * nt);
+        dim3 dgrid(m_tiles8 * a.n_tiles, 1, d->B);
+        const bool tr = !no_direct && nt > 1 && a.out_f32 && !a.oh && !a.addend && !a.gate && !a.acc;
+#define LAUNCH_DIRECT(N, KGG, TRR, DD)                                                                                 \
+    {                                                                                                                  \
+        const int ring_ = (KGG) * (DD) * 2 * (N) * 2048;                                                               \
+        const int epi_ = (TRR) ? 2 * 4 * 32 * (N) * 4 : (2 * 4 * (KGG) * 32 * (N) + 4 * (KGG) * (N) * 32 * CONV_STG_STRIDE) * 4; \
+        const int lds = ring_ > epi_ ? ring_ : epi_;                                                                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_kernel<N, KGG, TRR, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((conv_direct_kernel<N, KGG, TRR, DD>), dgrid, dim3(CT * (KGG)), lds, s, a);                 \
+    }
+        // prefetch depth (k-tiles in flight + 1): 3; BFLOW_CONV_DIRECT_DEPTH = 4 for A/B (measured equal on the encoder shapes; a depth of 6 on
+        // the batch-1 grids was slower than 3)
+        static const int depth_env = [] { const char* e = getenv("BFLOW_CONV_DIRECT_DEPTH"); return e ? atoi(e) : 0; }();
+        if (nt == 2) {
+            if (depth_env == 4) { if (tr) LAUNCH_DIRECT(2, 1, true, 4) else LAUNCH_DIRECT(2, 1, false, 4) }
+            else { if (tr) LAUNCH_DIRECT(2, 1, true, 3) else LAUNCH_DIRECT(2, 1, false, 3) }
+        } else {
+            if (depth_env == 4) { if (tr) LAUNCH_DIRECT(3, 1, true, 4) else LAUNCH_DIRECT(3, 1, false, 4) }
+            else { if (tr) LAUNCH_DIRECT(3, 1, true, 3) else LAUNCH_DIRECT(3, 1, false, 3) }
+        }
+#undef LAUNCH_DIRECT
+        return bflow::launch_status("conv_split(direct)");
     }
     const bool deep = nblocks <= 320;   // at most ~1 workgroup per CU: spend the LDS on prefetch depth instead of co-residency
 #define LAUNCH(N, SS, KGG)                                                                                             \
