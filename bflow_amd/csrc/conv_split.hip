@@ -55,7 +55,33 @@ struct ConvArgs {
     const float* gz;           // z (B, CBo, P_out, 32)
     float* acc;                // fp32 (B, Cout, Ho*Wo) accumulated in place, or null
     int w_sets;                // > 1: image b multiplies weight set b % w_sets (generic kernel only; the weight-gradient GEMMs)
+    const float* xraw;         // NIN halo kernel: pre-normalisation fp32 input (B, CB, P_in, 32) + its InstanceNorm statistics
+    const double* xstats;      // (R, B, CB*32, 2)
+    int xstats_reps;
+    float xeps;
 };
+
+// InstanceNorm / affine coefficients of one channel: y = x * mul + add (shared by the normalisation kernel and the NIN halo kernel)
+__device__ __forceinline__ void norm_coeffs(const double* stats, const float* scale, const float* shift, int b, int c, int C, int HW,
+                                            float eps, float& mul, float& add, int reps, long long rep_stride) {
+    if (c >= C) { mul = 0.f; add = 0.f; return; }   // padded channels of the last block stay zero
+    if (stats) {   // F.instance_norm: biased variance, eps inside the sqrt
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < reps; ++r) {
+            s1 += stats[r * rep_stride + ((long long)b * C + c) * 2];
+            s2 += stats[r * rep_stride + ((long long)b * C + c) * 2 + 1];
+        }
+        const double mean = s1 / HW;
+        double var = s2 / HW - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        mul = rstd;
+        add = (float)(-mean) * rstd;
+    } else {
+        mul = scale ? scale[c] : 1.f;
+        add = shift ? shift[c] : 0.f;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Epilogue shared by both kernels.  The MFMAs are issued with the WEIGHT fragment as the A operand and the activation
@@ -733,7 +759,13 @@ __device__ __forceinline__ int slab_col(int n) { return ((n >> 3) & 3) * 4 + (n 
 // (A 16 x 16 patch / 8-wave / up-to-128-channel variant -- half the weight bytes per MFMA -- was measured 10-25 % SLOWER on
 // every encoder and batch-8 shape: eight waves that meet at one barrier per tap serialise more than two independent 4-wave
 // workgroups per CU do.  NW stays a constant so that the index arithmetic below reads generally.)
-template <int NT, int KH, int KW, bool TR = false>    // TR: transposed accumulators D[pixel][channel] + the direct epilogue (fp32 output only)
+// NIN: the input is the previous convolution's PRE-NORMALISATION fp32 output + its InstanceNorm statistics (ConvArgs.xraw / xstats): the
+// halo patch of a channel block is loaded into registers (float4 = 4 channels of a halo row per thread), turned into
+// relu((x - mean) * rstd) with the coefficients the normalisation kernel would use, split into hi / lo and written to the halo buffer
+// by ds_write -- the same LDS image the LDS-DMA path produces from a normalised split tensor, so everything downstream is unchanged and
+// the result is bit-identical to "normalise, then convolve", without the normalisation pass over the activation (38 us per 64-channel
+// half-resolution map of the 5 event windows).
+template <int NT, int KH, int KW, bool TR = false, bool NIN = false>    // TR: transposed accumulators D[pixel][channel] + the direct epilogue
 __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = 4;
@@ -824,9 +856,77 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
             xx[n][r] = 0.f;
         }
 
-    HALO_ISSUE_A(0, 0)
+    // ---- NIN: thread -> 4 channels (tid & 7) of halo rows (tid >> 3) + 32 i; float4 loads, normalise + ReLU + split, ds_write_b64
+    constexpr int NHL = NIN ? (HR + 31) / 32 : 0;                  // halo loads per thread per channel block
+    // coefficient tables (mul / add per input channel, <= 128 channels): in the rows HR .. 16 A_UNITS of halo buffer 0 that no tap ever
+    // reads (hi plane: mul, lo plane: add) -- one more KB of LDS would cost the second workgroup of the CU
+    static_assert(!NIN || (A_UNITS * 16 - HR) * 64 >= 128 * 4, "no room for the coefficient tables");
+    float* const nmul = reinterpret_cast<float*>(lds + HR * 64);
+    float* const nadd = reinterpret_cast<float*>(lds + A_PLANE + HR * 64);
+    unsigned noff[NHL > 0 ? NHL : 1];
+    float4 nv[NHL > 0 ? NHL : 1];
+    const int ng = tid & 7;
+    rsrc_t r_raw = r_a1;
+    if constexpr (NIN) {
+#pragma unroll
+        for (int i = 0; i < NHL; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            const int hy = row / HWD, hx = row - hy * HWD;
+            const int py = y0 - a.pad_h + hy, px = x0 - a.pad_w + hx;
+            const bool ok = row < HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
+            noff[i] = ok ? (unsigned)(((py * a.W + px) * 32 + ng * 4) * 4) : 0x80000000u;
+        }
+        r_raw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xraw + (long long)b * a.CB * a.P_in * 32), 0, a.CB * a.P_in * 128, 0x00020000);
+        for (int c = tid; c < a.CB * 32; c += CT) {                // coefficients of every input channel of image b, once per workgroup
+            float m_, a_;
+            norm_coeffs(a.xstats, nullptr, nullptr, b, c, a.CB * 32, a.H * a.W, a.xeps, m_, a_, a.xstats_reps, (long long)gridDim.z * a.CB * 32 * 2);
+            nmul[c] = m_;
+            nadd[c] = a_;
+        }
+    }
+#define NIN_LOAD(CBI)                                                                                                    \
+    {                                                                                                                    \
+        const int cbi_ = (CBI) < a.CB ? (CBI) : a.CB - 1;                                                                \
+        _Pragma("unroll") for (int i = 0; i < NHL; ++i)                                                                  \
+            nv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_raw, noff[i], cbi_ * a.P_in * 128, 0)); \
+    }
+#define NIN_WRITE(CBI, BUF, I0, I1)                                                                                      \
+    {                                                                                                                    \
+        const int cbi_ = (CBI) < a.CB ? (CBI) : a.CB - 1;                                                                \
+        const float4 m4 = *reinterpret_cast<const float4*>(nmul + cbi_ * 32 + ng * 4);                                   \
+        const float4 a4 = *reinterpret_cast<const float4*>(nadd + cbi_ * 32 + ng * 4);                                   \
+        _Pragma("unroll") for (int i = (I0); i < (I1) && i < NHL; ++i) {                                                 \
+            const int row = (tid >> 3) + 32 * i;                                                                         \
+            if (row < HR) {                                                                                              \
+                const bool in_ = noff[i] != 0x80000000u;          /* zero padding applies to the NORMALISED activation */  \
+                const float v_[4] = {in_ ? fmaxf(nv[i].x * m4.x + a4.x, 0.f) : 0.f, in_ ? fmaxf(nv[i].y * m4.y + a4.y, 0.f) : 0.f, \
+                                     in_ ? fmaxf(nv[i].z * m4.z + a4.z, 0.f) : 0.f, in_ ? fmaxf(nv[i].w * m4.w + a4.w, 0.f) : 0.f}; \
+                half4v h4_, l4_;                                                                                         \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                          \
+                    _Float16 x1_, x2_;                                                                                   \
+                    split1(v_[k], x1_, x2_);                                                                             \
+                    h4_[k] = x1_;                                                                                        \
+                    l4_[k] = x2_;                                                                                        \
+                }                                                                                                        \
+                char* d_ = lds + (BUF) * A_BUF + row * 64 + ((((ng >> 1) ^ ((row >> 2) & 3))) << 4) + ((ng & 1) << 3);    \
+                *reinterpret_cast<half4v*>(d_) = h4_;                                                                    \
+                *reinterpret_cast<half4v*>(d_ + A_PLANE) = l4_;                                                          \
+            }                                                                                                            \
+        }                                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        /* visible to the other waves at the next barrier */   \
+    }
+
+    if constexpr (NIN) {
+        NIN_LOAD(0)
+    } else {
+        HALO_ISSUE_A(0, 0)
+    }
 #pragma unroll
     for (int t = 0; t <= LA; ++t) HALO_ISSUE_B(0, t, t)
+    if constexpr (NIN) {
+        __syncthreads();                                           // coefficient table complete
+        NIN_WRITE(0, 0, 0, NHL)
+    }
 
     // this lane's pixel inside the patch (MFMA B-operand row = pixel) and its halo row for tap (0, 0)
     const int R0 = (wave * 2 + slab_row(l31)) * HWD + slab_col(l31);
@@ -865,11 +965,25 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
             // s-2 (after that step's halo issue, if any).  Issued since: the tile of step s-1 and, when s-1 was tap 1, the next
             // block's halo.  A slot / halo buffer is refilled two barriers after its last reader (hipcc lets fragment reads
             // complete after the next barrier): ring of 4 = {being drained, being read, 2 in flight}.
-            if (t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + AP) : "memory");
+            if (t == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + (NIN ? NHL : AP)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (t == 1) HALO_ISSUE_A(cb + 1, (cb + 1) & 1)
+            if constexpr (NIN) {
+                if (t == 1) NIN_LOAD(cb + 1)
+                // the loads have landed behind the counted wait of tap 3; buffer (cb + 1) & 1 was last read two barriers before tap 1.  The
+                // conversion is spread over taps 3 .. NTAPS - 2 (its ~40 VALU instructions per item sit between the taps' MFMAs instead
+                // of stalling all eight waves of the CU at one tap); the buffer is read from tap NTAPS - 1 on
+                if constexpr (NTAPS >= 6) {
+                    constexpr int slots = NTAPS - 4;                             // taps 3 .. NTAPS - 2
+                    constexpr int per = (NHL + slots - 1) / slots;
+                    if (t >= 3 && t <= NTAPS - 2) NIN_WRITE(cb + 1, (cb + 1) & 1, (t - 3) * per, (t - 2) * per)
+                } else {
+                    if (t == 3) NIN_WRITE(cb + 1, (cb + 1) & 1, 0, NHL)
+                }
+            } else {
+                if (t == 1) HALO_ISSUE_A(cb + 1, (cb + 1) & 1)
+            }
             {
                 constexpr int tn = (t + LA + 1) % NTAPS;
                 const int cbn = cb + (t + LA + 1) / NTAPS;
@@ -914,6 +1028,8 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 #undef HALO_READ
 #undef HALO_ISSUE_A
 #undef HALO_ISSUE_B
+#undef NIN_LOAD
+#undef NIN_WRITE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -1553,26 +1669,6 @@ struct NormArgs {
     int stats_reps;        // replicas of the statistics tables (summed here)
 };
 
-__device__ __forceinline__ void norm_coeffs(const double* stats, const float* scale, const float* shift, int b, int c, int C, int HW,
-                                            float eps, float& mul, float& add, int reps, long long rep_stride) {
-    if (c >= C) { mul = 0.f; add = 0.f; return; }   // padded channels of the last block stay zero
-    if (stats) {   // F.instance_norm: biased variance, eps inside the sqrt
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < reps; ++r) {
-            s1 += stats[r * rep_stride + ((long long)b * C + c) * 2];
-            s2 += stats[r * rep_stride + ((long long)b * C + c) * 2 + 1];
-        }
-        const double mean = s1 / HW;
-        double var = s2 / HW - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        mul = rstd;
-        add = (float)(-mean) * rstd;
-    } else {
-        mul = scale ? scale[c] : 1.f;
-        add = shift ? shift[c] : 0.f;
-    }
-}
 
 __global__ __launch_bounds__(256) void norm_act_split_kernel(NormArgs p) {
     __shared__ float tile[32][65];                    // NCHW input only: 32 channels x 64 pixels
@@ -1683,7 +1779,11 @@ __global__ __launch_bounds__(256) void split_to_nchw_kernel(const _Float16* __re
 }  // namespace
 
 extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t stream) {
-    BFLOW_REQUIRE(d && d->x_hi && d->x_lo && d->w_hi && d->w_lo, BFLOW_E_ARG, "conv_split: null operand");
+    BFLOW_REQUIRE(d && ((d->x_hi && d->x_lo) || (d->x_raw && d->x_stats)) && d->w_hi && d->w_lo, BFLOW_E_ARG, "conv_split: null operand");
+    if (d->x_raw)
+        BFLOW_REQUIRE(d->x_stats && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && !d->x2_hi && d->out_f32 && !d->out_hi &&
+                          !d->addend && !d->gate && !d->acc_nchw && d->weight_sets <= 1 && d->C <= 128 && d->tile_n == 64,
+                      BFLOW_E_ARG, "conv_split: x_raw (normalised-on-load input) needs a stride-1 3x3 with fp32 (+ stats) output, C <= 128, 64-channel tiles");
     BFLOW_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % 32 == 0, BFLOW_E_ARG, "conv_split: C=%d must be a multiple of 32", d->C);
     BFLOW_REQUIRE(d->KH > 0 && d->KW > 0 && (d->stride == 1 || d->stride == 2) && d->Cout > 0, BFLOW_E_ARG, "conv_split: bad filter");
     BFLOW_REQUIRE(d->out_f32 || (d->out_hi && d->out_lo), BFLOW_E_ARG, "conv_split: no output");
@@ -1717,6 +1817,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     a.stats_reps = d->stats_replicas > 0 ? d->stats_replicas : 1; a.stats_rep_stride = (long long)d->B * d->Cout * 2;
     a.acc = d->acc_nchw;
     a.w_sets = d->weight_sets > 1 ? d->weight_sets : 1;
+    a.xraw = d->x_raw; a.xstats = d->x_stats; a.xstats_reps = d->x_stats_replicas > 0 ? d->x_stats_replicas : 1; a.xeps = d->x_eps;
     a.gate = d->gate; a.gh = (const _Float16*)d->gate_h_hi; a.gl = (const _Float16*)d->gate_h_lo; a.gz = d->gate_z;
     if (d->gate) {
         BFLOW_REQUIRE((d->gate == 1 || d->gate == 2) && d->gate_h_hi && d->gate_h_lo && d->out_hi && d->out_lo && !d->stats && d->act == 0 &&
@@ -1736,14 +1837,17 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     if (same && shape && a.w_sets == 1 && !(force && strncmp(force, "halo", 4) != 0)) {
         const int patches = bflow::ceil_div(d->H, 8) * bflow::ceil_div(d->W, 16);
         // 64-channel tiles unless that leaves most CUs without a workgroup (batch-1 update block: 40 patches)
-        const int nt = ((long long)patches * d->B * bflow::ceil_div(d->Cout, 64) >= 200) ? 2 : 1;
+        const int nt = (a.xraw || (long long)patches * d->B * bflow::ceil_div(d->Cout, 64) >= 200) ? 2 : 1;
         a.n_tiles = bflow::ceil_div(d->Cout, 32 * nt);
         dim3 hgrid((patches + 7) / 8 * 8 * a.n_tiles, 1, d->B);
 #define LAUNCH_HALO(N, KHH, KWW)                                                                                       \
     {                                                                                                                  \
         constexpr int units_ = (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16 + 1) / 2 * 2;                           \
         const int lds = 2 * 2 * units_ * 1024 + 4 * (N) * 4096;                                                        \
-        if ((N) == 2 && (KHH) == 3 && direct) {   /* fp32 (+ statistics) output: transposed accumulators, stores without an LDS transpose */ \
+        if ((N) == 2 && (KHH) == 3 && a.xraw) {   /* ... and the input normalised on its way into LDS */                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 3, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            hipLaunchKernelGGL((conv_halo_kernel<2, 3, 3, true, true>), hgrid, dim3(CT), lds, s, a);                   \
+        } else if ((N) == 2 && (KHH) == 3 && direct) {   /* fp32 (+ statistics) output: transposed accumulators, stores without an LDS transpose */ \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 3, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             hipLaunchKernelGGL((conv_halo_kernel<2, 3, 3, true>), hgrid, dim3(CT), lds, s, a);                         \
         } else {                                                                                                       \

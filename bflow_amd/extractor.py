@@ -8,6 +8,7 @@ conv epilogues, and one normalise + activate + residual kernel sits between conv
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Sequence, Union
 
 import torch
@@ -19,6 +20,7 @@ from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backwa
 from .norm_train import norm_act  # [relu](norm(x)): hand-written forward / backward in GPU training mode
 
 STATS_R = 8
+FUSE_NORM_IN = os.environ.get("BFLOW_NO_NORM_IN") is None     # A/B switch (tools/): conv2 of a residual block normalises its input on load
 
 
 def _make_norm(kind: str, channels: int) -> nn.Module:
@@ -178,9 +180,19 @@ class BasicEncoder(nn.Module):
             for bi, blk in enumerate(layer):
                 stride = blk.conv1.stride[0]
                 pre = f"layer{li}.{bi}"
-                a1 = conv_norm_relu_split(pre + ".conv1", blk.conv1, blk.norm1, cur, stride)
-                c2, st2 = conv_norm(pre + ".conv2", blk.conv2, blk.norm2, a1, 1, True)
-                shape = (n, a1.H, a1.W, blk.conv2.out_channels)
+                if kind == "instance" and FUSE_NORM_IN and blk.conv1.out_channels <= 128 and blk.conv1.out_channels % 32 == 0:
+                    # relu(norm1(conv1(x))) is never materialised: conv2 normalises conv1's fp32 output while it stages its halo
+                    # (bflow_conv_desc_t.x_raw): the same arithmetic, one read + write of the activation and one launch less
+                    f1, st1 = conv_norm(pre + ".conv1", blk.conv1, blk.norm1, cur, stride, True)
+                    ho, wo = out_hw(cur, blk.conv1, stride)
+                    st2 = new_stats(blk.conv2.out_channels)
+                    c2 = S.conv_norm_in(f1, (n, ho, wo, blk.conv1.out_channels), st1, self._packed(pre + ".conv2", blk.conv2), stats=st2,
+                                        eps=blk.norm1.eps)
+                    shape = (n, ho, wo, blk.conv2.out_channels)
+                else:
+                    a1 = conv_norm_relu_split(pre + ".conv1", blk.conv1, blk.norm1, cur, stride)
+                    c2, st2 = conv_norm(pre + ".conv2", blk.conv2, blk.norm2, a1, 1, True)
+                    shape = (n, a1.H, a1.W, blk.conv2.out_channels)
                 if blk.downsample is None:
                     # relu(x + relu(norm2(conv2)))          (extractor.py:50-55)
                     cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU if kind == "instance" else S.ACT_NONE, res=cur,

@@ -56,7 +56,8 @@ class ConvDesc(ctypes.Structure):
                 ("x_split_channels", ctypes.c_int), ("addend", ctypes.c_void_p),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("act", ctypes.c_int), ("stats", ctypes.c_void_p),
                 ("gate", ctypes.c_int), ("gate_h_hi", ctypes.c_void_p), ("gate_h_lo", ctypes.c_void_p), ("gate_z", ctypes.c_void_p),
-                ("stats_replicas", ctypes.c_int), ("acc_nchw", ctypes.c_void_p), ("weight_sets", ctypes.c_int)]
+                ("stats_replicas", ctypes.c_int), ("acc_nchw", ctypes.c_void_p), ("weight_sets", ctypes.c_int),
+                ("x_raw", ctypes.c_void_p), ("x_stats", ctypes.c_void_p), ("x_stats_replicas", ctypes.c_int), ("x_eps", ctypes.c_float)]
 
 
 class StemDesc(ctypes.Structure):

@@ -308,6 +308,31 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
     return out_split, out_f32
 
 
+def conv_norm_in(raw: torch.Tensor, shape_bhwc, x_stats: torch.Tensor, packed, stats: Optional[torch.Tensor] = None, eps: float = 1e-5,
+                 out_f32: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 stride-1 "same" convolution of relu(instance_norm(raw)) where `raw` is the previous convolution's blocked fp32 output
+    (B, C/32, H*W, 32) and `x_stats` (R, B, C, 2) the statistics its epilogue accumulated (extractor.py:47-48: relu(norm1(conv1(x)))
+    feeding conv2): the normalisation is applied while the halo is staged (bflow_conv_desc_t.x_raw), bit-identical to
+    norm_act(...) followed by conv(...), one pass over the activation less.  Returns the blocked fp32 output (+= statistics into `stats`)."""
+    planes, (cout, cin_pad, kh, kw, cout_pad) = packed
+    B, H, W, C = shape_bhwc
+    assert (kh, kw) == (3, 3) and C == cin_pad and C % 32 == 0 and C <= 128 and tuple(raw.shape) == (B, C // 32, H * W, 32) and raw.dtype == torch.float32
+    if out_f32 is None:
+        out_f32 = torch.empty((B, (cout + 31) // 32, H * W, 32), dtype=torch.float32, device=raw.device)
+    d = hip.ConvDesc()
+    d.x_raw, d.x_stats, d.x_eps = hip._dev(raw, name="raw"), hip._dev(x_stats, torch.float64, "x_stats"), eps
+    d.x_stats_replicas = _stats_replicas(x_stats, B, C)
+    d.w_hi, d.w_lo = planes[0].data_ptr(), planes[1].data_ptr()
+    d.B, d.H, d.W, d.C, d.Cout, d.cout_pad = B, H, W, C, cout, cout_pad
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.tile_n = 3, 3, 1, 1, 1, 64
+    d.out_f32 = out_f32.data_ptr()
+    d.out_channel_stride, d.out_channel_offset, d.out_rows_per_image, d.in_rows_per_image = (cout + 31) // 32 * 32, 0, H * W, H * W
+    d.stats = None if stats is None else hip._dev(stats, torch.float64, "stats")
+    d.stats_replicas = _stats_replicas(stats, B, cout)
+    hip._check(hip.lib().bflow_conv_split(ctypes.byref(d), hip._stream()), "bflow_conv_split")
+    return out_f32
+
+
 def wgrad_pack(src: torch.Tensor, out_hw, ksize=(1, 1), stride: int = 1, padding=(0, 0), rows: Optional[int] = None,
                k_blocks: Optional[int] = None, scale: Optional[torch.Tensor] = None, taps_in_rows: bool = False) -> torch.Tensor:
     """NCHW fp32 -> split planes with the pixel index k = (b*Ho + yo)*Wo + xo in the block position (bflow_wgrad_pack):

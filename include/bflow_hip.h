@@ -129,6 +129,16 @@ typedef struct bflow_conv_desc {
                                          b is multiplied with filter b % S (generic kernel).  Used by the weight-gradient GEMMs of the
                                          training path: "image" = (filter tap, k-chunk), "filter" = the packed output gradient of that
                                          k-chunk (bflow_wgrad_pack).                                                               */
+    const float* x_raw;               /* optional: the input given as the PRE-NORMALISATION fp32 output of the previous convolution, blocked
+                                         (B, C/32, P_in, 32), together with its InstanceNorm statistics `x_stats` (R, B, C, 2) fp64 as that
+                                         convolution's epilogue accumulated them (x_stats_replicas = R, x_eps).  The kernel applies
+                                         relu((x - mean) * rstd) -- extractor.py:47-48: relu(norm1(conv1(x))) -- while it stages the
+                                         halo, with the coefficients bflow_norm_act_split would use, so the result equals the two-launch
+                                         form bit for bit and the normalisation pass (a read and a write of the whole activation)
+                                         disappears.  x_hi / x_lo are then ignored (may be NULL).  Stride-1 3x3, fp32 (+ stats) output only. */
+    const double* x_stats;
+    int x_stats_replicas;
+    float x_eps;
 } bflow_conv_desc_t;
 /* bflow_conv_stem: the 7x7 stride-2 entry convolution of BasicEncoder (extractor.py:63,110) on a few-channel fp32 NCHW input
  * (5 / 8 / 25 / 41 / 3 channels): im2col in LDS over a TIGHT k = (channel, tap) index instead of 32-channel blocks per tap.
