@@ -42,7 +42,7 @@ PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s (
 
 
 def kernel_source_hash() -> str:
-    """Hash of everything that determines the kernels' HBM traffic: the HIP sources and the ABI header.  profiles/r02_pmc.json
+    """Hash of everything that determines the kernels' HBM traffic: the HIP sources and the ABI header.  profiles/r03_pmc.json
     records it; bench.py only quotes the PMC traffic of kernels built from the SAME sources."""
     h = hashlib.sha256()
     cs = os.path.join(ROOT, "bflow_amd", "csrc")
@@ -164,6 +164,8 @@ def main():
     # (8 frames at N = 8: two concurrent micro-batches of 4 = 358 frames/s, one of 8 = 332; tools/two_frame_probe.py)
     micro = min(MICRO_BATCH, max(1, (s1 - s0) // 2)) if not args.no_graph else min(MICRO_BATCH, s1 - s0)
     n_micro = (s1 - s0) // micro
+    # every frame of the shard must be run: frames/s counts s1 - s0 frames per step (a remainder micro-batch would be counted, not run)
+    assert n_micro * micro == s1 - s0, f"the rank's {s1 - s0} frames do not split into micro-batches of {micro}: use a world size that divides {GLOBAL_BATCH} into even shards"
     vox8 = None
 
     def setup_c4():
@@ -270,7 +272,7 @@ def main():
         torch.cuda.empty_cache()
         src_hash = kernel_source_hash()
         try:
-            pmc_doc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+            pmc_doc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
         except Exception:
             pmc_doc = {}
         pmc_ok = pmc_doc.get("kernel_source_hash") == src_hash
@@ -301,14 +303,17 @@ def main():
             if k.get("note"):
                 r["note"] = k["note"]
             # HBM traffic per launch cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the SAME launches
-            # (tools/collect_profiles.sh -> profiles/r02_pmc.json), and only when that file was collected on kernels built from these sources
+            # (tools/collect_profiles.sh -> profiles/r03_pmc.json), and only when that file was collected on kernels built from these sources
             if k["name"] in pmc:
                 r["traffic"] = pmc[k["name"]]["traffic"]
-                r["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; same kernel sources)"
+                r["traffic_source"] = "profiles/r03_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; same kernel sources)"
             elif pmc_doc and not pmc_ok:
-                r["traffic_source"] = "none: profiles/r02_pmc.json was collected on different kernel sources (re-run tools/collect_profiles.sh)"
+                r["traffic_source"] = "none: profiles/r03_pmc.json was collected on different kernel sources (re-run tools/collect_profiles.sh)"
             out[k["key"]] = r
             k.clear()
+        if world == 1:
+            out["gpu_stage_ms"] = gpu_stage_ms(cfg, sd, vox1, dev)
+            out["voxel_kernels"] = voxel_kernels(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, torch.from_numpy(vox1_np[:1]))
             out["gpu_over_cpu"] = round(out["c2_weak"]["value"] / out["cpu_baseline"]["value"], 1)
@@ -339,26 +344,114 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(cfg, sd, vox_cpu, budget_s=25.0):
-    """The CPU oracle (op-for-op restatement of the reference, pinned to it in the build container) on this host's cores.
-    Bounded sample: 1 warm-up + up to 4 timed forwards of the same workload (one 640x480 frame, 12 iterations)."""
+def cpu_baseline(cfg, sd, vox_cpu, budget_s=32.0):
+    """The CPU oracle (op-for-op restatement of the reference, pinned to it in the build container) on this host's cores, with the
+    protocol of SURVEY 8(d): torch.set_num_threads(all usable cores) AND 1 thread (the reference's own data path pins torch to one
+    thread, representations.py:5-6; val.py:5-9 exports OMP_NUM_THREADS=1), inference_mode, 2 warm-ups (utils/timers.py:64) + 5 timed
+    forwards of the same frame (the 1-thread leg stops at `budget_s` seconds of timed work, >= 3 forwards), per-stage milliseconds under
+    the reference's CudaTimer names (raft.py:116-186).  Bounded sample: one 640x480 frame, 12 iterations."""
     import numpy as np
     import torch
     from oracle import raft_spline_oracle as O   # checker / baseline only -- never on the product path
     cores = usable_cores()
+
+    def leg(threads, warmups, forwards, budget):
+        torch.set_num_threads(threads)
+        stages, opened = {}, {}
+
+        def hook(name, begin):
+            t = time.perf_counter()
+            if begin:
+                opened[name] = t
+            else:
+                stages.setdefault(name, []).append(t - opened.pop(name))
+
+        with torch.inference_mode():
+            for _ in range(warmups):
+                O.forward(sd, cfg, vox_cpu, None, iters=ITERS, test_mode=True)
+            times = []
+            t_start = time.perf_counter()
+            while len(times) < forwards and (len(times) < 3 or time.perf_counter() - t_start < budget):
+                t0 = time.perf_counter()
+                O.forward(sd, cfg, vox_cpu, None, iters=ITERS, test_mode=True, stage_hook=hook)
+                times.append(time.perf_counter() - t0)
+        sec = float(np.mean(times))
+        return {"value": round(1.0 / sec, 4), "unit": "frames/s", "threads": threads, "ms_per_frame": round(sec * 1e3, 1),
+                "forwards": len(times), "warmups": warmups,
+                "stage_ms": {k: round(float(np.mean(v)) * 1e3, 2) for k, v in stages.items()}}
+
+    full = leg(cores, 2, 5, budget_s)
+    one = leg(1, 1, 5, budget_s) if cores > 1 else full
     torch.set_num_threads(cores)
-    with torch.inference_mode():
-        O.forward(sd, cfg, vox_cpu, None, iters=ITERS, test_mode=True)
-        times = []
-        t_start = time.perf_counter()
-        while len(times) < 4 and (time.perf_counter() - t_start) < budget_s:
-            t0 = time.perf_counter()
-            O.forward(sd, cfg, vox_cpu, None, iters=ITERS, test_mode=True)
-            times.append(time.perf_counter() - t0)
-    sec = float(np.mean(times))
-    return {"value": round(1.0 / sec, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} forwards of 1 frame (640x480, {ITERS} iters) after 1 warm-up, torch CPU fp32, {cores} threads",
-            "ms_per_frame": round(sec * 1e3, 1)}
+    return {"value": full["value"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{full['forwards']} forwards of 1 frame (640x480, {ITERS} iters) after {full['warmups']} warm-ups, torch CPU fp32, {cores} threads; "
+                      f"1-thread leg: {one['forwards']} forwards after {one['warmups']} warm-up",
+            "ms_per_frame": full["ms_per_frame"], "ms_per_gru_iter": full["stage_ms"].get("1 iter"),
+            "stage_ms": full["stage_ms"], "single_thread": one,
+            "stage_names": "the reference's CudaTimer hooks, models/raft_spline/raft.py:116-186 (per-iteration stages: mean per occurrence)"}
+
+
+def gpu_stage_ms(cfg, sd, vox, dev):
+    """Per-stage milliseconds of the HIP path under the reference's hook names: EAGER launches (a hipGraph replay has no place to record
+    events) bracketed by hipEvents on the launch stream (bflow_amd/timers.py), 2 warm-ups + 5 forwards.  Eager mode pays the host's
+    enqueue latency per launch, so these are upper bounds of the stage times inside the graph replay that `value` measures."""
+    import bflow_amd
+    m = bflow_amd.RAFTSpline(cfg).eval()
+    m.load_state_dict(sd)
+    m.to(dev)
+    m.enable_stage_timing()
+    for _ in range(7):
+        m(voxel_grid=vox, iters=ITERS, test_mode=True)
+    per = {"1 iter": ITERS, "corr lookup (per iter)": ITERS, "update (per iter)": ITERS, "get_flow (per iter)": ITERS}
+    out = {k: round(v, 4) for k, v in m.stage_timer.summary_ms(per).items()}
+    out["note"] = "eager launches + hipEvents (upper bounds: host enqueue latency included); 'get_flow (per iter)' is fused into the look-up kernel"
+    return out
+
+
+def voxel_kernels(dev):
+    """K1 / K2 on synthetic DSEC-shaped events: 2 M events per 100 ms window into the 15-bin 480x640 grid the two-step
+    assembly uses; algorithmic bytes per SURVEY 8(d): 16 B per event + 8 (float xy) or 2 (int xy) fp32 atomic read-modify-writes +
+    the zero-initialisation of the grid; K2: four passes over the grid."""
+    import numpy as np
+    import torch
+    from bflow_amd import synthetic
+    from bflow_amd.representations import VoxelGrid, norm_voxel_grid
+    C, Hh, Ww, n_ev = 15, H, W, 2_000_000
+    out = {}
+    for tag, int_xy in (("float_xy", False), ("int_xy", True)):
+        ev = synthetic.events(n_ev, Hh, Ww, 0, 100_000, seed=7, int_xy=int_xy)
+        x, y, p, t = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in ev)
+        vg = VoxelGrid(C, Hh, Ww)
+        for _ in range(3):
+            g = vg.convert(x, y, p, t, 0, 100_000)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            g = vg.convert(x, y, p, t, 0, 100_000)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        atom = 2 if int_xy else 8
+        by = n_ev * (16 + atom * 8) + C * Hh * Ww * 4
+        out["k1_" + tag] = {"ms": round(ms, 4), "events_per_s": round(n_ev / ms * 1e3), "atomics_per_s": round(n_ev * atom / ms * 1e3),
+                            "algorithmic_gb_s": round(by / ms / 1e6, 1), "events": n_ev, "grid": [C, Hh, Ww],
+                            "note": "whole VoxelGrid.convert call (dtype conversions + zero fill + scatter kernel)"}
+    g = torch.randn(9, Hh, Ww, device=dev) * (torch.rand(9, Hh, Ww, device=dev) < 0.3)
+    for _ in range(3):
+        norm_voxel_grid(g.clone())
+    gs = [g.clone() for _ in range(10)]
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for q in gs:
+        norm_voxel_grid(q)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 10
+    out["k2_norm"] = {"ms": round(ms, 4), "algorithmic_gb_s": round(4 * g.numel() * 4 / ms / 1e6, 1), "grid": [9, Hh, Ww],
+                      "note": "three reading passes + one writing pass over the 11-MB grid"}
+    return out
 
 
 if __name__ == "__main__":

@@ -184,8 +184,19 @@ def _weight_grad(x: torch.Tensor, dy: torch.Tensor, s: torch.Tensor, inv: torch.
         return S.wgrad_reduce(part, G, cout, cin, ksize, 1, inv)
 
 
+def _refuse_library(x: torch.Tensor, what: str):
+    """A GPU call that does not take the engine path would silently run on the vendor library (MIOpen): refuse it.  The module forward of
+    this package is the DIFFERENTIABLE path only (grad enabled, something requires grad, a filter the engine supports); inference runs
+    `forward_split` / `RAFTSpline.forward` in eval mode.  `ENABLED = False` is the explicit A/B switch of tools / tests and keeps torch's path."""
+    if ENABLED and x.is_cuda:
+        raise hip.BflowHipError(f"{what} on a GPU tensor outside the conv engine's differentiable path (grad disabled, nothing requires grad, or a "
+                                "grouped / dilated / non-zero-padded filter): there is no library fall-back -- run inference through "
+                                "RAFTSpline.forward in eval() mode (forward_split), or enable grad for training")
+
+
 class Conv2d(nn.Conv2d):
-    """nn.Conv2d whose GPU forward under autograd runs (and differentiates) on the HIP conv engine.  State-dict compatible."""
+    """nn.Conv2d whose GPU forward under autograd runs (and differentiates) on the HIP conv engine.  State-dict compatible.
+    A GPU forward that cannot take that path raises (no MIOpen fall-through); CPU tensors behave like nn.Conv2d."""
 
     def forward(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
         if (ENABLED and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad) and self.groups == 1
@@ -193,6 +204,7 @@ class Conv2d(nn.Conv2d):
                 and not isinstance(self.padding, str)):
             cache = self.__dict__.setdefault("_hip_pack", _PackCache())
             return _ConvFn.apply(x, self.weight, self.bias, self.stride[0], tuple(self.padding), cache, (self.weight,), relu)
+        _refuse_library(x, "Conv2d.forward")
         y = super().forward(x)
         return torch.relu(y) if relu else y
 
@@ -206,4 +218,5 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias, padding, cache: _PackCac
     built from (the cache key)."""
     if ENABLED and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
         return _ConvFn.apply(x, weight, bias, stride, tuple(padding), cache, tuple(srcs))
+    _refuse_library(x, "conv2d")
     return torch.nn.functional.conv2d(x, weight, bias, stride=stride, padding=padding)

@@ -899,8 +899,8 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
             const int row = (tid >> 3) + 32 * i;                                                                         \
             if (row < HR) {                                                                                              \
                 const bool in_ = noff[i] != 0x80000000u;          /* zero padding applies to the NORMALISED activation */  \
-                const float v_[4] = {in_ ? fmaxf(nv[i].x * m4.x + a4.x, 0.f) : 0.f, in_ ? fmaxf(nv[i].y * m4.y + a4.y, 0.f) : 0.f, \
-                                     in_ ? fmaxf(nv[i].z * m4.z + a4.z, 0.f) : 0.f, in_ ? fmaxf(nv[i].w * m4.w + a4.w, 0.f) : 0.f}; \
+                const float v_[4] = {in_ ? fmaxf(fmaf(nv[i].x, m4.x, a4.x), 0.f) : 0.f, in_ ? fmaxf(fmaf(nv[i].y, m4.y, a4.y), 0.f) : 0.f, \
+                                     in_ ? fmaxf(fmaf(nv[i].z, m4.z, a4.z), 0.f) : 0.f, in_ ? fmaxf(fmaf(nv[i].w, m4.w, a4.w), 0.f) : 0.f}; \
                 half4v h4_, l4_;                                                                                         \
                 _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                          \
                     _Float16 x1_, x2_;                                                                                   \
@@ -1727,9 +1727,9 @@ __global__ __launch_bounds__(256) void norm_act_split_kernel(NormArgs p) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int c = cb * 32 + c8 + k;
-            float x = v[k] * coef[0][c8 + k] + coef[1][c8 + k];
+            float x = fmaf(v[k], coef[0][c8 + k], coef[1][c8 + k]);   // (explicit fma: the NIN halo kernel applies the same expression, bit for bit)
             if (p.act_a == 1) x = fmaxf(x, 0.f);
-            if (p.b) x += bv[k] * coef[2][c8 + k] + coef[3][c8 + k];
+            if (p.b) x += fmaf(bv[k], coef[2][c8 + k], coef[3][c8 + k]);
             if (p.rh) x += (float)rh8[k] + (float)rl8[k] * LO_INV;
             if (p.act_out == 1) x = fmaxf(x, 0.f);
             else if (p.act_out == 2) x = tanhf(x);

@@ -127,11 +127,12 @@ class TwoStepAssembler:
         if self.voxel_grid_dir is None or file_index is None:
             return self.construct_voxel_grid(events, ts_from, ts_to)
         f = voxel_cache.dsec_voxel_grid_file(self.voxel_grid_dir, file_index)
-        if not f.exists():
+        cached = voxel_cache.h5_to_np_array(f) if f.exists() else None     # None: unreadable / truncated file = a miss, rebuilt and overwritten
+        if cached is None:
             grid = self.construct_voxel_grid(events, ts_from, ts_to)
             voxel_cache.np_array_to_h5(grid.cpu().numpy(), f)
             return grid
-        return torch.from_numpy(voxel_cache.h5_to_np_array(f)).to(self.device)
+        return torch.from_numpy(cached).to(self.device)
 
     # twostep.py:44-92 ------------------------------------------------------------------------------------------------
     def assemble(self, events, forward_flow_timestamps, index: int, check: bool = True, flow_file_index: Optional[int] = None) -> torch.Tensor:

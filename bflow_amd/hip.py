@@ -516,6 +516,7 @@ BRANCHING = True        # tools: False issues every branch on the current stream
 
 # ------------------------------------------------------------------------------------------------ training path (f-4)
 _const_cache: dict = {}
+_captured_consts: dict = {}
 
 
 def const_tensor(arr, device) -> torch.Tensor:
@@ -524,11 +525,20 @@ def const_tensor(arr, device) -> torch.Tensor:
     import numpy as np
     a = np.ascontiguousarray(arr)
     key = (a.dtype.str, a.shape, a.tobytes(), str(device))
-    t = _const_cache.get(key)
+    t = _const_cache.pop(key, None)
     if t is None:
-        if len(_const_cache) > 256:
-            _const_cache.clear()
-        t = _const_cache[key] = torch.from_numpy(a.copy()).to(device)
+        if torch.cuda.is_current_stream_capturing():
+            # a miss here would issue a pageable host-to-device copy inside the capture, and an eviction could free a table an earlier
+            # graph still points at: both are silent failures -- refuse (warm the cache with one eager step first)
+            raise BflowHipError("const_tensor: constant not cached while a stream capture is in progress (run the step once eagerly first)")
+        while len(_const_cache) >= 256:          # least recently used first (dict order = recency, see the re-insert below); never all at once
+            _const_cache.pop(next(iter(_const_cache)))
+        t = torch.from_numpy(a.copy()).to(device)
+    _const_cache[key] = t                       # (re-)insert as most recent
+    if torch.cuda.is_current_stream_capturing():
+        # a captured graph keeps only the raw pointer of the table: pin the tensor for the life of the process (a few hundred bytes each), so
+        # that a later eviction can never hand its memory to somebody else while a graph still replays on it
+        _captured_consts[id(t)] = t
     return t
 
 

@@ -75,8 +75,8 @@ def _supported(module: nn.Module, x: torch.Tensor):
         return None
     if isinstance(module, nn.InstanceNorm2d) and not module.affine and not module.track_running_stats:
         return 0
-    if isinstance(module, nn.BatchNorm2d) and module.affine:
-        return 1
+    if isinstance(module, nn.BatchNorm2d) and module.affine and module.momentum is not None:
+        return 1      # (momentum = None means a cumulative average with factor 1 / num_batches_tracked: not implemented here, refused below)
     return None
 
 
@@ -84,6 +84,10 @@ def norm_act(module: nn.Module, x: torch.Tensor, relu: bool) -> torch.Tensor:
     """[relu](module(x)) for the norm layers of the encoders: on the HIP kernels in GPU training mode, otherwise the module itself."""
     mode = _supported(module, x)
     if mode is None:
+        if ENABLED and x.is_cuda and not isinstance(module, nn.Sequential):     # ("none" norm = empty Sequential: nothing to compute)
+            raise hip.BflowHipError(f"norm_act({type(module).__name__}) on a GPU tensor outside the HIP training kernels (grad disabled, eval mode, "
+                                    "or an unsupported norm layer): there is no library fall-back -- run inference through RAFTSpline.forward "
+                                    "in eval() mode, or train with grad enabled")
         y = module(x)
         return torch.relu_(y) if relu else y
     affine = mode == 1

@@ -184,6 +184,10 @@ class RAFTSpline(nn.Module):
             raise hip.BflowHipError("RAFTSpline (bflow_amd) runs on MI355X only: move the inputs and the module to the GPU "
                                     "(the CPU restatement lives in oracle/ and is test infrastructure)")
         if self.training:
+            if not torch.is_grad_enabled():
+                raise hip.BflowHipError("RAFTSpline.forward in train() mode under no_grad / inference_mode: the differentiable forward would run "
+                                        "every convolution outside the conv engine's autograd path.  Call model.eval() for inference (BatchNorm "
+                                        "running statistics, as val.py does) or enable grad for a training step")
             # differentiable forward (HIP forward/backward for K5-K7/K13, torch autograd for the convolutions)
             from .training import forward_train
             with torch.cuda.device(ref.device):

@@ -33,6 +33,7 @@ from __future__ import annotations
 
 import ctypes
 import ctypes.util
+import os
 import struct
 import zlib
 from pathlib import Path
@@ -589,8 +590,12 @@ def write_h5_dataset(path: Union[str, Path], array: np.ndarray, name: str = DATA
     snod += b"\0" * (snod_size - len(snod))
     blob = sb + root + heap + gtree + snod + dataset_header(ctree_root) + ctree + b"".join(payloads)
     assert len(blob) == eof, (len(blob), eof)
-    with open(path, "wb") as f:
+    # atomically: DataLoader workers racing on one index, or an interrupted write, must never leave a truncated file that later passes
+    # the exists() check (the reader would return None for it on every epoch)
+    tmp = f"{path}.tmp.{os.getpid()}"
+    with open(tmp, "wb") as f:
         f.write(blob)
+    os.replace(tmp, path)
 
 
 def np_array_to_h5(array: np.ndarray, outpath: Union[str, Path]) -> None:

@@ -375,8 +375,10 @@ def lookup_times(cfg: Dict[str, Any]) -> List[float]:
 
 def forward(sd: StateDict, cfg: Dict[str, Any], voxel_grid: Optional[Tensor] = None,
             images: Optional[List[Tensor]] = None, iters: int = 12, flow_init: Optional[Tensor] = None,
-            test_mode: bool = False, return_intermediates: bool = False, training: bool = False):
+            test_mode: bool = False, return_intermediates: bool = False, training: bool = False, stage_hook=None):
     """RAFTSpline.forward, models/raft_spline/raft.py:101-200.
+    stage_hook(name, begin: bool), optional: called at the boundaries of the reference's CudaTimer stages (raft.py:116-186, same names) --
+    the per-stage CPU timing of bench.py's cpu_baseline; it does not touch the arithmetic.
     Returns (bezier_low_params, bezier_up_params) if test_mode else [bezier_up_params per iteration]
     (the reference wraps these tensors in BezierCurves).  training=True: BatchNorm on batch statistics (module.train()); the
     function is plain differentiable torch, so autograd over it is the gradient oracle of the training path."""
@@ -394,17 +396,23 @@ def forward(sd: StateDict, cfg: Dict[str, Any], voxel_grid: Optional[Tensor] = N
         idxs = [0] + list(cfg["correlation"]["ev"]["target_indices"])        # raft.py:93-94
         grids = [voxel_grid[:, i:i + ncorr] for i in idxs]
         context_input = voxel_grid[:, -nctx:]
+        if stage_hook: stage_hook("fnet_ev", True)
         fm = [x.float() for x in encoder(sd, "fnet_ev", grids, fnorm, training)]
+        if stage_hook: stage_hook("fnet_ev", False)
         groups.append((fm[0], torch.stack(fm[1:], dim=0), list(cfg["correlation"]["ev"]["levels"])))
     if cfg["use_boundary_images"]:
         assert len(images) == 2
         images = [2 * (x.float().contiguous() / 255) - 1 for x in images]    # raft.py:134
+        if stage_hook: stage_hook("fnet_img", True)
         fi = encoder(sd, "fnet_img", images, fnorm, training)
+        if stage_hook: stage_hook("fnet_img", False)
         groups.append((fi[0], fi[1].unsqueeze(0), [int(cfg["correlation"]["img"]["levels"])]))
         context_input = images[0] if context_input is None else torch.cat((context_input, images[0]), dim=-3)
+    if stage_hook: stage_hook("cnet", True)
     cnet = encoder(sd, "cnet", context_input, cnorm, training)
     net, inp = torch.split(cnet, [hdim, cdim], dim=1)
     net, inp = torch.tanh(net), torch.relu(inp)
+    if stage_hook: stage_hook("cnet", False)
 
     B, _, H, W = context_input.shape
     assert H % 8 == 0 and W % 8 == 0                                         # bezier.py:67-68
@@ -415,6 +423,7 @@ def forward(sd: StateDict, cfg: Dict[str, Any], voxel_grid: Optional[Tensor] = N
         bezier = bezier + flow_init
 
     # corr.py:223-262: 1-to-N for a single reference, M-to-N (fmap1 expanded per target) otherwise
+    if stage_hook: stage_hook("corr computation", True)
     if len(groups) == 1:
         volume = corr_volume(groups[0][0], groups[0][1])
     else:
@@ -422,24 +431,32 @@ def forward(sd: StateDict, cfg: Dict[str, Any], voxel_grid: Optional[Tensor] = N
         volume = corr_volume(f1, torch.cat([g[1] for g in groups], dim=0))
     levels = sum((g[2] for g in groups), [])
     pyramid = corr_pyramid(volume, levels)
+    if stage_hook: stage_hook("corr computation", False)
     times = lookup_times(cfg)
 
     ups = []
     inter = []
     bezier_up = None
+    if stage_hook: stage_hook("all iters", True)
     for itr in range(iters):
+        if stage_hook: stage_hook("1 iter", True)
         if cfg.get("detach_bezier", False):                                  # raft.py:167-168
             bezier = bezier.detach()
+        if stage_hook: stage_hook("get_flow (per iter)", True)
         flows = bezier_flow(bezier, times)
         coords1 = coords0 + flows
+        if stage_hook: stage_hook("get_flow (per iter)", False); stage_hook("corr lookup (per iter)", True)
         corr_feat = corr_lookup(pyramid, coords1)
+        if stage_hook: stage_hook("corr lookup (per iter)", False); stage_hook("update (per iter)", True)
         net, up_mask, delta = update_block(sd, net, inp, corr_feat, bezier)
         bezier = bezier + delta                                              # bezier.py:137-139
+        if stage_hook: stage_hook("update (per iter)", False); stage_hook("1 iter", False)
         if return_intermediates:
             inter.append(dict(corr=corr_feat, net=net, delta=delta))
         if (not test_mode) or itr == iters - 1:
             bezier_up = cvx_upsample(bezier, up_mask)                        # bezier.py:81-84
             ups.append(bezier_up)
+    if stage_hook: stage_hook("all iters", False)
     if return_intermediates:
         return bezier, bezier_up, dict(volume=volume, pyramid=pyramid, iters=inter, net0=torch.tanh(cnet[:, :hdim]))
     if test_mode:

@@ -719,6 +719,88 @@ def test_conv_split_engine_vs_fp64(cin, cout, k, stride, pad, H, W, B):
     assert (back.cpu().double() - got_s).abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,H,W,B", [
+    (64, 64, (3, 3), 1, (1, 1), 100, 150, 2),      # transposed halo kernel + direct epilogue, ragged patches
+    (64, 96, (3, 3), 1, (1, 1), 70, 90, 2),        # ... Cout = 96: the second 64-channel tile is half empty
+    (64, 96, (3, 3), 2, (1, 1), 240, 320, 3),      # direct-activation kernel, 96-channel tile, stride 2 (encoder layer2 entry at its own size)
+    (64, 96, (1, 1), 2, (0, 0), 240, 320, 3),      # ... the 1x1 stride-2 down-sampling branch
+    (128, 256, (1, 1), 1, (0, 0), 121, 160, 2),    # ... 64-channel tiles, ragged last pixel tile (output projection)
+])
+def test_conv_fp32_stats_and_direct_kernels_vs_fp64(cin, cout, k, stride, pad, H, W, B):
+    """The round-3 kernels behind bflow_conv_split: (1) fp32 (+ InstanceNorm statistics) output -> transposed accumulators D[pixel][channel]
+    with the direct store epilogue (halo kernel for the stride-1 3x3s, direct-activation kernel for 1x1 / stride 2 on large grids);
+    (2) the same shapes with split output (shared LDS-transpose epilogue behind the direct-activation kernel).  Against fp64 with the
+    analytic bound of the split format, statistics included."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, *k)) / np.sqrt(cin * k[0] * k[1])).astype(np.float32)
+    xd, wd = cu(x).double(), cu(w).double()
+    ref = torch.nn.functional.conv2d(xd, wd, None, stride=stride, padding=pad)
+    mag = torch.nn.functional.conv2d(xd.abs(), wd.abs(), None, stride=stride, padding=pad) + 1.0
+    xs = S.from_nchw(cu(x))
+    pk = S.PackedConvWeight().get(cu(w))
+    Ho, Wo = ref.shape[2:]
+    stats = torch.zeros((4, B, cout, 2), dtype=torch.float64, device=DEV)       # 4 replicas, summed below
+    _, o_f32 = S.conv(xs, pk, stride=stride, padding=pad, want_split=False, want_f32=True, stats=stats)
+    got = S.blocked_f32_to_nhwc(o_f32, Ho, Wo, cout).permute(0, 3, 1, 2).double()
+    err = float(((got - ref).abs() / mag).max())
+    o_split, _ = S.conv(xs, pk, stride=stride, padding=pad, act=S.ACT_RELU)
+    err_s = float(((o_split.float_nhwc().permute(0, 3, 1, 2).double() - ref.clamp(min=0)).abs() / mag).max())
+    print(f"conv {cin}->{cout} {k} s{stride} {H}x{W}: err / sum|x||w| fp32 + stats path {err:.2e}, split path {err_s:.2e}")
+    assert err < 5e-7 and err_s < 1e-6
+    st = stats.sum(dim=0)
+    np.testing.assert_allclose(st[..., 0].cpu().numpy(), ref.sum(dim=(2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(st[..., 1].cpu().numpy(), (ref * ref).sum(dim=(2, 3)).cpu().numpy(), rtol=1e-5, atol=2e-3)
+    if cout % 32:
+        assert not bool(o_f32.view(B, -1, Ho * Wo, 32)[:, -1, :, cout % 32:].any())
+
+
+# (grids of >= 200 workgroups, as in the encoder: both forms then run the SAME 64-channel-tile halo kernel, hence the same summation order)
+@pytest.mark.parametrize("c1,c2,H,W,B", [(64, 64, 117, 150, 2), (96, 96, 99, 150, 1), (128, 128, 60, 80, 3)])
+def test_conv_norm_in_equals_normalise_then_convolve(c1, c2, H, W, B):
+    """bflow_conv_desc_t.x_raw: conv2 of a residual block takes conv1's PRE-normalisation fp32 output + statistics and applies
+    relu(instance_norm(.)) while it stages its halo (extractor.py:47-48).  Same coefficients, same split -> the volume must equal the
+    two-launch form (bflow_norm_act_split, then bflow_conv_split) BIT FOR BIT; statistics agree to fp64 summation order."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(11)
+    raw = cu((rs.standard_normal((B, c1 // 32, H * W, 32)) * 3 + 0.5).astype(np.float32))
+    w = cu((rs.standard_normal((c2, c1, 3, 3)) / np.sqrt(c1 * 9)).astype(np.float32))
+    pk = S.PackedConvWeight().get(w)
+    nchw = S.blocked_f32_to_nhwc(raw, H, W, c1).permute(0, 3, 1, 2).double()
+    st_in = torch.zeros((8, B, c1, 2), dtype=torch.float64, device=DEV)
+    st_in[3, :, :, 0] = nchw.sum(dim=(2, 3))             # the replicas are summed by both consumers
+    st_in[5, :, :, 1] = (nchw * nchw).sum(dim=(2, 3))
+    a1, _ = S.norm_act(raw, (B, H, W, c1), stats_a=st_in, act_a=S.ACT_RELU)
+    st_a = torch.zeros((8, B, c2, 2), dtype=torch.float64, device=DEV)
+    _, want = S.conv(a1, pk, padding=1, want_split=False, want_f32=True, stats=st_a)
+    st_b = torch.zeros((8, B, c2, 2), dtype=torch.float64, device=DEV)
+    got = S.conv_norm_in(raw, (B, H, W, c1), st_in, pk, stats=st_b)
+    assert torch.equal(got, want)
+    np.testing.assert_allclose(st_b.sum(0).cpu().numpy(), st_a.sum(0).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    ref = torch.relu(torch.nn.functional.instance_norm(nchw)).float()        # and the normalisation itself is F.instance_norm
+    assert (a1.float_nhwc().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-5
+
+
+def test_no_silent_library_paths():
+    """No convolution / norm layer of the package may fall through to the vendor library on a GPU tensor: a train()-mode forward under
+    no_grad / inference_mode and an eval-mode MODULE call of an encoder raise instead (inference = RAFTSpline.forward in eval mode)."""
+    cfg, m, sd = _model("E_LU4_BD2")
+    vox = torch.from_numpy(synthetic.voxel_grid(1, 9, 64, 96, seed=3)).to(DEV)
+    m.train()
+    with torch.inference_mode(), pytest.raises(hip.BflowHipError):
+        m(voxel_grid=vox, iters=2, test_mode=True)
+    with torch.no_grad(), pytest.raises(hip.BflowHipError):
+        m(voxel_grid=vox, iters=2, test_mode=True)
+    m.eval()
+    with torch.no_grad(), pytest.raises(hip.BflowHipError):
+        m.fnet_ev(vox[:, :5])
+    with torch.no_grad(), pytest.raises(hip.BflowHipError):
+        m.update_block.encoder.convc1(torch.zeros(1, 567, 8, 12, device=DEV))
+    low, up = m(voxel_grid=vox, iters=2, test_mode=True)       # the inference path itself is untouched
+    assert torch.isfinite(up.get_params()).all()
+
+
 @pytest.mark.parametrize("cin,cout,k,pad,H,W,B,force", [
     (288, 256, (1, 5), (0, 2), 60, 80, 1, None),      # z|r of the GRU at DSEC size: 320 workgroups of 8x16 patches -> 240 of 10x16 (auto)
     (288, 256, (5, 1), (2, 0), 60, 80, 1, None),
