@@ -34,6 +34,7 @@ PRECISIONS = {"split": (hip.ARITH_SPLIT, False), "f32": (None, False), "f16": (h
               "split/h": (hip.ARITH_SPLIT, True), "split8/h": (hip.ARITH_SPLIT8, True), "f16/w": (hip.ARITH_F16, False)}
 TILED_ONLY = frozenset(("f16", "split8", "split/h", "split8/h", "f16/w"))      # written by bflow_corr_build_tiled only
 PRECISION = os.environ.get("BFLOW_CORR_PRECISION", "split")
+FUSE_POOL1 = os.environ.get("BFLOW_NO_FUSED_POOL") is None     # A/B switch (tools/): level 1 of the pyramid written by the K5 launch
 
 
 def _x8_planes(p1: torch.Tensor, p2: torch.Tensor):
@@ -147,10 +148,21 @@ class CorrComputation:
         precision = PRECISION if precision is None else precision
         return (precision == "split" and self.dim in (64, 128, 256)) or (precision in TILED_ONLY and self.dim in (128, 256))
 
-    def get_correlation_volume(self, tiled: bool = False, precision: Optional[str] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def pool1_fusable(self, precision: Optional[str] = None) -> bool:
+        """True when the K5 launch of this precision can write the level-1 planes itself (get_correlation_volume(pool1=...))."""
+        precision = PRECISION if precision is None else precision
+        if precision not in PRECISIONS or PRECISIONS[precision][0] is None or not self.tiled_supported(precision):
+            return False
+        ar, st16 = PRECISIONS[precision]
+        return hip.pool_fusable(ar, st16, self.dim, max(f2.shape[0] for f2 in self._fmap2))
+
+    def get_correlation_volume(self, tiled: bool = False, precision: Optional[str] = None, out: Optional[torch.Tensor] = None,
+                               pool1=None) -> torch.Tensor:
         """(T, B*N, 1, h, w) fp32 -- corr.py:229-272.  One K5 launch per reference group, written straight into its
         slice of the volume (the reference expands fmap1 per target and concatenates, corr.py:254-259).
-        tiled=True: (T, B, N, tiled_plane_size(h, w)) with every plane stored as 4 x 8 tiles (the look-up's layout)."""
+        tiled=True: (T, B, N, tiled_plane_size(h, w)) with every plane stored as 4 x 8 tiles (the look-up's layout).
+        pool1 = (level1 (T1, B, N, tiled_plane_size(h//2, w//2)), keep): the level-1 planes of the targets `keep` (overall target indices,
+        corr.py:297-305) are written by the K5 launches themselves (tiled, fusable precisions: `pool1_fusable`)."""
         B, D, h, w = self._bdhw
         N = h * w
         T = self.num_targets_overall
@@ -171,26 +183,32 @@ class CorrComputation:
         thw = (h, w) if tiled else None
         split = precision != "f32" and D % 64 == 0
 
-        def build(p1, p2, dst, tg):
-            if precision in TILED_ONLY:
+        def build(p1, p2, dst, tg, t_first):
+            if precision in TILED_ONLY or pool1 is not None:
                 x8 = None
                 if arithmetic == hip.ARITH_SPLIT8:   # ONE conversion launch when the two operands are neighbours in one tensor (the encoder's output)
                     x8 = _x8_planes(p1, p2)
-                hip.corr_build_tiled(p1, p2, dst, tg, B, N, shared_f1=True, tiled_hw=thw, arithmetic=arithmetic, x8=x8)
+                pool = None
+                if pool1 is not None:                # rows of this group's targets in the level-1 tensor (-1: the target has a single level)
+                    index = [pool1[1].index(t) if t in pool1[1] else -1 for t in range(t_first, t_first + tg)]
+                    pool = (pool1[0], index) if any(k >= 0 for k in index) else None
+                hip.corr_build_tiled(p1, p2, dst, tg, B, N, shared_f1=True, tiled_hw=thw, arithmetic=arithmetic, x8=x8, pool=pool)
             else:
                 hip.corr_build_split(p1, p2, dst, tg, B, N, shared_f1=True, tiled_hw=thw)
 
+        if pool1 is not None:
+            assert tiled and self.pool1_fusable(precision)
         t0 = 0
         for f1, f2, packed in zip(self._fmap1, self._fmap2, self._packed):
             tg = f2.shape[0]
             if packed is not None:
-                build(packed[0], packed[1], vol[t0:t0 + tg], tg)
+                build(packed[0], packed[1], vol[t0:t0 + tg], tg, t0)
                 t0 += tg
                 continue
             f1 = f1.float().contiguous().view(B, D, N)
             f2 = f2.float().contiguous().view(tg * B, D, N)
             if split:   # split-fp16 MFMA engine
-                build(hip.split_pack(f1), hip.split_pack(f2), vol[t0:t0 + tg], tg)
+                build(hip.split_pack(f1), hip.split_pack(f2), vol[t0:t0 + tg], tg, t0)
             else:       # exact-fp32 MFMA
                 hip.corr_build_f32(f1, f2.view(tg, B, D, N), vol[t0:t0 + tg])
             t0 += tg
@@ -227,9 +245,15 @@ class CorrBlockParallelMultiTarget:
         B, h, w = cc.batch, cc.height, cc.width
         N = h * w
 
+        fused1 = None    # (level-1 tensor, targets): written by the K5 launches themselves (fused K6, level 0 -> 1)
         if self._tiled:
             vout = None if volume_out is None else volume_out.view(len(levels), B, N, hip.tiled_plane_size(h, w))   # a caller-owned level 0
-            base = cc.get_correlation_volume(tiled=True, precision=precision, out=vout).view(len(levels), B * N, hip.tiled_plane_size(h, w))
+            keep1 = [t for t, lv in enumerate(levels) if lv >= 2]
+            if keep1 and FUSE_POOL1 and h >= 2 and w >= 2 and cc.pool1_fusable(precision):
+                prec = PRECISION if precision is None else precision
+                fused1 = (torch.empty((len(keep1), B, N, hip.tiled_plane_size(h // 2, w // 2)), dtype=torch.float16 if PRECISIONS[prec][1] else torch.float32,
+                                      device=cc._packed[0][0].device if cc._packed[0] is not None else cc._fmap1[0].device), keep1)
+            base = cc.get_correlation_volume(tiled=True, precision=precision, out=vout, pool1=fused1).view(len(levels), B * N, hip.tiled_plane_size(h, w))
         else:
             assert volume_out is None, "volume_out: tiled layout only"
             base = cc.get_correlation_volume(precision=precision).view(len(levels), B * N, h, w)
@@ -241,7 +265,10 @@ class CorrBlockParallelMultiTarget:
             prev, prev_idx = self._pyramid[-1]
             keep = [t for t, lv in enumerate(levels) if lv >= num_levels]
             ph, pw = self._level_hw[-1]
-            if self._tiled:
+            if self._tiled and num_levels == 2 and fused1 is not None:
+                assert fused1[1] == keep
+                cur = fused1[0].view(len(keep), B * N, hip.tiled_plane_size(ph // 2, pw // 2))
+            elif self._tiled:
                 cur = torch.empty((len(keep), B * N, hip.tiled_plane_size(ph // 2, pw // 2)), dtype=base.dtype, device=base.device)
                 for k, t in enumerate(keep):
                     hip.corr_pool2x2_tiled(prev[prev_idx.index(t)], cur[k], ph, pw)

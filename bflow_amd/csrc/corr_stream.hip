@@ -74,6 +74,12 @@ struct StreamArgs {
     int n_pan;              // panels = T * B * JP
     int ph, pw;             // > 0: tiled planes (bflow_hip.h: 4x8 tiles); 0: row-major (N, N) slabs
     int PS;                 // elements of one plane of the volume: N (row-major) or tiles * 32
+    // fused K6, level 0 -> 1 (corr.py:108-125,297-305): targets with more than one pyramid level get the 2 x 2 mean of their level-0 planes
+    // written next to the volume (tiled planes only): pool_out (T1, B, N, PS1) in the volume's element type, pool_index[t] = row of target t
+    // in it or -1
+    void* pool_out;
+    int pool_index[8];
+    int PS1;                // elements of one level-1 plane: tiles1 * 32
     unsigned long long* stamps;   // STREAM_STAMPS builds only
 };
 
@@ -101,7 +107,9 @@ enum { M_SPLIT = 0, M_F16 = 1, M_X8 = 2 };
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-template <int KB, bool POW2, int MODE, bool ST16>
+// POOL: the fused level-1 pooling epilogue (one more buffer store per accumulator register, dropped by the bounds check for the targets
+// that have no level 1 -- the counted vmcnt waits need the same number of operations in every chunk).
+template <int KB, bool POW2, int MODE, bool ST16, bool POOL>
 __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // SLOTS x (4*KB KB) ring; the only shared object
     constexpr bool F16 = MODE == M_F16, X8 = MODE == M_X8;
@@ -112,7 +120,8 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     constexpr int PLANE_BYTES = 2 * KB * 1024;
     constexpr int OB = ST16 ? 2 : 4;           // bytes per volume element
     static_assert(PW >= 1, "F16 needs D >= 128");
-    constexpr int ST_PER_STEP = 16 / NS > 0 ? 16 / NS : 1;
+    constexpr int ST_PER_STEP = (16 / NS > 0 ? 16 / NS : 1);
+    constexpr int OPS_PER_REG = POOL ? 2 : 1;      // buffer stores per accumulator register
     static_assert(16 % NS == 0 || NS % 16 == 0, "k-steps and accumulator registers must divide");
     static_assert(NS <= 16, "D <= 256");
 
@@ -213,7 +222,26 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
 
     // ---- target panel -> registers: lane holds column (wave*32 + l31) of the panel, 8 consecutive k per k16 step
     half8 Bh[NS], Bl[NS];                      // M_X8: Bl[2 kb], Bl[2 kb + 1] = the 32 x8 bytes of block kb (lo8 for lanes 0-31, hi8 for 32-63)
+    // fused pooling: this lane's role in the level-1 store of the wave's tile (set per panel).  The 2 x 2 mean of tile (ty, tx) is 2 x 4
+    // values of level-1 tile (ty / 2, tx / 2), held by the lanes with even (y, x).  The other lanes are idle -- they write the ZEROS of the
+    // level-1 positions no level-0 tile reaches (below the last tile row / right of the last tile column when their count is odd), so that
+    // every element of the level-1 planes is written by this kernel (the look-up weighs pad positions with 0 and needs them finite).
+    unsigned p1lane = OOB;                     // byte offset inside a level-1 plane, or OOB
+    bool p1pool = false;                       // this lane stores a pooled value (else 0)
+    auto pool_roles = [&](int jp) {
+        const int tw0 = (a.pw + 7) >> 3, th0 = (a.ph + 3) >> 2, h1 = a.ph >> 1, w1 = a.pw >> 1;
+        const int tw1 = (w1 + 7) >> 3, th1 = (h1 + 3) >> 2;
+        const int tile = jp * 8 + wave, ty = tile / tw0, tx = tile - ty * tw0;
+        const int y = l31 >> 3, x = l31 & 7;
+        const bool below_missing = !(ty & 1) && ty + 1 >= th0, right_missing = !(tx & 1) && tx + 1 >= tw0;
+        const bool oy = y & 1, ox = x & 1;
+        const bool active = ty < th0 && (ty >> 1) < th1 && (tx >> 1) < tw1 && (!oy || below_missing) && (!ox || right_missing);
+        const int y1l = (oy ? 2 : (ty & 1) * 2) + (y >> 1), x1l = (ox ? 4 : (tx & 1) * 4) + (x >> 1);
+        p1lane = active ? (unsigned)((((ty >> 1) * tw1 + (tx >> 1)) * 32 + y1l * 8 + x1l) * OB) : OOB;
+        p1pool = !oy && !ox && ty * 2 + (y >> 1) < h1 && tx * 4 + (x >> 1) < w1;
+    };
     auto load_panel = [&](int tb, int jp) {
+        if (POOL) pool_roles(jp);
         int col = jp * COLS_WG + wave * 32 + l31;   // row-major planes: 32 consecutive target pixels per wave
         if (a.pw > 0) {
             // tiled planes: the wave's 32 columns are the 4 x 8 pixels of ONE tile, so that an accumulator register is one 128-B line of
@@ -250,17 +278,46 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
         return col < a.PS ? (unsigned)((row * a.PS + col) * OB) : OOB;   // rows >= N fall off the end of the slab by themselves
     };
     const unsigned rowstep = (unsigned)a.PS * (unsigned)OB;
+    const unsigned rowstep1 = (unsigned)a.PS1 * (unsigned)OB;
+    bool p1on = false, p1val = false;          // p1val: p1pool of the panel the pending stores belong to (latched with p1base)
+    auto store_base1 = [&](const Item& im, __amdgpu_buffer_rsrc_t& rs, bool& on) -> unsigned {
+        const int k1 = a.pool_index[im.t];
+        on = k1 >= 0;
+        p1val = p1pool;
+        char* slab = reinterpret_cast<char*>(a.pool_out) + (long long)((on ? k1 : 0) * a.B + im.b) * a.N * a.PS1 * OB;
+        rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, on ? a.N * a.PS1 * OB : 0, 0x00020000);   // no level 1: every store is dropped
+        return p1lane != OOB ? (unsigned)((im.i0 + 4 * kh) * a.PS1 * OB) + p1lane : OOB;
+    };
 
-    auto store_reg = [&](float hh_, float xx_, const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
-        float v = F16 ? hh_ : fmaf(xx_, LO_INV, hh_);
-        v = POW2 ? v * a.scale : v / a.scale;
-        if (STREAM_ABL == 1) {
-            asm volatile("" ::"v"(v), "v"(off));
-        } else if (ST16) {
+    __amdgpu_buffer_rsrc_t p1rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, 0x00020000);
+    unsigned p1base = OOB;
+    auto put = [&](float v, const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+        if (ST16) {
             const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rs, off, 0, STREAM_STORE_AUX);
         } else {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, STREAM_STORE_AUX);
+        }
+    };
+    auto store_reg = [&](float hh_, float xx_, const __amdgpu_buffer_rsrc_t& rs, unsigned off, unsigned off1) {
+        float v = F16 ? hh_ : fmaf(xx_, LO_INV, hh_);
+        v = POW2 ? v * a.scale : v / a.scale;
+        if (STREAM_ABL == 1) {
+            asm volatile("" ::"v"(v), "v"(off));
+            return;
+        }
+        if (ST16) v = (float)(_Float16)fminf(fmaxf(v, -65504.f), 65504.f);     // the pooled value is the mean of the STORED values
+        put(v, rs, off);
+        if (POOL) {
+            float m = 0.f;
+            if (p1on) {   // wave-uniform.  F.avg_pool2d's order (corr.py:119): ((q[2y][2x] + q[2y][2x+1]) + q[2y+1][2x]) + q[2y+1][2x+1], then / 4
+                const int vi = __builtin_bit_cast(int, v);
+                const int sw = __builtin_amdgcn_mov_dpp(vi, 0xB1 /* quad_perm [1,0,3,2]: lane ^ 1 */, 0xf, 0xf, false);
+                const float c = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0x128 /* row_ror:8: lane ^ 8 */, 0xf, 0xf, false));
+                const float d = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(sw, 0x128, 0xf, 0xf, false));
+                m = p1val ? (((v + __builtin_bit_cast(float, sw)) + c) + d) * 0.25f : 0.f;
+            }
+            put(m, p1rs, off1);
         }
     };
 
@@ -286,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     // stored.  vmcnt at the top = ops issued after this wave's last piece of chunk it+1 (in chunk it-2): the stores behind it there +
     // the 16 stores and PW pieces of chunk it-1.
     constexpr int DMA_S0 = NS >= 8 ? 2 : 1;
-    constexpr int VMCNT_TOP = (NS - (DMA_S0 + PW)) * ST_PER_STEP + 16 + PW;
+    constexpr int VMCNT_TOP = (NS - (DMA_S0 + PW)) * ST_PER_STEP * OPS_PER_REG + 16 * OPS_PER_REG + PW;
     static_assert(DMA_S0 + PW <= NS && VMCNT_TOP < 64, "DMA schedule");
     half8 fh[2], fl[2], ale;
 #define STREAM_STEP(CH_, CX_, PH_, PX_)                                                                                     \
@@ -330,11 +387,13 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
             }                                                                                                               \
             _Pragma("unroll") for (int u = 0; u < ST_PER_STEP; ++u) {                                                       \
                 const int r = s * ST_PER_STEP + u;                                                                          \
-                store_reg(PH_[r], PX_[r], prs, pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);                       \
+                store_reg(PH_[r], PX_[r], prs, pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep,                        \
+                          p1base + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep1);                                          \
             }                                                                                                               \
             if (STREAM_ABL != 2 && s >= DMA_S0 && s < DMA_S0 + PW) issue_piece(q3, (it + 3) & 3, s - DMA_S0);              \
         }                                                                                                                   \
         pbase = store_base(q0, prs);                                                                                        \
+        if (POOL) p1base = store_base1(q0, p1rs, p1on);                                                                     \
         q0 = q1;                                                                                                            \
         q1 = q2;                                                                                                            \
         q2 = q3;                                                                                                            \
@@ -366,14 +425,14 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     // ---- drain: the last chunk's accumulators
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        store_reg(Y_hh[r], Y_xx[r], prs, pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep);
+        store_reg(Y_hh[r], Y_xx[r], prs, pbase + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep, p1base + (unsigned)((r & 3) + 8 * (r >> 2)) * rowstep1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMA pieces must not outlive the workgroup's LDS
     STAMP(61)
     STAMP_RT(63)
 }
 
-template <int KB, int MODE, bool ST16>
+template <int KB, int MODE, bool ST16, bool POOL>
 int launch_kb(const StreamArgs& a, bool pow2, hipStream_t s) {
     constexpr bool F16 = MODE == M_F16;
     const int lds = SLOTS * (F16 ? 2 : 4) * KB * 1024;
@@ -384,16 +443,16 @@ int launch_kb(const StreamArgs& a, bool pow2, hipStream_t s) {
         static const int f16_wgs = [] { const char* e = getenv("BFLOW_CORR_F16_WGS"); return e && atoi(e) == 256 ? 256 : 512; }();
         hipLaunchKernelGGL(kern, dim3(F16 ? f16_wgs : 256), dim3(512), lds, s, a);
     };
-    if (pow2) go(corr_stream_kernel<KB, true, MODE, ST16>);
-    else go(corr_stream_kernel<KB, false, MODE, ST16>);
+    if (pow2) go(corr_stream_kernel<KB, true, MODE, ST16, POOL>);
+    else go(corr_stream_kernel<KB, false, MODE, ST16, POOL>);
     return bflow::launch_status(MODE == M_F16 ? "corr_build(stream, fp16 operands)" : MODE == M_X8 ? "corr_build(stream, fp8 cross terms)" : "corr_build_split(stream)");
 }
 
-template <int MODE, bool ST16>
+template <int MODE, bool ST16, bool POOL = false>
 int launch_mode(const StreamArgs& a, int D, bool pow2, hipStream_t s) {
-    if (D == 256) return launch_kb<8, MODE, ST16>(a, pow2, s);
-    if (D == 128) return launch_kb<4, MODE, ST16>(a, pow2, s);
-    if constexpr (MODE == M_SPLIT && !ST16) return launch_kb<2, MODE, ST16>(a, pow2, s);   // D = 64: the fp32 split volume only
+    if (D == 256) return launch_kb<8, MODE, ST16, POOL>(a, pow2, s);
+    if (D == 128) return launch_kb<4, MODE, ST16, POOL>(a, pow2, s);
+    if constexpr (MODE == M_SPLIT && !ST16 && !POOL) return launch_kb<2, MODE, ST16, false>(a, pow2, s);   // D = 64: the fp32 split volume only
     return BFLOW_E_ARG;
 }
 
@@ -410,8 +469,10 @@ bool corr_stream_supported(int T, int B, int D, int N, int Np) {
 // plane_h x plane_w > 0 (= N): the volume is written as TILED planes (see bflow_corr_build_split_tiled); 0, 0: row-major (T, B, N, N)
 // arithmetic: 0 split (f*_lo = lo planes), 1 fp16 operands (f*_lo ignored, may be null), 2 fp8 cross terms (f*_lo = x8 planes, bflow_split_to_x8);
 // out_fp16: `out` is an fp16 volume.  Everything but (split, fp32) needs D in {128, 256}.
+// pool_out / pool_index (or null): the fused level-1 pooling epilogue (tiled planes; (split | split8, fp32) and (fp16, fp16) only; D in {128, 256})
 int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, void* out, int T, int B, int D, int N, int Np,
-                       long long f1_target_stride, int plane_h, int plane_w, int arithmetic, bool out_fp16, hipStream_t stream) {
+                       long long f1_target_stride, int plane_h, int plane_w, int arithmetic, bool out_fp16, void* pool_out, const int* pool_index,
+                       hipStream_t stream) {
     StreamArgs a;
     a.f1h = (const _Float16*)f1_hi;
     a.f1l = (const _Float16*)f1_lo;
@@ -438,6 +499,18 @@ int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, 
 #else
     a.stamps = nullptr;
 #endif
+    a.pool_out = pool_out;
+    a.PS1 = plane_w > 0 ? ceil_div(plane_h / 2, 4) * ceil_div(plane_w / 2, 8) * 32 : 0;
+    for (int t = 0; t < 8; ++t) a.pool_index[t] = (pool_out && pool_index && t < T) ? pool_index[t] : -1;
+    if (pool_out) {
+        if (plane_w <= 0 || plane_h < 2 || plane_w < 2 || T > 8 || D == 64 || (long long)N * a.PS1 * 4 >= (1LL << 31)) return BFLOW_E_ARG;
+        switch (arithmetic * 2 + (out_fp16 ? 1 : 0)) {
+            case 0: return launch_mode<M_SPLIT, false, true>(a, D, pow2, stream);
+            case 3: return launch_mode<M_F16, true, true>(a, D, pow2, stream);
+            case 4: return launch_mode<M_X8, false, true>(a, D, pow2, stream);
+            default: return BFLOW_E_ARG;
+        }
+    }
     switch (arithmetic * 2 + (out_fp16 ? 1 : 0)) {
         case 0: return launch_mode<M_SPLIT, false>(a, D, pow2, stream);
         case 1: return launch_mode<M_SPLIT, true>(a, D, pow2, stream);

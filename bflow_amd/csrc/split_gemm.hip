@@ -234,7 +234,8 @@ __global__ __launch_bounds__(V2_T, 2) void corr_build_split_v2_kernel(const _Flo
 namespace bflow {
 bool corr_stream_supported(int T, int B, int D, int N, int Np);
 int corr_stream_launch(const void* f1_hi, const void* f1_lo, const void* f2_hi, const void* f2_lo, void* out, int T, int B, int D, int N, int Np,
-                       long long f1_target_stride, int plane_h, int plane_w, int arithmetic, bool out_fp16, hipStream_t stream);
+                       long long f1_target_stride, int plane_h, int plane_w, int arithmetic, bool out_fp16, void* pool_out, const int* pool_index,
+                       hipStream_t stream);
 }
 
 extern "C" int bflow_split_pack(const float* src, void* hi, void* lo, int R, int D, int N, int Np, bflow_stream_t stream) {
@@ -253,7 +254,7 @@ extern "C" int bflow_corr_build_split(const void* f1_hi, const void* f1_lo, cons
     // D in {64, 128, 256}: the A-stationary streaming kernel (corr_stream.hip); anything else: the 256x128 tile kernel below
     static const bool force_tile = getenv("BFLOW_CORR_TILE_KERNEL") != nullptr;   // A/B timing only (tools/)
     if (!force_tile && bflow::corr_stream_supported(T, B, D, N, Np))
-        return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, 0, 0, 0, false, (hipStream_t)stream);
+        return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, 0, 0, 0, false, nullptr, nullptr, (hipStream_t)stream);
     BFLOW_REQUIRE((long long)T * B <= 65535, BFLOW_E_LIMIT, "corr_build_split: T*B too large");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_build_split_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               V2_STAGES * V2_STAGE);   // 144 KB of dynamic LDS; idempotent, per device
@@ -276,7 +277,7 @@ extern "C" int bflow_corr_build_split_tiled(const void* f1_hi, const void* f1_lo
                   B, h, w, Np);
     BFLOW_REQUIRE(bflow::corr_stream_supported(T, B, D, N, Np), BFLOW_E_ARG, "corr_build_split_tiled: needs D in {64, 128, 256} and < 2 GiB slabs (D=%d N=%d)",
                   D, N);
-    return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, h, w, 0, false, (hipStream_t)stream);
+    return bflow::corr_stream_launch(f1_hi, f1_lo, f2_hi, f2_lo, out, T, B, D, N, Np, f1_target_stride, h, w, 0, false, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // BASELINE configs[4] ("fp16 MFMA correlation ... HBM-bound 4D volume stress"): the volume from PLAIN fp16 operands (the hi planes of the
@@ -291,7 +292,7 @@ extern "C" int bflow_corr_build_f16_tiled(const void* f1_hi, const void* f2_hi, 
                   h, w, Np);
     BFLOW_REQUIRE((D == 128 || D == 256) && bflow::corr_stream_supported(T, B, D, N, Np), BFLOW_E_ARG,
                   "corr_build_f16_tiled: needs D in {128, 256} and < 2 GiB slabs (D=%d N=%d)", D, N);
-    return bflow::corr_stream_launch(f1_hi, nullptr, f2_hi, nullptr, out, T, B, D, N, Np, f1_target_stride, h, w, 1, true, (hipStream_t)stream);
+    return bflow::corr_stream_launch(f1_hi, nullptr, f2_hi, nullptr, out, T, B, D, N, Np, f1_target_stride, h, w, 1, true, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -331,14 +332,23 @@ extern "C" int bflow_split_to_x8(const void* hi, const void* lo, void* x8, long 
 //              2: hi*hi on fp16 + both cross terms on the fp8 rate (f*_second = x8 planes written by bflow_split_to_x8)
 //   out_fp16    : the volume is stored as fp16 tiled planes instead of fp32.
 // D in {128, 256} (and 64 for arithmetic 0 with an fp32 volume).
+//   pool_out    : optional (T1, B, N, tiles1*32) buffer of the volume's element type, pool_index (HOST, T ints): row of target t in it or -1.  The
+//                 2 x 2 mean of the level-0 planes of those targets (K6, level 0 -> 1: corr.py:108-125,297-305; F.avg_pool2d's summation order,
+//                 floor on odd sizes, pad positions zero) is written by the same launch -- bflow_corr_pool2x2_tiled no longer re-reads the
+//                 level-0 planes it was just handed.  (split | split8, fp32) and (fp16, fp16) only; D in {128, 256}; T <= 8.
 extern "C" int bflow_corr_build_tiled(const void* f1_hi, const void* f1_second, const void* f2_hi, const void* f2_second, void* out, int T, int B,
-                                      int D, int h, int w, int Np, long long f1_target_stride, int arithmetic, int out_fp16, bflow_stream_t stream) {
+                                      int D, int h, int w, int Np, long long f1_target_stride, int arithmetic, int out_fp16, void* pool_out,
+                                      const int* pool_index, bflow_stream_t stream) {
     BFLOW_REQUIRE(f1_hi && f2_hi && out && arithmetic >= 0 && arithmetic <= 2, BFLOW_E_ARG, "corr_build_tiled: bad arguments");
     BFLOW_REQUIRE(arithmetic == 1 || (f1_second && f2_second), BFLOW_E_ARG, "corr_build_tiled: arithmetic %d needs the second operand planes", arithmetic);
     const int N = h * w;
     BFLOW_REQUIRE(T > 0 && B > 0 && h > 0 && w > 0 && Np >= N && Np % 128 == 0, BFLOW_E_ARG, "corr_build_tiled: bad sizes T=%d B=%d h=%d w=%d Np=%d", T, B, h, w, Np);
     BFLOW_REQUIRE(bflow::corr_stream_supported(T, B, D, N, Np) && (D != 64 || (arithmetic == 0 && !out_fp16)), BFLOW_E_ARG,
                   "corr_build_tiled: needs D in {128, 256} (64: split / fp32 only) and < 2 GiB slabs (D=%d N=%d)", D, N);
-    return bflow::corr_stream_launch(f1_hi, f1_second, f2_hi, f2_second, out, T, B, D, N, Np, f1_target_stride, h, w, arithmetic, out_fp16 != 0,
-                                     (hipStream_t)stream);
+    BFLOW_REQUIRE(!pool_out || (pool_index && T <= 8 && D != 64 && ((arithmetic != 1 && !out_fp16) || (arithmetic == 1 && out_fp16))), BFLOW_E_ARG,
+                  "corr_build_tiled: the fused level-1 pooling needs (split | split8, fp32 volume) or (fp16, fp16 volume), D in {128, 256}, T <= 8");
+    const int rc = bflow::corr_stream_launch(f1_hi, f1_second, f2_hi, f2_second, out, T, B, D, N, Np, f1_target_stride, h, w, arithmetic, out_fp16 != 0,
+                                             pool_out, pool_index, (hipStream_t)stream);
+    BFLOW_REQUIRE(rc != BFLOW_E_ARG, BFLOW_E_ARG, "corr_build_tiled: unsupported combination (D=%d, arithmetic=%d, out_fp16=%d, pool=%d)", D, arithmetic, out_fp16, pool_out != nullptr);
+    return rc;
 }

@@ -110,7 +110,7 @@ def lib() -> ctypes.CDLL:
         "bflow_corr_pool2x2_tiled": [vp, vp, ll, i, i, vp],
         "bflow_corr_pool2x2_tiled_f16": [vp, vp, ll, i, i, vp],
         "bflow_corr_build_f16_tiled": [vp, vp, vp, i, i, i, i, i, i, ll, vp],
-        "bflow_corr_build_tiled": [vp, vp, vp, vp, vp, i, i, i, i, i, i, ll, i, i, vp],
+        "bflow_corr_build_tiled": [vp, vp, vp, vp, vp, i, i, i, i, i, i, ll, i, i, vp, ctypes.POINTER(ctypes.c_int), vp],
         "bflow_split_to_x8": [vp, vp, vp, ll, vp],
         "bflow_corr_lookup_bezier_split_tiled_f16": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_corr_lookup_bezier_split_tiled": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
@@ -267,10 +267,17 @@ def split_to_x8(p: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pool_fusable(arithmetic: int, fp16_volume: bool, D: int, T: int) -> bool:
+    """Combinations for which bflow_corr_build_tiled writes the level-1 planes itself (`pool=`)."""
+    return D in (128, 256) and T <= 8 and ((arithmetic in (ARITH_SPLIT, ARITH_SPLIT8) and not fp16_volume) or (arithmetic == ARITH_F16 and fp16_volume))
+
+
 def corr_build_tiled(p1: torch.Tensor, p2: torch.Tensor, out: torch.Tensor, T: int, B: int, N: int, shared_f1: bool, tiled_hw: Sequence[int],
-                     arithmetic: int = ARITH_SPLIT, x8: Optional[Sequence[torch.Tensor]] = None):
+                     arithmetic: int = ARITH_SPLIT, x8: Optional[Sequence[torch.Tensor]] = None, pool=None):
     """The tiled volume with any arithmetic (ARITH_*) and fp32 or fp16 storage (out.dtype).  ARITH_SPLIT8 takes the x8 planes of both
-    operands (`x8 = (split_to_x8(p1), split_to_x8(p2))`; computed here when omitted)."""
+    operands (`x8 = (split_to_x8(p1), split_to_x8(p2))`; computed here when omitted).
+    pool = (level1, index): level1 (T1, B, N, tiled_plane_size(h//2, w//2)) of out.dtype receives the 2 x 2 mean (K6, level 0 -> 1) of the
+    level-0 planes of every target t with index[t] >= 0 (its row in level1), written by the same launch (pool_fusable(...) combinations)."""
     _, R2, KB, Np, _32 = p2.shape
     D = KB * 32
     h, w = int(tiled_hw[0]), int(tiled_hw[1])
@@ -284,8 +291,15 @@ def corr_build_tiled(p1: torch.Tensor, p2: torch.Tensor, out: torch.Tensor, T: i
         s1, s2 = x8[0].data_ptr(), x8[1].data_ptr()
     else:
         s1, s2 = p1[1].data_ptr(), p2[1].data_ptr()
+    pout, pidx = None, None
+    if pool is not None:
+        lvl1, index = pool
+        assert len(index) == T and pool_fusable(arithmetic, out.dtype == torch.float16, D, T)
+        assert lvl1.dtype == out.dtype and lvl1.is_cuda and lvl1.is_contiguous() and tuple(lvl1.shape[1:]) == (B, N, tiled_plane_size(h // 2, w // 2))
+        assert all(-1 <= k < lvl1.shape[0] for k in index)
+        pout, pidx = lvl1.data_ptr(), (ctypes.c_int * T)(*[int(k) for k in index])
     _check(lib().bflow_corr_build_tiled(p1[0].data_ptr(), s1, p2[0].data_ptr(), s2, out.data_ptr(), T, B, D, h, w, Np,
-                                        0 if shared_f1 else B * Np * D, int(arithmetic), 1 if out.dtype == torch.float16 else 0, _stream()),
+                                        0 if shared_f1 else B * Np * D, int(arithmetic), 1 if out.dtype == torch.float16 else 0, pout, pidx, _stream()),
            "bflow_corr_build_tiled")
 
 

@@ -361,10 +361,16 @@ int bflow_corr_pool2x2_tiled_f16(const void* in, void* out, long long planes, in
  *   out_fp16    : the volume is stored as fp16 tiled planes (half the bytes) instead of fp32.
  * D in {128, 256}; 64 for (arithmetic 0, fp32 volume) only.
  * bflow_split_to_x8: hi, lo (rows, 32) fp16 planes of a split tensor -> x8 (rows, 64): [e4m3(hi) x 32 | e4m3(lo) x 32] per row (OCP e4m3,
- * round to nearest even, saturating at +-448; |x| < 2^-10 becomes 0: such elements keep fp16 accuracy in the product).                      */
+ * round to nearest even, saturating at +-448; |x| < 2^-10 becomes 0: such elements keep fp16 accuracy in the product).
+ *   pool_out    : optional (T1, B, N, tiles1*32) buffer of the volume's element type + pool_index (HOST array of T ints: row of target t in
+ *                 pool_out, or -1): K6's level 0 -> 1 step (CorrData.get_downsampled, corr.py:108-125, as the pyramid constructor applies it,
+ *                 corr.py:297-305) fused into the build: the 2 x 2 mean (F.avg_pool2d's summation order, floor on odd sizes, pad positions zero) of
+ *                 the level-0 planes of the targets with more than one level is written by the same launch, every element of the level-1
+ *                 planes included.  (arithmetic 0 | 2 with an fp32 volume) or (arithmetic 1 with an fp16 volume); D in {128, 256}; T <= 8.  */
 int bflow_split_to_x8(const void* hi, const void* lo, void* x8, long long rows, bflow_stream_t stream);
 int bflow_corr_build_tiled(const void* f1_hi, const void* f1_second, const void* f2_hi, const void* f2_second, void* out, int T, int B, int D,
-                           int h, int w, int Np, long long f1_target_stride, int arithmetic, int out_fp16, bflow_stream_t stream);
+                           int h, int w, int Np, long long f1_target_stride, int arithmetic, int out_fp16, void* pool_out, const int* pool_index,
+                           bflow_stream_t stream);
 int bflow_corr_lookup_bezier_split_tiled_f16(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
                                              void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
                                              bflow_stream_t stream);
