@@ -333,7 +333,8 @@ class CorrBlockParallelMultiTarget:
         """Zero-initialised blocked split tensor for lookup_bezier_split (pad channels of the last block stay zero)."""
         from .split import SplitTensor
         h, w = self._hw
-        return SplitTensor.empty(self._batch, h, w, self.num_planes * 81, self._pyramid[0][0].device, zero=True)
+        # the tiled look-up writes every channel of the last block itself (pads as zeros): only the row-major kernel needs a zeroed buffer
+        return SplitTensor.empty(self._batch, h, w, self.num_planes * 81, self._pyramid[0][0].device, zero=not self._tiled)
 
     def lookup_bezier_split(self, params: torch.Tensor, coef: np.ndarray, out):
         """lookup_bezier writing the conv engine's blocked split layout directly (no NCHW intermediate)."""

@@ -55,6 +55,7 @@ struct ConvArgs {
     const float* gz;           // z (B, CBo, P_out, 32)
     float* acc;                // fp32 (B, Cout, Ho*Wo) accumulated in place, or null
     int w_sets;                // > 1: image b multiplies weight set b % w_sets (generic kernel only; the weight-gradient GEMMs)
+    int keep_pad;              // split output: channels >= Cout of the last block are left untouched instead of zeroed (Cout % 4 == 0)
     const float* xraw;         // NIN halo kernel: pre-normalisation fp32 input (B, CB, P_in, 32) + its InstanceNorm statistics
     const double* xstats;      // (R, B, CB*32, 2)
     int xstats_reps;
@@ -257,7 +258,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                     }
                 } else if (mok) {
                     if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + ob + (long long)m * 32) = make_float4(v[0], v[1], v[2], v[3]);
-                    if (a.oh) {
+                    if (a.oh && !(a.keep_pad && !cok[0])) {     // keep_pad: a group of 4 pad channels belongs to somebody else
                         half4v h4, l4;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -1817,6 +1818,8 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     a.stats_reps = d->stats_replicas > 0 ? d->stats_replicas : 1; a.stats_rep_stride = (long long)d->B * d->Cout * 2;
     a.acc = d->acc_nchw;
     a.w_sets = d->weight_sets > 1 ? d->weight_sets : 1;
+    a.keep_pad = d->keep_pad_channels;
+    BFLOW_REQUIRE(!d->keep_pad_channels || (d->Cout % 4 == 0 && !d->gate && !d->out_f32), BFLOW_E_ARG, "conv_split: keep_pad_channels needs Cout %% 4 == 0, split output only");
     a.xraw = d->x_raw; a.xstats = d->x_stats; a.xstats_reps = d->x_stats_replicas > 0 ? d->x_stats_replicas : 1; a.xeps = d->x_eps;
     a.gate = d->gate; a.gh = (const _Float16*)d->gate_h_hi; a.gl = (const _Float16*)d->gate_h_lo; a.gz = d->gate_z;
     if (d->gate) {

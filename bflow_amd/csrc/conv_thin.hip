@@ -30,6 +30,7 @@ struct ThinArgs {
     float* acc;                // (B, Cout, H*W) fp32, updated in place: acc += conv + bias
     _Float16 *oh, *ol;         // split output block or null: (B, CBo, P_out, 32), block cb_off receives [acc values | zeros]
     int B, H, W, CB, P_in, Cout, CBo, cb_off, P_out;
+    int c_off;                 // first channel of the emitted values inside block cb_off; > 0: the rest of the block is NOT touched
 };
 
 // Workgroup = 4 waves; the weights of CO output channels (all taps, 256 input channels, fp32: 36 KB for 3x3) sit in LDS, filled once per
@@ -156,13 +157,13 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(ThinArgs a) {
                     if (a.oh) {
                         _Float16 hi, lo;
                         bflow::split1(v, hi, lo);
-                        const long long o = (((long long)b * a.CBo + a.cb_off) * a.P_out + n0 + ei) * 32 + c0 + ek;
+                        const long long o = (((long long)b * a.CBo + a.cb_off) * a.P_out + n0 + ei) * 32 + a.c_off + c0 + ek;
                         a.oh[o] = hi;
                         a.ol[o] = lo;
                     }
                 }
                 // channels [Cout, 32) of the emitted block are zero
-                if (c0 == 0 && a.oh && lane >= a.Cout && lane < 32) {
+                if (c0 == 0 && a.oh && a.c_off == 0 && lane >= a.Cout && lane < 32) {
 #pragma unroll
                     for (int i = 0; i < GPW; ++i)
                         if (n0 + i < HW) {
@@ -180,13 +181,14 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(ThinArgs a) {
 
 extern "C" int bflow_conv_thin_acc(const void* x_hi, const void* x_lo, const float* w_packed, const float* bias, float* acc_nchw, void* out_hi,
                                    void* out_lo, int B, int H, int W, int C, int in_rows_per_image, int Cout, int KH, int KW,
-                                   int out_channel_blocks, int out_block, int out_rows_per_image, bflow_stream_t stream) {
+                                   int out_channel_blocks, int out_block, int out_rows_per_image, int out_channel_in_block, bflow_stream_t stream) {
     BFLOW_REQUIRE(x_hi && x_lo && w_packed && acc_nchw, BFLOW_E_ARG, "conv_thin_acc: null pointer");
     BFLOW_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && C <= 256 && Cout >= 1 && Cout <= 32, BFLOW_E_ARG, "conv_thin_acc: needs C %% 32 == 0, C <= 256, Cout <= 32 (got C=%d Cout=%d)", C, Cout);
     BFLOW_REQUIRE((KH == 3 && KW == 3) || (KH == 1 && KW == 1), BFLOW_E_ARG, "conv_thin_acc: 3x3 and 1x1 filters are built (got %dx%d)", KH, KW);
     BFLOW_REQUIRE(in_rows_per_image >= H * W && B <= 65535, BFLOW_E_ARG, "conv_thin_acc: bad row count / batch");
     BFLOW_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), BFLOW_E_ARG, "conv_thin_acc: out_hi / out_lo go together");
-    if (out_hi) BFLOW_REQUIRE(out_block >= 0 && out_block < out_channel_blocks && out_rows_per_image >= H * W, BFLOW_E_ARG, "conv_thin_acc: bad output block");
+    if (out_hi) BFLOW_REQUIRE(out_block >= 0 && out_block < out_channel_blocks && out_rows_per_image >= H * W && out_channel_in_block >= 0 &&
+                                  out_channel_in_block + Cout <= 32, BFLOW_E_ARG, "conv_thin_acc: bad output block");
     ThinArgs a;
     a.xh = (const _Float16*)x_hi;
     a.xl = (const _Float16*)x_lo;
@@ -196,7 +198,7 @@ extern "C" int bflow_conv_thin_acc(const void* x_hi, const void* x_lo, const flo
     a.oh = (_Float16*)out_hi;
     a.ol = (_Float16*)out_lo;
     a.B = B; a.H = H; a.W = W; a.CB = C / 32; a.P_in = in_rows_per_image; a.Cout = Cout;
-    a.CBo = out_channel_blocks; a.cb_off = out_block; a.P_out = out_rows_per_image;
+    a.CBo = out_channel_blocks; a.cb_off = out_block; a.P_out = out_rows_per_image; a.c_off = out_channel_in_block;
     const int n_groups = bflow::ceil_div((long long)H * W, 4 * GPW);
     // one pass over the pixels per workgroup up to ~4 workgroups per CU, beyond that a workgroup walks several group pairs on one weight fill
     dim3 grid(std::min(bflow::ceil_div(n_groups, GPB), std::max(1, 1024 / B)), B);

@@ -20,7 +20,7 @@ __device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
 __global__ __launch_bounds__(256) void bezier_update_kernel(float* __restrict__ params, const float* __restrict__ delta, int C2,
                                                             _Float16* __restrict__ bh, _Float16* __restrict__ bl, int CBt, int cb_off,
                                                             _Float16* __restrict__ b2h, _Float16* __restrict__ b2l, int CBt2, int cb_off2, int B,
-                                                            int P) {
+                                                            int P, int c_off) {
     const long long total = (long long)B * P;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(e / P), pix = (int)(e - (long long)b * P);
@@ -43,10 +43,17 @@ __global__ __launch_bounds__(256) void bezier_update_kernel(float* __restrict__ 
             o1[c >> 3][c & 7] = a;
             o2[c >> 3][c & 7] = d;
         }
+        if (c_off > 0) {          // the parameters share their block with other channels: write the C2 values only
+            for (int c = 0; c < C2; ++c) {
+                bh[ob + c_off + c] = o1[c >> 3][c & 7];
+                bl[ob + c_off + c] = o2[c >> 3][c & 7];
+            }
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *reinterpret_cast<half8*>(bh + ob + g * 8) = o1[g];
-            *reinterpret_cast<half8*>(bl + ob + g * 8) = o2[g];
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<half8*>(bh + ob + g * 8) = o1[g];
+                *reinterpret_cast<half8*>(bl + ob + g * 8) = o2[g];
+            }
         }
         if (b2h) {
             const long long ob2 = (((long long)b * CBt2 + cb_off2) * P + pix) * 32;
@@ -64,11 +71,11 @@ __global__ __launch_bounds__(256) void bezier_update_kernel(float* __restrict__ 
 
 
 extern "C" int bflow_bezier_update(float* params, const float* delta, int C2, void* blk_hi, void* blk_lo, int CB_total, int cb_off,
-                                   void* blk2_hi, void* blk2_lo, int CB_total2, int cb_off2, int B, int P, bflow_stream_t stream) {
-    BFLOW_REQUIRE(params && blk_hi && blk_lo && C2 > 0 && C2 <= 32 && CB_total > 0 && cb_off >= 0 && cb_off < CB_total && B > 0 && P > 0,
-                  BFLOW_E_ARG, "bezier_update: bad arguments");
+                                   void* blk2_hi, void* blk2_lo, int CB_total2, int cb_off2, int B, int P, int channel_in_block, bflow_stream_t stream) {
+    BFLOW_REQUIRE(params && blk_hi && blk_lo && C2 > 0 && C2 <= 32 && CB_total > 0 && cb_off >= 0 && cb_off < CB_total && B > 0 && P > 0 &&
+                      channel_in_block >= 0 && channel_in_block + C2 <= 32, BFLOW_E_ARG, "bezier_update: bad arguments");
     hipLaunchKernelGGL(bezier_update_kernel, dim3(bflow::stream_grid((long long)B * P, 256)), dim3(256), 0, (hipStream_t)stream, params, delta,
-                       C2, (_Float16*)blk_hi, (_Float16*)blk_lo, CB_total, cb_off, (_Float16*)blk2_hi, (_Float16*)blk2_lo, CB_total2, cb_off2, B, P);
+                       C2, (_Float16*)blk_hi, (_Float16*)blk_lo, CB_total, cb_off, (_Float16*)blk2_hi, (_Float16*)blk2_lo, CB_total2, cb_off2, B, P, channel_in_block);
     return bflow::launch_status("bezier_update");
 }
 

@@ -57,7 +57,8 @@ class ConvDesc(ctypes.Structure):
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("act", ctypes.c_int), ("stats", ctypes.c_void_p),
                 ("gate", ctypes.c_int), ("gate_h_hi", ctypes.c_void_p), ("gate_h_lo", ctypes.c_void_p), ("gate_z", ctypes.c_void_p),
                 ("stats_replicas", ctypes.c_int), ("acc_nchw", ctypes.c_void_p), ("weight_sets", ctypes.c_int),
-                ("x_raw", ctypes.c_void_p), ("x_stats", ctypes.c_void_p), ("x_stats_replicas", ctypes.c_int), ("x_eps", ctypes.c_float)]
+                ("x_raw", ctypes.c_void_p), ("x_stats", ctypes.c_void_p), ("x_stats_replicas", ctypes.c_int), ("x_eps", ctypes.c_float),
+                ("keep_pad_channels", ctypes.c_int)]
 
 
 class StemDesc(ctypes.Structure):
@@ -118,7 +119,7 @@ def lib() -> ctypes.CDLL:
         "bflow_conv_pack_weights_adjoint": [vp, vp, vp, i, i, i, i, i, i, vp],
         "bflow_conv_stem": [ctypes.POINTER(StemDesc), vp],
         "bflow_conv_split": [ctypes.POINTER(ConvDesc), vp],
-        "bflow_conv_thin_acc": [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, vp],
+        "bflow_conv_thin_acc": [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, vp],
         "bflow_wgrad_pack": [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, vp],
         "bflow_blocked_f32_to_nchw": [vp, vp, i, i, i, i, i, vp, vp],
         "bflow_pow2_scale": [vp, ll, f, vp, vp, vp],
@@ -139,7 +140,7 @@ def lib() -> ctypes.CDLL:
         "bflow_plane_stats": [vp, vp, ll, i, vp],
         "bflow_norm_act_split": [ctypes.POINTER(NormDesc), vp],
         "bflow_split_to_nchw": [vp, vp, vp, i, i, i, i, i, ll, vp],
-        "bflow_bezier_update": [vp, vp, i, vp, vp, i, i, vp, vp, i, i, i, i, vp],
+        "bflow_bezier_update": [vp, vp, i, vp, vp, i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_im2col_small": [vp, vp, vp, i, i, i, i, i, i, i, i, i, vp],
         "bflow_corr_pool2x2": [vp, vp, ll, i, i, vp],
         "bflow_corr_lookup": [ctypes.POINTER(PlaneDesc), i, vp, vp, i, i, i, i, vp],

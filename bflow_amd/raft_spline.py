@@ -306,7 +306,7 @@ class RAFTSpline(nn.Module):
         if pr: pr("joined")
 
         corr_feat = corr_block.new_output_split()
-        S.bezier_update(bezier, None, ws.M, ub.motion_dim // 32)     # emit the initial Bezier channel block
+        S.bezier_update(bezier, None, ws.M, ws.bez_channel // 32, channel_in_block=ws.bez_channel % 32)     # emit the initial Bezier channels
         return EncodedFrame(corr_block, ws, bezier, corr_feat)
 
     def _iterate(self, fr: "EncodedFrame", iters: int, test_mode: bool):

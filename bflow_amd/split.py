@@ -142,7 +142,7 @@ def conv_thin_acc(x: SplitTensor, packed, bias: Optional[torch.Tensor], acc_nchw
     B, H, W, _ = x.shape
     assert cin == x.channels_padded, f"input has {x.channels_padded} (padded) channels, weight expects {cin}"
     assert acc_nchw.dtype == torch.float32 and acc_nchw.is_contiguous() and tuple(acc_nchw.shape) == (B, cout, H, W)
-    assert channel_offset % 32 == 0
+    assert channel_offset % 32 == 0 or channel_offset % 32 + cout <= 32      # inside a block: the other channels of it are left alone
     oh = ol = None
     cbo = rows_o = 0
     if out_split is not None:
@@ -150,7 +150,7 @@ def conv_thin_acc(x: SplitTensor, packed, bias: Optional[torch.Tensor], acc_nchw
         oh, ol, cbo, rows_o = out_split.hi.data_ptr(), out_split.lo.data_ptr(), out_split.planes.shape[2], out_split.rows
     hip._check(hip.lib().bflow_conv_thin_acc(x.hi.data_ptr(), x.lo.data_ptr(), hip._dev(w, name="weight"),
                                              None if bias is None else hip._dev(bias, name="bias"), acc_nchw.data_ptr(), oh, ol, B, H, W, cin,
-                                             x.rows, cout, kh, kw, cbo, channel_offset // 32, rows_o, hip._stream()), "bflow_conv_thin_acc")
+                                             x.rows, cout, kh, kw, cbo, channel_offset // 32, rows_o, channel_offset % 32, hip._stream()), "bflow_conv_thin_acc")
 
 
 def _stats_replicas(stats: Optional[torch.Tensor], B: int, C: int) -> int:
@@ -242,7 +242,7 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
          want_split: bool = True, want_f32: bool = False, out_rows: Optional[int] = None, zero_rows: bool = False,
          x2: Optional[SplitTensor] = None, addend: Optional[torch.Tensor] = None, tile: Optional[int] = None,
          gate: int = GATE_NONE, gate_h: Optional[SplitTensor] = None, gate_z: Optional[torch.Tensor] = None,
-         acc_nchw: Optional[torch.Tensor] = None, weight_sets: int = 1):
+         acc_nchw: Optional[torch.Tensor] = None, weight_sets: int = 1, keep_pad: bool = False):
     """Implicit-GEMM convolution.  `packed` = PackedConvWeight.get(weight).  Returns (split_out or None, f32_out or None);
     f32_out is blocked fp32 (B, Cs/32, P_out, 32).  When out_* buffers are given the result is written at channel
     `channel_offset` (a multiple of 32) of their channel dimension (free concatenation).  out_rows > Ho*Wo allocates
@@ -304,6 +304,7 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
         d.gate, d.gate_h_hi, d.gate_h_lo = gate, gate_h.hi.data_ptr(), gate_h.lo.data_ptr()
         d.gate_z = None if gate_z is None else gate_z.data_ptr()
     d.weight_sets = weight_sets
+    d.keep_pad_channels = int(keep_pad)     # the pad channels of the last output block belong to another producer: do not zero them
     hip._check(hip.lib().bflow_conv_split(ctypes.byref(d), hip._stream()), "bflow_conv_split")
     return out_split, out_f32
 
@@ -492,15 +493,16 @@ def from_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> SplitTen
 
 
 def bezier_update(params: torch.Tensor, delta: Optional[torch.Tensor], dst: SplitTensor, dst_block: int,
-                  dst2: Optional[SplitTensor] = None, dst2_block: int = 0):
-    """params (B, 2deg, h, w) fp32 += delta (blocked fp32, first 2deg channels); re-emit as split channel block(s)."""
+                  dst2: Optional[SplitTensor] = None, dst2_block: int = 0, channel_in_block: int = 0):
+    """params (B, 2deg, h, w) fp32 += delta (blocked fp32, first 2deg channels); re-emit as split channel block(s), or (channel_in_block
+    > 0) as channels [channel_in_block, + 2deg) of block `dst_block`, leaving the rest of that block alone."""
     B, C2 = params.shape[:2]
     P = params.shape[2] * params.shape[3]
     assert dst.rows == P and (dst2 is None or dst2.rows == P)
     hip._check(hip.lib().bflow_bezier_update(hip._dev(params, name="params"), None if delta is None else hip._dev(delta, name="delta"), C2,
                                              dst.hi.data_ptr(), dst.lo.data_ptr(), dst.planes.shape[2], dst_block,
                                              None if dst2 is None else dst2.hi.data_ptr(), None if dst2 is None else dst2.lo.data_ptr(),
-                                             0 if dst2 is None else dst2.planes.shape[2], dst2_block, B, P, hip._stream()), "bflow_bezier_update")
+                                             0 if dst2 is None else dst2.planes.shape[2], dst2_block, B, P, channel_in_block, hip._stream()), "bflow_bezier_update")
 
 
 def im2col_small(x: torch.Tensor, kh: int, kw: int, padding, out: Optional[SplitTensor] = None) -> SplitTensor:

@@ -14,6 +14,7 @@ configurations the engine cannot run raise `BflowHipError` (`check_engine_suppor
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, Optional
 
 import torch
@@ -26,6 +27,7 @@ from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backwa
 # head2 (Conv2d(256, 2*deg, 3)): the vector-ALU kernel takes 5 us per 4800 pixels, the MFMA halo kernel 17 us at 4800 pixels but only
 # 40 us at 38400 (batch 8) where its grid fills the chip -- measured cross-over near 24000 pixels.
 THIN_HEAD_MAX_PIXELS = 20000
+MERGE_BEZIER_BLOCK = os.environ.get("BFLOW_NO_MERGED_BEZIER") is None     # A/B switch (tools/): see SplitWorkspace
 
 
 class BezierHead(nn.Module):
@@ -75,10 +77,18 @@ class SplitWorkspace:
 
     def __init__(self, blk: "BasicUpdateBlock", batch: int, h: int, w: int, device):
         hd, md = blk.hidden_dim, blk.motion_dim
+        # Layout of the GRU's motion input M.  merged: exactly cat([out, bezier]) of update.py:95-97 -- the 2*deg Bezier channels sit behind
+        # the motion convolution's md - 2*deg channels INSIDE the last 32-channel block (md channels = md/32 k-blocks for the four gate
+        # convolutions of an iteration instead of md/32 + 1: one k-block in nine less at DSEC size).  Needs producers that write a few channels
+        # of a block and leave the rest alone: the thin head kernel (batch <= THIN_HEAD_MAX_PIXELS pixels) and a degree with 2*deg % 4 == 0.
+        # Otherwise: [motion conv (md - 2deg, zero padded to md) | Bezier block (2*deg, zero padded to 32)].
+        bz = blk.bezier_planes
+        self.merged = MERGE_BEZIER_BLOCK and bz % 4 == 0 and batch * h * w <= THIN_HEAD_MAX_PIXELS and (md - bz) // 32 == (md - 1) // 32
+        self.bez_channel = md - bz if self.merged else md                        # first Bezier channel of M
         self.H = S.SplitTensor.empty(batch, h, w, hd, device)                    # hidden state
         self.RH = S.SplitTensor.empty(batch, h, w, hd, device)                   # r * h
         self.Z = torch.empty((batch, hd // 32, h * w, 32), dtype=torch.float32, device=device)   # update gate z (blocked fp32)
-        self.M = S.SplitTensor.empty(batch, h, w, md + 32, device, zero=True)    # [motion conv (md-2deg, zero padded to md) | Bezier block]
+        self.M = S.SplitTensor.empty(batch, h, w, md if self.merged else md + 32, device, zero=True)
         self.INP = None                                                          # relu(context) split, set by set_context
         self.corbez = S.SplitTensor.empty(batch, h, w, 256, device)
         self.inp_terms = None
@@ -122,7 +132,7 @@ class BasicUpdateBlock(nn.Module):
             entry[1] = key
         return entry[0].get(entry[2], cin_pad)
 
-    def _gate_weights(self, sfx: str):
+    def _gate_weights(self, sfx: str, merged: bool = False):
         """Gate convolutions re-indexed for the engine's inputs.  The reference convolves cat([h, inp, motion]) (update.py:34-37);
         here the loop-invariant `inp` part is split off (it is convolved ONCE per frame and enters as an addend), and the
         remaining input is the virtual concatenation [h | motion conv (zero padded) | Bezier block (zero padded to 32)]."""
@@ -130,8 +140,10 @@ class BasicUpdateBlock(nn.Module):
         hd, cd, md, bz = self.hidden_dim, self.context_dim, self.motion_dim, self.bezier_planes
         cz, cr, cq = getattr(g, "convz" + sfx), getattr(g, "convr" + sfx), getattr(g, "convq" + sfx)
 
-        def hm(w):   # (Cout, hd+cd+md, kh, kw) -> (Cout, hd + md + 32, kh, kw)
+        def hm(w):   # (Cout, hd+cd+md, kh, kw) -> (Cout, hd + md + 32, kh, kw); merged layout: (Cout, hd + md, kh, kw), the reference's own order
             co, _, kh, kw = w.shape
+            if merged:
+                return torch.cat([w[:, :hd], w[:, hd + cd:hd + cd + md]], dim=1)
             z = w.new_zeros
             mconv = w[:, hd + cd:hd + cd + md - bz]
             return torch.cat([w[:, :hd], mconv, z((co, bz, kh, kw)), w[:, hd + cd + md - bz:], z((co, 32 - bz, kh, kw))], dim=1)
@@ -141,7 +153,8 @@ class BasicUpdateBlock(nn.Module):
         def zr_inp(a=cz.weight, b=cr.weight): return torch.cat([a, b], dim=0)[:, hd:hd + cd]
         def q_inp(a=cq.weight): return a[:, hd:hd + cd]
         def zr_bias(a=cz.bias, b=cr.bias): return torch.cat([a, b], dim=0)
-        return (self._pk("zr_hm" + sfx, zr_hm), self._pk("q_hm" + sfx, q_hm), self._pk("zr_inp" + sfx, zr_inp),
+        tag = sfx + ("m" if merged else "")
+        return (self._pk("zr_hm" + tag, zr_hm), self._pk("q_hm" + tag, q_hm), self._pk("zr_inp" + sfx, zr_inp),
                 self._pk("q_inp" + sfx, q_inp), zr_bias, cq.bias, cz.padding)
 
     def new_split_workspace(self, batch: int, h: int, w: int, device) -> SplitWorkspace:
@@ -199,10 +212,10 @@ class BasicUpdateBlock(nn.Module):
                out_split=ws.corbez, channel_offset=192)
         corr_branch.join()
         S.conv(ws.corbez, self._pk("conv", lambda a=enc.conv.weight: a), padding=1, shift=enc.conv.bias, act=S.ACT_RELU,
-               out_split=ws.M, channel_offset=0)
+               out_split=ws.M, channel_offset=0, keep_pad=ws.merged)     # merged: the pad channels of the last block hold the Bezier parameters
         # ---- separable conv-GRU (update.py:33-48)
         for sfx, (t_zr, t_q) in zip(("1", "2"), ws.inp_terms):
-            zr_hm, q_hm, _, _, _, _, pad = self._gate_weights(sfx)
+            zr_hm, q_hm, _, _, _, _, pad = self._gate_weights(sfx, ws.merged)
             # z | r in one convolution; sigmoid, r * h (-> RH) and the final blend (-> H, in place) live in the conv epilogues
             S.conv(ws.H, zr_hm, x2=ws.M, padding=pad, addend=t_zr, gate=S.GATE_ZR, gate_h=ws.H, out_split=ws.RH, out_f32=ws.Z)
             S.conv(ws.RH, q_hm, x2=ws.M, padding=pad, addend=t_q, gate=S.GATE_BLEND, gate_h=ws.H, gate_z=ws.Z, out_split=ws.H)
@@ -220,8 +233,9 @@ class BasicUpdateBlock(nn.Module):
         if d1.shape[0] * d1.H * d1.W <= THIN_HEAD_MAX_PIXELS:
             # a 2*deg-channel output on a grid of 40 patches: the thin vector-ALU kernel, not a 32-wide MFMA tile on 40 workgroups
             S.conv_thin_acc(d1, self.__dict__.setdefault("_head2_w", S.ThinConvWeight()).get(bh.conv2.weight), bh.conv2.bias, bezier,
-                            out_split=ws.M, channel_offset=self.motion_dim)
+                            out_split=ws.M, channel_offset=ws.bez_channel)
         else:
+            assert not ws.merged
             S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, acc_nchw=bezier, out_split=ws.M,
                    channel_offset=self.motion_dim)
         mask_branch.join()
@@ -239,6 +253,6 @@ class BasicUpdateBlock(nn.Module):
         self._hoist_inp_terms(ws)
         before = bezier.float().contiguous()
         after = before.clone()
-        S.bezier_update(after, None, ws.M, self.motion_dim // 32)       # emit the Bezier channel block of the GRU input
+        S.bezier_update(after, None, ws.M, ws.bez_channel // 32, channel_in_block=ws.bez_channel % 32)   # emit the Bezier channels of the GRU input
         mask = self.step_split(ws, corr.float().contiguous(), after, need_mask=True)
         return ws.H.to_nchw(), 0.25 * mask, after - before

@@ -139,6 +139,9 @@ typedef struct bflow_conv_desc {
     const double* x_stats;
     int x_stats_replicas;
     float x_eps;
+    int keep_pad_channels;            /* split output with Cout % 32 != 0: the channels [Cout, next multiple of 32) of the last block are left
+                                         untouched instead of written as zeros (they belong to another producer: the Bezier parameters that
+                                         follow the motion features inside one block, update.py:95-97).  Cout % 4 == 0.                       */
 } bflow_conv_desc_t;
 /* bflow_conv_stem: the 7x7 stride-2 entry convolution of BasicEncoder (extractor.py:63,110) on a few-channel fp32 NCHW input
  * (5 / 8 / 25 / 41 / 3 channels): im2col in LDS over a TIGHT k = (channel, tap) index instead of 32-channel blocks per tap.
@@ -255,10 +258,12 @@ int bflow_conv_wgrad_halo(const void* x_hi, const void* x_lo, const void* dy_hi,
  *               the inputs are re-assembled as hi + lo * 2^-11);
  *   acc_nchw  : (B, Cout, H*W) fp32, updated in place;
  *   out_hi/lo : NULL, or a split buffer (B, out_channel_blocks, out_rows_per_image, 32) whose block `out_block` receives the
- *               UPDATED acc values (channels >= Cout of that block: zero) -- the Bezier block of the next GRU input.        */
+ *               UPDATED acc values at channels [out_channel_in_block, + Cout) -- the Bezier channels of the next GRU input.  With
+ *               out_channel_in_block = 0 the other channels of the block are written as zeros; > 0: they are not touched (the
+ *               parameters follow the motion features inside one block, exactly cat([out, bezier]) of update.py:95-97).      */
 int bflow_conv_thin_acc(const void* x_hi, const void* x_lo, const float* w_packed, const float* bias, float* acc_nchw, void* out_hi,
                         void* out_lo, int B, int H, int W, int C, int in_rows_per_image, int Cout, int KH, int KW,
-                        int out_channel_blocks, int out_block, int out_rows_per_image, bflow_stream_t stream);
+                        int out_channel_blocks, int out_block, int out_rows_per_image, int out_channel_in_block, bflow_stream_t stream);
 
 /* bflow_plane_stats: stats[p] = (sum, sum of squares) of plane p of an NCHW fp32 tensor (planes = B*C, HW % 4 == 0).
  * bflow_norm_act_split: out = act_out( res + act_a( norm_a(a) ) ) -> split NHWC (and/or fp32 NHWC), where
@@ -290,9 +295,10 @@ int bflow_split_to_nchw(const void* x_hi, const void* x_lo, float* out, int B, i
  *   bflow_bezier_update    : params[b, c, pix] += delta[b, c, pix] (delta blocked fp32, first 2*deg channels) and the
  *                            updated parameters are re-emitted as one split channel block at block `cb_off` of a
  *                            (B, CB_total, P, 32) split buffer (the GRU input of the next iteration) and, if blk2 is
- *                            not NULL, of a second buffer.  delta may be NULL (only re-emit).  params: plain (B, C2, P) fp32 (the layout the look-up kernel reads).     */
+ *                            not NULL, of a second buffer.  delta may be NULL (only re-emit).  params: plain (B, C2, P) fp32 (the layout the look-up kernel reads).
+ *                            channel_in_block > 0: the C2 values go to channels [channel_in_block, + C2) of the block and nothing else of it is written. */
 int bflow_bezier_update(float* params, const float* delta, int C2, void* blk_hi, void* blk_lo, int CB_total, int cb_off,
-                        void* blk2_hi, void* blk2_lo, int CB_total2, int cb_off2, int B, int P, bflow_stream_t stream);
+                        void* blk2_hi, void* blk2_lo, int CB_total2, int cb_off2, int B, int P, int channel_in_block, bflow_stream_t stream);
 
 /* bflow_im2col_small: out[b, pix, tap*C + c] = x[b, c, y+r-pad_h, x+q-pad_w] (zeros outside) as a blocked split tensor with
  *   ceil(KH*KW*C/32) channel blocks: turns the 7x7 convolution over the 2*deg Bezier channels (update.py:62,91) into a 1x1 GEMM. */
