@@ -1,46 +1,76 @@
 #!/usr/bin/env python
-"""Regenerates profiles/README.md from profiles/r02_bench.json + r02_pmc.json (tools only)."""
+"""Regenerates profiles/README.md from profiles/r03_bench.json + r03_pmc.json (tools only)."""
 import json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-b = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
-p = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))["kernels"]
+P = os.path.join(ROOT, "profiles")
+b = json.load(open(os.path.join(P, "r03_bench.json")))
+pm = json.load(open(os.path.join(P, "r03_pmc.json")))
+p = pm["kernels"]
 r, rk, rl, cb = b["roofline"], b["roofline_corr_build"], b["roofline_lookup"], b["cpu_baseline"]
-train = " / ".join(l.strip() for l in open(os.path.join(ROOT, "profiles", "r02_train_probe.txt")).read().strip().replace("train step ", "").splitlines())
+one = cb["single_thread"]
+gs = b["gpu_stage_ms"]
+vk = b["voxel_kernels"]
+train = " / ".join(l.strip() for l in open(os.path.join(P, "r03_train_probe.txt")).read().strip().replace("train step ", "").splitlines())
+tl = " · ".join(" ".join(l.split()) for l in open(os.path.join(P, "r03_stamp_timeline.txt")).read().strip().splitlines())
+
+
+def mf(k):
+    m = p[k["kernel"]]["mfma"]
+    return f'{m.get("mfma_utilisation", 0):.2f}'
+
+
 txt = f'''# profiles/ — measured evidence, MI355X (gfx950)
 
-Round-2 files (`r02_*`) were produced on a `gpurun` MI355X box by `tools/collect_profiles.sh` (the only writer of these files) and this
-page by `tools/make_profiles_readme.py`; round-1 files (`r01_*`) are kept for comparison.  `gpurun_out/` is scratch, these are the copies
-to be judged.  `r02_pmc.json` records a hash of the kernel sources it was collected on; `bench.py` quotes its `traffic` only while the
-sources still hash to the same value.
+Round-3 files (`r03_*`) were produced on a `gpurun` MI355X box by `tools/collect_profiles.sh` (the only writer of these files) and this
+page by `tools/make_profiles_readme.py`; `r01_*` / `r02_*` are the earlier rounds, kept for comparison.  `gpurun_out/` is scratch, these are
+the copies to be judged.  `r03_pmc.json` records a hash of the kernel sources it was collected on; `bench.py` quotes its `traffic` only
+while the sources still hash to the same value.
 
 | File | Command | What it shows |
 |---|---|---|
-| `r02_bench.json` | `python bench.py --steps 30 --warmup 5` | the BENCH line: {b["value"]:.1f} frames/s, {b["ms_per_step"]:.2f} ms/frame, {b["ms_per_gru_iter"]:.3f} ms per GRU iteration at BASELINE configs[1] (E_LU4_BD2, 640×480, B=1, 12 iters); `c4_strong` = configs[3] (global batch 64 in micro-batches of 8) on one GPU: {b["c4_strong"]["value"]:.1f} frames/s; rooflines; CPU baseline {cb["value"]:.2f} frames/s on the box's {cb["cores"]}-core quota |
-| `r02_rocprofv3_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline` (top 45 rows) | per-kernel totals/averages over the same command (both workloads of the bench: batch 1 and batch 8, so the averages mix the two): every row is a kernel of this repository or torch's copy / fill plumbing — no library convolution or GEMM |
-| `r02_pmc_{{FETCH,WRITE}}_SIZE_<key>.csv` | `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) on `tools/roofline_probe.py --key <key>` — the same launchers `bench.py` times (`tools/roofline_kernels.py`); last 5 launches of the kernel | fabric-side traffic per launch of the three roofline kernels |
-| `r02_pmc.json` | `tools/pmc_to_json.py` on the six CSVs | bytes per launch incl. the gfx950 ×2 FETCH_SIZE correction for wide coalesced streams (MI355X_MICROARCH.md §HBM) + the kernel-source hash |
-| `r02_train_probe.txt`, `r02_train_rocprofv3_kernel_stats.csv` | `BFLOW_TRAIN_PROBE_GRAPH=1 python tools/train_probe.py 10`; `BFLOW_TRAIN_PROBE_GRAPH=engine rocprofv3 --kernel-trace --stats -- python tools/train_probe.py 5` | training path (SURVEY §8 f-4) with the convolutions (forward, dgrad, wgrad) on the conv engine, eagerly (host-bound) and as one hipGraph per step (`training.GraphedTrainStep`), the latter also on torch / MIOpen convolutions (`conv_train.ENABLED = False`): {train} |
+| `r03_bench.json` | `python bench.py --steps 30 --warmup 5` | the BENCH line: {b["value"]:.1f} frames/s, {b["ms_per_step"]:.2f} ms/frame, {b["ms_per_gru_iter"]:.3f} ms per GRU iteration at BASELINE configs[1] (E_LU4_BD2, 640×480, B=1, 12 iters); `c4_strong` = configs[3] (global batch 64 in micro-batches of 8) on one GPU: {b["c4_strong"]["value"]:.1f} frames/s; rooflines; `cpu_baseline` (all cores + 1 thread, per-stage ms); `gpu_stage_ms`; `voxel_kernels` (K1 / K2) |
+| `r03_rocprofv3_kernel_stats_c2only.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 30 --warmup 5 --no-extras` (top rows) | **batch-1 C2 only** (38 forwards): per-kernel totals — the frame's budget per kernel; every row is a kernel of this repository or torch's copy / fill plumbing |
+| `r03_rocprofv3_kernel_stats.csv` | the same on the default command (`--no-cpu-baseline`) | both workloads of the bench (batch 1 and batch 8): use the C2-only file for averages |
+| `r03_pmc_{{FETCH_SIZE,WRITE_SIZE,MFMA}}_<key>.csv` | `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE` (separate passes) on `tools/roofline_probe.py --key <key>` — the launchers `bench.py` times; last 5 launches; `..._calib.csv`: the same SQ / GRBM set on `tools/micro/fp8_cross` (pure MFMA streams: the 100 % mark) | fabric traffic and matrix-core busy cycles per launch of the three roofline kernels |
+| `r03_pmc.json` | `tools/pmc_to_json.py` on those CSVs | bytes per launch incl. the gfx950 ×2 FETCH_SIZE correction (MI355X_MICROARCH.md §HBM), MFMA utilisation = busy / GRBM cycles relative to the calibration launch, the kernel-source hash |
+| `r03_mfma_clock_fp8_cross.txt` | `tools/micro/fp8_cross` | (1) the fp8 K = 64 MFMA with the operand halves K5 uses is exact on realistic operands; (2) pure MFMA streams on random data, every SIMD busy: 3-pass split vs fp16 + fp8 cross terms — time per 32-channel block and the shader clock (`s_memtime` ÷ wall clock): the power-limited clock of the matrix pipes |
+| `r03_store_patterns.txt` | `tools/micro/store_patterns` | a pure store stream of K5's shape: 4 B vs 16 B per lane, K5's item order vs lockstep, `nt`; linear fills; `hipMemset` — the write ceiling (≈ 0.6 of 8 TB/s) and that store width does not move it |
+| `r03_k5_stamps_split8.txt`, `r03_k5_stamps_split.txt` | `BFLOW_HIP_LIB=…/libbflow_hip_stamps.so python tools/k5_probe.py --time-only --stamps --stamp-mode <mode>` (`tools/k5_ablate.sh stamps:-DSTREAM_STAMPS`) | per-workgroup cycle stamps of K5 at C2: prologue, cycles per 64-row pair, end times per XCD, sustained clock = cycles ÷ `s_memrealtime` |
+| `r03_smi_roofline.txt`, `r03_smi_roofline_corr_build.txt` | `amd-smi metric --clock --power` every 0.25 s while `tools/roofline_probe.py --key <key> --reps 20000` repeats the launch | sclk and socket power under the layer-1 convolution / K5 |
+| `r03_k5_modes.txt` | `python tools/k5_modes_probe.py --big` | K5 per arithmetic / storage (`split`, `split8`, `f16/w`, `split/h`, `split8/h`, `f16`): error vs an fp64 GEMM and duration at C2 / C4 shard / C5 |
+| `r03_corr_precision_e2e.txt` | `python tools/corr_precision_probe.py --c5` | end-to-end EPE vs the fp32 oracle and frame time per `corr_precision` at C2 (two inputs) and C5: the decomposition of the fp16 variant's error |
+| `r03_stamp_timeline.txt` | `python tools/stamp_timeline.py` | stage boundaries INSIDE the captured graph (no tracer): {tl} |
+| `r03_train_probe.txt` | `BFLOW_TRAIN_PROBE_GRAPH=1 python tools/train_probe.py 10` | training path (SURVEY §8 f-4), unchanged this round, re-measured for regressions: {train} |
 
-## Round-2 numbers (C2 = E_LU4_BD2 events-only, DSEC 640×480, batch 1, 12 iterations)
+## Round-3 numbers (C2 = E_LU4_BD2 events-only, DSEC 640×480, batch 1, 12 iterations)
 
-| Quantity | Round 2 | Round 1 |
-|---|---|---|
-| frames/s, 1 GPU, hipGraph replay | **{b["value"]:.1f}** ({b["ms_per_step"]:.2f} ms/frame) | 236.8 (4.22 ms) |
-| ms per GRU iteration (marginal, under replay) | **{b["ms_per_gru_iter"]:.3f}** | 0.181–0.186 |
-| fixed part (encoders + volume + pyramid + up-sampling) | {b["ms_fixed_part"]:.2f} ms | 1.94–2.1 ms |
-| configs[3] global batch 64 on ONE GPU (8 micro-batches of 8, two at a time as parallel branches of one graph) | {b["c4_strong"]["value"]:.1f} frames/s | (batch 8: 300–314) |
-| two batch-1 frames in flight (`c2_two_in_flight`, next to `value`, never `value`) | {b["c2_two_in_flight"]["value"]:.1f} frames/s | — |
-| CPU baseline (oracle = op-for-op port, torch CPU fp32, {cb["cores"]} threads) | {cb["value"]:.2f} frames/s ({cb["ms_per_frame"]:.0f} ms/frame) | 0.75 |
+| Quantity | Round 3 | Round 2 | Round 1 |
+|---|---|---|---|
+| frames/s, 1 GPU, hipGraph replay | **{b["value"]:.1f}** ({b["ms_per_step"]:.2f} ms/frame) | 244.3 (4.09 ms) | 236.8 (4.22 ms) |
+| ms per GRU iteration (marginal, under replay) | **{b["ms_per_gru_iter"]:.3f}** | 0.171 | 0.181–0.186 |
+| fixed part (encoders + volume + pyramid + up-sampling) | {b["ms_fixed_part"]:.2f} ms | 2.06 ms | 1.94–2.1 ms |
+| configs[3] global batch 64 on ONE GPU (8 micro-batches of 8, two at a time as parallel branches of one graph) | {b["c4_strong"]["value"]:.1f} frames/s | 363 | (batch 8: 300–314) |
+| two batch-1 frames in flight (`c2_two_in_flight`, next to `value`, never `value`) | {b["c2_two_in_flight"]["value"]:.1f} frames/s | 290 | — |
+| CPU baseline (oracle = op-for-op port, torch CPU fp32), {cb["cores"]} threads / 1 thread | {cb["value"]:.2f} frames/s ({cb["ms_per_frame"]:.0f} ms/frame) / {one["value"]:.3f} frames/s ({one["ms_per_frame"]:.0f} ms/frame) | 0.77 | 0.75 |
 
-| Kernel (as `bench.py` launches it) | bound | achieved | peak | frac | launch | PMC traffic vs algorithmic |
-|---|---|---|---|---|---|---|
-| `conv_halo_kernel<2,3,3>` encoder layer1 3×3 (dominant kernel) | fp16 MFMA / 3 | {r["achieved"]:.0f} TFLOP/s-equiv. | 833 | **{r["frac"]:.2f}** | {r["avg_launch_ms"]*1e3:.0f} µs | {p[r["kernel"]]["traffic"]/1e6:.0f} MB vs 197 MB |
-| `corr_stream_kernel<8,true>` K5 (was the 256×128 tile kernel: 0.23) | HBM | {rk["achieved"]/1e3:.2f} TB/s | 8 | **{rk["frac"]:.2f}** | {rk["avg_launch_ms"]*1e3:.0f} µs | {p[rk["kernel"]]["traffic"]/1e6:.0f} MB vs 393 MB: writes exact ({p[rk["kernel"]]["write"]/1e6:.0f} MB); reads = the reference slice re-streamed by every workgroup + panel loads, served by L2 / Infinity Cache (counted at the fabric) |
-| `corr_lookup_tile_kernel<float,2,256>` K7 on tiled planes (was the one-plane row kernel: 0.15) | HBM (gather) | {rl["achieved"]/1e3:.2f} TB/s | 8 | **{rl["frac"]:.2f}** | {rl["avg_launch_ms"]*1e3:.1f} µs | {p[rl["kernel"]]["traffic"]/1e6:.1f} MB vs 24.3 MB |
+| Kernel (as `bench.py` launches it) | bound | achieved | peak | frac | launch | PMC traffic vs algorithmic | MFMA utilisation (PMC) |
+|---|---|---|---|---|---|---|---|
+| `conv_halo_kernel<2,3,3,TR>` encoder layer1 3×3 (dominant kernel) | fp16 MFMA / 3 | {r["achieved"]:.0f} TFLOP/s-equiv. | 833 | **{r["frac"]:.2f}** (round 2: 0.31) | {r["avg_launch_ms"]*1e3:.0f} µs | {p[r["kernel"]]["traffic"]/1e6:.0f} MB vs 197 MB | {mf(r)} |
+| `corr_stream_kernel<8,true,2,false>` K5, the product launch: tiled planes, fp8 cross terms | HBM (2nd roof: matrix, 2 units / product) | {rk["achieved"]/1e3:.2f} TB/s; {rk.get("tflops_equivalent", 0):.0f} TFLOP/s-equiv. | 8 TB/s; 1250 | **{rk["frac"]:.2f}** (round 2: 0.34); matrix {rk.get("frac_mfma", 0):.2f} | {rk["avg_launch_ms"]*1e3:.0f} µs | {p[rk["kernel"]]["traffic"]/1e6:.0f} MB vs 393 MB (round 2: 645 MB): writes {p[rk["kernel"]]["write"]/1e6:.0f} MB, reads {p[rk["kernel"]]["fetch_corrected"]/1e6:.0f} MB for 24.6 MB of operands | {mf(rk)} |
+| `corr_lookup_tile_kernel<float,2,256>` K7 on tiled planes | HBM (gather) | {rl["achieved"]/1e3:.2f} TB/s | 8 | **{rl["frac"]:.2f}** | {rl["avg_launch_ms"]*1e3:.1f} µs | {p[rl["kernel"]]["traffic"]/1e6:.1f} MB vs 24.3 MB | — |
 
-Other probes of this round (numbers quoted in DESIGN.md §8): `tools/k5_probe.py [--big] [--f16] [--stamps]` (K5 at every BASELINE shape, per-workgroup
-cycle stamps, ablation builds via `tools/k5_ablate.sh`), `tools/k7_probe.py` (look-up: row-major one-plane kernel vs tile kernel vs fp16 planes;
-`BFLOW_LOOKUP_ABL` phase ablation), `tools/c5_check.py [--f16]` (C5 frame rate and peak memory).
+Per-stage milliseconds under the reference's CudaTimer names (`raft.py:116-186`):
+
+| stage | HIP path (eager + hipEvents: upper bounds) | CPU oracle, {cb["cores"]} threads | CPU oracle, 1 thread |
+|---|---|---|---|
+''' + "".join(f'| `{k}` | {gs.get(k, "—")} | {cb["stage_ms"].get(k, "—")} | {one["stage_ms"].get(k, "—")} |\n'
+              for k in ("fnet_ev", "cnet", "corr computation", "all iters", "1 iter", "get_flow (per iter)", "corr lookup (per iter)", "update (per iter)")) + f'''
+K1 / K2 (`voxel_kernels`, 2 M synthetic events into the 15 × 480 × 640 grid): float x/y {vk["k1_float_xy"]["ms"]:.3f} ms = {vk["k1_float_xy"]["events_per_s"]/1e9:.2f} G events/s
+({vk["k1_float_xy"]["atomics_per_s"]/1e9:.1f} G atomics/s, {vk["k1_float_xy"]["algorithmic_gb_s"]:.0f} GB/s algorithmic); int x/y {vk["k1_int_xy"]["ms"]:.3f} ms = {vk["k1_int_xy"]["events_per_s"]/1e9:.2f} G events/s;
+K2 {vk["k2_norm"]["ms"]*1e3:.0f} µs ({vk["k2_norm"]["algorithmic_gb_s"]:.0f} GB/s over its four passes).
+
+Other probes (numbers quoted in DESIGN.md §8 / §9): `tools/k5_probe.py [--big] [--f16] [--stamps]`, `tools/k5_ablate.sh` (timing-only ablation
+builds of K5), `tools/k7_probe.py`, `tools/micro/load_paths.hip` (LDS-DMA vs register loads per CU), `tools/c5_check.py [--f16]`.
 '''
-open(os.path.join(ROOT, "profiles", "README.md"), "w").write(txt)
+open(os.path.join(P, "README.md"), "w").write(txt)
 print(txt)
