@@ -1405,6 +1405,7 @@ struct StemArgs {
     // n % B_src -- RAFTSpline.gen_voxel_grids (raft.py:88-99) followed by torch.cat, without the copy.  B_src = 0: x is plain.
     int B_src, C_src;
     int win[8];
+    int layout;                // 0: k = (channel, tap) im2col tiles built in LDS (conv_stem_kernel); 1: row windows (conv_stem_rows_kernel)
 };
 
 #ifndef STEM_ABL
@@ -1590,6 +1591,180 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
     }
     if constexpr (TR) {
         // register r of lane (channel, kh): pixel (r & 3) + 8 (r >> 2) + 4 kh of the wave's 2 x 16 row-major slab
+        const int kh_ = lane >> 5, c4 = (lane & 31) * 4;
+        conv_epilogue_direct<NT>(a, hh, xx, b, [=](int r) {
+            const int y = yw + (r >> 3), x = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh_;
+            return (y < Ho && x < Wo) ? (unsigned)((y * Wo + x) * 128 + c4) : 0x80000000u; }, n0, lane, wave, tid, reinterpret_cast<float*>(lds));
+    } else {
+        conv_epilogue<NT>(a, hh, xx, b, [=](int row) {
+            const int y = yw + (row >> 4), x = x0 + (row & 15);
+            return (y < Ho && x < Wo) ? y * Wo + x : -1; }, n0, lane, wave, tid, true, reinterpret_cast<float*>(lds));
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem kernel, row-window form (round 3; StemArgs.layout = 1).  The im2col form above spends its time building 128 x 32 activation
+// tiles on the vector ALU (a table gather + split per k element: 128 KB of LDS writes per workgroup for 32 KB of output; 50 of the
+// launch's 157 us).  Here the input patch of a channel chunk is split ONCE (one conversion per input element: 8x less) and laid out
+// [row][column][channel] in LDS, so that the 7 x CH values a filter ROW needs for one output pixel are CONTIGUOUS: k = (q, c) is a
+// window of 7 CH halves starting at column 2 x_out.  A lane's MFMA fragment is 8 consecutive halves of that window -- four
+// ds_read_b32 (the window starts on a 4-byte, not a 16-byte boundary; adjacent pixels are 4 CH bytes apart: 5 dwords for CH = 5, so the
+// 32 lanes of a read spread over all 32 banks) -- and nothing is ever gathered.  K per filter row is 7 CH rounded up to 16 (CH = 5: 48
+// for 35; the surplus columns are the next pixels' finite values against ZERO weights), 7 rows per chunk; the weights are an ordinary
+// packed tensor in (chunk, row, window) order, two 16-deep steps per 32-wide k-block, streamed by LDS-DMA as before.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS, int STRIDE, bool TR>
+__global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemArgs sa) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NT = 2, TH = 8, TW = 16;
+    constexpr int PR = STRIDE * (TH - 1) + KS, PC = STRIDE * (TW - 1) + KS;     // input patch rows / cols (21 x 37)
+    constexpr int W_TILE = 2 * NT * 2048;                 // 64 weight rows x 64 B x (hi, lo)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int CH = sa.chunk;
+    const int pitch = (PC * CH + 1) & ~1;                 // halves per patch row (even: rows start on 4-byte boundaries)
+    const int plane_h = PR * pitch + 64;                  // + slack read by the last pixels' window surplus (zeroed)
+    const int O_W = ((2 * plane_h * 2 + 15) & ~15);       // weight tiles behind the two planes
+    _Float16* const ph_ = reinterpret_cast<_Float16*>(lds);
+    _Float16* const pl_ = ph_ + plane_h;
+    const int KSTEPS = (KS * CH + 15) >> 4;               // 16-deep steps per filter row
+    const int nsteps = KS * KSTEPS;                       // per chunk
+    const int kbpc = (nsteps + 1) >> 1;                   // 32-wide weight k-blocks per chunk
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.z;
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    int y0, x0, n0;
+    {
+        const int ntn = a.n_tiles;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int mt = (slot / ntn) * 8 + xcd;
+        if (mt >= tiles_x * tiles_y) return;
+        n0 = (slot - (slot / ntn) * ntn) * 32 * NT;
+        const int ty = mt / tiles_x;
+        y0 = ty * TH;
+        x0 = (mt - ty * tiles_x) * TW;
+    }
+    const int gy0 = y0 * STRIDE - a.pad_h, gx0 = x0 * STRIDE - a.pad_w;
+
+    const int urow = lane >> 2;
+    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    unsigned wvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wvo[j] = (unsigned)(((n0 + ((wave * 2 + j) & 3) * 16 + urow) * 32 + uchunk) * 2);
+    const int wtile_b = a.cout_pad * 64;
+    const int nchunks = (sa.Cin + CH - 1) / CH;
+    const int nkb = nchunks * kbpc;
+    const rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)((wave >> 1) ? a.wl : a.wh), 0, nkb * wtile_b, 0x00020000);
+    char* const w_dst = lds + O_W + ((wave >> 1) ? NT * 2048 : 0);
+#define STEMR_ISSUE_W(KB, BUF)                                                                                           \
+    {                                                                                                                    \
+        const int so_ = ((KB) < nkb ? (KB) : nkb - 1) * wtile_b;                                                         \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (BUF) * W_TILE + ((wave * 2 + j) & 3) * 1024), 16, wvo[j], so_, 0, 0); \
+    }
+
+    f32x16 hh[NT], xx[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            hh[n][r] = 0.f;
+            xx[n][r] = 0.f;
+        }
+    // this lane's pixel of the patch and the half index of its window start (row 0)
+    const int yo = 2 * wave + (l31 >> 4), xo = l31 & 15;
+    const int win0 = (STRIDE * yo) * pitch + STRIDE * xo * CH + kh * 8;
+    const int sw = (l31 >> 2) & 3;
+
+    for (int i = tid; i < 64; i += CT) { ph_[PR * pitch + i] = (_Float16)0.f; pl_[PR * pitch + i] = (_Float16)0.f; }   // the slack
+    STEMR_ISSUE_W(0, 0)
+    int kb = 0;
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const int c_first = ck * CH;
+        const int nch = min(CH, sa.Cin - c_first);
+        __syncthreads();                                                      // the previous chunk's patch is drained
+        {   // ---- the chunk's input patch: thread = patch pixel, all channels; out-of-image = out-of-range buffer offset = 0
+            const long long img = (long long)sa.H * sa.W;
+            const long long x_base = sa.B_src > 0 ? ((long long)(b % sa.B_src) * sa.C_src + sa.win[b / sa.B_src] + c_first) * img
+                                                  : ((long long)b * sa.Cin + c_first) * img;
+            const rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.x + x_base), 0, (int)(nch * img * 4), 0x00020000);
+            constexpr int NPX = (PR * PC + CT - 1) / CT;
+            float pv[NPX][8];
+#pragma unroll
+            for (int j = 0; j < NPX; ++j) {
+                const int p = tid + j * CT;
+                const int pr = p / PC, pc = p - pr * PC;
+                const int gy = gy0 + pr, gx = gx0 + pc;
+                const bool ok = p < PR * PC && gy >= 0 && gy < sa.H && gx >= 0 && gx < sa.W;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const unsigned off = (ok && c < nch) ? (unsigned)(((c * sa.H + gy) * sa.W + gx) * 4) : 0x80000000u;
+                    pv[j][c] = c < CH ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_x, off, 0, 0)) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NPX; ++j) {
+                const int p = tid + j * CT;
+                if (p < PR * PC) {
+                    const int pr = p / PC, pc = p - pr * PC;
+                    const int o = pr * pitch + pc * CH;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < CH) {
+                            _Float16 hi, lo;
+                            split1(pv[j][c], hi, lo);
+                            ph_[o + c] = hi;
+                            pl_[o + c] = lo;
+                        }
+                    if (pc == PC - 1 && (PC * CH & 1)) { ph_[o + CH] = (_Float16)0.f; pl_[o + CH] = (_Float16)0.f; }   // the pitch's pad half
+                }
+            }
+        }
+        for (int kbl = 0; kbl < kbpc; ++kbl, ++kb) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // weight tile kb landed
+            __syncthreads();                                                  // ... everywhere; (kbl = 0: the patch is complete)
+            STEMR_ISSUE_W(kb + 1, (kb + 1) & 1)
+            const char* wt = lds + O_W + (kb & 1) * W_TILE;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int st = 2 * kbl + h;
+                if (st < nsteps) {                                            // (an odd step count leaves the last half k-block empty)
+                    const int r = st / KSTEPS, ks = st - r * KSTEPS;
+                    const int wo_ = win0 + r * pitch + ks * 16;              // halves; 4-byte aligned
+                    const unsigned* qh = reinterpret_cast<const unsigned*>(ph_ + wo_);
+                    const unsigned* ql = reinterpret_cast<const unsigned*>(pl_ + wo_);
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 vh = {qh[0], qh[1], qh[2], qh[3]}, vl = {ql[0], ql[1], ql[2], ql[3]};
+                    const half8 xh = __builtin_bit_cast(half8, vh), xl = __builtin_bit_cast(half8, vl);
+                    const int co = ((h * 2 + kh) ^ sw) * 16;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int wo = (n * 32 + l31) * 64 + co;
+                        const half8 wh = *reinterpret_cast<const half8*>(wt + wo);
+                        const half8 wl = *reinterpret_cast<const half8*>(wt + NT * 2048 + wo);
+                        if constexpr (TR) {
+                            hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, hh[n], 0, 0, 0);
+                            xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, xx[n], 0, 0, 0);
+                            xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, xx[n], 0, 0, 0);
+                        } else {
+                            hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh[n], 0, 0, 0);
+                            xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, xx[n], 0, 0, 0);
+                            xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, xx[n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#undef STEMR_ISSUE_W
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int Wo = a.Wo, Ho = a.Ho, yw = y0 + wave * 2;
+    if constexpr (TR) {
         const int kh_ = lane >> 5, c4 = (lane & 31) * 4;
         conv_epilogue_direct<NT>(a, hh, xx, b, [=](int r) {
             const int y = yw + (r >> 3), x = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh_;
@@ -2015,9 +2190,12 @@ extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream
             sa.win[i] = d->window_starts[i];
         }
     }
-    BFLOW_REQUIRE(d->k_blocks == ((d->Cin + sa.chunk - 1) / sa.chunk) * sa.kblocks_per_chunk, BFLOW_E_ARG,
-                  "conv_stem: the packed weights hold %d k-blocks, expected %d (chunks of %d channels)", d->k_blocks,
-                  ((d->Cin + sa.chunk - 1) / sa.chunk) * sa.kblocks_per_chunk, sa.chunk);
+    sa.layout = d->layout;
+    BFLOW_REQUIRE(d->layout == 0 || d->layout == 1, BFLOW_E_ARG, "conv_stem: layout must be 0 (im2col tiles) or 1 (row windows)");
+    const int ksteps_row = (d->ksize * sa.chunk + 15) / 16;                       // layout 1: 16-deep steps per filter row
+    const int kb_expected = ((d->Cin + sa.chunk - 1) / sa.chunk) * (d->layout == 1 ? (d->ksize * ksteps_row + 1) / 2 : sa.kblocks_per_chunk);
+    BFLOW_REQUIRE(d->k_blocks == kb_expected, BFLOW_E_ARG,
+                  "conv_stem: the packed weights hold %d k-blocks, expected %d (chunks of %d channels, layout %d)", d->k_blocks, kb_expected, sa.chunk, d->layout);
     ConvArgs a = {};
     a.wh = (const _Float16*)d->w_hi; a.wl = (const _Float16*)d->w_lo;
     a.H = d->H; a.W = d->W; a.Ho = Ho; a.Wo = Wo; a.Cout = d->Cout; a.cout_pad = d->cout_pad;
@@ -2032,6 +2210,21 @@ extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream
     dim3 grid((patches + 7) / 8 * 8 * a.n_tiles, 1, d->B);
     const int lds = 2 * (2 * CBM * 64) + 2 * (2 * 2 * 2048) + 8 * 21 * 37 * 4 + sa.kblocks_per_chunk * 32 * 4;
     static const bool no_direct = getenv("BFLOW_CONV_NO_DIRECT") != nullptr;      // A/B timing (tools/)
+    if (d->layout == 1) {
+        const int pitch = (37 * sa.chunk + 1) & ~1, plane_h = 21 * pitch + 64;
+        const int body = ((2 * plane_h * 2 + 15) & ~15) + 2 * (2 * 2 * 2048);
+        const bool tr = !no_direct && a.out_f32 && !a.oh;
+        const int epi = tr ? 2 * 4 * 64 * 4 : (2 * 4 * 64 + 4 * 2 * 32 * CONV_STG_STRIDE) * 4;
+        const int lds1 = body > epi ? body : epi;
+        if (tr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_rows_kernel<7, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+            hipLaunchKernelGGL((conv_stem_rows_kernel<7, 2, true>), grid, dim3(CT), lds1, (hipStream_t)stream, a, sa);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_rows_kernel<7, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+            hipLaunchKernelGGL((conv_stem_rows_kernel<7, 2, false>), grid, dim3(CT), lds1, (hipStream_t)stream, a, sa);
+        }
+        return bflow::launch_status("conv_stem(rows)");
+    }
     if (!no_direct && a.out_f32 && !a.oh) {     // fp32 (+ statistics) output: transposed accumulators, direct stores (see conv_epilogue_direct)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_kernel<7, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((conv_stem_kernel<7, 2, true>), grid, dim3(CT), lds, (hipStream_t)stream, a, sa);

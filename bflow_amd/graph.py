@@ -44,12 +44,14 @@ class _Captured:
                 gc.enable()
 
     def replay(self, voxel_grid, images, flow_init):
-        if voxel_grid is not None:
+        # (a frame that already lives in the static buffer is not copied onto itself)
+        if voxel_grid is not None and voxel_grid.data_ptr() != self.static_voxel.data_ptr():
             self.static_voxel.copy_(voxel_grid)
         if images is not None:
             for dst, src in zip(self.static_images, images):
-                dst.copy_(src)
-        if flow_init is not None:
+                if src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src)
+        if flow_init is not None and flow_init.data_ptr() != self.static_init.data_ptr():
             self.static_init.copy_(flow_init)
         self.graph.replay()
         return self.low, self.ups

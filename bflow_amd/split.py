@@ -7,6 +7,7 @@ statistics / normalisation + activation + residual, and conversion from / to ord
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -161,12 +162,18 @@ def _stats_replicas(stats: Optional[torch.Tensor], B: int, C: int) -> int:
     return stats.shape[0] if stats.dim() == 4 else 1
 
 
-class PackedStemWeight:
-    """The 7x7 stem filter (Cout, Cin, 7, 7) laid out for bflow_conv_stem: a 1x1 filter over K = chunks x (c_local, r, q) columns,
-    every chunk of min(Cin, 8) channels zero padded to a multiple of 32, then packed like any conv weight."""
+STEM_LAYOUT = 0 if os.environ.get("BFLOW_STEM_IM2COL") else 1     # bflow_stem_desc_t.layout: 1 = row windows (round 3), 0 = im2col tiles (A/B)
 
-    def __init__(self):
+
+class PackedStemWeight:
+    """The 7x7 stem filter (Cout, Cin, 7, 7) laid out for bflow_conv_stem as a 1x1 filter over K columns in chunks of min(Cin, 8)
+    channels, packed like any conv weight.  layout 0: K = (chunk, c_local, r, q), every chunk zero padded to a multiple of 32;
+    layout 1 (row windows): K = (chunk, r, q * chunk + c_local), every filter row zero padded to a multiple of 16 and every chunk's seven
+    rows to a multiple of 32."""
+
+    def __init__(self, layout: Optional[int] = None):
         self._key = None
+        self.layout = STEM_LAYOUT if layout is None else layout
 
     def get(self, weight: torch.Tensor):
         cout, cin, kh, kw = weight.shape
@@ -178,13 +185,19 @@ class PackedStemWeight:
             cols = []
             w = weight.detach().float()
             for c0 in range(0, cin, chunk):
+                if self.layout == 1:
+                    blk = torch.nn.functional.pad(w[:, c0:c0 + chunk], (0, 0, 0, 0, 0, chunk - w[:, c0:c0 + chunk].shape[1]))   # missing channels: zero
+                    rows = blk.permute(0, 2, 3, 1).reshape(cout, kh, kw * chunk)               # (r, q * chunk + c_local)
+                    rows = torch.nn.functional.pad(rows, (0, (kw * chunk + 15) // 16 * 16 - kw * chunk)).reshape(cout, -1)
+                    cols.append(torch.nn.functional.pad(rows, (0, (rows.shape[1] + 31) // 32 * 32 - rows.shape[1])))
+                    continue
                 blk = w[:, c0:c0 + chunk].reshape(cout, -1)                      # (c_local, r, q), c_local slowest
                 cols.append(torch.nn.functional.pad(blk, (0, kpc - blk.shape[1])))
             wm = torch.cat(cols, dim=1).contiguous().view(cout, -1, 1, 1)
             self._inner = PackedConvWeight()
             planes, meta = self._inner.get(wm)
             self._key, self.planes, self.meta = key, planes, (cout, cin, planes.shape[1], meta[4])   # (cout, cin, k_blocks, cout_pad)
-        return self.planes, self.meta
+        return self.planes, self.meta, self.layout
 
 
 class ChannelWindows:
@@ -206,7 +219,7 @@ def conv_stem(x, packed, scale: Optional[torch.Tensor] = None, shift: Optional[t
               stats: Optional[torch.Tensor] = None, want_split: bool = True, want_f32: bool = False):
     """7x7 / stride 2 / pad 3 convolution of a few-channel fp32 NCHW tensor or ChannelWindows (BasicEncoder.conv1) -> (split_out or
     None, blocked fp32 or None), epilogue as `conv`.  `packed` = PackedStemWeight.get(weight)."""
-    planes, (cout, cin, k_blocks, cout_pad) = packed
+    planes, (cout, cin, k_blocks, cout_pad) = packed[0], packed[1]
     windows = x if isinstance(x, ChannelWindows) else None
     B, C, H, W = x.shape
     if windows is not None:
@@ -220,6 +233,7 @@ def conv_stem(x, packed, scale: Optional[torch.Tensor] = None, shift: Optional[t
     d.x, d.w_hi, d.w_lo = hip._dev(x, name="x"), planes[0].data_ptr(), planes[1].data_ptr()
     d.B, d.Cin, d.H, d.W, d.Cout, d.cout_pad, d.k_blocks = B, C, H, W, cout, cout_pad, k_blocks
     d.ksize, d.stride, d.pad = 7, 2, 3
+    d.layout = STEM_LAYOUT if len(packed) < 3 else packed[2]
     d.out_f32 = None if out_f32 is None else out_f32.data_ptr()
     d.out_hi = None if out_split is None else out_split.hi.data_ptr()
     d.out_lo = None if out_split is None else out_split.lo.data_ptr()

@@ -167,6 +167,12 @@ typedef struct bflow_stem_desc {
                                          gen_voxel_grids + torch.cat (raft.py:88-99,121) without materialising the stacked batch   */
     int src_channels;
     const int* window_starts;         /* host array, n_windows <= 8 entries */
+    int layout;                       /* order of the packed filter's K axis (chunks of min(Cin, 8) channels):
+                                         0: (chunk, c_local, r, q), each chunk zero padded to a multiple of 32 -- im2col tiles built in LDS;
+                                         1: (chunk, r, window) with window = q * chunk + c_local zero padded to a multiple of 16 per filter row,
+                                            each chunk's 7 rows zero padded to a multiple of 32 -- the row-window kernel (round 3): the input
+                                            patch is split once and laid out [row][column][channel], a filter row's 7 x chunk values of an
+                                            output pixel are contiguous and nothing is gathered                                              */
 } bflow_stem_desc_t;
 int bflow_conv_stem(const bflow_stem_desc_t* desc, bflow_stream_t stream);
 int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
