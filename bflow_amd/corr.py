@@ -34,7 +34,12 @@ PRECISIONS = {"split": (hip.ARITH_SPLIT, False), "f32": (None, False), "f16": (h
               "split/h": (hip.ARITH_SPLIT, True), "split8/h": (hip.ARITH_SPLIT8, True), "f16/w": (hip.ARITH_F16, False)}
 TILED_ONLY = frozenset(("f16", "split8", "split/h", "split8/h", "f16/w"))      # written by bflow_corr_build_tiled only
 PRECISION = os.environ.get("BFLOW_CORR_PRECISION", "split")
-FUSE_POOL1 = os.environ.get("BFLOW_NO_FUSED_POOL") is None     # A/B switch (tools/): level 1 of the pyramid written by the K5 launch
+# Level 1 of the pyramid written by the K5 launch itself (bflow_corr_build_tiled pool_out).  Built, bit-identical to the separate pooling
+# pass (tests) and NEUTRAL in frames/s (271.0 / 273.3 / 274.6 vs 271.0 / 273.4 / 276.0 over three A/B pairs): the fused launch takes 122 us
+# against 92 us + 24.7 us for the pooling pass -- the two DPP exchanges, the selects and 16 more (partial-line) stores per chunk cost the
+# panels of the pooled target ~40 %, and those panels sit on two XCDs, which then set the kernel's time.  Off by default, so that the
+# product's K5 launch is the plain streaming kernel; BFLOW_FUSED_POOL=1 (or corr.FUSE_POOL1 = True) enables it.
+FUSE_POOL1 = os.environ.get("BFLOW_FUSED_POOL") is not None
 
 
 def _x8_planes(p1: torch.Tensor, p2: torch.Tensor):

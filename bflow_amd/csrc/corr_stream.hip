@@ -27,6 +27,7 @@
 // 7150 cycles per 64 reference rows per CU against a matrix-core floor of 6144 (stores cost ~900 of the difference: with them
 // removed the same loop runs at 6250), 18 k cycles of prologue (first panel), 1.65 GHz sustained.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 // STREAM_ABL (tools/k5_ablate.sh only; timing builds with WRONG results): 1 no stores, 2 no in-loop DMA, 3 no barrier / DMA wait,
@@ -37,6 +38,9 @@
 // STREAM_STORE_AUX (tools A/B): cache-policy bits of the volume stores (gfx950 buffer aux: 1 sc0, 2 nt, 16 sc1)
 #ifndef STREAM_STORE_AUX
 #define STREAM_STORE_AUX 2   // nt: the write stream must not evict the reference rows the XCD re-reads (C5, fp8 cross terms: 2242 -> 1653 us)
+#endif
+#ifndef STREAM_POOL_AUX
+#define STREAM_POOL_AUX 0
 #endif
 #ifdef STREAM_STAMPS   // tools/k5_ablate.sh "stamps" build: s_memtime stamps of wave 0 of every workgroup (64 x u64 per workgroup)
 static unsigned long long* g_stamp_buf = nullptr;
@@ -291,12 +295,13 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
 
     __amdgpu_buffer_rsrc_t p1rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, 0x00020000);
     unsigned p1base = OOB;
-    auto put = [&](float v, const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+    auto put = [&](float v, const __amdgpu_buffer_rsrc_t& rs, unsigned off, auto aux) {
+        constexpr int AUX = decltype(aux)::value;
         if (ST16) {
             const _Float16 h = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rs, off, 0, STREAM_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rs, off, 0, AUX);
         } else {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, STREAM_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, AUX);
         }
     };
     auto store_reg = [&](float hh_, float xx_, const __amdgpu_buffer_rsrc_t& rs, unsigned off, unsigned off1) {
@@ -307,17 +312,19 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
             return;
         }
         if (ST16) v = (float)(_Float16)fminf(fmaxf(v, -65504.f), 65504.f);     // the pooled value is the mean of the STORED values
-        put(v, rs, off);
-        if (POOL) {
+        put(v, rs, off, std::integral_constant<int, STREAM_STORE_AUX>{});
+        if (POOL && p1on) {   // wave-uniform: only the chunks of targets with a level 1 carry the second store (see VMCNT_TOP / pooled history)
             float m = 0.f;
-            if (p1on) {   // wave-uniform.  F.avg_pool2d's order (corr.py:119): ((q[2y][2x] + q[2y][2x+1]) + q[2y+1][2x]) + q[2y+1][2x+1], then / 4
+            {   //  F.avg_pool2d's order (corr.py:119): ((q[2y][2x] + q[2y][2x+1]) + q[2y+1][2x]) + q[2y+1][2x+1], then / 4
                 const int vi = __builtin_bit_cast(int, v);
                 const int sw = __builtin_amdgcn_mov_dpp(vi, 0xB1 /* quad_perm [1,0,3,2]: lane ^ 1 */, 0xf, 0xf, false);
                 const float c = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0x128 /* row_ror:8: lane ^ 8 */, 0xf, 0xf, false));
                 const float d = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(sw, 0x128, 0xf, 0xf, false));
                 m = p1val ? (((v + __builtin_bit_cast(float, sw)) + c) + d) * 0.25f : 0.f;
             }
-            put(m, p1rs, off1);
+            // default cache policy: a level-1 line is assembled from 16-B pieces of four waves (two of them in another workgroup); the L2
+            // merges them, a non-temporal partial line goes out as it is
+            put(m, p1rs, off1, std::integral_constant<int, STREAM_POOL_AUX>{});
         }
     };
 
@@ -343,15 +350,22 @@ __global__ __launch_bounds__(512, 2) void corr_stream_kernel(StreamArgs a) {
     // stored.  vmcnt at the top = ops issued after this wave's last piece of chunk it+1 (in chunk it-2): the stores behind it there +
     // the 16 stores and PW pieces of chunk it-1.
     constexpr int DMA_S0 = NS >= 8 ? 2 : 1;
-    constexpr int VMCNT_TOP = (NS - (DMA_S0 + PW)) * ST_PER_STEP * OPS_PER_REG + 16 * OPS_PER_REG + PW;
-    static_assert(DMA_S0 + PW <= NS && VMCNT_TOP < 64, "DMA schedule");
+    // fused pooling: a chunk whose stores belong to a target with a level 1 issues 32 stores instead of 16.  The counted wait uses the larger
+    // number only when BOTH chunks whose operations it skips over carried them (pm1 && pm2); otherwise the smaller one, which then waits for a
+    // few stores more than necessary (never fewer: retirement is in order) -- that happens for two chunks at a change of target only.
+    constexpr int VMCNT_TOP = (NS - (DMA_S0 + PW)) * ST_PER_STEP + 16 + PW;
+    constexpr int VMCNT_TOP2 = (NS - (DMA_S0 + PW)) * ST_PER_STEP * OPS_PER_REG + 16 * OPS_PER_REG + PW;
+    bool pm1 = false, pm2 = false;                 // pooled stores issued in the previous / the one before the previous chunk iteration
+    static_assert(DMA_S0 + PW <= NS && VMCNT_TOP2 < 64, "DMA schedule");
     half8 fh[2], fl[2], ale;
 #define STREAM_STEP(CH_, CX_, PH_, PX_)                                                                                     \
     {                                                                                                                       \
         if (STREAM_ABL != 3) {                                                                                              \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT_TOP) : "memory");                                                \
+            if (POOL && pm1 && pm2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT_TOP2) : "memory");                       \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT_TOP) : "memory");                                           \
             __builtin_amdgcn_s_barrier();                                                                                   \
         }                                                                                                                   \
+        if (POOL) { pm2 = pm1; pm1 = p1on; }   /* this iteration's stores carry the pooled ones iff p1on (latched at the end of the last one) */ \
         const Item q3 = next_item();                                                                                        \
         const char* sb = lds + (it & 3) * SLOT_BYTES;                                                                       \
         const char* sn = lds + ((it + 1) & 3) * SLOT_BYTES;                                                                 \

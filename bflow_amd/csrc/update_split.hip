@@ -44,10 +44,12 @@ __global__ __launch_bounds__(256) void bezier_update_kernel(float* __restrict__ 
             o2[c >> 3][c & 7] = d;
         }
         if (c_off > 0) {          // the parameters share their block with other channels: write the C2 values only
-            for (int c = 0; c < C2; ++c) {
-                bh[ob + c_off + c] = o1[c >> 3][c & 7];
-                bl[ob + c_off + c] = o2[c >> 3][c & 7];
-            }
+#pragma unroll
+            for (int c = 0; c < 32; ++c)         // (compile-time register indices: a runtime-indexed loop sends o1 / o2 to scratch)
+                if (c < C2) {
+                    bh[ob + c_off + c] = o1[c >> 3][c & 7];
+                    bl[ob + c_off + c] = o2[c >> 3][c & 7];
+                }
         } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

@@ -180,11 +180,15 @@ def test_lookup_fused_bezier_matches_unfused(deg):
     assert sp.planes.shape[2] == (C + 31) // 32 and float(sp.planes[:, :, -1, :, C % 32:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("fused_pool", [False, True])
 @pytest.mark.parametrize("B,D,h,w,levels", [(2, 64, 9, 11, [1, 2, 3]), (1, 128, 15, 20, [1, 4]), (1, 256, 60, 80, [1, 1, 1, 4]), (2, 256, 33, 40, [2])])
-def test_tiled_volume_and_pyramid_equal_row_major(B, D, h, w, levels):
+def test_tiled_volume_and_pyramid_equal_row_major(B, D, h, w, levels, fused_pool, monkeypatch):
     """The inference product path stores every plane as 4 x 8 tiles (bflow_corr_build_split_tiled, bflow_corr_pool2x2_tiled).  Untiled, the
     volume and every pyramid level must equal the row-major build BIT FOR BIT (same MFMA chains, same 2x2 means), for plane sizes that are
-    no multiples of the tile (9x11, 15x20 -> 7x10 -> 3x5, 33x40) and at DSEC size."""
+    no multiples of the tile (9x11, 15x20 -> 7x10 -> 3x5, 33x40) and at DSEC size.  fused_pool: level 1 written by the K5 launch itself
+    (bflow_corr_build_tiled pool_out; D in {128, 256}) instead of the separate pooling pass -- the same bits, every pad position included."""
+    from bflow_amd import corr as corr_mod
+    monkeypatch.setattr(corr_mod, "FUSE_POOL1", fused_pool)
     T = len(levels)
     rs = np.random.RandomState(11)
     f1, f2 = cu(rs.standard_normal((B, D, h, w)).astype(np.float32)), cu(rs.standard_normal((T, B, D, h, w)).astype(np.float32))
