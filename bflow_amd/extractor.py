@@ -109,11 +109,12 @@ class BasicEncoder(nn.Module):
             cache[id(norm)] = hit
         return hit[1], hit[2]
 
-    def forward_split(self, x, out_rows: Optional[int] = None, trunk_only: bool = False):
+    def forward_split(self, x, out_rows: Optional[int] = None, trunk_only: bool = False, after_layer=None):
         """The same network on the split-fp16 MFMA engine (csrc/conv_split.hip): channels-last split activations, implicit-GEMM
         convolutions with bias / folded BatchNorm / ReLU / InstanceNorm statistics fused into their epilogues, and one
         normalise+activate+residual kernel between convolutions; the 7x7 stem reads the fp32 NCHW input directly (im2col in LDS).  x: (n, c_in, H, W) fp32 -> SplitTensor (n, H/8, W/8, out_dim); `out_rows` pads the
-        pixel rows of the result with zeros (K5 wants a multiple of 128)."""
+        pixel rows of the result with zeros (K5 wants a multiple of 128).  after_layer = (i, fn): fn() is called once the launches of
+        layer i are enqueued (the caller forks work there that should start behind them, e.g. the context encoder)."""
         kind = self.norm_fn
         assert kind in ("instance", "batch"), kind
         n = x.shape[0]
@@ -201,6 +202,8 @@ class BasicEncoder(nn.Module):
                     d, std = conv_norm(pre + ".downsample.0", blk.downsample[0], blk.norm3, cur, stride, False)
                     cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU if kind == "instance" else S.ACT_NONE, b=d, stats_b=std,
                                         act_out=S.ACT_RELU)
+            if after_layer is not None and after_layer[0] == li:
+                after_layer[1]()
         if trunk_only:      # the caller applies the 1x1 projection itself (e.g. split into tanh / relu halves, raft.py:145-147)
             return cur
         pk = self._packed("conv2", self.conv2)

@@ -37,6 +37,8 @@ class _Captured:
         gc_was_on = gc.isenabled()
         gc.disable()
         try:
+            # (a HIGH-priority capture stream was tried so that the forked context encoder yields to the feature encoder: the replay took
+            # 8.8 ms instead of 3.7 -- priority queues serialise badly on this runtime; default priority everywhere)
             with torch.cuda.graph(self.graph):
                 self.low, self.ups = model._forward_impl(self.static_voxel, self.static_images, iters, self.static_init, test_mode)
         finally:

@@ -57,6 +57,10 @@ class EncodedFrame:
         return out
 
 
+# layer of the event feature encoder behind which the context encoder is forked (0: at the start); BFLOW_CNET_FORK_LAYER for A/B
+CNET_FORK_LAYER = int(os.environ.get("BFLOW_CNET_FORK_LAYER", "0"))     # measured: 0 -> 272.8 / 272.3, 1 -> 271.9 / 271.3, 2 -> 263.2 / 263.6 frames/s
+
+
 class RAFTSpline(nn.Module):
     def __init__(self, model_params: Dict[str, Any]):
         super().__init__()
@@ -239,13 +243,13 @@ class RAFTSpline(nn.Module):
 
         self.check_engine_support()
 
-        def encode_pair(net, x, n_ref, levels):
+        def encode_pair(net, x, n_ref, levels, after_layer=None):
             """Feature encoder on a stacked batch [reference | targets] -> CorrComputation.  The last convolution writes K5's operand
             format directly: (2, nb, D/32, Np, 32), tail rows zero."""
             nb, _, Hh, Ww = x.shape
             h8, w8 = Hh // 8, Ww // 8
             D = net.conv2.out_channels
-            planes = net.forward_split(x, out_rows=hip.padded_rows(h8 * w8)).planes
+            planes = net.forward_split(x, out_rows=hip.padded_rows(h8 * w8), after_layer=after_layer).planes
             return CorrComputation.from_packed(planes[:, :n_ref], planes[:, n_ref:], n_ref, D, h8, w8, levels)
 
         # ---- inputs of the three encoders (raft.py:118-141)
@@ -264,19 +268,29 @@ class RAFTSpline(nn.Module):
         h, w = H // 8, W // 8
         device = context_input.device
 
-        # ---- context encoder on a side stream: a batch-1 chain of small launches that hides under the 5-image feature encoder
+        # ---- context encoder on a side stream: a batch-1 chain of small launches that hides under the 5-image feature encoder.  It is
+        # can be forked BEHIND layer `CNET_FORK_LAYER` of the feature encoder (0 = at the start, the default): starting it later, next to the
+        # smaller stages and K5 only, conserves the total (the work is the same and the chip is busy either way) -- measured, no gain
         ub = self.update_block
-        if tm: tm.start("cnet")
-        with hip.Branch(tm is None) as cnet_branch:
-            if pr: pr("cnet.begin")
-            ws = ub.new_split_workspace(B, h, w, device)
-            ws.overlap = tm is None and hip.BRANCHING
-            ctx_in = context_input
-            if self.fnet_img is None:      # the context bins are the LAST channels of the voxel grid: one window, read in place
-                ctx_in = S.ChannelWindows(voxel_grid, [voxel_grid.shape[1] - self.nbins_context], self.nbins_context)
-            ub.set_context_split(ws, self.cnet.forward_split(ctx_in, trunk_only=True), self.cnet.conv2)
-            if pr: pr("cnet.end")
-        if tm: tm.stop("cnet")
+        state = {}
+
+        def run_cnet():
+            if tm: tm.start("cnet")
+            with hip.Branch(tm is None) as br:
+                if pr: pr("cnet.begin")
+                ws_ = ub.new_split_workspace(B, h, w, device)
+                ws_.overlap = tm is None and hip.BRANCHING
+                ctx_in = context_input
+                if self.fnet_img is None:      # the context bins are the LAST channels of the voxel grid: one window, read in place
+                    ctx_in = S.ChannelWindows(voxel_grid, [voxel_grid.shape[1] - self.nbins_context], self.nbins_context)
+                ub.set_context_split(ws_, self.cnet.forward_split(ctx_in, trunk_only=True), self.cnet.conv2)
+                if pr: pr("cnet.end")
+            if tm: tm.stop("cnet")
+            state["ws"], state["branch"] = ws_, br
+
+        fork_layer = CNET_FORK_LAYER if (self.fnet_ev is not None and tm is None) else 0
+        if fork_layer == 0:
+            run_cnet()
 
         # ---- feature encoders + correlation volumes
         if pr: pr("fnet.begin")
@@ -284,7 +298,7 @@ class RAFTSpline(nn.Module):
             if tm: tm.start("fnet_ev")
             # [reference | targets] = channel windows of the voxel grid, read in place by the stem kernel (no torch.cat)
             stacked = S.ChannelWindows(voxel_grid, [0] + list(self.ev_corr_target_indices), self.nbins_corr)
-            corr_ev = encode_pair(self.fnet_ev, stacked, B, self.ev_corr_levels)
+            corr_ev = encode_pair(self.fnet_ev, stacked, B, self.ev_corr_levels, after_layer=(fork_layer, run_cnet) if fork_layer else None)
             if tm: tm.stop("fnet_ev")
         if self.fnet_img is not None:
             if tm: tm.start("fnet_img")
@@ -302,7 +316,8 @@ class RAFTSpline(nn.Module):
                                                   precision=self.resolved_corr_precision(), volume_out=volume_out)
         if tm: tm.stop("corr computation")
         if pr: pr("corr.end")
-        cnet_branch.join()
+        ws = state["ws"]
+        state["branch"].join()
         if pr: pr("joined")
 
         corr_feat = corr_block.new_output_split()
