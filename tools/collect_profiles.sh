@@ -44,6 +44,7 @@ for mode in split8 split; do
   BFLOW_HIP_LIB="$REPO/bflow_amd/lib/ab/libbflow_hip_stamps.so" python "$REPO/tools/k5_probe.py" --time-only --stamps --stamp-mode $mode 2>/dev/null | sed -n '/stamped launch/,$p' > "$OUT/r03_k5_stamps_$mode.txt"
 done
 SMI=$(command -v amd-smi || command -v rocm-smi || true)
+if [[ "$SMI" == *amd-smi ]]; then $SMI static --limit 2>/dev/null | grep -iE "POWER|GPU:" | head -12 > "$OUT/r03_power_limit.txt"; fi
 for key in roofline_corr_build roofline; do
   ( for i in $(seq 1 12); do
       if [[ "$SMI" == *amd-smi ]]; then $SMI metric --clock --power 2>/dev/null | grep -E "GFX_0|CLK:|SOCKET_POWER|MIN_CLK|MAX_CLK" | head -8 | tr '\n' ' '; echo

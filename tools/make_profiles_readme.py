@@ -36,7 +36,7 @@ while the sources still hash to the same value.
 | `r03_mfma_clock_fp8_cross.txt` | `tools/micro/fp8_cross` | (1) the fp8 K = 64 MFMA with the operand halves K5 uses is exact on realistic operands; (2) pure MFMA streams on random data, every SIMD busy: 3-pass split vs fp16 + fp8 cross terms — time per 32-channel block and the shader clock (`s_memtime` ÷ wall clock): the power-limited clock of the matrix pipes |
 | `r03_store_patterns.txt` | `tools/micro/store_patterns` | a pure store stream of K5's shape: 4 B vs 16 B per lane, K5's item order vs lockstep, `nt`; linear fills; `hipMemset` — the write ceiling (≈ 0.6 of 8 TB/s) and that store width does not move it |
 | `r03_k5_stamps_split8.txt`, `r03_k5_stamps_split.txt` | `BFLOW_HIP_LIB=…/libbflow_hip_stamps.so python tools/k5_probe.py --time-only --stamps --stamp-mode <mode>` (`tools/k5_ablate.sh stamps:-DSTREAM_STAMPS`) | per-workgroup cycle stamps of K5 at C2: prologue, cycles per 64-row pair, end times per XCD, sustained clock = cycles ÷ `s_memrealtime` |
-| `r03_smi_roofline.txt`, `r03_smi_roofline_corr_build.txt` | `amd-smi metric --clock --power` every 0.25 s while `tools/roofline_probe.py --key <key> --reps 20000` repeats the launch | sclk and socket power under the layer-1 convolution / K5 |
+| `r03_smi_roofline.txt`, `r03_smi_roofline_corr_build.txt` | `amd-smi metric --clock --power` every 0.25 s while `tools/roofline_probe.py --key <key> --reps 20000` repeats the launch | sclk and socket power under the layer-1 convolution / K5 (`r03_power_limit.txt`: `amd-smi static --limit`, the board's power cap) |
 | `r03_k5_modes.txt` | `python tools/k5_modes_probe.py --big` | K5 per arithmetic / storage (`split`, `split8`, `f16/w`, `split/h`, `split8/h`, `f16`): error vs an fp64 GEMM and duration at C2 / C4 shard / C5 |
 | `r03_corr_precision_e2e.txt` | `python tools/corr_precision_probe.py --c5` | end-to-end EPE vs the fp32 oracle and frame time per `corr_precision` at C2 (two inputs) and C5: the decomposition of the fp16 variant's error |
 | `r03_stamp_timeline.txt` | `python tools/stamp_timeline.py` | stage boundaries INSIDE the captured graph (no tracer): {tl} |
