@@ -12,7 +12,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-f
 OBJS=(); PIDS=()
 for f in "$HERE"/*.hip; do
   o="$OUT/$(basename "${f%.hip}").o"
-  if [ $FORCE = 1 ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/../../include/bflow_hip.h" -nt "$o" ]; then
+  if [ $FORCE = 1 ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/conv_engine.h" -nt "$o" ] || [ "$HERE/../../include/bflow_hip.h" -nt "$o" ]; then
     rm -f "$o"
     "$HIPCC" $FLAGS -c "$f" -o "$o" &
     PIDS+=($!)

@@ -14,6 +14,7 @@ import gc
 from typing import Dict, Optional, Tuple
 
 import torch
+from . import corr as _corr      # the kernel-selection switches are part of a captured graph's identity
 
 
 class _Captured:
@@ -82,7 +83,7 @@ class GraphCache:
 
     def run(self, voxel_grid, images, iters: int, flow_init, test_mode: bool):
         key = (self._sig(voxel_grid), None if images is None else tuple(self._sig(x) for x in images), int(iters),
-               self._sig(flow_init), bool(test_mode), self.model.resolved_corr_precision())
+               self._sig(flow_init), bool(test_mode), self.model.resolved_corr_precision(), _corr.FUSE_POOL1, _corr.FUSE_LOOKUP_CONV)
         wkey = self._weights_signature()
         if wkey != self._weights_key:
             self.clear()                         # destroyed here, outside any capture

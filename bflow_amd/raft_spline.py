@@ -33,7 +33,7 @@ from .bezier import BezierCurves, polynomial_coefficients
 from .corr import CorrBlockParallelMultiTarget, CorrComputation
 from .extractor import BasicEncoder
 from .timers import StageTimer
-from .update import BasicUpdateBlock
+from .update import BasicUpdateBlock, FusedLookup
 
 
 
@@ -331,12 +331,14 @@ class RAFTSpline(nn.Module):
         corr_block, ws, bezier, corr_feat = fr.corr_block, fr.ws, fr.bezier, fr.corr_feat
         coef = self._coefficients()
         ups: List[torch.Tensor] = []
+        fused = FusedLookup(corr_block, bezier, coef) if corr_block.conv1x1_fusable(ub.encoder.convc1.out_channels) else None
         if tm: tm.start("all iters")
         for itr in range(iters):
             need_mask = (not test_mode) or itr == iters - 1
             if tm is None:
                 # the look-up runs inside the step, next to the (independent) Bezier branch of the motion encoder
-                mask = ub.step_split(ws, lambda: corr_block.lookup_bezier_split(bezier, coef, out=corr_feat), bezier, need_mask)
+                mask = ub.step_split(ws, fused if fused is not None else (lambda: corr_block.lookup_bezier_split(bezier, coef, out=corr_feat)),
+                                     bezier, need_mask)
             else:
                 # stage timing (eager): the same kernels, the look-up timed on its own, no side-stream overlap
                 tm.start("1 iter")

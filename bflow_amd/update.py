@@ -72,6 +72,14 @@ class BasicMotionEncoder(nn.Module):
         return out
 
 
+class FusedLookup:
+    """`corr` argument of `step_split` when the look-up can run fused with convc1 (CorrBlockParallelMultiTarget.conv1x1_fusable):
+    the pyramid, the Bezier parameters the look-up evaluates (read at launch time: they are updated in place) and the time coefficients."""
+
+    def __init__(self, corr_block, bezier: torch.Tensor, coef):
+        self.corr_block, self.bezier, self.coef = corr_block, bezier, coef
+
+
 class SplitWorkspace:
     """Buffers of one forward when the update block runs on the split-fp16 engine (blocked channels-last split tensors)."""
 
@@ -91,6 +99,7 @@ class SplitWorkspace:
         self.M = S.SplitTensor.empty(batch, h, w, md if self.merged else md + 32, device, zero=True)
         self.INP = None                                                          # relu(context) split, set by set_context
         self.corbez = S.SplitTensor.empty(batch, h, w, 256, device)
+        self.C1 = None                                                           # relu(convc1(look-up)) of the fused look-up launch
         self.inp_terms = None
         self.overlap = True                                                      # independent branches on a side stream
 
@@ -189,8 +198,8 @@ class BasicUpdateBlock(nn.Module):
         ws.inp_terms = terms
 
     def step_split(self, ws: SplitWorkspace, corr, bezier: torch.Tensor, need_mask: bool):
-        """One iteration of update.py:116-126 on the split-fp16 engine.  corr: (B, P*81, h, w) fp32 (look-up output), the same as a blocked SplitTensor, or a
-        callable producing either (then the look-up itself overlaps with the Bezier branch), bezier: (B, 2*deg, h, w) fp32 updated IN PLACE.
+        """One iteration of update.py:116-126 on the split-fp16 engine.  corr: (B, P*81, h, w) fp32 (look-up output), the same as a blocked SplitTensor, a
+        callable producing either (then the look-up itself overlaps with the Bezier branch), or a FusedLookup (look-up + convc1 in one launch), bezier: (B, 2*deg, h, w) fp32 updated IN PLACE.
         Returns the mask logits incl. bias (B, 576, h, w) fp32 or None."""
         enc = self.encoder
         # ---- motion encoder (update.py:88-97); every bias + relu lives in a conv epilogue, every cat is a channel offset
@@ -198,10 +207,17 @@ class BasicUpdateBlock(nn.Module):
         # The LONGER one is issued on the side stream: the graph keeps the captured stream's nodes on one hardware queue, and a
         # cross-queue join costs ~10 us unless the other side finished long before (measured both ways).
         with hip.Branch(ws.overlap) as corr_branch:
-            cs = corr() if callable(corr) else corr
-            if not isinstance(cs, S.SplitTensor):
-                cs = S.from_nchw(cs)
-            c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
+            if isinstance(corr, FusedLookup):
+                # look-up + convc1 + ReLU as ONE launch (bflow_corr_lookup_conv1x1): the correlation features stay in the CU
+                if ws.C1 is None:
+                    ws.C1 = S.SplitTensor.empty(ws.H.shape[0], ws.H.H, ws.H.W, enc.convc1.out_channels, ws.H.planes.device)
+                c1 = corr.corr_block.lookup_bezier_conv1x1(corr.bezier, corr.coef, self._pk("convc1", lambda a=enc.convc1.weight: a),
+                                                           enc.convc1.bias, S.ACT_RELU, ws.C1)
+            else:
+                cs = corr() if callable(corr) else corr
+                if not isinstance(cs, S.SplitTensor):
+                    cs = S.from_nchw(cs)
+                c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
             S.conv(c1, self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
                    out_split=ws.corbez, channel_offset=0)
         kh, kw = enc.convf1.kernel_size

@@ -234,6 +234,44 @@ def test_lookup_tiled_split_vs_oracle(deg, B, h, w, levels):
     assert (sp2.float_nhwc() - sp.float_nhwc()).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("deg,B,h,w,levels,cout", [(2, 1, 60, 80, [1, 1, 1, 4], 256), (2, 2, 18, 22, [1, 2, 4], 256), (10, 1, 15, 20, [1, 1, 3], 96),
+                                                   (2, 3, 9, 11, [3], 64), (3, 1, 20, 33, [4], 256), (2, 1, 12, 16, [2, 2, 4], 128), (2, 1, 8, 8, [1], 32), (2, 2, 9, 11, [1, 2, 3], 160), (2, 1, 16, 9, [2], 256)])
+def test_lookup_conv1x1_fused_vs_separate_and_fp64(deg, B, h, w, levels, cout, monkeypatch):
+    """bflow_corr_lookup_conv1x1 (look-up + convc1 + ReLU in one launch; opt-in, BFLOW_LOOKUP_CONV=1) against
+    (a) the same two operations as separate launches (tile look-up -> bflow_conv_split 1x1): same features, the split product in a
+    different summation order, and (b) an fp64 convolution of the separately looked-up features: fp32-class (a few fp32 ulps of the
+    accumulated magnitude).  Plane counts 1 .. 8 (one and two gather passes), tile sizes with partial last workgroups, far-outside
+    coordinates (all-zero windows), output-channel counts that leave waves idle, batch > 1."""
+    from bflow_amd import corr as corr_mod, split as S
+    monkeypatch.setattr(corr_mod, "FUSE_LOOKUP_CONV", True)      # opt-in path (off by default: not faster inside the iteration, see corr.py)
+    T, D = len(levels), 64
+    rs = np.random.RandomState(21)
+    f1, f2 = cu(rs.standard_normal((B, D, h, w)).astype(np.float32)), cu(rs.standard_normal((T, B, D, h, w)).astype(np.float32))
+    params = (rs.standard_normal((B, 2 * deg, h, w)) * 2).astype(np.float32)
+    params[:, :, 0, :3] *= 60.0
+    params[:, :, 1, :] = np.round(params[:, :, 1, :])
+    coef = hip.bezier_coeffs([(i + 1) / T for i in range(T)], deg)
+    blk = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, levels), layout="tiled")
+    C = blk.num_planes * 81
+    assert blk.conv1x1_fusable(cout)
+    weight = cu((rs.standard_normal((cout, C, 1, 1)) / np.sqrt(C)).astype(np.float32))
+    bias = cu(rs.standard_normal(cout).astype(np.float32))
+    packed = S.PackedConvWeight().get(weight)
+    feat = blk.lookup_bezier_split(cu(params), coef, blk.new_output_split())
+    sep, _ = S.conv(feat, packed, shift=bias, act=S.ACT_RELU)
+    out = S.SplitTensor.empty(B, h, w, cout + 32, DEV, zero=True)             # written at channel block 1 of a wider buffer
+    blk.lookup_bezier_conv1x1(cu(params), coef, packed, bias, S.ACT_RELU, out, channel_offset=32)
+    got = out.float_nhwc()[..., 32:32 + cout]
+    assert float(out.float_nhwc()[..., :32].abs().max()) == 0.0             # the neighbouring block is left alone
+    x = feat.float_nhwc().double()                                           # (B, h, w, C): the split features ARE the operands of both paths
+    ref = torch.relu(x @ weight.double().reshape(cout, C).t() + bias.double())
+    mag = (x.abs() @ weight.double().reshape(cout, C).abs().t() + bias.double().abs()).clamp_min(1e-3)
+    err_fused = ((got.double() - ref).abs() / mag).max().item()
+    err_sep = ((sep.float_nhwc().double() - ref).abs() / mag).max().item()
+    assert err_fused < 4e-7 and err_sep < 4e-7, (err_fused, err_sep)        # ~3 fp32 ulps of the accumulated magnitude (output split: 2^-22)
+    assert (got - sep.float_nhwc()).abs().max().item() < 2e-6 * float(ref.abs().max())
+
+
 # ------------------------------------------------------------------------------------------------- fp16 correlation (BASELINE configs[4])
 @pytest.mark.parametrize("B,D,h,w,levels,shared", [(1, 256, 60, 80, [1, 1, 1, 4], True), (2, 128, 15, 20, [2, 3], True), (2, 256, 17, 24, [1, 2], False)])
 def test_corr_f16_volume_pyramid_and_lookup(B, D, h, w, levels, shared):
@@ -596,6 +634,24 @@ def test_e2e_forward_vs_reference_golden(golden_dir, name, graph):
     print(f"{name} graph={graph}: EPE(t=1)={e1:.2e} EPE(t=.5)={e05:.2e} EPE(low)={elow:.2e}")
     assert e1 < EPE_TOL and e05 < EPE_TOL and elow < EPE_TOL
     assert (up.get_params()[:, :, ::4, ::4].cpu() - torch.from_numpy(d["bezier_up_sub"])).abs().max().item() < 2e-2
+
+
+def test_e2e_fused_lookup_conv_equals_separate_launches(golden_dir, monkeypatch):
+    """The opt-in fused look-up + convc1 launch inside the whole forward (captured graph): flow within 1e-5 px of the default path (same
+    features, one convolution in a different summation order) and inside the golden bar."""
+    from bflow_amd import corr as corr_mod
+    d = g(golden_dir, "e2e_E_LU4_BD2")
+    cfg, m, sd = _model(str(d["config"]))
+    vox, imgs = _e2e_inputs(d, cfg)
+    flows = []
+    for fused in (False, True):
+        monkeypatch.setattr(corr_mod, "FUSE_LOOKUP_CONV", fused)
+        low, up = m(voxel_grid=vox, images=imgs, iters=int(d["iters"]), test_mode=True)
+        flows.append(up.get_flow_from_reference(1.0).contiguous())
+    assert float(epe_masked(flows[1], cu(d["flow_t1"]))) < EPE_TOL
+    diff = float((flows[0] - flows[1]).norm(dim=1).max())
+    print(f"fused vs separate look-up + convc1: max flow difference {diff:.2e} px")
+    assert diff < 1e-4
 
 
 def test_e2e_train_mode_list_and_flow_init():
