@@ -58,6 +58,15 @@ done
 python "$REPO/tools/k5_modes_probe.py" --big 2>/dev/null | grep -E "^C|sum" > "$OUT/r03_k5_modes.txt"
 python "$REPO/tools/corr_precision_probe.py" --c5 2>/dev/null | grep corr_precision > "$OUT/r03_corr_precision_e2e.txt"
 
+# the two restructurings of the update iteration that were built and measured this round
+{ python "$REPO/tools/lookup_conv_probe.py" --shapes c2,c4 2>/dev/null | grep -E "^c[0-9]"
+  BFLOW_HIP_LIB="$REPO/bflow_amd/lib/ab/libbflow_hip_lcstamps.so" python "$REPO/tools/lookup_conv_probe.py" --shapes c2 --stamps 2>/dev/null | grep -vE "^c2:"
+  for i in 1 2; do
+    BFLOW_LOOKUP_CONV=1 python "$REPO/bench.py" --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench, fused look-up + convc1  :', d['value'], 'frames/s,', d['ms_per_gru_iter'], 'ms per iteration')"
+    python "$REPO/bench.py" --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench, separate launches (default):', d['value'], 'frames/s,', d['ms_per_gru_iter'], 'ms per iteration')"
+  done; } > "$OUT/r03_lookup_conv_probe.txt" 2>&1
+python "$REPO/tools/gru_conv_probe.py" 2>/dev/null | grep Cin > "$OUT/r03_gru_conv_probe.txt"
+
 # keep only the rows of the three kernels in the committed counter CSVs
 python - "$OUT" <<'PY'
 import csv, sys, os

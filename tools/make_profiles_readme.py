@@ -39,6 +39,8 @@ while the sources still hash to the same value.
 | `r03_smi_roofline.txt`, `r03_smi_roofline_corr_build.txt` | `amd-smi metric --clock --power` every 0.25 s while `tools/roofline_probe.py --key <key> --reps 20000` repeats the launch | sclk and socket power under the layer-1 convolution / K5 (`r03_power_limit.txt`: `amd-smi static --limit`, the board's power cap) |
 | `r03_k5_modes.txt` | `python tools/k5_modes_probe.py --big` | K5 per arithmetic / storage (`split`, `split8`, `f16/w`, `split/h`, `split8/h`, `f16`): error vs an fp64 GEMM and duration at C2 / C4 shard / C5 |
 | `r03_corr_precision_e2e.txt` | `python tools/corr_precision_probe.py --c5` | end-to-end EPE vs the fp32 oracle and frame time per `corr_precision` at C2 (two inputs) and C5: the decomposition of the fp16 variant's error |
+| `r03_lookup_conv_probe.txt` | `python tools/lookup_conv_probe.py --shapes c2,c4`, `... --stamps` on the `tools/lookup_conv_stamps.sh` build, `BFLOW_LOOKUP_CONV=1 python bench.py` vs default | the fused look-up + convc1 launch (opt-in): in-graph duration against the two separate launches, per-wave cycle stamps of its phases, and the A/B inside the captured forward |
+| `r03_gru_conv_probe.txt` | `python tools/gru_conv_probe.py` | a batch-1 GRU gate convolution: plain fp32 output vs fused gate epilogue, full input [h \| M] vs one half — the numbers behind the input-split experiment |
 | `r03_stamp_timeline.txt` | `python tools/stamp_timeline.py` | stage boundaries INSIDE the captured graph (no tracer): {tl} |
 | `r03_train_probe.txt` | `BFLOW_TRAIN_PROBE_GRAPH=1 python tools/train_probe.py 10` | training path, unchanged this round, re-measured for regressions: {train} |
 
