@@ -49,6 +49,19 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Gate non-linearities of the fused GRU epilogues (conv_engine.h) on the transcendental unit: v_exp_f32 / v_rcp_f32 (1 ulp each) instead
+// of libm's expf / tanhf and a true division.  The epilogue of a batch-1 gate convolution spends ~2.7 k of its ~25 k cycles in this
+// arithmetic (8 values per lane on 2 waves per SIMD; tools/gru_conv_probe.py --stamps).  Accuracy: sigmoid <= 4 ulps; tanh: absolute
+// error <= 2e-7 for |x| >= 0.04 (relative <= 4e-6 there, shrinking with |x|), odd polynomial (relative 1e-7) below.
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+__device__ __forceinline__ float gate_tanh(float x) {
+    const float x2 = x * x;
+    const float small = x * fmaf(x2, fmaf(x2, 0.133333333f, -0.333333333f), 1.0f);   // x - x^3/3 + 2 x^5/15
+    const float e = __builtin_amdgcn_exp2f(2.88539008f * x);                          // e^(2x): inf -> 1, 0 -> -1
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return fabsf(x) < 0.04f ? small : big;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -44,6 +44,7 @@ struct ConvArgs {
     const double* xstats;      // (R, B, CB*32, 2)
     int xstats_reps;
     float xeps;
+    unsigned long long* stamps;   // H8_STAMPS builds only (tools/conv_stamps.sh)
 };
 
 // InstanceNorm / affine coefficients of one channel: y = x * mul + add (shared by the normalisation kernel and the NIN halo kernel)
@@ -220,8 +221,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                     // "zr" convolution and a "blend" convolution map 1:1, the r half is shifted down by CBo blocks.
                     const long long gb = gbase + (long long)m * 32;
                     if (a.gate == 1 && !r_half) {
-                        *reinterpret_cast<float4*>(a.out_f32 + gb) = make_float4(bflow::sigmoidf_(v[0]), bflow::sigmoidf_(v[1]),
-                                                                                 bflow::sigmoidf_(v[2]), bflow::sigmoidf_(v[3]));
+                        *reinterpret_cast<float4*>(a.out_f32 + gb) = make_float4(bflow::gate_sigmoid(v[0]), bflow::gate_sigmoid(v[1]),
+                                                                                 bflow::gate_sigmoid(v[2]), bflow::gate_sigmoid(v[3]));
                     } else {
                         const half4v hh4 = g_hh[it], hl4 = g_hl[it];
                         float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -231,7 +232,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float h = (float)hh4[k] + (float)hl4[k] * LO_INV;
-                            const float o = (a.gate == 1) ? bflow::sigmoidf_(v[k]) * h : (1.f - zz[k]) * h + zz[k] * tanhf(v[k]);
+                            const float o = (a.gate == 1) ? bflow::gate_sigmoid(v[k]) * h : (1.f - zz[k]) * h + zz[k] * bflow::gate_tanh(v[k]);
                             _Float16 x1, x2;
                             split1(o, x1, x2);
                             h4[k] = x1;

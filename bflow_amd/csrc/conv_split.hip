@@ -19,6 +19,18 @@
 //            2-KB / 4-KB run).
 #include "conv_engine.h"
 
+#ifdef H8_STAMPS   // tools/conv_stamps.sh build: s_memtime stamps of every wave of conv_halo8_kernel at its phase boundaries (16 x u64 per wave)
+static unsigned long long* g_h8_stamp_buf = nullptr;
+extern "C" __attribute__((visibility("default"))) void bflow_conv_set_stamp_buffer(void* p) { g_h8_stamp_buf = (unsigned long long*)p; }
+#define H8STAMP(i) \
+    if (a.stamps && lane == 0) a.stamps[((blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave_all) * 16 + (i)] = __builtin_readcyclecounter();
+#define H8STAMP_RT(i) \
+    if (a.stamps && lane == 0) a.stamps[((blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave_all) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define H8STAMP(i)
+#define H8STAMP_RT(i)
+#endif
+
 namespace {
 
 
@@ -880,8 +892,10 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
         x2[r] = 0.f;
     }
 
+    H8STAMP_RT(14) H8STAMP(0)
     H8_ISSUE_A(0, 0)
     H8_ISSUE_B(0, 0, 0)
+    H8STAMP(1)
 
     const int R0 = (wave * 2 + slab_row(l31)) * HWD + slab_col(l31);
     const int kq = grp * 2 + kh;                                    // this lane's 16-B k-chunk of the 64-B row
@@ -898,6 +912,8 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                if (cb == 0 && st == 0) { H8STAMP(2) }
+                if (cb == 1 && st == 0) { H8STAMP(3) }
                 {
                     constexpr int stn = (st + 1) % NST;
                     const int cbn = cb + (st + 1) / NST;
@@ -924,8 +940,10 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
     }
 #undef H8_ISSUE_A
 #undef H8_ISSUE_B
+    H8STAMP(4)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    H8STAMP(5)
 
     // ---- the two k-halves are combined on the read side of the shared epilogue (each group stages its partial sums)
     f32x16 xx[1];
@@ -935,6 +953,10 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
     conv_epilogue<1, 8, 2>(a, hh, xx, b, [=](int row) {
         const int y = yw + slab_row(row), x = x0 + slab_col(row);
         return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, grp == 0, reinterpret_cast<float*>(lds), grp);
+#ifdef H8_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    H8STAMP(6) H8STAMP_RT(15)
 #endif
 }
 
@@ -1711,6 +1733,11 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     a.acc = d->acc_nchw;
     a.w_sets = d->weight_sets > 1 ? d->weight_sets : 1;
     a.keep_pad = d->keep_pad_channels;
+#ifdef H8_STAMPS
+    a.stamps = g_h8_stamp_buf;
+#else
+    a.stamps = nullptr;
+#endif
     BFLOW_REQUIRE(!d->keep_pad_channels || (d->Cout % 4 == 0 && !d->gate && !d->out_f32), BFLOW_E_ARG, "conv_split: keep_pad_channels needs Cout %% 4 == 0, split output only");
     a.xraw = d->x_raw; a.xstats = d->x_stats; a.xstats_reps = d->x_stats_replicas > 0 ? d->x_stats_replicas : 1; a.xeps = d->x_eps;
     a.gate = d->gate; a.gh = (const _Float16*)d->gate_h_hi; a.gl = (const _Float16*)d->gate_h_lo; a.gz = d->gate_z;
