@@ -24,6 +24,8 @@ for k, pad, nm in (((1, 5), (0, 2), "1x5"), ((5, 1), (2, 0), "5x1")):
         ozr = torch.empty_like(azr); oq = torch.empty_like(aq)
         t = {}
         t["zr plain f32"] = graph_time(lambda: S.conv(h, wzr, x2=x2, padding=pad, want_split=False, out_f32=ozr))
+        bias = torch.randn(2 * hd, device=dev)
+        t["zr +bias f32"] = graph_time(lambda: S.conv(h, wzr, x2=x2, padding=pad, shift=bias, want_split=False, out_f32=ozr))
         t["zr +addend f32"] = graph_time(lambda: S.conv(h, wzr, x2=x2, padding=pad, addend=azr, want_split=False, out_f32=ozr))
         t["zr gate"] = graph_time(lambda: S.conv(h, wzr, x2=x2, padding=pad, addend=azr, gate=S.GATE_ZR, gate_h=h, out_split=rh, out_f32=z))
         t["q plain f32"] = graph_time(lambda: S.conv(h, wq, x2=x2, padding=pad, want_split=False, out_f32=oq))
