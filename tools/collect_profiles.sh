@@ -65,7 +65,8 @@ python "$REPO/tools/corr_precision_probe.py" --c5 2>/dev/null | grep corr_precis
     BFLOW_LOOKUP_CONV=1 python "$REPO/bench.py" --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench, fused look-up + convc1  :', d['value'], 'frames/s,', d['ms_per_gru_iter'], 'ms per iteration')"
     python "$REPO/bench.py" --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench, separate launches (default):', d['value'], 'frames/s,', d['ms_per_gru_iter'], 'ms per iteration')"
   done; } > "$OUT/r03_lookup_conv_probe.txt" 2>&1
-python "$REPO/tools/gru_conv_probe.py" 2>/dev/null | grep Cin > "$OUT/r03_gru_conv_probe.txt"
+{ python "$REPO/tools/gru_conv_probe.py" 2>/dev/null | grep Cin
+  BFLOW_HIP_LIB="$REPO/bflow_amd/lib/ab/libbflow_hip_h8stamps.so" python "$REPO/tools/gru_conv_probe.py" --stamps 2>/dev/null | grep -vE "Cin=|amdgpu"; } > "$OUT/r03_gru_conv_probe.txt"
 
 # keep only the rows of the three kernels in the committed counter CSVs
 python - "$OUT" <<'PY'
