@@ -24,6 +24,8 @@ import math
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+from collections import OrderedDict
+
 import torch
 import torch.nn.functional as F
 
@@ -491,6 +493,10 @@ class GraphedTrainStep:
         self._sig = None
         self._times = None
         self._graph = None
+        # the most recently used signatures keep their captured graph (a smaller last batch per epoch, alternating shapes or timestamp sets
+        # would otherwise pay two warm-up steps + a capture at every change): signature -> (graph, static inputs, static outputs, times)
+        self._lru: "OrderedDict[Tuple, Tuple]" = OrderedDict()
+        self.max_graphs = 3
 
     @staticmethod
     def _sig_of(v):
@@ -575,13 +581,21 @@ class GraphedTrainStep:
     def __call__(self, batch: Dict[Any, Any]) -> Dict[str, Any]:
         times = self.step.timestamps(batch)                 # MultiFlow: host floats frozen into the graph (Bezier coefficient tables) -> part of the signature
         sig = self._signature(batch, times)
-        first = self._sig != sig
-        if first:
-            if self._graph is not None:
-                torch.cuda.synchronize()
+        if self._sig != sig:
+            if self._graph is not None:                     # park the current graph under its signature
+                self._lru[self._sig] = (self._graph, self._static, self._out, self._times)
+                self._lru.move_to_end(self._sig)
+            hit = self._lru.pop(sig, None)
+            if hit is not None:
+                self._graph, self._static, self._out, self._times = hit
+                self._sig = sig
+            else:
+                while len(self._lru) >= self.max_graphs:    # destroyed here, outside any capture
+                    torch.cuda.synchronize()
+                    self._lru.popitem(last=False)
                 self._graph = None
-            self._sig, self._times = sig, times
-            self._capture(batch)                            # warm-up steps + the capture itself do NOT count as training steps of `batch` ...
+                self._sig, self._times = sig, times
+                self._capture(batch)                        # warm-up steps + the capture itself do NOT count as training steps of `batch` ...
         for k, v in batch.items():
             self._copy_into(self._static[k], v)
         self._graph.replay()                                # ... this replay does

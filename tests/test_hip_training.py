@@ -415,6 +415,52 @@ def test_graphed_train_step_matches_eager_steps():
     del gstep
 
 
+def test_graphed_train_step_keeps_graphs_of_alternating_signatures():
+    """A smaller last batch per epoch / alternating shapes: GraphedTrainStep keeps the captured graph of the most recently used signatures
+    (LRU of 3) instead of re-capturing at every change, and the alternating replays still train like eager steps."""
+    from bflow_amd import configs, synthetic
+    from bflow_amd.weights import deterministic_state_dict
+    cfg = configs.model_config("E_LU4_BD2")
+    H, W = 64, 96
+    tp = dict(learning_rate=2e-4, weight_decay=1e-4, lr_scheduler=dict(use=False))
+
+    def batch(B, seed):
+        rs = np.random.RandomState(seed)
+        return {DataLoading.EV_REPR: cu(synthetic.voxel_grid(B, 9, H, W, seed=seed)),
+                DataLoading.FLOW: cu(rs.standard_normal((B, 2, H, W)).astype(np.float32) * 4),
+                DataLoading.FLOW_VALID: cu(rs.rand(B, H, W) > 0.2), DataLoading.DATASET_TYPE: [DataSetType.DSEC] * B}
+
+    batches = [batch(2, 1), batch(1, 2), batch(2, 3), batch(1, 4), batch(2, 5)]
+
+    def make(capturable):
+        m = bflow_amd.RAFTSpline(cfg)
+        m.load_state_dict(deterministic_state_dict(m, seed=0))
+        m.to(DEV).train()
+        opt, sch = training.configure_optimizers(m, tp, capturable=capturable)
+        return m, opt, training.TrainStep(m, num_iter_train=2)
+
+    m1, opt1, step1 = make(False)
+    eager = []
+    for b in batches:
+        opt1.zero_grad(set_to_none=True)
+        out = step1(b)
+        out["loss"].backward()
+        opt1.step()
+        eager.append(float(out["loss"].detach()))
+    m2, opt2, step2 = make(True)
+    gstep = training.GraphedTrainStep(step2, opt2)
+    captures = []
+    orig = gstep._capture
+    gstep._capture = lambda b: (captures.append(1), orig(b))[1]
+    graphed = [float(gstep(b)["loss"].detach()) for b in batches]
+    print("losses eager", eager, "graphed", graphed, "captures", len(captures))
+    assert len(captures) == 2                                            # one per signature, not one per change
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) < 3e-3 * abs(a), (eager, graphed)
+    torch.cuda.synchronize()
+    del gstep
+
+
 def test_graphed_train_step_multiflow_targets():
     """GraphedTrainStep on a MultiFlow batch (lists of GT tensors and timestamps, multi-target sequence loss, degree-10 curves): the
     timestamps are read on the host OUTSIDE the capture and frozen into the graph (part of its signature); losses equal the eager step's."""
