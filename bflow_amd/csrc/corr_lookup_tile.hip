@@ -45,7 +45,7 @@ struct TilePlane {
 
 struct TileArgs {
     TilePlane planes[BFLOW_MAX_PLANES];
-    float coef[BFLOW_MAX_TARGETS * BFLOW_MAX_DEGREE];
+    float pcoef[BFLOW_MAX_PLANES * BFLOW_MAX_DEGREE];   // time coefficients of each plane's target: row p = coef[planes[p].target]
     int P, T, deg;
 };
 
@@ -94,6 +94,10 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     VT* patch = reinterpret_cast<VT*>(stage + TP * cstride);  // [npair][12][PCOLS] (+ 1 KB: the last DMA instruction's idle lanes land there)
 
     // ---- phase A: thread = (plane, pixel) pair: Bezier evaluation -> sampling centre and patch origin ---------------------------
+    // Every global load of a pair's thread is issued up front: the pair's plane record and time
+    // coefficients sit in kernel-argument memory indexed per lane, i.e. they are global loads like the parameters, and as
+    // "record -> coefficient row -> parameters" they were a chain of three dependent round trips at the head of a latency-bound kernel
+    // (the phase was 3.7 of its 13.2 us at DSEC size).
     if (tid < P) {
         s_base[tid] = reinterpret_cast<const char*>(args.planes[tid].base);
         s_h[tid] = args.planes[tid].h;
@@ -101,30 +105,42 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     }
     if (tid < npair) {
         const int p = tid / TP, i = tid - p * TP;
-        const TilePlane pl = args.planes[p];
         const int n = n0 + i;
-        float cx = 0.f, cy = 0.f;
-        if (n < N) {
-            // coords = coords0 + sum_i coef[t][i] * P_i   (bezier.py:185, raft.py:181); params (B, 2*deg, N)
-            const int deg = args.deg;
-            const float* pp = params + (long long)b * 2 * deg * N + n;
-            const float* cf = args.coef + pl.target * deg;
-            float fx = 0.f, fy = 0.f;
-            for (int k = 0; k < deg; ++k) {
-                fx = fmaf(pp[(long long)k * N], cf[k], fx);
-                fy = fmaf(pp[(long long)(deg + k) * N], cf[k], fy);
-            }
-            const int y = n / w1, x = n - y * w1;
-            cx = ((float)x + fx) * pl.inv_scale;   // corr.py:333 (division by 2^level == exact multiply)
-            cy = ((float)y + fy) * pl.inv_scale;
+        const int deg = args.deg;
+        const float* const pp = params + (long long)b * 2 * deg * N + min(n, N - 1);
+        float px[4], py[4], pcf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = min(j, deg - 1);
+            px[j] = pp[(long long)k * N];
+            py[j] = pp[(long long)(deg + k) * N];
+            pcf[j] = args.pcoef[p * BFLOW_MAX_DEGREE + k];
         }
+        const int pl_h = args.planes[p].h, pl_w = args.planes[p].w;
+        const float pl_inv = args.planes[p].inv_scale;
+        // coords = coords0 + sum_i coef[t][i] * P_i   (bezier.py:185, raft.py:181); params (B, 2*deg, N)
+        float fx = 0.f, fy = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < deg) {
+                fx = fmaf(px[j], pcf[j], fx);
+                fy = fmaf(py[j], pcf[j], fy);
+            }
+        for (int k = 4; k < deg; ++k) {                  // higher degrees: same accumulation order
+            const float cfk = args.pcoef[p * BFLOW_MAX_DEGREE + k];
+            fx = fmaf(pp[(long long)k * N], cfk, fx);
+            fy = fmaf(pp[(long long)(deg + k) * N], cfk, fy);
+        }
+        const int y = n / w1, x = n - y * w1;
+        const float cx = n < N ? ((float)x + fx) * pl_inv : 0.f;   // corr.py:333 (division by 2^level == exact multiply)
+        const float cy = n < N ? ((float)y + fy) * pl_inv : 0.f;
+        // patch origin from the (clamped) centre; far-away centres see an all-zero neighbourhood, as zero padding demands
+        const float ccx = fminf(fmaxf(cx, -64.f), (float)pl_w + 64.f);
+        const float ccy = fminf(fmaxf(cy, -64.f), (float)pl_h + 64.f);
+        const int ox = (int)floorf(ccx) - (R + 1);
         s_cx[tid] = cx;
         s_cy[tid] = cy;
-        // patch origin from the (clamped) centre; far-away centres see an all-zero neighbourhood, as zero padding demands
-        const float ccx = fminf(fmaxf(cx, -64.f), (float)pl.w + 64.f);
-        const float ccy = fminf(fmaxf(cy, -64.f), (float)pl.h + 64.f);
-        const int ox = (int)floorf(ccx) - (R + 1);
-        s_ox[tid] = ox & ~(EPU - 1);              // floor to a unit boundary (two's complement: also for negative origins)
+        s_ox[tid] = ox & ~(EPU - 1);                  // floor to a unit boundary (two's complement: also for negative origins)
         s_oy[tid] = (int)floorf(ccy) - (R + 1);
     }
     __syncthreads();
@@ -273,7 +289,8 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
         a.planes[p].inv_scale = 1.0f / (float)(1 << planes[p].level);
         a.planes[p].target = planes[p].target;
     }
-    for (int i = 0; i < T * deg; ++i) a.coef[i] = coef[i];
+    for (int p = 0; p < P; ++p)
+        for (int i = 0; i < deg; ++i) a.pcoef[p * BFLOW_MAX_DEGREE + i] = coef[planes[p].target * deg + i];
     // tile = 2 query pixels x all planes, 256 threads: 16-33 KB of LDS per workgroup -> 5-8 workgroups per CU (measured best of
     // {2, 4, 8} pixels x {128, 256} threads at every BASELINE shape; BFLOW_LOOKUP_TP / BFLOW_LOOKUP_ABL are timing knobs for tools/)
     static const int tp_env = [] { const char* e = getenv("BFLOW_LOOKUP_TP"); return e ? atoi(e) : 0; }();
