@@ -2,17 +2,22 @@
 // Reference: CorrBlockParallelMultiTarget.__call__ (models/raft_utils/corr.py:307-351), bilinear_sampler (models/raft_utils/utils.py:5-21),
 // BezierCurves.get_flow_from_reference + coords0 (models/raft_spline/raft.py:180-184), cor = relu(convc1(corr)) (models/raft_spline/update.py:88).
 //
-// Why.  At batch 1 an update iteration is a chain of dependent launches of 12-18 us on a 60 x 80 grid; look-up (13-15 us: a latency chain
-// parameters -> gather -> interpolate -> store) and convc1 (15 us for 3 us of matrix work: 152 workgroups staging 128-pixel activation tiles
-// and the weights through LDS) were two of them, with the (B, 352, N) look-up features written to memory and read back in between.  Here a
-// workgroup owns TP <= 28 consecutive query pixels x ALL planes x ALL output channels:
-//   * phases A-C are the tile look-up of corr_lookup_tile.hip (same arithmetic, same order: the features are bit-identical), with the
-//     interpolation writing the split-fp16 features straight into an LDS operand tile [hi | lo][k-block][32 pixels][32 channels];
+// Why.  At batch 1 an update iteration is a chain of dependent launches of 12-18 us on a 60 x 80 grid; look-up (13 us: a latency chain
+// parameters -> gather -> interpolate -> store) and convc1 (14 us for 3 us of matrix work: 152 workgroups staging 128-pixel activation tiles
+// and the weights through LDS) are two of them, with the (B, 576, N) look-up features written to memory and read back in between.  Here a
+// workgroup owns TP <= 28 consecutive query pixels x ALL planes (<= 8) x ALL output channels (<= 256):
+//   * phase A, gather, tap tables and interpolation are the tile look-up of corr_lookup_tile.hip (same arithmetic, same order: the features
+//     are bit-identical); the planes are gathered in two passes of four (58 KB of patches at 19 pixels), and the interpolation writes the
+//     split-fp16 features straight into an LDS operand tile [hi | lo][k-block][TP pixels][32 channels];
 //   * the 1x1 convolution is D[channel][pixel] = W x features on the matrix cores: wave w owns output channels 32 w .. 32 w + 31, and its
-//     WEIGHT fragments (private to the wave: 4 x 16 B per lane and 32-channel k-block, 176 VGPRs for the 11 k-blocks of 4 planes) are
-//     requested straight into registers BEHIND the gather, so they land while the look-up phases run -- the matrix phase reads only LDS;
-//   * the epilogue is the conv engine's (bias, ReLU, hi / lo split, memory-order stores through a per-wave LDS slab).
-// One workgroup per CU (512 threads, 2 waves per SIMD, up to 256 VGPRs each), TP chosen so that the grid is a whole number of rounds.
+//     WEIGHT fragments (private to the wave: 4 x 16 B per lane and 32-channel k-block) are requested straight into REGISTERS: the k-blocks
+//     the first pass completes at the start of the kernel, those of the second pass while the MFMAs of the first run (refilling its
+//     registers), under the second gather -- the matrix phases read only LDS;
+//   * the epilogue is the conv engine's arithmetic (bias, activation, hi / lo split, memory-order stores through a per-wave LDS slab).
+// One workgroup per CU (512 threads, 2 waves per SIMD, <= 256 VGPRs each), TP chosen so that the grid is a whole number of rounds.
+// Status: parity-green; 26.0 us against 13.3 + 14.2 us for the two launches alone at DSEC size, but 2-5 us per
+// iteration SLOWER inside the captured forward (it shares the chip with nothing; the two launches run next to the Bezier branch), so the
+// model uses it only on request (BFLOW_LOOKUP_CONV=1).  Several notes below are about hipcc's wait-count bookkeeping around LDS-DMA.
 #include "conv_engine.h"
 
 namespace {
