@@ -9,14 +9,15 @@
 
 Metric (BASELINE.json): frames/s of the whole job + ms per GRU iteration, raft-spline E_LU4_BD2 (events only), DSEC 640x480,
 12 iterations.
-  N = 1 : `value` = BASELINE configs[1] -- batch 1, one frame per step (weak-scaling anchor; also reported as `c2_weak`).
-  N > 1 : `value` = BASELINE configs[3] -- GLOBAL batch 64 sharded over the N ranks (64/N frames per rank and step, processed in
-          micro-batches of 8 = C4's per-GPU batch at N = 8): strong scaling, no data-path collective; `c2_weak` (batch 1 per GPU,
-          the N = 1 workload on every rank) is measured in the same run and reported next to it.  At N = 1 the same global-64
-          workload is reported as `c4_strong`, so that both curves have their N = 1 point.
+  `value` is ONE workload at every N: BASELINE configs[1] -- batch 1 per GPU, one frame per rank and step (weak scaling; the same
+          number is repeated as `c2_weak`).  A 1/2/4/8 series of `value` therefore never changes workload between two points.
+  `c4_strong` (every N, next to `value`): BASELINE configs[3] -- GLOBAL batch 64 sharded over the N ranks (64/N frames per rank and
+          step, processed in micro-batches of at most 8 = C4's per-GPU batch at N = 8): strong scaling, no data-path collective.
           A rank's micro-batches are independent: they run two at a time as parallel branches of one captured graph
           (bflow_amd/pipeline.py; same frames, bit-identical outputs).  `c2_two_in_flight` (N = 1 extras) is the same mechanism on two
           batch-1 frames: a frame-stream throughput, reported next to `value`, never as `value`.
+  BFLOW_DIST_BACKEND (default nccl = RCCL) / BFLOW_DEVICE (default LOCAL_RANK) exist so that the N > 1 code path can be exercised on a
+          one-GPU box (two gloo ranks on device 0: tests/test_multi_gpu.py); a driver never sets them.
 After the timed regions the per-rank EPE state is all-gathered once over RCCL (the path's single exchange step).
 
 One "step" = one forward (voxel grids resident in HBM -> full-resolution Bezier flow) over the rank's frames of that step,
@@ -39,10 +40,11 @@ H, W, ITERS, CFG = 480, 640, 12, "E_LU4_BD2"
 GLOBAL_BATCH, MICRO_BATCH = 64, 8          # BASELINE configs[3]
 PEAK_SPLIT_TFLOPS = round(2500.0 / 3, 1)   # fp16 dense MFMA peak (~2.5 PFLOP/s) / 3 MFMA passes per fp32-class product
 PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+PMC_FILE = "r04_pmc.json"                  # rocprofv3 --pmc evidence of this round (tools/collect_profiles.sh)
 
 
 def kernel_source_hash() -> str:
-    """Hash of everything that determines the kernels' HBM traffic: the HIP sources and the ABI header.  profiles/r03_pmc.json
+    """Hash of everything that determines the kernels' HBM traffic: the HIP sources and the ABI header.  profiles/<PMC_FILE>
     records it; bench.py only quotes the PMC traffic of kernels built from the SAME sources."""
     h = hashlib.sha256()
     cs = os.path.join(ROOT, "bflow_amd", "csrc")
@@ -93,7 +95,10 @@ def main():
     from bflow_amd.metrics import epe_masked
     from bflow_amd.weights import deterministic_state_dict
 
-    rank, world, local = bdist.init_from_env("nccl")
+    backend = os.environ.get("BFLOW_DIST_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm; "gloo" only for the one-GPU test of the N > 1 path
+    rank, world, local = bdist.init_from_env(backend)
+    if "BFLOW_DEVICE" in os.environ:                                # every rank on one device (the same test)
+        local = int(os.environ["BFLOW_DEVICE"])
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with `python bench.py --gpus {args.gpus}` (self-launching) "
                          f"or `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}`")
@@ -113,7 +118,7 @@ def main():
             fn()
         torch.cuda.synchronize()
         barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t.item())
@@ -196,17 +201,13 @@ def main():
         el = time_steps(step, steps)
         return {"value": round(world * frames_per_step_per_rank * steps / el, 3), "ms_per_step": round(el / steps * 1e3, 4), "steps": steps}
 
-    primary_is_c4 = world > 1
-    res_c2 = res_c4 = None
-    if not primary_is_c4:
-        res_c2 = measure(step_c2, 1, args.steps, args.warmup)
-        if not args.no_extras:
-            setup_c4()
-            res_c4 = measure(step_c4, s1 - s0, max(2, min(args.steps, 6)), 1)
-    else:
+    # `value` = C2 weak at EVERY N (one workload for the whole 1/2/4/8 series); C4 strong is measured next to it
+    res_c2 = measure(step_c2, 1, args.steps, args.warmup)
+    res_c4 = None
+    if world > 1 or not args.no_extras:
         setup_c4()
-        res_c4 = measure(step_c4, s1 - s0, args.steps, args.warmup)
-        res_c2 = measure(step_c2, 1, args.steps, args.warmup)
+        res_c4 = measure(step_c4, s1 - s0, args.steps if world > 1 else max(2, min(args.steps, 6)), max(1, args.warmup if world > 1 else 1))
+        vox8 = None
 
     # ---- the path's single exchange step: per-rank EPE state all-gathered over RCCL (outside the timed regions)
     low, up = step_c2()
@@ -216,7 +217,6 @@ def main():
 
     out = None
     if rank == 0:
-        prim = res_c4 if primary_is_c4 else res_c2
         wl_c2 = (f"raft-spline {CFG} events-only, DSEC-shaped voxel grid (9x{H}x{W}), batch 1/GPU, {ITERS} GRU iters (BASELINE configs[1]), "
                  "random-init deterministic weights")
         wl_c4 = (f"raft-spline {CFG} events-only, DSEC-shaped voxel grids (9x{H}x{W}), GLOBAL batch {GLOBAL_BATCH} sharded over {world} GPU(s) "
@@ -224,20 +224,21 @@ def main():
                  f"), {ITERS} GRU iters (BASELINE configs[3]), random-init deterministic weights")
         out = {
             "metric": "frames/sec (whole node), raft-spline DSEC 640x480 12-iter",
-            "value": prim["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": "strong" if primary_is_c4 else "weak",
+            "value": res_c2["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res_c2["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (split-fp16 pairs)",
-            "arithmetic": "fp32 values carried as split fp16 pairs (hi + lo*2^-11) on the fp16 matrix cores, fp32 accumulation; correlation cross terms (hi*lo + lo*hi) on the fp8 matrix rate; parity 2e-5 px EPE vs the fp32 CPU reference",
+            "arithmetic": "fp32 values carried as split fp16 pairs (hi + lo*2^-11) on the fp16 matrix cores, fp32 accumulation; correlation cross terms (hi*lo + lo*hi) on the fp8 matrix rate; parity 2e-5 px EPE vs the fp32 CPU reference; `value_split` = the same frame with the correlation on three fp16 passes (fp32 class everywhere)",
             "data": "synthetic",
-            "config": {"workload": wl_c4 if primary_is_c4 else wl_c2, "global_batch": GLOBAL_BATCH if primary_is_c4 else world,
-                       "frames_per_rank_per_step": (s1 - s0) if primary_is_c4 else 1, "iters": ITERS, "hipgraph": not args.no_graph,
+            "config": {"workload": wl_c2, "global_batch": world, "frames_per_rank_per_step": 1, "iters": ITERS, "hipgraph": not args.no_graph,
+                       "same_workload_at_every_n_gpus": True,
                        "input_handover": "every step copies its resident frame (device to device, 11 MB) into the captured graph's static input buffer, inside "
                                          "the timed region (measured: no difference to a zero-copy hand-over, 277-279 frames/s either way)"},
             "c2_weak": dict(res_c2, unit="frames/s", workload=wl_c2, scaling="weak"),
             "epe_vs_synthetic_gt": round(float(epe_mean), 4), "epe_ranks_gathered": int(epe_cnt),
         }
         if res_c4 is not None:
-            out["c4_strong"] = dict(res_c4, unit="frames/s", workload=wl_c4, scaling="strong")
+            out["c4_strong"] = dict(res_c4, unit="frames/s", workload=wl_c4, scaling="strong", frames_per_rank_per_step=s1 - s0, micro_batch=micro,
+                                    micro_batches_per_rank=n_micro)
 
     # ---- extras outside the timed region: ms/GRU-iter (N=1), rooflines of the hand-written kernels (rank 0), CPU baseline (N=1)
     if world == 1 and not args.no_extras:
@@ -265,22 +266,44 @@ def main():
                                        "note": "two independent batch-1 forwards as parallel branches of one hipGraph; outputs bit-identical to the sequential forward"}
         out["ms_per_gru_iter"] = round((t12 - t6) / (ITERS // 2) * 1e3, 4)
         out["ms_fixed_part"] = round((t12 - ITERS * (t12 - t6) / (ITERS // 2)) * 1e3, 4)
+        # the fp32-class number next to `value`: the same frame with the correlation volume on THREE fp16 MFMA passes ("split": 2^-22 per
+        # product, the arithmetic of every convolution of the network) instead of hi*hi + fp8 cross terms ("split8", 2^-16 per product)
+        if not args.no_graph:
+            model.corr_precision = "split"
+            r_split = measure(step_c2, 1, max(args.steps // 2, 5), 2)
+            model.corr_precision = None
+            out["value_split"] = dict(r_split, unit="frames/s", corr_precision="split",
+                                      note="whole frame, correlation on three fp16 MFMA passes: fp32-class arithmetic everywhere (1.3e-5 px vs the fp32 oracle)")
+            step_c2()        # back on the default graph
+        # frame-level matrix roofline: algorithmic FLOPs as executed (context share of the gate convolutions hoisted, mask head once) over
+        # the frame / the marginal iteration, against the split format's peak (fp16 dense / 3)
+        from tools.roofline_kernels import frame_flops
+        ff, fi, parts = frame_flops(model, 1, H, W, ITERS)
+        out["roofline_frame"] = {"bound": "mfma", "flop_per_frame": ff, "achieved": round(ff / (res_c2["ms_per_step"] * 1e-3) / 1e12, 1), "peak": PEAK_SPLIT_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": round(ff / (res_c2["ms_per_step"] * 1e-3) / 1e12 / PEAK_SPLIT_TFLOPS, 4),
+                                 "parts_gflop": {k: round(v / 1e9, 2) for k, v in parts.items()},
+                                 "note": "whole frame incl. its HBM-bound and latency-bound stages; FLOPs after hoisting the context share of the gate "
+                                         "convolutions and running the mask head once"}
+        out["roofline_update_iter"] = {"bound": "mfma", "flop_per_iteration": fi, "achieved": round(fi / (out["ms_per_gru_iter"] * 1e-3) / 1e12, 1),
+                                       "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": round(fi / (out["ms_per_gru_iter"] * 1e-3) / 1e12 / PEAK_SPLIT_TFLOPS, 4),
+                                       "note": "one pass of raft.py:166-195 at batch 1: ten dependent launches on <= 240 workgroups each"}
 
     if rank == 0 and not args.no_extras:
         # rooflines of the hand-written kernels (tools/roofline_kernels.py), each timed with hipEvents on the launch stream on the operands
         # of the C2 workload (the timed region above is graph replays, inside which events cannot be recorded)
-        from tools.roofline_kernels import build as roofline_kernels
+        from tools.roofline_kernels import build as roofline_kernels, build_big
         vox8 = None
         torch.cuda.empty_cache()
         src_hash = kernel_source_hash()
         try:
-            pmc_doc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+            pmc_doc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
         except Exception:
             pmc_doc = {}
         pmc_ok = pmc_doc.get("kernel_source_hash") == src_hash
         pmc = pmc_doc.get("kernels", {}) if pmc_ok else {}
         out["kernel_source_hash"] = src_hash
-        for k in roofline_kernels(model, vox1, cfg, low.get_params()):
+
+        def price(k):
             for _ in range(3):
                 k["launch"]()
             ms = kernel_event_ms(k["launch"], max(args.steps, 10))
@@ -302,17 +325,53 @@ def main():
                     if k.get("mfma_peak"):     # the kernel's second roof: matrix cores (fp32-equivalent peak of its arithmetic)
                         r["mfma_peak_tflops_equivalent"] = round(k["mfma_peak"], 1)
                         r["frac_mfma"] = round(k["flops"] / (ms * 1e-3) / 1e12 / k["mfma_peak"], 4)
+                if k.get("line_bytes"):        # the look-up: what a materialised fp32 volume allows at 128-B line granularity
+                    r["line_bytes"] = round(k["line_bytes"])
+                    r["frac_of_line_granular_cap"] = round(k["line_bytes"] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                    r["line_note"] = ("line_bytes = the 128-B lines (4 x 8-element tiles) a 10 x 10 tap window touches on tiled fp32 planes + the 81 values written: the "
+                                      "floor of ANY gather on a materialised volume; frac_of_line_granular_cap = line_bytes / time / 8 TB/s")
             if k.get("note"):
-                r["note"] = k["note"]
+                r["note"] = (r.get("note", "") + "; " if r.get("note") else "") + k["note"]
             # HBM traffic per launch cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the SAME launches
-            # (tools/collect_profiles.sh -> profiles/r03_pmc.json), and only when that file was collected on kernels built from these sources
+            # (tools/collect_profiles.sh -> profiles/<PMC_FILE>), and only when that file was collected on kernels built from these sources
             if k["name"] in pmc:
                 r["traffic"] = pmc[k["name"]]["traffic"]
-                r["traffic_source"] = "profiles/r03_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; same kernel sources)"
+                r["traffic_source"] = f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; same kernel sources)"
             elif pmc_doc and not pmc_ok:
-                r["traffic_source"] = "none: profiles/r03_pmc.json was collected on different kernel sources (re-run tools/collect_profiles.sh)"
+                r["traffic_source"] = f"none: profiles/{PMC_FILE} was collected on different kernel sources (re-run tools/collect_profiles.sh)"
             out[k["key"]] = r
             k.clear()
+
+        for k in roofline_kernels(model, vox1, cfg, low.get_params()):
+            price(k)
+        torch.cuda.empty_cache()
+        for k in build_big(model, cfg, dev):
+            price(k)
+        torch.cuda.empty_cache()
+        # K5 is bound by its STORE stream: the ceiling of a pure store stream, measured in this process on this box -- hipMemsetAsync of the
+        # C2 volume (368.6 MB; torch's zero_() is that call) -- and, when the tools binary is there, K5's own store shape
+        # (tools/micro/store_patterns: 256 persistent 8-wave workgroups, 32 rows x 1 KB per item, 4 B per lane, nt)
+        volz = torch.empty((4, 4800, 4800), device=dev)
+        ms_set = kernel_event_ms(lambda: volz.zero_(), 10)
+        ceil = {"hipMemsetAsync_gbs": round(volz.numel() * 4 / (ms_set * 1e-3) / 1e9, 1)}
+        del volz
+        sp = os.path.join(ROOT, "tools", "micro", "store_patterns")
+        if os.path.isfile(sp) and os.access(sp, os.X_OK):
+            try:
+                txt = subprocess.run([sp], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120).stdout
+                for line in txt.splitlines():
+                    if line.startswith("k5 order,   4 B/lane, nt"):
+                        ceil["k5_shape_4B_nt_gbs"] = float(line.split("us")[1].split("GB/s")[0])
+                    if line.startswith("lock order, 4 B/lane, nt"):
+                        ceil["lockstep_4B_nt_gbs"] = float(line.split("us")[1].split("GB/s")[0])
+            except Exception as e:       # a tools binary: its absence or failure must not take the bench line down
+                ceil["store_patterns_error"] = repr(e)[:200]
+        for key in ("roofline_corr_build", "roofline_corr_build_split"):
+            if key in out:
+                best = max(v for k_, v in ceil.items() if k_.endswith("_gbs"))
+                out[key]["store_ceiling_gbs"] = best
+                out[key]["store_ceilings"] = ceil
+                out[key]["frac_of_store_ceiling"] = round(out[key]["achieved"] / best, 4)
         if world == 1:
             out["gpu_stage_ms"] = gpu_stage_ms(cfg, sd, vox1, dev)
             out["voxel_kernels"] = voxel_kernels(dev)

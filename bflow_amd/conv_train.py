@@ -185,13 +185,12 @@ def _weight_grad(x: torch.Tensor, dy: torch.Tensor, s: torch.Tensor, inv: torch.
 
 
 def _refuse_library(x: torch.Tensor, what: str):
-    """A GPU call that does not take the engine path would silently run on the vendor library (MIOpen): refuse it.  The module forward of
-    this package is the DIFFERENTIABLE path only (grad enabled, something requires grad, a filter the engine supports); inference runs
-    `forward_split` / `RAFTSpline.forward` in eval mode.  `ENABLED = False` is the explicit A/B switch of tools / tests and keeps torch's path."""
+    """A GPU call that does not take the engine path would silently run on the vendor library (MIOpen): refuse it.  Every filter shape of
+    the network is on the engine (with or without grad; a frozen encoder too), so only a foreign filter (grouped / dilated / ...) ends here.
+    `ENABLED = False` is the explicit A/B switch of tools / tests and keeps torch's path."""
     if ENABLED and x.is_cuda:
-        raise hip.BflowHipError(f"{what} on a GPU tensor outside the conv engine's differentiable path (grad disabled, nothing requires grad, or a "
-                                "grouped / dilated / non-zero-padded filter): there is no library fall-back -- run inference through "
-                                "RAFTSpline.forward in eval() mode (forward_split), or enable grad for training")
+        raise hip.BflowHipError(f"{what} on a GPU tensor with a filter the conv engine does not implement (grouped, dilated, non-zero padding mode, "
+                                "stride other than 1 / 2): there is no library fall-back")
 
 
 class Conv2d(nn.Conv2d):
@@ -199,7 +198,9 @@ class Conv2d(nn.Conv2d):
     A GPU forward that cannot take that path raises (no MIOpen fall-through); CPU tensors behave like nn.Conv2d."""
 
     def forward(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
-        if (ENABLED and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad) and self.groups == 1
+        # every GPU call with a filter the engine supports runs on it -- also with grad disabled or a frozen encoder (nothing requires grad:
+        # autograd then records nothing and _ConvFn.forward is just the engine's forward)
+        if (ENABLED and x.is_cuda and self.groups == 1
                 and self.dilation == (1, 1) and self.stride[0] == self.stride[1] and self.stride[0] in (1, 2) and self.padding_mode == "zeros"
                 and not isinstance(self.padding, str)):
             cache = self.__dict__.setdefault("_hip_pack", _PackCache())
@@ -216,7 +217,7 @@ class Conv2d(nn.Conv2d):
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias, padding, cache: _PackCache, srcs, stride: int = 1) -> torch.Tensor:
     """Functional form for derived filters (the merged z|r convolution of the training forward); `srcs` = the parameters `weight` was
     built from (the cache key)."""
-    if ENABLED and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+    if ENABLED and x.is_cuda:
         return _ConvFn.apply(x, weight, bias, stride, tuple(padding), cache, tuple(srcs))
     _refuse_library(x, "conv2d")
     return torch.nn.functional.conv2d(x, weight, bias, stride=stride, padding=padding)

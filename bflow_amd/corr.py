@@ -20,11 +20,11 @@ import torch
 from . import hip
 
 # Correlation arithmetic (all hand-written HIP; override the default with BFLOW_CORR_PRECISION or per block / per model):
-#   "split" : split-fp16 MFMA engine, fp32 volume -- fp32-class accuracy (~2^-22 per product); the default
+#   "split" : split-fp16 MFMA engine, fp32 volume -- fp32-class accuracy (~2^-22 per product); the default on row-major planes
 #   "f32"   : exact fp32 MFMA, fp32 volume (row-major planes only)
 #   "f16"   : plain fp16 operands, fp16 tiled volume (BASELINE configs[4]: "fp16 MFMA correlation"): half the volume bytes, a third of the
 #             matrix-core work, fp16 accuracy (2^-11 per operand and stored value) -- measured EPE vs the fp32 oracle: tests/, DESIGN.md
-#   "split8": hi*hi on the fp16 rate + BOTH cross terms (hi*lo + lo*hi) of a 32-channel block in one fp8 (e4m3) K = 64 MFMA, fp32 tiled volume:
+#   "split8": (the default on tiled planes with feature dim 128 / 256 -- `default_precision`) hi*hi on the fp16 rate + BOTH cross terms (hi*lo + lo*hi) of a 32-channel block in one fp8 (e4m3) K = 64 MFMA, fp32 tiled volume:
 #             two matrix-pipe units per product instead of three and a higher sustained clock (the matrix cores are power-limited on real
 #             data); the cross terms carry 2^-11 of a product, so their 2^-4 operand rounding leaves ~2^-16 per product
 #   "split/h", "split8/h", "f16/w": the same arithmetics with the other storage type (fp16 / fp16 / fp32 volume) -- the decomposition of the
@@ -33,7 +33,24 @@ from . import hip
 PRECISIONS = {"split": (hip.ARITH_SPLIT, False), "f32": (None, False), "f16": (hip.ARITH_F16, True), "split8": (hip.ARITH_SPLIT8, False),
               "split/h": (hip.ARITH_SPLIT, True), "split8/h": (hip.ARITH_SPLIT8, True), "f16/w": (hip.ARITH_F16, False)}
 TILED_ONLY = frozenset(("f16", "split8", "split/h", "split8/h", "f16/w"))      # written by bflow_corr_build_tiled only
-PRECISION = os.environ.get("BFLOW_CORR_PRECISION", "split")
+
+
+def default_precision(dim: int, tiled: bool = True) -> str:
+    """THE resolver of the correlation arithmetic when none is named (model, CorrBlockParallelMultiTarget and CorrComputation all ask here):
+    BFLOW_CORR_PRECISION when set (read at call time, validated against PRECISIONS up front), else "split8" where it exists -- tiled planes,
+    feature dim 128 / 256 -- and "split" otherwise (row-major planes: the reference-shaped API and the training path)."""
+    env = os.environ.get("BFLOW_CORR_PRECISION")
+    if env is not None:
+        check_precision(env)
+        return env
+    return "split8" if tiled and dim in (128, 256) else "split"
+
+
+def check_precision(name: str) -> str:
+    if name not in PRECISIONS:
+        raise ValueError(f"correlation precision {name!r}: expected one of {sorted(PRECISIONS)}")
+    return name
+
 # Level 1 of the pyramid written by the K5 launch itself (bflow_corr_build_tiled pool_out).  Built, bit-identical to the separate pooling
 # pass (tests) and NEUTRAL in frames/s (271.0 / 273.3 / 274.6 vs 271.0 / 273.4 / 276.0 over three A/B pairs): the fused launch takes 122 us
 # against 92 us + 24.7 us for the pooling pass -- the two DPP exchanges, the selects and 16 more (partial-line) stores per chunk cost the
@@ -156,13 +173,13 @@ class CorrComputation:
     def tiled_supported(self, precision: Optional[str] = None) -> bool:
         """The tiled-plane volume is written by the streaming K5 kernel only: split operands with D in {64, 128, 256}, fp16 with D in
         {128, 256}."""
-        precision = PRECISION if precision is None else precision
+        precision = default_precision(self.dim, True) if precision is None else check_precision(precision)
         return (precision == "split" and self.dim in (64, 128, 256)) or (precision in TILED_ONLY and self.dim in (128, 256))
 
     def pool1_fusable(self, precision: Optional[str] = None) -> bool:
         """True when the K5 launch of this precision can write the level-1 planes itself (get_correlation_volume(pool1=...))."""
-        precision = PRECISION if precision is None else precision
-        if precision not in PRECISIONS or PRECISIONS[precision][0] is None or not self.tiled_supported(precision):
+        precision = default_precision(self.dim, True) if precision is None else check_precision(precision)
+        if PRECISIONS[precision][0] is None or not self.tiled_supported(precision):
             return False
         ar, st16 = PRECISIONS[precision]
         return hip.pool_fusable(ar, st16, self.dim, max(f2.shape[0] for f2 in self._fmap2))
@@ -178,9 +195,7 @@ class CorrComputation:
         N = h * w
         T = self.num_targets_overall
         device = self._packed[0][0].device if self._packed[0] is not None else self._fmap1[0].device
-        precision = PRECISION if precision is None else precision
-        if precision not in PRECISIONS:
-            raise ValueError(f"correlation precision {precision!r}: expected one of {sorted(PRECISIONS)}")
+        precision = default_precision(D, tiled) if precision is None else check_precision(precision)
         if (tiled or precision in TILED_ONLY) and not (tiled and self.tiled_supported(precision)):
             raise hip.BflowHipError(f"correlation volume (tiled={tiled}, precision={precision!r}, D={D}): the tiled layout needs 'split' with D in "
                                     f"(64, 128, 256) or one of {sorted(TILED_ONLY)} with D in (128, 256), which exist in the tiled layout only")
@@ -236,7 +251,7 @@ class CorrBlockParallelMultiTarget:
                  volume_out: Optional[torch.Tensor] = None):
         """layout = "rows": the reference's (T, B*N, h_L, w_L) planes (any K5 variant; every look-up entry point).
         layout = "tiled": planes stored as 4 x 8 tiles -- the inference product path (lookup_bezier_split); the reference-shaped
-        accessors untile on demand.  precision: None = module default (PRECISION); "f16" needs layout = "tiled"."""
+        accessors untile on demand.  precision: None = `default_precision(dim, tiled)`; "f16" needs layout = "tiled"."""
         assert corr_computation_events is not None or corr_computation_frames is not None
         assert radius == hip.LOOKUP_RADIUS, "the look-up radius is 4 everywhere in the reference (raft.py:40, corr.py:279)"
         assert layout in ("rows", "tiled")
@@ -247,6 +262,8 @@ class CorrBlockParallelMultiTarget:
         else:
             cc = corr_computation_events + corr_computation_frames
         levels = cc.levels_flat()
+        precision = default_precision(cc.dim, layout == "tiled") if precision is None else check_precision(precision)   # resolved ONCE, up front
+        self.precision = precision
         self._num_targets_base = len(levels)
         self._radius = radius
         self._batch = cc.batch
@@ -261,8 +278,7 @@ class CorrBlockParallelMultiTarget:
             vout = None if volume_out is None else volume_out.view(len(levels), B, N, hip.tiled_plane_size(h, w))   # a caller-owned level 0
             keep1 = [t for t, lv in enumerate(levels) if lv >= 2]
             if keep1 and FUSE_POOL1 and h >= 2 and w >= 2 and cc.pool1_fusable(precision):
-                prec = PRECISION if precision is None else precision
-                fused1 = (torch.empty((len(keep1), B, N, hip.tiled_plane_size(h // 2, w // 2)), dtype=torch.float16 if PRECISIONS[prec][1] else torch.float32,
+                fused1 = (torch.empty((len(keep1), B, N, hip.tiled_plane_size(h // 2, w // 2)), dtype=torch.float16 if PRECISIONS[precision][1] else torch.float32,
                                       device=cc._packed[0][0].device if cc._packed[0] is not None else cc._fmap1[0].device), keep1)
             base = cc.get_correlation_volume(tiled=True, precision=precision, out=vout, pool1=fused1).view(len(levels), B * N, hip.tiled_plane_size(h, w))
         else:

@@ -308,9 +308,13 @@ __global__ __launch_bounds__(256) void split_to_x8_kernel(const _Float16* __rest
     const int g = (int)(i & 3);
     typedef _Float16 half8v __attribute__((ext_vector_type(8)));
     const half8v h = *reinterpret_cast<const half8v*>(hi + row * 32 + g * 8), l = *reinterpret_cast<const half8v*>(lo + row * 32 + g * 8);
-    auto pack4 = [](float a, float b, float c, float d) {
-        int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-        return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    // v_cvt_pk_fp8_f32 does NOT saturate by itself (no clamp modifier, MODE.FP16_OVFL clear): |x| > 448 would become the e4m3 NaN 0x7F and
+    // poison a whole row / column of the volume.  v_med3_f32 clamps to +-448 first; a NaN input stays NaN (med3 of (NaN, -448, 448) with
+    // IEEE mode returns the NaN-propagating min/max result, and the split planes of a NaN feature are NaN in the fp16 term anyway).
+    auto sat = [](float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); };
+    auto pack4 = [&](float a, float b, float c, float d) {
+        int v = __builtin_amdgcn_cvt_pk_fp8_f32(sat(a), sat(b), 0, false);
+        return __builtin_amdgcn_cvt_pk_fp8_f32(sat(c), sat(d), v, true);
     };
     const int2 ph = make_int2(pack4((float)h[0], (float)h[1], (float)h[2], (float)h[3]), pack4((float)h[4], (float)h[5], (float)h[6], (float)h[7]));
     const int2 pl = make_int2(pack4((float)l[0], (float)l[1], (float)l[2], (float)l[3]), pack4((float)l[4], (float)l[5], (float)l[6], (float)l[7]));

@@ -21,7 +21,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("BFLOW_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -41,6 +41,11 @@ def all_gather_records(record: torch.Tensor) -> torch.Tensor:
     """record: (k,) float64 on this rank -> (world, k).  One all-gather (RCCL ncclAllGather on GPU tensors)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return record.unsqueeze(0)
+    if record.is_cuda and dist.get_backend() == "gloo":      # gloo ranks on a GPU box (the one-GPU test of the N > 1 path): exchange on the host
+        host = record.detach().cpu().contiguous()
+        out = [torch.empty_like(host) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, host)
+        return torch.stack(out, dim=0).to(record.device)
     out = [torch.empty_like(record) for _ in range(dist.get_world_size())]
     dist.all_gather(out, record.contiguous())
     return torch.stack(out, dim=0)

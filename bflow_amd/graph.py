@@ -46,15 +46,22 @@ class _Captured:
             if gc_was_on:
                 gc.enable()
 
+    @staticmethod
+    def _same_buffer(src: torch.Tensor, dst: torch.Tensor) -> bool:
+        """True only when `src` IS the static buffer's memory in the static buffer's layout: same address AND same strides (a transposed /
+        strided view that merely starts at the same address holds different contents and must be copied)."""
+        return src is dst or (src.data_ptr() == dst.data_ptr() and src.stride() == dst.stride() and src.shape == dst.shape
+                              and src.dtype == dst.dtype)
+
     def replay(self, voxel_grid, images, flow_init):
         # (a frame that already lives in the static buffer is not copied onto itself)
-        if voxel_grid is not None and voxel_grid.data_ptr() != self.static_voxel.data_ptr():
+        if voxel_grid is not None and not self._same_buffer(voxel_grid, self.static_voxel):
             self.static_voxel.copy_(voxel_grid)
         if images is not None:
             for dst, src in zip(self.static_images, images):
-                if src.data_ptr() != dst.data_ptr():
+                if not self._same_buffer(src, dst):
                     dst.copy_(src)
-        if flow_init is not None and flow_init.data_ptr() != self.static_init.data_ptr():
+        if flow_init is not None and not self._same_buffer(flow_init, self.static_init):
             self.static_init.copy_(flow_init)
         self.graph.replay()
         return self.low, self.ups

@@ -4,8 +4,8 @@ The reference trains `torch.nn.InstanceNorm2d` (feature encoders) and `torch.nn.
 by ReLU except on the down-sampling shortcut (models/raft_utils/extractor.py:5-55,58-125).  `norm_act(module, x, relu)` routes GPU tensors in
 training mode through `_NormActFn` (csrc/norm_train.hip: statistics, normalise + activate, and the two-pass backward; BatchNorm's running
 statistics are updated by the forward's finalise kernel exactly as torch does: momentum, unbiased variance, `num_batches_tracked`).
-Everything else -- CPU tensors (the oracle tests), eval mode, GroupNorm, planes that are not 16-byte aligned -- falls through to the
-module itself.  Only x and the per-plane (mean, rstd, scale, shift) are kept for the backward pass; the ReLU mask is recomputed."""
+CPU tensors (the oracle tests) run the module itself; GPU cases outside the kernels (eval-mode BatchNorm after freeze_bn(), planes that are
+not 16-byte aligned, ...) run as torch element-wise arithmetic (`_norm_elementwise`), never on the vendor library; GroupNorm is refused.  Only x and the per-plane (mean, rstd, scale, shift) are kept for the backward pass; the ReLU mask is recomputed."""
 from __future__ import annotations
 
 import torch
@@ -80,14 +80,58 @@ def _supported(module: nn.Module, x: torch.Tensor):
     return None
 
 
+def _norm_elementwise(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """InstanceNorm2d / BatchNorm2d written with torch reductions + element-wise ops (autograd differentiates them; no MIOpen kernel is
+    involved -- `F.batch_norm` / `F.instance_norm` on ROCm would be).  The cases `_NormActFn` does not take on a GPU tensor:
+      * BatchNorm2d in eval() mode -- the reference API `RAFTSpline.freeze_bn()` (raft.py:75-78) followed by a training forward: a
+        per-channel affine from the running statistics;
+      * planes that are not 16-byte aligned (H*W % 4), B*C > 65535, BatchNorm with momentum=None (cumulative average), grad disabled.
+    Same arithmetic as torch's modules: biased variance for the normalisation, unbiased for the running update."""
+    xf = x.float()
+    if isinstance(module, nn.BatchNorm2d):
+        use_batch = module.training or module.running_mean is None
+        if use_batch:
+            mean = xf.mean(dim=(0, 2, 3))
+            var = xf.var(dim=(0, 2, 3), unbiased=False)
+            if module.training and module.track_running_stats and module.running_mean is not None:
+                with torch.no_grad():
+                    n = xf.numel() // xf.shape[1]
+                    if module.num_batches_tracked is not None:
+                        module.num_batches_tracked.add_(1)
+                    f = (1.0 / float(module.num_batches_tracked)) if module.momentum is None else float(module.momentum)
+                    module.running_mean.mul_(1 - f).add_(mean.detach(), alpha=f)
+                    module.running_var.mul_(1 - f).add_(var.detach() * (n / max(n - 1, 1)), alpha=f)
+        else:
+            mean, var = module.running_mean.float(), module.running_var.float()
+        scale = torch.rsqrt(var + module.eps)
+        if module.affine:
+            scale = scale * module.weight.float()
+        shift = -mean * scale
+        if module.affine:
+            shift = shift + module.bias.float()
+        return xf * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    assert isinstance(module, nn.InstanceNorm2d) and not module.track_running_stats, type(module)
+    mean = xf.mean(dim=(2, 3), keepdim=True)
+    var = xf.var(dim=(2, 3), unbiased=False, keepdim=True)
+    y = (xf - mean) * torch.rsqrt(var + module.eps)
+    if module.affine:
+        y = y * module.weight.float().view(1, -1, 1, 1) + module.bias.float().view(1, -1, 1, 1)
+    return y
+
+
 def norm_act(module: nn.Module, x: torch.Tensor, relu: bool) -> torch.Tensor:
-    """[relu](module(x)) for the norm layers of the encoders: on the HIP kernels in GPU training mode, otherwise the module itself."""
+    """[relu](module(x)) for the norm layers of the encoders: on the HIP kernels in GPU training mode; the GPU cases those kernels do not
+    cover (eval-mode BatchNorm after `freeze_bn()`, unaligned planes, ...) as torch element-wise arithmetic (`_norm_elementwise`), never on
+    the vendor library; GroupNorm on a GPU tensor is refused (the engine has no GroupNorm, RAFTSpline.check_engine_support says so up front).
+    CPU tensors (the oracle tests) run the module itself."""
     mode = _supported(module, x)
     if mode is None:
         if ENABLED and x.is_cuda and not isinstance(module, nn.Sequential):     # ("none" norm = empty Sequential: nothing to compute)
-            raise hip.BflowHipError(f"norm_act({type(module).__name__}) on a GPU tensor outside the HIP training kernels (grad disabled, eval mode, "
-                                    "or an unsupported norm layer): there is no library fall-back -- run inference through RAFTSpline.forward "
-                                    "in eval() mode, or train with grad enabled")
+            if isinstance(module, nn.BatchNorm2d) or (isinstance(module, nn.InstanceNorm2d) and not module.track_running_stats):
+                y = _norm_elementwise(module, x)
+                return torch.relu_(y) if relu else y
+            raise hip.BflowHipError(f"norm_act({type(module).__name__}) on a GPU tensor: only InstanceNorm2d / BatchNorm2d are implemented "
+                                    "(there is no library fall-back)")
         y = module(x)
         return torch.relu_(y) if relu else y
     affine = mode == 1

@@ -123,19 +123,20 @@ class RAFTSpline(nn.Module):
         # (hi*hi on the fp16 matrix rate, both cross terms on the fp8 rate, fp32 volume: 2.2e-5 px against the fp32 oracle at C2 / C5 where
         # the three-pass "split" measures 1.3e-5, K5 142 -> 95 us) for feature dims 128 / 256, "split" otherwise.
         # "f16" = fp16 operands AND fp16 volume (BASELINE configs[4]; 2.3-2.7e-3 px: outside the 1e-3 bar, opt-in).
-        self.corr_precision: Optional[str] = None
+        # An OPTIONAL model key `correlation.precision` (absent from the reference's YAML files, so they mean what they always meant)
+        # presets it: configs.BASELINE_CONFIGS[4] ("fp16 MFMA correlation") selects "f16/w" this way.
+        self.corr_precision: Optional[str] = corr_params.get("precision") if hasattr(corr_params, "get") else None
         self._graphs = None
         self.stage_timer: Optional[StageTimer] = None
         self._probe = None            # tools only: callable(name) invoked at stage boundaries inside the captured forward
 
     def resolved_corr_precision(self) -> str:
         """The correlation arithmetic a forward will use (see `corr_precision`)."""
+        from . import corr as _corr
         if self.corr_precision is not None:
-            return self.corr_precision
-        if "BFLOW_CORR_PRECISION" in os.environ:
-            return os.environ["BFLOW_CORR_PRECISION"]
+            return _corr.check_precision(self.corr_precision)
         enc = self.fnet_ev if self.fnet_ev is not None else self.fnet_img
-        return "split8" if enc.conv2.out_channels in (128, 256) else "split"
+        return _corr.default_precision(enc.conv2.out_channels, tiled=True)      # the ONE resolver (BFLOW_CORR_PRECISION, else split8 / split)
 
     # ---------------------------------------------------------------------------------------- reference API
     def freeze_bn(self):

@@ -485,7 +485,7 @@ class GraphedTrainStep:
 
     _epochs = 0
 
-    def __init__(self, step: TrainStep, optimizer: torch.optim.Optimizer, scheduler=None, warmup: int = 2, grad_sync=None):
+    def __init__(self, step: TrainStep, optimizer: torch.optim.Optimizer, scheduler=None, warmup: int = 2, grad_sync=None, max_graphs: int = 1):
         """grad_sync: a `dist.GradientBuckets` of the model (data-parallel training, one process per GPU): its bucketed RCCL all-reduces are
         launched by the gradient hooks during the backward pass and finished before the optimiser step -- recorded into the graph like
         every other node (stream-ordered collectives are capturable).  On one rank it is a no-op."""
@@ -496,7 +496,10 @@ class GraphedTrainStep:
         # the most recently used signatures keep their captured graph (a smaller last batch per epoch, alternating shapes or timestamp sets
         # would otherwise pay two warm-up steps + a capture at every change): signature -> (graph, static inputs, static outputs, times)
         self._lru: "OrderedDict[Tuple, Tuple]" = OrderedDict()
-        self.max_graphs = 3
+        # max_graphs = captured graphs alive at a time (the current one + parked ones).  Every graph owns a private memory pool with ALL
+        # activations of a training step, so the default keeps ONE (what fitted before the LRU existed still fits); a run whose batch shape
+        # alternates (a smaller last batch per epoch) can buy back the re-captures with max_graphs = 2 or 3 at 2-3x the activation memory.
+        self.max_graphs = max(1, int(max_graphs))
 
     @staticmethod
     def _sig_of(v):
@@ -593,9 +596,17 @@ class GraphedTrainStep:
                 while len(self._lru) >= self.max_graphs:    # destroyed here, outside any capture
                     torch.cuda.synchronize()
                     self._lru.popitem(last=False)
-                self._graph = None
-                self._sig, self._times = sig, times
-                self._capture(batch)                        # warm-up steps + the capture itself do NOT count as training steps of `batch` ...
+                # a capture can fail part-way (a constant missing from the cache, out of memory): the step then has NO current graph --
+                # signature, times and graph are only adopted after a successful capture, so the next call captures again instead of
+                # replaying a half-built graph on stale static buffers
+                self._graph, self._sig = None, None
+                prev_times, self._times = self._times, times      # _capture reads self._times (frozen into the graph)
+                try:
+                    self._capture(batch)                    # warm-up steps + the capture itself do NOT count as training steps of `batch` ...
+                except Exception:
+                    self._graph, self._times = None, prev_times
+                    raise
+                self._sig = sig
         for k, v in batch.items():
             self._copy_into(self._static[k], v)
         self._graph.replay()                                # ... this replay does

@@ -181,6 +181,49 @@ def test_training_step_gradients_match_reference_golden(golden_dir, name):
             assert np.abs(v.cpu().numpy() - d[f"buf/{k}"]).max() < 1e-4
 
 
+def test_freeze_bn_then_training_step_matches_oracle():
+    """The reference API `RAFTSpline.freeze_bn()` (raft.py:75-78) followed by a training forward + backward (round-3 advisor finding: the
+    eval-mode BatchNorm layers of cnet used to raise).  Frozen BatchNorm = per-channel affine from the running statistics; the oracle with
+    training=False is exactly that network under autograd.  Also covers a crop whose 1/8-resolution plane is not 16-byte aligned
+    ((H/8)*(W/8) % 4 != 0: the statistics kernel's fast path does not apply) and a FROZEN feature encoder (requires_grad False on every fnet
+    parameter: its convolutions run with nothing requiring grad).  Loss 1e-4 relative, gradients 2e-3 of each parameter's scale, running
+    statistics untouched."""
+    cfg = O.model_config("E_LU4_BD2")
+    B, H, W, iters = 1, 88, 104, 2                      # 11 x 13 = 143 pixels at 1/8: not a multiple of 4
+    model = _product_model(cfg)
+    model.freeze_bn()
+    for p in model.fnet_ev.parameters():
+        p.requires_grad_(False)
+    bufs0 = {k: v.clone() for k, v in model.named_buffers()}
+    vox, _ = TC.inputs(cfg, B, H, W)
+    gts, valids, _ = TC.train_targets(B, H, W, "dsec")
+    preds = model(voxel_grid=vox.to(DEV), iters=iters, test_mode=False)
+    loss = training.l1_seq_loss_channel_masked([p.get_flow_from_reference(1.0) for p in preds], cu(gts[0]), cu(valids[0]))
+    loss.backward()
+    for k, v in model.named_buffers():
+        assert torch.equal(v, bufs0[k]), k                # frozen: running statistics and num_batches_tracked do not move
+    sd = {k: v.clone() for k, v in O.make_state_dict(cfg, seed=0).items()}
+    train_keys = [k for k, p in model.named_parameters() if p.requires_grad]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    ups = O.forward(sd, cfg, vox, None, iters=iters, test_mode=False, training=False)
+    rloss = O.l1_seq_loss_channel_masked([O.bezier_flow(u, 1.0) for u in ups], torch.from_numpy(gts[0]), torch.from_numpy(valids[0]))
+    rloss.backward()
+    assert abs(float(loss) - float(rloss)) < 1e-4 * abs(float(rloss)), (float(loss), float(rloss))
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None, k
+            continue
+        want = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        scale = float(want.abs().max()) + 1e-12
+        e = float((got.cpu() - want).abs().max()) / scale
+        worst = max(worst, e)
+        assert e < 2e-3 or scale < 1e-9, (k, e, scale)
+    print(f"freeze_bn + frozen fnet training step: worst scaled gradient error {worst:.2e}")
+
+
 def test_train_step_and_optimizer():
     """TrainStep (training_step without Lightning) + AdamW/OneCycleLR as configure_optimizers builds them: two steps run, the loss
     is finite and every parameter with a gradient moves."""
@@ -417,7 +460,7 @@ def test_graphed_train_step_matches_eager_steps():
 
 def test_graphed_train_step_keeps_graphs_of_alternating_signatures():
     """A smaller last batch per epoch / alternating shapes: GraphedTrainStep keeps the captured graph of the most recently used signatures
-    (LRU of 3) instead of re-capturing at every change, and the alternating replays still train like eager steps."""
+    (`max_graphs=3`; the default keeps one) instead of re-capturing at every change, and the alternating replays still train like eager steps."""
     from bflow_amd import configs, synthetic
     from bflow_amd.weights import deterministic_state_dict
     cfg = configs.model_config("E_LU4_BD2")
@@ -448,7 +491,7 @@ def test_graphed_train_step_keeps_graphs_of_alternating_signatures():
         opt1.step()
         eager.append(float(out["loss"].detach()))
     m2, opt2, step2 = make(True)
-    gstep = training.GraphedTrainStep(step2, opt2)
+    gstep = training.GraphedTrainStep(step2, opt2, max_graphs=3)       # (default 1: every graph owns a full set of activations)
     captures = []
     orig = gstep._capture
     gstep._capture = lambda b: (captures.append(1), orig(b))[1]

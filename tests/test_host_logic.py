@@ -327,3 +327,78 @@ print("OK")
 """.format(dropin=os.path.join(ROOT, "dropin"), root=ROOT)
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout
+
+
+def test_root_configs_compose_like_the_reference_entry_points():
+    """train.yaml -> general.yaml + groups (train.py:26), val.yaml (val.py:22): same top-level sections, the experiment file's overrides win,
+    and the one interpolation of the tree (`training.lr_scheduler.total_steps: ${..max_steps}`) resolves against the MERGED config."""
+    c = configs.compose(root="train", dataset="dsec", experiment="dsec/raft_spline/E_LU4_BD2_lowpyramid")
+    assert sorted(c) == ["dataset", "debugging", "hardware", "logging", "model", "training", "wandb"]
+    assert c["training"]["max_steps"] == 250000 and c["training"]["lr_scheduler"]["total_steps"] == 250000     # experiment override + interpolation
+    assert c["training"]["multi_loss"] is False and c["training"]["learning_rate"] == 1e-4 and c["wandb"]["project_name"] == "contflow"
+    g = configs.compose(root="train", dataset="dsec", model="raft-spline")   # no experiment file: general.yaml's own values
+    assert g["training"]["max_steps"] == 200000 and g["training"]["lr_scheduler"]["total_steps"] == 200000 and g["training"]["multi_loss"] is True
+    v = configs.compose(root="val", dataset="dsec", experiment="dsec/raft_spline/E_LU4_BD2_lowpyramid")
+    assert v["batch_size"] == 8 and v["hardware"] == {"num_workers": 4, "gpus": 0} and v["checkpoint"] == "???"
+    if os.path.isdir("/root/reference/config"):      # the shipped files carry the reference's keys and values
+        import yaml
+        for f in ("general", "train", "val"):
+            assert yaml.safe_load(open(f"/root/reference/config/{f}.yaml")) == yaml.safe_load(open(os.path.join(configs.CONFIG_ROOT, f + ".yaml"))), f
+
+
+def test_baseline_configs_and_the_precision_resolver(monkeypatch):
+    """BASELINE.json configs in order; configs[4] ("fp16 MFMA correlation") selects `correlation.precision = "f16/w"` and the model takes it
+    from its config; everything else resolves through ONE function (corr.default_precision): split8 on tiled planes with D in {128, 256},
+    split otherwise, BFLOW_CORR_PRECISION read at call time and validated up front."""
+    from bflow_amd import corr
+    monkeypatch.delenv("BFLOW_CORR_PRECISION", raising=False)
+    names = [(c["name"], c["experiment"], c["height"], c["width"], c["batch"], c["iters"]) for c in configs.BASELINE_CONFIGS]
+    assert names == [("C1", "E_LU5_BD10", 384, 384, 1, 4), ("C2", "E_LU4_BD2", 480, 640, 1, 12), ("C3", "E_I_LU4_BD2", 480, 640, 8, 12),
+                     ("C4", "E_LU4_BD2", 480, 640, 8, 12), ("C5", "E_I_LU5_BD10", 1024, 1024, 1, 20)]
+    c5 = configs.baseline_config(4)
+    assert c5["model"]["correlation"]["precision"] == "f16/w"
+    assert bflow_amd.RAFTSpline(c5["model"]).resolved_corr_precision() == "f16/w"
+    m2 = bflow_amd.RAFTSpline(configs.baseline_config(1)["model"])
+    assert "precision" not in configs.baseline_config(1)["model"]["correlation"] and m2.corr_precision is None
+    assert m2.resolved_corr_precision() == "split8" == corr.default_precision(256, tiled=True)
+    assert corr.default_precision(256, tiled=False) == "split" == corr.default_precision(64, tiled=True)
+    monkeypatch.setenv("BFLOW_CORR_PRECISION", "split")
+    assert m2.resolved_corr_precision() == "split" == corr.default_precision(256, True)
+    monkeypatch.setenv("BFLOW_CORR_PRECISION", "fp13")
+    with pytest.raises(ValueError):
+        m2.resolved_corr_precision()
+    with pytest.raises(ValueError):
+        corr.default_precision(256)
+    monkeypatch.delenv("BFLOW_CORR_PRECISION")
+    m2.corr_precision = "nonsense"
+    with pytest.raises(ValueError):
+        m2.resolved_corr_precision()
+
+
+def test_lightning_checkpoint_loads_strictly(tmp_path):
+    """weights.load_lightning_checkpoint: a file shaped like the reference's published checkpoints (`RAFTSplineModule.state_dict()`:
+    every model tensor under the `net.` prefix, modules/raft_spline.py:24, next to Lightning's bookkeeping keys; loaded by
+    `load_from_checkpoint`, val.py:58) loads STRICTLY into RAFTSpline -- and a bare state dict (no wrapper, no prefix) too.
+    (The published files themselves cannot be fetched here: README.md:63-95, no network.)"""
+    from bflow_amd.weights import load_lightning_checkpoint
+    cfg = configs.model_config("E_I_LU4_BD2")
+    src = bflow_amd.RAFTSpline(cfg)
+    sd = deterministic_state_dict(src, seed=3)
+    ckpt = {"epoch": 7, "global_step": 1234, "pytorch-lightning_version": "1.8.6", "state_dict": {"net." + k: v.clone() for k, v in sd.items()},
+            "optimizer_states": [], "lr_schedulers": [], "hyper_parameters": {"config": {"model": cfg}}}
+    path = str(tmp_path / "E_I_LU4_BD2.ckpt")
+    torch.save(ckpt, path)
+    dst = bflow_amd.RAFTSpline(cfg)
+    res = load_lightning_checkpoint(dst, path, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    got = dst.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    bare = str(tmp_path / "bare.pt")
+    torch.save(sd, bare)
+    dst2 = bflow_amd.RAFTSpline(cfg)
+    load_lightning_checkpoint(dst2, bare, strict=True)
+    assert all(torch.equal(dst2.state_dict()[k], sd[k]) for k in sd)
+    # a checkpoint of ANOTHER configuration is refused under strict=True (events-only model: no fnet_img, 567 correlation channels)
+    other = bflow_amd.RAFTSpline(configs.model_config("E_LU4_BD2"))
+    with pytest.raises(RuntimeError):
+        load_lightning_checkpoint(other, path, strict=True)
