@@ -99,14 +99,16 @@ __device__ __forceinline__ float sum_lanes_mod8(float v) {
     return x + y;
 }
 
-// GROUPS = 2 (8-wave split-k kernels): each k-group stages ITS partial sums in its own slab set; after ONE workgroup barrier both
-// groups walk the two slabs of their pixel slab index `wave` -- group g takes row groups 2g, 2g+1 and adds the two partials -- so
-// the k-split is combined for free on the read side and the sigmoid / tanh / split work is spread over all 8 waves.
+// GROUPS = 2 (8- / 10-wave split-k kernels) or 4 (12-wave kernel: 2 k-halves x 2 channel-block parities): each k-group stages ITS partial
+// sums in its own slab set; after ONE workgroup barrier every group walks the GROUPS slabs of its pixel slab index `wave` -- group g takes
+// the 4 / GROUPS row groups from g * 4 / GROUPS on and adds the partials -- so the k-split is combined for free on the read side and the
+// sigmoid / tanh / split work is spread over all waves.
 template <int NT, int NW = 4, int GROUPS = 1, typename PixelOf>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT], f32x16 (&xx)[NT], int b, PixelOf pixel_of, int n0,
                                               int lane, int wave, int tid, bool writer, float* red, int grp = 0) {
     constexpr int BN = 32 * NT;
     constexpr int RS = CONV_STG_STRIDE;
+    static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4, "row groups must divide over the k-groups");
     constexpr int NIT = 4 / GROUPS;                       // row groups of 8 pixels per wave on the read side
     const int it0 = grp * NIT;
     constexpr int SLABS = NW / GROUPS;                    // pixel slabs (waves per k-group): 4, or 5 in the 10-wave kernel
@@ -158,12 +160,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
             float4 ads[NIT];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) raws[it] = *reinterpret_cast<const float4*>(stg + ((it0 + it) * 8 + rr) * RS + ch);
-            if (GROUPS > 1) {                                // + the other k-group's partial sums
+            if (GROUPS > 1) {                                // + the other k-groups' partial sums (group order: the same sum in every build)
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const float4 o4 = *reinterpret_cast<const float4*>(stg + GSTRIDE + ((it0 + it) * 8 + rr) * RS + ch);
-                    raws[it].x += o4.x; raws[it].y += o4.y; raws[it].z += o4.z; raws[it].w += o4.w;
-                }
+                for (int g = 1; g < GROUPS; ++g)
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const float4 o4 = *reinterpret_cast<const float4*>(stg + g * GSTRIDE + ((it0 + it) * 8 + rr) * RS + ch);
+                        raws[it].x += o4.x; raws[it].y += o4.y; raws[it].z += o4.z; raws[it].w += o4.w;
+                    }
             }
             if (a.addend) {
 #pragma unroll

@@ -19,6 +19,10 @@
 //            2-KB / 4-KB run).
 #include "conv_engine.h"
 
+#ifndef CONV_SPREAD_DMA
+#define CONV_SPREAD_DMA 0     // tools A/B (tools/build_flag_variant.sh): 1 = the small-grid kernels issue a step's LDS-DMA pieces between its taps
+#endif
+
 #ifdef H8_STAMPS   // tools/conv_stamps.sh build: s_memtime stamps of every wave of conv_halo8_kernel at its phase boundaries (16 x u64 per wave)
 static unsigned long long* g_h8_stamp_buf = nullptr;
 extern "C" __attribute__((visibility("default"))) void bflow_conv_set_stamp_buffer(void* p) { g_h8_stamp_buf = (unsigned long long*)p; }
@@ -859,18 +863,18 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
     char* const a_dst = lds + (lo_p ? A_PLANE : 0);
     char* const w_dst = lds + O_B + (lo_p ? 2048 : 0);
 
-#define H8_ISSUE_A(CBI, BUF)                                                                                             \
+#define H8_ISSUE_A(CBI, BUF, SEL, NSEL)                                                                                  \
     {                                                                                                                    \
         const int cbi_ = (CBI) < a.CB ? (CBI) : a.CB - 1;                                                                \
         const bool first_ = cbi_ < a.CB1;                                                                                \
         const rsrc_t ra_ = first_ ? r_a1 : r_a2;                                                                         \
         const int so_ = (first_ ? cbi_ : cbi_ - a.CB1) * plane_b;                                                        \
         _Pragma("unroll") for (int i = 0; i < NIA; ++i)                                                                  \
-            if (i < NFA || half_on)                                                                                      \
+            if (i % (NSEL) == (SEL) && (i < NFA || half_on))                                                             \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lptr_t)(a_dst + (BUF) * A_BUF + a_unit[i] * 1024), 16, aoff[i], so_, 0, 0); \
     }
     // weight slot for step (CBI, ST): taps ST*TPS .. ; piece idx -> tap idx / 2, unit idx & 1.  ST is a compile-time constant.
-#define H8_ISSUE_B(CBI, ST, SLOT)                                                                                        \
+#define H8_ISSUE_B(CBI, ST, SLOT, SEL, NSEL)                                                                             \
     {                                                                                                                    \
         constexpr int ntp_ = (NTAPS - (ST) * TPS) < TPS ? (NTAPS - (ST) * TPS) : TPS;      /* taps of this step */       \
         constexpr int nfb_ = (2 * ntp_) / 4;                                                                             \
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
         _Pragma("unroll") for (int i = 0; i < nfb_ + (halfb_ ? 1 : 0); ++i) {                                            \
             const int idx_ = (i < nfb_) ? q + 4 * i : 4 * nfb_ + (q >> 1);                                               \
             const int so_ = (((ST) * TPS + (idx_ >> 1)) * a.CB + (CBI)) * wtile_b;   /* past the end: out of range, never consumed */ \
-            if (i < nfb_ || half_on)                                                                                     \
+            if (i % (NSEL) == (SEL) && (i < nfb_ || half_on))                                                            \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (SLOT) * B_SLOT + (idx_ >> 1) * B_TAP + (idx_ & 1) * 1024), 16, \
                                                          (idx_ & 1) ? wvo1 : wvo0, so_, 0, 0);                           \
         }                                                                                                                \
@@ -893,8 +897,8 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
     }
 
     H8STAMP_RT(14) H8STAMP(0)
-    H8_ISSUE_A(0, 0)
-    H8_ISSUE_B(0, 0, 0)
+    H8_ISSUE_A(0, 0, 0, 1)
+    H8_ISSUE_B(0, 0, 0, 0, 1)
     H8STAMP(1)
 
     const int R0 = (wave * 2 + slab_row(l31)) * HWD + slab_col(l31);
@@ -908,19 +912,26 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
             constexpr int st = t / TPS, j = t % TPS;
             if (j == 0) {                          // ---- step boundary
                 // in flight, oldest first: [halo of block cb+1 (issued at st 0, AFTER that step's weights)], weights of this step
-                if (NST > 1 && st == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
+                if (!CONV_SPREAD_DMA && NST > 1 && st == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (cb == 0 && st == 0) { H8STAMP(2) }
                 if (cb == 1 && st == 0) { H8STAMP(3) }
-                {
+                if (!CONV_SPREAD_DMA) {
                     constexpr int stn = (st + 1) % NST;
                     const int cbn = cb + (st + 1) / NST;
-                    H8_ISSUE_B(cbn, stn, cur ^ 1)
+                    H8_ISSUE_B(cbn, stn, cur ^ 1, 0, 1)
+                    if (st == 0) H8_ISSUE_A(cb + 1, (cb + 1) & 1, 0, 1)
                 }
-                if (st == 0) H8_ISSUE_A(cb + 1, (cb + 1) & 1)
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (CONV_SPREAD_DMA) {   // A/B build: the step's LDS-DMA pieces dealt over its taps (issued in front of each tap's fragment reads) instead of one burst
+                constexpr int ntc = (NTAPS - st * TPS) < TPS ? (NTAPS - st * TPS) : TPS;
+                constexpr int stn = (st + 1) % NST;
+                const int cbn = cb + (st + 1) / NST;
+                if (st == 0) H8_ISSUE_A(cb + 1, (cb + 1) & 1, j, ntc)
+                H8_ISSUE_B(cbn, stn, cur ^ 1, j, ntc)
             }
             const char* wcur = lds + O_B + cur * B_SLOT;
             const int R = R0 + (t / KW) * HWD + (t % KW);
@@ -1032,18 +1043,19 @@ __global__ __launch_bounds__(128 * NSL, 1) void conv_halo10_kernel(ConvArgs a) {
     char* const a_dst = lds + (lo_p ? A_PLANE : 0);
     char* const w_dst = lds + O_B + (lo_p ? 2048 : 0);
 
-#define H8_ISSUE_A(CBI, BUF)                                                                                             \
+#define H8_ISSUE_A(CBI, BUF, SEL, NSEL)                                                                                  \
     {                                                                                                                    \
         const int cbi_ = (CBI) < a.CB ? (CBI) : a.CB - 1;                                                                \
         const bool first_ = cbi_ < a.CB1;                                                                                \
         const rsrc_t ra_ = first_ ? r_a1 : r_a2;                                                                         \
         const int so_ = (first_ ? cbi_ : cbi_ - a.CB1) * plane_b;                                                        \
         _Pragma("unroll") for (int i = 0; i < NIA; ++i)                                                                  \
+            if (i % (NSEL) == (SEL))                                                                                     \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lptr_t)(a_unit[i] < A_UNITS ? a_dst + (BUF) * A_BUF + a_unit[i] * 1024 : lds + O_SCR), 16, \
                                                      aoff[i], so_, 0, 0);                                                \
     }
     // weight slot for step (CBI, ST): taps ST*TPS .. ; piece idx -> tap idx / 2, unit idx & 1.  ST is a compile-time constant.
-#define H8_ISSUE_B(CBI, ST, SLOT)                                                                                        \
+#define H8_ISSUE_B(CBI, ST, SLOT, SEL, NSEL)                                                                             \
     {                                                                                                                    \
         constexpr int ntp_ = (NTAPS - (ST) * TPS) < TPS ? (NTAPS - (ST) * TPS) : TPS;      /* taps of this step */       \
         constexpr int nib_ = (2 * ntp_ + NSL - 1) / NSL;                                                                 \
@@ -1051,6 +1063,7 @@ __global__ __launch_bounds__(128 * NSL, 1) void conv_halo10_kernel(ConvArgs a) {
             const int idx_ = q + NSL * i;                                                                                \
             const bool real_ = idx_ < 2 * ntp_;                                                                          \
             const int so_ = (((ST) * TPS + (idx_ >> 1)) * a.CB + (CBI)) * wtile_b;   /* past the end: out of range, never consumed */ \
+            if (i % (NSEL) == (SEL))                                                                                     \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(real_ ? w_dst + (SLOT) * B_SLOT + (idx_ >> 1) * B_TAP + (idx_ & 1) * 1024 : lds + O_SCR), 16, \
                                                      real_ ? ((idx_ & 1) ? wvo1 : wvo0) : 0x80000000u, so_, 0, 0);       \
         }                                                                                                                \
@@ -1064,8 +1077,8 @@ __global__ __launch_bounds__(128 * NSL, 1) void conv_halo10_kernel(ConvArgs a) {
         x2[r] = 0.f;
     }
 
-    H8_ISSUE_A(0, 0)
-    H8_ISSUE_B(0, 0, 0)
+    H8_ISSUE_A(0, 0, 0, 1)
+    H8_ISSUE_B(0, 0, 0, 0, 1)
 
     const int R0 = (wave * 2 + slab_row(l31)) * HWD + slab_col(l31);
     const int kq = grp * 2 + kh;                                    // this lane's 16-B k-chunk of the 64-B row
@@ -1078,17 +1091,24 @@ __global__ __launch_bounds__(128 * NSL, 1) void conv_halo10_kernel(ConvArgs a) {
             constexpr int st = t / TPS, j = t % TPS;
             if (j == 0) {                          // ---- step boundary
                 // in flight, oldest first: [halo of block cb+1 (issued at st 0, AFTER that step's weights)], weights of this step
-                if (NST > 1 && st == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
+                if (!CONV_SPREAD_DMA && NST > 1 && st == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                {
+                if (!CONV_SPREAD_DMA) {
                     constexpr int stn = (st + 1) % NST;
                     const int cbn = cb + (st + 1) / NST;
-                    H8_ISSUE_B(cbn, stn, cur ^ 1)
+                    H8_ISSUE_B(cbn, stn, cur ^ 1, 0, 1)
+                    if (st == 0) H8_ISSUE_A(cb + 1, (cb + 1) & 1, 0, 1)
                 }
-                if (st == 0) H8_ISSUE_A(cb + 1, (cb + 1) & 1)
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (CONV_SPREAD_DMA) {   // A/B build: the step's LDS-DMA pieces dealt over its taps (issued in front of each tap's fragment reads) instead of one burst
+                constexpr int ntc = (NTAPS - st * TPS) < TPS ? (NTAPS - st * TPS) : TPS;
+                constexpr int stn = (st + 1) % NST;
+                const int cbn = cb + (st + 1) / NST;
+                if (st == 0) H8_ISSUE_A(cb + 1, (cb + 1) & 1, j, ntc)
+                H8_ISSUE_B(cbn, stn, cur ^ 1, j, ntc)
             }
             const char* wcur = lds + O_B + cur * B_SLOT;
             const int R = R0 + (t / KW) * HWD + (t % KW);
@@ -1117,6 +1137,192 @@ __global__ __launch_bounds__(128 * NSL, 1) void conv_halo10_kernel(ConvArgs a) {
     for (int r = 0; r < 16; ++r) xx[0][r] = x1[r] + x2[r];
     const int W = a.W, H = a.H, yw = y0 + wave * 2;
     conv_epilogue<1, 2 * NSL, 2>(a, hh, xx, b, [=](int row) {
+        const int y = yw + slab_row(row), x = x0 + slab_col(row);
+        return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, grp == 0, reinterpret_cast<float*>(lds), grp);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 12-wave variant of the small-grid kernel for the <= 128-output-channel convolutions of the batch-1 update block (q of both GRU halves,
+// the motion encoder's last 3x3).  On the 60 x 80 grid those are 40 patches x 4 channel tiles = 160 workgroups of the 8-wave kernel: 96
+// CUs idle and every busy CU carries four 32 x 32 wave tiles of matrix work.  The chip holds 600 such tiles, i.e. three per CU is the
+// floor.  A 6 x 16 patch = NSL = 3 pixel slabs gives 50 patches x 4 = 200 workgroups with THREE tiles each -- but three slabs x two
+// k-halves = 6 waves load the four SIMDs 2 / 2 / 1 / 1 and nothing is gained (measured in round 3: 12.2 vs 11.9 us).  So the k range is
+// split FOUR ways: wave (slab, khalf, parity) -- besides its 16-deep half of every 32-channel block a wave only takes the channel blocks
+// of its PARITY.  A stage holds BP = 2 consecutive channel blocks (halo + weights of both), the two parities work on them concurrently:
+// 12 waves = 3 per SIMD, each SIMD carries 3/4 of the matrix work of the 8-wave kernel's, in half as many (twice as long) steps, so the
+// per-step skeleton (wait, barrier, DMA issue) is paid half as often and hidden by three waves instead of two.
+// Everything else is conv_halo10_kernel: stages, rings, one barrier per 3-tap step, the shared epilogue -- with four partial-sum slab sets
+// that the four groups add on the read side (group g takes row group g).  A block past the end (odd CB) is staged as ZERO weights.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KH, int KW, int NSL, int BP>
+__global__ __launch_bounds__(128 * NSL * BP, 1) void conv_halo_bp_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TH = 2 * NSL, TW = 16;
+    constexpr int HWD = TW + KW - 1, HR = HWD * (TH + KH - 1);
+    constexpr int A_UNITS = (HR + 15) / 16;
+    constexpr int A_PLANE = A_UNITS * 1024, A_BLK = 2 * A_PLANE, A_BUF = BP * A_BLK;     // one stage = BP channel blocks x (hi, lo)
+    constexpr int NTAPS = KH * KW;
+    constexpr int TPS = 3;                                          // taps per step (the last step of a 5-tap filter has 2)
+    constexpr int NST = (NTAPS + TPS - 1) / TPS;                    // steps per stage (3 or 2)
+    constexpr int B_TAP = 4096, B_BLK = TPS * B_TAP, B_SLOT = BP * B_BLK;   // per tap and block: 32 weight rows x 64 B x 2 planes
+    constexpr int O_B = 2 * A_BUF;
+    constexpr int NW = 2 * BP * NSL;                                // waves
+    constexpr int NQ = NW / 2;                                      // DMA roles per plane: wave (q, plane), plane = wave_all & 1, q = wave_all >> 1
+    // per plane a stage is BP * A_UNITS halo pieces of 1 KB and a weight slot BP * 2 * ntp; wave q takes pieces q + NQ i.  Every wave issues the
+    // SAME number of LDS-DMA instructions (the counted vmcnt waits are compile-time): indices past the end are dummy pieces.
+    constexpr int NIA = (BP * A_UNITS + NQ - 1) / NQ;               // halo load instructions per wave per stage
+    constexpr int O_SCR = O_B + 2 * B_SLOT;                         // 1 KB scratch behind the weight slots
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave_all / NSL, wave = wave_all - grp * NSL;    // compute role: pixel slab `wave`, k-group grp = parity * 2 + khalf
+    const int khalf = grp & 1, bpar = grp >> 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.z;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    int y0, x0, n0;
+    {
+        const int ntn = a.n_tiles;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int mt = (slot / ntn) * 8 + xcd;
+        if (mt >= tiles_x * tiles_y) return;
+        n0 = (slot - (slot / ntn) * ntn) * 32;
+        const int ty = mt / tiles_x;
+        y0 = ty * TH;
+        x0 = (mt - ty * tiles_x) * TW;
+    }
+
+    // ---- LDS-DMA sources ------------------------------------------------------------------------------------------
+    const int urow = lane >> 2;
+    const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    const int q = wave_all >> 1;
+    const bool lo_p = wave_all & 1;
+    unsigned aoff[NIA];
+    int a_dst_off[NIA], a_blk[NIA];                                 // destination inside a stage (or the scratch KB) and block of the stage
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int pi = q + NQ * i;
+        const int blk = pi / A_UNITS, unit = pi - blk * A_UNITS;
+        const bool real = pi < BP * A_UNITS;
+        const int row = unit * 16 + urow;
+        const int hy = row / HWD, hx = row - hy * HWD;
+        const int py = y0 - a.pad_h + hy, px = x0 - a.pad_w + hx;
+        const bool ok = real && row < HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
+        aoff[i] = ok ? (unsigned)(((py * a.W + px) * 32 + uchunk) * 2) : 0x80000000u;
+        a_blk[i] = real ? blk : 0;
+        a_dst_off[i] = real ? blk * A_BLK + unit * 1024 + (lo_p ? A_PLANE : 0) : -1;
+    }
+    const unsigned wvo0 = (unsigned)(((n0 + urow) * 32 + uchunk) * 2), wvo1 = wvo0 + 16 * 64;   // weight rows of unit 0 / 1
+    const int CB2 = a.CB - a.CB1;
+    const int plane_b = a.P_in * 64;
+    const rsrc_t r_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_p ? a.xl : a.xh) + (long long)b * a.CB1 * a.P_in * 32), 0, a.CB1 * plane_b, 0x00020000);
+    const rsrc_t r_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_p ? a.x2l : a.x2h) + (long long)b * CB2 * a.P_in * 32), 0, CB2 * plane_b, 0x00020000);
+    const int wtile_b = a.cout_pad * 64;
+    const rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(lo_p ? a.wl : a.wh), 0, NTAPS * a.CB * wtile_b, 0x00020000);
+    char* const w_dst = lds + O_B + (lo_p ? 2048 : 0);
+
+    // halo of stage SG (channel blocks SG * BP ...) into stage buffer BUF; a block past the end re-reads the last one (its weights are zero)
+#define HB_ISSUE_A(SG, BUF, SEL, NSEL)                                                                                   \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NIA; ++i) if (i % (NSEL) == (SEL)) {                                       \
+            const int cb0_ = (SG) * BP + a_blk[i];                                                                       \
+            const int cbi_ = cb0_ < a.CB ? cb0_ : a.CB - 1;                                                              \
+            const bool first_ = cbi_ < a.CB1;                                                                            \
+            const int so_ = (first_ ? cbi_ : cbi_ - a.CB1) * plane_b;                                                    \
+            char* const dst_ = a_dst_off[i] >= 0 ? lds + (BUF) * A_BUF + a_dst_off[i] : lds + O_SCR;                     \
+            if (first_) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a1, (lptr_t)dst_, 16, aoff[i], so_, 0, 0);            \
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a2, (lptr_t)dst_, 16, aoff[i], so_, 0, 0);                   \
+        }                                                                                                                \
+    }
+    // weight slot for step (SG, ST): taps ST*TPS .. of the BP blocks; piece idx -> block idx / (2 ntp), tap (idx % (2 ntp)) / 2, unit idx & 1.
+    // ST is a compile-time constant.  A block >= CB: out-of-range source = ZEROS in LDS (its MFMAs run on them and add nothing).
+#define HB_ISSUE_B(SG, ST, SLOT, SEL, NSEL)                                                                              \
+    {                                                                                                                    \
+        constexpr int ntp_ = (NTAPS - (ST) * TPS) < TPS ? (NTAPS - (ST) * TPS) : TPS;      /* taps of this step */       \
+        constexpr int nib_ = (BP * 2 * ntp_ + NQ - 1) / NQ;                                                              \
+        _Pragma("unroll") for (int i = 0; i < nib_; ++i) if (i % (NSEL) == (SEL)) {                                      \
+            const int pj_ = q + NQ * i;                                                                                  \
+            const int blk_ = pj_ / (2 * ntp_), idx_ = pj_ - blk_ * (2 * ntp_);                                           \
+            const int cbi_ = (SG) * BP + blk_;                                                                           \
+            const bool real_ = pj_ < BP * 2 * ntp_;                                                                      \
+            const bool data_ = real_ && cbi_ < a.CB;                                                                     \
+            const int so_ = data_ ? (((ST) * TPS + (idx_ >> 1)) * a.CB + cbi_) * wtile_b : 0;                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(real_ ? w_dst + (SLOT) * B_SLOT + blk_ * B_BLK + (idx_ >> 1) * B_TAP + (idx_ & 1) * 1024 : lds + O_SCR), 16, \
+                                                     data_ ? ((idx_ & 1) ? wvo1 : wvo0) : 0x80000000u, so_, 0, 0);       \
+        }                                                                                                                \
+    }
+
+    f32x16 hh[1], x1, x2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        hh[0][r] = 0.f;
+        x1[r] = 0.f;
+        x2[r] = 0.f;
+    }
+
+    HB_ISSUE_A(0, 0, 0, 1)
+    HB_ISSUE_B(0, 0, 0, 0, 1)
+
+    const int R0 = (wave * 2 + slab_row(l31)) * HWD + slab_col(l31);
+    const int kq = khalf * 2 + kh;                                  // this lane's 16-B k-chunk of the 64-B row
+    const int wro = l31 * 64 + ((kq ^ ((l31 >> 2) & 3)) * 16);      // weight fragment offset inside a (tap, plane) tile
+    const int nstages = (a.CB + BP - 1) / BP;
+    int cur = 0;
+    for (int sg = 0; sg < nstages; ++sg) {
+        const char* abuf = lds + (sg & 1) * A_BUF + bpar * A_BLK;
+        static_for<0, NTAPS>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int st = t / TPS, j = t % TPS;
+            if (j == 0) {                          // ---- step boundary
+                // in flight, oldest first: [halo of stage sg+1 (issued at st 0, AFTER that step's weights)], weights of this step
+                if (!CONV_SPREAD_DMA && NST > 1 && st == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (!CONV_SPREAD_DMA) {
+                    constexpr int stn = (st + 1) % NST;
+                    const int sgn = sg + (st + 1) / NST;
+                    HB_ISSUE_B(sgn, stn, cur ^ 1, 0, 1)
+                    if (st == 0) HB_ISSUE_A(sg + 1, (sg + 1) & 1, 0, 1)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (CONV_SPREAD_DMA) {
+                constexpr int ntc = (NTAPS - st * TPS) < TPS ? (NTAPS - st * TPS) : TPS;
+                constexpr int stn = (st + 1) % NST;
+                const int sgn = sg + (st + 1) / NST;
+                if (st == 0) HB_ISSUE_A(sg + 1, (sg + 1) & 1, j, ntc)
+                HB_ISSUE_B(sgn, stn, cur ^ 1, j, ntc)
+            }
+            const char* wcur = lds + O_B + cur * B_SLOT + bpar * B_BLK;
+            const int R = R0 + (t / KW) * HWD + (t % KW);
+            const int ao = R * 64 + ((kq ^ ((R >> 2) & 3)) * 16);
+            const half8 xh = *reinterpret_cast<const half8*>(abuf + ao);
+            const half8 xl = *reinterpret_cast<const half8*>(abuf + A_PLANE + ao);
+            const half8 wh = *reinterpret_cast<const half8*>(wcur + j * B_TAP + wro);
+            const half8 wl = *reinterpret_cast<const half8*>(wcur + j * B_TAP + 2048 + wro);
+            hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh[0], 0, 0, 0);   // D[channel][pixel]
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, x1, 0, 0, 0);
+            x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, x2, 0, 0, 0);
+            if (j == TPS - 1 || t == NTAPS - 1) {
+                __builtin_amdgcn_sched_barrier(0);   // fragment reads complete before the next barrier releases the refill
+                cur ^= 1;
+            }
+        });
+    }
+#undef HB_ISSUE_A
+#undef HB_ISSUE_B
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- the 2 * BP partial sums are combined on the read side of the shared epilogue (each group stages its partial sums)
+    f32x16 xx[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xx[0][r] = x1[r] + x2[r];
+    const int W = a.W, H = a.H, yw = y0 + wave * 2;
+    conv_epilogue<1, NW, 2 * BP>(a, hh, xx, b, [=](int row) {
         const int y = yw + slab_row(row), x = x0 + slab_col(row);
         return (y < H && x < W) ? y * W + x : -1; }, n0, lane, wave, tid, grp == 0, reinterpret_cast<float*>(lds), grp);
 #endif
@@ -1785,6 +1991,16 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         hipLaunchKernelGGL((conv_halo10_kernel<KHH, KWW, NSLL>), gridn, dim3(128 * (NSLL)), lds, s, a);                \
     }
 #define LAUNCH_HALO10(KHH, KWW) LAUNCH_HALO_NSL(KHH, KWW, 5, patches10)
+#define LAUNCH_HALO12(KHH, KWW)                                                                                        \
+    {                                                                                                                  \
+        constexpr int au_ = ((16 + (KWW) - 1) * (6 + (KHH) - 1) + 15) / 16;                                            \
+        const int main_ = 2 * 2 * 2 * au_ * 1024 + 2 * 2 * 3 * 4096 + 1024;                                            \
+        const int epi_ = (2 * 12 * 32 + 4 * 3 * 32 * CONV_STG_STRIDE) * 4;                                             \
+        const int lds = main_ > epi_ ? main_ : epi_;                                                                   \
+        dim3 gridn((patches6 + 7) / 8 * 8 * a.n_tiles, 1, d->B);                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_bp_kernel<KHH, KWW, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((conv_halo_bp_kernel<KHH, KWW, 3, 2>), gridn, dim3(768), lds, s, a);                        \
+    }
 #define LAUNCH_HALO8(KHH, KWW)                                                                                         \
     {                                                                                                                  \
         const int lds = 2 * 2 * (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16) * 1024 + 2 * 3 * 4096;                   \
@@ -1797,14 +2013,23 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         // 10 x 16 patches when the 8 x 16 grid needs a second workgroup on some CUs and the 10 x 16 grid does not
         const int patches10 = bflow::ceil_div(d->H, 10) * bflow::ceil_div(d->W, 16);
         const long long wg8 = (long long)patches * d->B * a.n_tiles, wg10 = (long long)patches10 * d->B * a.n_tiles;
-        // (6 x 16 patches = 3 slabs, for the 128-channel convolutions that leave 96 CUs idle, were measured: q 12.2 vs 11.9 us -- not built)
-        const bool ten = small8 && ((force && strncmp(force, "halo", 4) == 0 && force[4]) ? strcmp(force, "halo10") == 0 : (wg8 > 256 && wg10 <= 256));
-        if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (ten) LAUNCH_HALO10(3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }
-        else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else if (ten) LAUNCH_HALO10(1, 5) else if (small8) LAUNCH_HALO8(1, 5) else LAUNCH_HALO(1, 1, 5) }
-        else { if (nt == 2) LAUNCH_HALO(2, 5, 1) else if (ten) LAUNCH_HALO10(5, 1) else if (small8) LAUNCH_HALO8(5, 1) else LAUNCH_HALO(1, 5, 1) }
+        // (6 x 16 patches = 3 slabs on SIX waves, two k-groups, were measured in round 3: q 12.2 vs 11.9 us -- 2 / 2 / 1 / 1 waves per SIMD)
+        const bool forced_variant = force && strncmp(force, "halo", 4) == 0 && force[4];
+        const bool ten = small8 && (forced_variant ? strcmp(force, "halo10") == 0 : (wg8 > 256 && wg10 <= 256));
+        // 6 x 16 patches on 12 waves (conv_halo_bp_kernel: four k-groups) when the 8 x 16 grid leaves more than a quarter of the chip idle and
+        // the 6 x 16 grid still fits one round: the <= 128-channel convolutions at 60 x 80 (160 -> 200 workgroups carrying 3 instead of 4
+        // wave tiles each).  BFLOW_CONV_KERNEL=halo12 / halo8x16 force either side (tests, A/B).
+        const int patches6 = bflow::ceil_div(d->H, 6) * bflow::ceil_div(d->W, 16);
+        const long long wg6 = (long long)patches6 * d->B * a.n_tiles;
+        static const bool no_h12 = getenv("BFLOW_CONV_NO_HALO12") != nullptr;
+        const bool twelve = small8 && !ten && (forced_variant ? strcmp(force, "halo12") == 0 : (!no_h12 && wg8 <= 192 && wg6 <= 256 && wg6 > wg8));
+        if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (ten) LAUNCH_HALO10(3, 3) else if (twelve) LAUNCH_HALO12(3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }
+        else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else if (ten) LAUNCH_HALO10(1, 5) else if (twelve) LAUNCH_HALO12(1, 5) else if (small8) LAUNCH_HALO8(1, 5) else LAUNCH_HALO(1, 1, 5) }
+        else { if (nt == 2) LAUNCH_HALO(2, 5, 1) else if (ten) LAUNCH_HALO10(5, 1) else if (twelve) LAUNCH_HALO12(5, 1) else if (small8) LAUNCH_HALO8(5, 1) else LAUNCH_HALO(1, 5, 1) }
 #undef LAUNCH_HALO
 #undef LAUNCH_HALO8
 #undef LAUNCH_HALO10
+#undef LAUNCH_HALO12
 #undef LAUNCH_HALO_NSL
         return bflow::launch_status("conv_split(halo)");
     }

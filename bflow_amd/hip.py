@@ -24,7 +24,7 @@ MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
-    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_build_tiled", "bflow_split_to_x8", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_rows_to_split", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_norm_train_finalize", "bflow_norm_train_apply", "bflow_norm_train_bwd_stats", "bflow_norm_train_bwd_finalize", "bflow_norm_train_bwd_apply", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
+    "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_build_tiled", "bflow_split_to_x8", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_conv_thin_mfma_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_rows_to_split", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_norm_train_finalize", "bflow_norm_train_apply", "bflow_norm_train_bwd_stats", "bflow_norm_train_bwd_finalize", "bflow_norm_train_bwd_apply", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_corr_lookup_conv1x1", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
@@ -121,6 +121,7 @@ def lib() -> ctypes.CDLL:
         "bflow_conv_stem": [ctypes.POINTER(StemDesc), vp],
         "bflow_conv_split": [ctypes.POINTER(ConvDesc), vp],
         "bflow_conv_thin_acc": [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, vp],
+        "bflow_conv_thin_mfma_acc": [vp, vp, vp, vp, i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, vp],
         "bflow_wgrad_pack": [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, vp],
         "bflow_blocked_f32_to_nchw": [vp, vp, i, i, i, i, i, vp, vp],
         "bflow_pow2_scale": [vp, ll, f, vp, vp, vp],

@@ -118,28 +118,40 @@ class PackedConvWeight:
         return self.planes, self.meta
 
 
+THIN_MFMA = os.environ.get("BFLOW_NO_THIN_MFMA") is None      # A/B switch (tools/): the matrix-core form of the thin head (bflow_conv_thin_mfma_acc)
+
+
 class ThinConvWeight:
-    """fp32 weights of a thin-output convolution laid out tap-major (KH*KW, Cout, Cin) for bflow_conv_thin_acc."""
+    """Weights of a thin-output convolution: fp32 tap-major (KH*KW, Cout, Cin) for bflow_conv_thin_acc, and -- for a 3 x 3 filter with
+    9 * Cout <= 64 -- the derived 1 x 1 filter W'[tap * Cout + co][c] packed as a split tensor for bflow_conv_thin_mfma_acc."""
 
     def __init__(self):
         self._key = None
         self.w = None
+        self.mfma = None
 
     def get(self, weight: torch.Tensor):
         key = (weight.data_ptr(), weight._version, str(weight.device))
         if self._key != key:
             cout, cin, kh, kw = weight.shape
             with torch.no_grad():
-                self.w = weight.detach().float().permute(2, 3, 0, 1).reshape(kh * kw, cout, cin).contiguous()
+                w = weight.detach().float()
+                self.w = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin).contiguous()
+                self.mfma = None
+                if (kh, kw) == (3, 3) and 9 * cout <= 64 and cin % 32 == 0 and cin <= 256 and weight.is_cuda:
+                    taps = self.w.reshape(9 * cout, cin, 1, 1).contiguous()          # row = tap * Cout + co
+                    self.mfma = PackedConvWeight().get(taps)
             self._key, self.meta = key, (cout, cin, kh, kw)
-        return self.w, self.meta
+        return self.w, self.meta, self.mfma
 
 
 def conv_thin_acc(x: SplitTensor, packed, bias: Optional[torch.Tensor], acc_nchw: torch.Tensor, out_split: Optional[SplitTensor] = None,
-                  channel_offset: int = 0):
-    """acc_nchw (B, cout, H, W) fp32 += conv(x, w) + bias ("same" zero padding, stride 1, cout <= 32) on the vector ALU in fp32;
-    out_split's 32-channel block at `channel_offset` receives the updated values (see bflow_conv_thin_acc)."""
-    w, (cout, cin, kh, kw) = packed
+                  channel_offset: int = 0, mfma: Optional[bool] = None):
+    """acc_nchw (B, cout, H, W) fp32 += conv(x, w) + bias ("same" zero padding, stride 1, cout <= 32); out_split's 32-channel block at
+    `channel_offset` receives the updated values.  3 x 3 with 9 * cout <= 64 (the degree-2 Bezier head): on the matrix cores
+    (bflow_conv_thin_mfma_acc, taps as output channels); otherwise on the vector ALU in fp32 (bflow_conv_thin_acc).  mfma=False forces the latter."""
+    w, (cout, cin, kh, kw) = packed[0], packed[1]
+    mf = packed[2] if len(packed) > 2 else None
     B, H, W, _ = x.shape
     assert cin == x.channels_padded, f"input has {x.channels_padded} (padded) channels, weight expects {cin}"
     assert acc_nchw.dtype == torch.float32 and acc_nchw.is_contiguous() and tuple(acc_nchw.shape) == (B, cout, H, W)
@@ -149,6 +161,15 @@ def conv_thin_acc(x: SplitTensor, packed, bias: Optional[torch.Tensor], acc_nchw
     if out_split is not None:
         assert out_split.planes.shape[1] == B and out_split.H == H and out_split.W == W and channel_offset < out_split.channels_padded
         oh, ol, cbo, rows_o = out_split.hi.data_ptr(), out_split.lo.data_ptr(), out_split.planes.shape[2], out_split.rows
+    use_mfma = (THIN_MFMA if mfma is None else mfma) and mf is not None
+    if use_mfma:
+        planes, (_, cin_pad, _, _, cout_pad) = mf
+        assert cin_pad == cin
+        hip._check(hip.lib().bflow_conv_thin_mfma_acc(x.hi.data_ptr(), x.lo.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr(), cout_pad,
+                                                      None if bias is None else hip._dev(bias, name="bias"), acc_nchw.data_ptr(), oh, ol, B, H, W, cin,
+                                                      x.rows, cout, cbo, channel_offset // 32, rows_o, channel_offset % 32, hip._stream()),
+                   "bflow_conv_thin_mfma_acc")
+        return
     hip._check(hip.lib().bflow_conv_thin_acc(x.hi.data_ptr(), x.lo.data_ptr(), hip._dev(w, name="weight"),
                                              None if bias is None else hip._dev(bias, name="bias"), acc_nchw.data_ptr(), oh, ol, B, H, W, cin,
                                              x.rows, cout, kh, kw, cbo, channel_offset // 32, rows_o, channel_offset % 32, hip._stream()), "bflow_conv_thin_acc")

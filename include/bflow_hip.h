@@ -271,6 +271,17 @@ int bflow_conv_thin_acc(const void* x_hi, const void* x_lo, const float* w_packe
                         void* out_lo, int B, int H, int W, int C, int in_rows_per_image, int Cout, int KH, int KW,
                         int out_channel_blocks, int out_block, int out_rows_per_image, int out_channel_in_block, bflow_stream_t stream);
 
+/* bflow_conv_thin_mfma_acc: the SAME operation as bflow_conv_thin_acc (BezierHead.conv2 + delta_update_params, update.py:12-18,
+ * bezier.py:137-139) for a 3 x 3 filter with 9 * Cout <= 64 (degree <= 3) on the matrix cores, "taps as output channels": one dense
+ * 1 x 1 GEMM  Y[pixel][tap * Cout + co] = sum_c x[pixel][c] w[co][c][tap]  over a workgroup's 4 x 18 halo patch (operands fetched once
+ * by LDS-DMA), then  out[p][co] = sum_tap Y[p + tap][tap * Cout + co]  through LDS.  Products are the engine's three-pass split products.
+ *   w_hi/w_lo : the derived 1 x 1 filter W'[tap * Cout + co][c] = w[co][c][tap / 3][tap % 3] packed by bflow_conv_pack_weights
+ *               (KH = KW = 1, Cout' = 9 * Cout, cout_pad >= 64, cin_pad = C): (C/32, cout_pad, 32) fp16 planes;
+ *   everything else as bflow_conv_thin_acc.                                                                                   */
+int bflow_conv_thin_mfma_acc(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, int cout_pad, const float* bias,
+                             float* acc_nchw, void* out_hi, void* out_lo, int B, int H, int W, int C, int in_rows_per_image, int Cout,
+                             int out_channel_blocks, int out_block, int out_rows_per_image, int out_channel_in_block, bflow_stream_t stream);
+
 /* bflow_plane_stats: stats[p] = (sum, sum of squares) of plane p of an NCHW fp32 tensor (planes = B*C, HW % 4 == 0).
  * bflow_norm_act_split: out = act_out( res + act_a( norm_a(a) ) ) -> split NHWC (and/or fp32 NHWC), where
  *     a     : fp32 NHWC (B, HW, C), or NCHW (B, C, HW) when a_is_nchw (transposed on the fly);

@@ -920,6 +920,51 @@ def test_no_silent_library_paths(monkeypatch):
 
 
 @pytest.mark.parametrize("cin,cout,k,pad,H,W,B,force", [
+    (256, 128, (1, 5), (0, 2), 60, 80, 1, None),      # q of the GRU at DSEC size: 160 workgroups of 8x16 patches -> 200 of 6x16 on 12 waves (auto)
+    (256, 128, (5, 1), (2, 0), 60, 80, 1, None),
+    (256, 126, (3, 3), (1, 1), 60, 80, 1, None),      # the motion encoder's last convolution (Cout not a multiple of 32)
+    (160, 96, (3, 3), (1, 1), 33, 47, 1, "halo12"),   # forced: ODD number of channel blocks (the last stage has one real block), ragged patches
+    (32, 64, (1, 5), (0, 2), 6, 16, 2, "halo12"),     # one channel block, exactly one patch per image
+    (224, 32, (5, 1), (2, 0), 21, 50, 1, "halo12"),
+])
+def test_conv_halo12_vs_fp64_and_8x16(cin, cout, k, pad, H, W, B, force, monkeypatch):
+    """The 12-wave / 6x16-patch small-grid kernel (conv_halo_bp_kernel: two k-halves x two channel-block parities) against fp64 and against
+    the 8x16 kernel.  The four partial sums are added in another order than the 8-wave kernel's two, so the comparison with it is a few
+    fp32 ulps of the accumulated magnitude, not bit-for-bit; gate epilogues on this kernel: test_update_block_step_split_vs_oracle and
+    the end-to-end goldens (q of both GRU halves takes it at every size those tests run)."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(6)
+    x = rs.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, *k)) / np.sqrt(cin * k[0] * k[1])).astype(np.float32)
+    bias = rs.standard_normal(cout).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(bias).double(), padding=pad)
+    mag = torch.nn.functional.conv2d(torch.from_numpy(np.abs(x)).double(), torch.from_numpy(np.abs(w)).double(), None, padding=pad) + 1.0
+    xs = S.from_nchw(cu(x))
+    pk = S.PackedConvWeight().get(cu(w))
+    if force:
+        monkeypatch.setenv("BFLOW_CONV_KERNEL", force)
+    stats = torch.zeros((B, cout, 2), dtype=torch.float64, device=DEV)
+    o_split, o_f32 = S.conv(xs, pk, padding=pad, shift=cu(bias), act=S.ACT_RELU, want_f32=True, stats=stats)
+    refr = torch.relu(ref)
+    got = S.blocked_f32_to_nhwc(o_f32, H, W, cout).permute(0, 3, 1, 2).cpu().double()
+    got_s = o_split.float_nhwc().permute(0, 3, 1, 2).cpu().double()
+    err, err_s = float(((got - refr).abs() / mag).max()), float(((got_s - refr).abs() / mag).max())
+    print(f"halo12 {cin}->{cout} {k}: err/sum|x||w| fp32-out {err:.2e} split-out {err_s:.2e}")
+    assert err < 5e-7 and err_s < 1e-6
+    np.testing.assert_allclose(stats[..., 0].cpu().numpy(), refr.sum(dim=(2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    # the same convolution as a two-source [x[:, :c1] | x[:, c1:]] input (the GRU's virtual concatenation [h | M]) gives the same bits
+    if cin >= 64:
+        c1 = (cin // 64) * 32
+        xa, xb = S.from_nchw(cu(x[:, :c1])), S.from_nchw(cu(x[:, c1:]))
+        _, o_two = S.conv(xa, pk, x2=xb, padding=pad, shift=cu(bias), act=S.ACT_RELU, want_split=False, want_f32=True)
+        assert torch.equal(o_two, o_f32)
+    monkeypatch.setenv("BFLOW_CONV_KERNEL", "halo8x16")
+    _, o2 = S.conv(xs, pk, padding=pad, shift=cu(bias), act=S.ACT_RELU, want_f32=True)
+    d8 = (S.blocked_f32_to_nhwc(o2, H, W, cout) - S.blocked_f32_to_nhwc(o_f32, H, W, cout)).abs().cpu().double()
+    assert float((d8.permute(0, 3, 1, 2) / mag).max()) < 3e-7
+
+
+@pytest.mark.parametrize("cin,cout,k,pad,H,W,B,force", [
     (288, 256, (1, 5), (0, 2), 60, 80, 1, None),      # z|r of the GRU at DSEC size: 320 workgroups of 8x16 patches -> 240 of 10x16 (auto)
     (288, 256, (5, 1), (2, 0), 60, 80, 1, None),
     (128, 256, (3, 3), (1, 1), 60, 80, 1, None),      # first head convolution
@@ -976,10 +1021,39 @@ def test_conv_thin_acc_vs_fp64(cin, cout, k, H, W, B, blocks, blk):
     acc = cu(acc0.copy())
     out = S.SplitTensor.empty(B, H, W, blocks * 32, DEV)
     out.planes.fill_(7.0)                                          # sentinel: only block `blk` may change
-    S.conv_thin_acc(xs, S.ThinConvWeight().get(cu(w)), cu(bias), acc, out_split=out, channel_offset=blk * 32)
+    pkw = S.ThinConvWeight().get(cu(w))
+    S.conv_thin_acc(xs, pkw, cu(bias), acc, out_split=out, channel_offset=blk * 32, mfma=False)
     err = float(((acc.cpu().double() - ref).abs() / mag).max())
     print(f"conv_thin {cin}->{cout} {k}x{k}: err/sum|x||w| {err:.2e}")
     assert err < 3e-7                                              # fp32 FMA accumulation over <= 2304 products
+    if k == 3 and 9 * cout <= 64:
+        # the matrix-core form (bflow_conv_thin_mfma_acc: taps as output channels, three-pass split products, weights split to 22 bits): same
+        # accumulator update, same emitted block, inside another block with its neighbours left alone (the merged Bezier channels of M)
+        assert pkw[2] is not None
+        accm = cu(acc0.copy())
+        outm = S.SplitTensor.empty(B, H, W, blocks * 32, DEV)
+        outm.planes.fill_(7.0)
+        S.conv_thin_acc(xs, pkw, cu(bias), accm, out_split=outm, channel_offset=blk * 32, mfma=True)
+        errm = float(((accm.cpu().double() - ref).abs() / mag).max())
+        print(f"conv_thin (MFMA) {cin}->{cout}: err/sum|x||w| {errm:.2e}")
+        assert errm < 5e-7
+        om = outm.float_nhwc().permute(0, 3, 1, 2).cpu()
+        assert float((om[:, blk * 32:blk * 32 + cout] - accm.cpu()).abs().max()) <= float(accm.abs().max()) * 2.0 ** -21
+        assert float(om[:, blk * 32 + cout:blk * 32 + 32].abs().max()) == 0.0
+        restm = torch.cat([om[:, :blk * 32], om[:, blk * 32 + 32:]], dim=1)
+        assert restm.numel() == 0 or bool((restm == 7.0 + 7.0 / 2048.0).all())
+        c_in_blk = 32 - cout - (32 - cout) % 4 if cout % 4 == 0 else 0
+        if c_in_blk:                                               # merged layout: channels [c_in_blk, + cout) of block blk, the rest untouched
+            accn = cu(acc0.copy())
+            outn = S.SplitTensor.empty(B, H, W, blocks * 32, DEV)
+            outn.planes.fill_(7.0)
+            S.conv_thin_acc(xs, pkw, cu(bias), accn, out_split=outn, channel_offset=blk * 32 + c_in_blk, mfma=True)
+            on = outn.float_nhwc().permute(0, 3, 1, 2).cpu()
+            assert torch.equal(accn, accm)
+            assert float((on[:, blk * 32 + c_in_blk:blk * 32 + c_in_blk + cout] - accn.cpu()).abs().max()) <= float(accn.abs().max()) * 2.0 ** -21
+            keep = torch.ones(on.shape[1], dtype=torch.bool)
+            keep[blk * 32 + c_in_blk:blk * 32 + c_in_blk + cout] = False
+            assert bool((on[:, keep] == 7.0 + 7.0 / 2048.0).all())
     o = out.float_nhwc().permute(0, 3, 1, 2).cpu()
     got_blk = o[:, blk * 32:blk * 32 + 32]
     a = acc.cpu()
@@ -989,7 +1063,7 @@ def test_conv_thin_acc_vs_fp64(cin, cout, k, H, W, B, blocks, blk):
     assert rest.numel() == 0 or bool((rest == 7.0 + 7.0 / 2048.0).all())
     # no output block: only the accumulator is updated
     acc2 = cu(acc0.copy())
-    S.conv_thin_acc(xs, S.ThinConvWeight().get(cu(w)), None, acc2)
+    S.conv_thin_acc(xs, S.ThinConvWeight().get(cu(w)), None, acc2, mfma=False)
     ref2 = ref - torch.from_numpy(bias).double().view(1, -1, 1, 1)
     assert float(((acc2.cpu().double() - ref2).abs() / mag).max()) < 3e-7
     with pytest.raises(hip.BflowHipError):

@@ -1,0 +1,14 @@
+set -uo pipefail
+REPO="${GRAFT_REPO_ROOT:-$PWD}"; OUT="$REPO/gpurun_out/r04_thin2"; mkdir -p "$OUT"
+cd "$REPO"
+timeout 900 python -m pytest tests -m gpu -x -q -k "conv_thin or update_block_step or e2e_forward_vs_reference" > "$OUT/pytest.txt" 2>&1
+tail -4 "$OUT/pytest.txt"
+cd /tmp && export TMPDIR=/tmp
+python "$REPO/tools/thin_probe.py" 2>/dev/null | tee "$OUT/thin_probe.txt"
+for abl in 0 1 2 4 8 3 7 15; do BFLOW_LOOKUP_ABL=$abl python "$REPO/tools/k7_abl_probe.py" 2>/dev/null | grep ABL | tee -a "$OUT/k7_abl.txt"; done
+for tp in 4 8; do BFLOW_LOOKUP_TP=$tp python "$REPO/tools/k7_abl_probe.py" 2>/dev/null | grep ABL | tee -a "$OUT/k7_abl.txt"; done
+run() { python "$REPO/bench.py" --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], 'frames/s,', d['ms_per_gru_iter'], 'ms/iter, fixed', d['ms_fixed_part'], 'c4', d['c4_strong']['value'])" | tee -a "$OUT/ab.txt"; }
+for i in 1 2; do
+  run default
+  BFLOW_NO_THIN_MFMA=1 run no_thin_mfma
+done

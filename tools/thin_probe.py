@@ -16,5 +16,9 @@ for cout in (4, 20):
     bez = torch.zeros(B, cout, H, W, device=dev)
     M = S.SplitTensor.empty(B, H, W, 128, dev, zero=True)
     off = 128 - cout if cout % 4 == 0 and cout <= 32 and (128 - cout) // 32 == 3 else 96
-    t = graph_time(lambda: S.conv_thin_acc(d1, w, bias, bez, out_split=M, channel_offset=off))
-    print(f"thin head 3x3 256 -> {cout}: {t*1e3:.1f} us in-graph")
+    t = graph_time(lambda: S.conv_thin_acc(d1, w, bias, bez, out_split=M, channel_offset=off, mfma=False))
+    line = f"thin head 3x3 256 -> {cout}: vector ALU {t*1e3:.1f} us in-graph"
+    if w[2] is not None:
+        t2 = graph_time(lambda: S.conv_thin_acc(d1, w, bias, bez, out_split=M, channel_offset=off, mfma=True))
+        line += f", matrix cores (taps as output channels) {t2*1e3:.1f} us"
+    print(line)
