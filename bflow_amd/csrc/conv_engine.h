@@ -81,7 +81,19 @@ __device__ __forceinline__ void norm_coeffs(const double* stats, const float* sc
 // fp16 contiguous per wave instruction).
 // ---------------------------------------------------------------------------------------------------------------------
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define CONV_STG_STRIDE 36                       // floats per staged pixel row (32 + 4 pad)
+// Output stores of the shared epilogue.  CONV_NT_STORES = 1 (tools A/B, tools/build_flag_variant.sh): non-temporal -- the consumer is the NEXT
+// kernel, which starts with a cold L2 anyway, so nothing is lost by writing around it, and the lines leave during the epilogue instead of
+// in the write-back at the end of the kernel.
+#ifndef CONV_NT_STORES
+#define CONV_NT_STORES 0
+#endif
+template <typename V>
+__device__ __forceinline__ void epi_store(V* p, V v) {
+    if (CONV_NT_STORES) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 // `pixel_of(row)` maps row 0..31 of the wave's slab to the pixel row of the output image (or -1: outside, not written).
 // Sum over the 8 lanes that share lane & 7 (xor 8, 16, 32) on the vector ALU: DPP row rotation inside a 16-lane row, then the
@@ -225,8 +237,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                     // "zr" convolution and a "blend" convolution map 1:1, the r half is shifted down by CBo blocks.
                     const long long gb = gbase + (long long)m * 32;
                     if (a.gate == 1 && !r_half) {
-                        *reinterpret_cast<float4*>(a.out_f32 + gb) = make_float4(bflow::gate_sigmoid(v[0]), bflow::gate_sigmoid(v[1]),
-                                                                                 bflow::gate_sigmoid(v[2]), bflow::gate_sigmoid(v[3]));
+                        epi_store(reinterpret_cast<f32x4v*>(a.out_f32 + gb), f32x4v{bflow::gate_sigmoid(v[0]), bflow::gate_sigmoid(v[1]),
+                                                                                     bflow::gate_sigmoid(v[2]), bflow::gate_sigmoid(v[3])});
                     } else {
                         const half4v hh4 = g_hh[it], hl4 = g_hl[it];
                         float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -242,11 +254,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                             h4[k] = x1;
                             l4[k] = x2;
                         }
-                        *reinterpret_cast<half4v*>(a.oh + gb) = h4;
-                        *reinterpret_cast<half4v*>(a.ol + gb) = l4;
+                        epi_store(reinterpret_cast<half4v*>(a.oh + gb), h4);
+                        epi_store(reinterpret_cast<half4v*>(a.ol + gb), l4);
                     }
                 } else if (mok) {
-                    if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + ob + (long long)m * 32) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (a.out_f32) epi_store(reinterpret_cast<f32x4v*>(a.out_f32 + ob + (long long)m * 32), f32x4v{v[0], v[1], v[2], v[3]});
                     if (a.oh && !(a.keep_pad && !cok[0])) {     // keep_pad: a group of 4 pad channels belongs to somebody else
                         half4v h4, l4;
 #pragma unroll
@@ -256,8 +268,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
                             h4[k] = x1;
                             l4[k] = x2;
                         }
-                        *reinterpret_cast<half4v*>(a.oh + ob + (long long)m * 32) = h4;
-                        *reinterpret_cast<half4v*>(a.ol + ob + (long long)m * 32) = l4;
+                        epi_store(reinterpret_cast<half4v*>(a.oh + ob + (long long)m * 32), h4);
+                        epi_store(reinterpret_cast<half4v*>(a.ol + ob + (long long)m * 32), l4);
                     }
                 }
             }

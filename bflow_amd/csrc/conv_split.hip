@@ -1351,6 +1351,15 @@ struct StemArgs {
     int B_src, C_src;
     int win[8];
     int layout;                // 0: k = (channel, tap) im2col tiles built in LDS (conv_stem_kernel); 1: row windows (conv_stem_rows_kernel)
+    // General input (row-window kernel only; `general` = 0 keeps the plain path above untouched): the Cin channels of an image are
+    //   segment 0: channels [0, c1) -- window group g = n / B_src reads channels [win[g], + c1) of image n % B_src of ITS OWN source tensor
+    //              xw[g] (C_src channels per image): the two images of raft.py:136 without torch.cat, or the voxel windows as before;
+    //   segment 1: channels [c1, Cin) -- image n % B_src of x2 (Cin - c1 channels per image): `img0` behind the context bins (raft.py:137-140);
+    // element type per segment (0 fp32, 1 uint8) and `norm`: 2 * (v / 255) - 1 applied to in-image elements (raft.py:134; padding stays 0).
+    int general, c1;
+    const void* xw[8];
+    const void* x2;
+    int dt0, dt1, norm0, norm1;
 };
 
 #ifndef STEM_ABL
@@ -1633,11 +1642,12 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
         __syncthreads();                                                      // the previous chunk's patch is drained
         {   // ---- the chunk's input patch: thread = patch pixel, all channels; out-of-image = out-of-range buffer offset = 0
             const long long img = (long long)sa.H * sa.W;
+            constexpr int NPX = (PR * PC + CT - 1) / CT;
+            float pv[NPX][8];
+            if (!sa.general) {
             const long long x_base = sa.B_src > 0 ? ((long long)(b % sa.B_src) * sa.C_src + sa.win[b / sa.B_src] + c_first) * img
                                                   : ((long long)b * sa.Cin + c_first) * img;
             const rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.x + x_base), 0, (int)(nch * img * 4), 0x00020000);
-            constexpr int NPX = (PR * PC + CT - 1) / CT;
-            float pv[NPX][8];
 #pragma unroll
             for (int j = 0; j < NPX; ++j) {
                 const int p = tid + j * CT;
@@ -1649,6 +1659,45 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
                     const unsigned off = (ok && c < nch) ? (unsigned)(((c * sa.H + gy) * sa.W + gx) * 4) : 0x80000000u;
                     pv[j][c] = c < CH ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_x, off, 0, 0)) : 0.f;
                 }
+            }
+            } else {
+            // two segments, each fp32 or uint8, each with the image normalisation or without: BOTH segments' loads are issued for every channel,
+            // the one the channel does not belong to with an out-of-range offset (returns 0, costs no traffic) -- no per-channel branch, every
+            // load of the thread in flight together.  The element is the sum of the two (one of them is 0 by construction).
+            const int g = sa.B_src > 0 ? b / sa.B_src : 0, bi = sa.B_src > 0 ? b - g * sa.B_src : b;
+            const int es0 = sa.dt0 ? 1 : 4, es1 = sa.dt1 ? 1 : 4;
+            const int n0c = max(0, min(nch, sa.c1 - c_first));                 // channels of this chunk that come from segment 0
+            const int cs1 = max(sa.c1 - c_first, 0);                           // chunk-local channel where segment 1 starts
+            const int n1c = max(0, nch - cs1);
+            const char* base0 = reinterpret_cast<const char*>(sa.xw[g]) + ((long long)bi * sa.C_src + sa.win[g] + c_first) * img * es0;
+            const char* base1 = reinterpret_cast<const char*>(sa.x2) + ((long long)bi * (sa.Cin - sa.c1) + max(c_first - sa.c1, 0)) * img * es1;
+            const rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)base0, 0, (int)(n0c * img * es0), 0x00020000);
+            const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.x2 ? base1 : base0), 0, sa.x2 ? (int)(n1c * img * es1) : 0, 0x00020000);
+            bool okp[NPX];
+#pragma unroll
+            for (int j = 0; j < NPX; ++j) {
+                const int p = tid + j * CT;
+                const int pr = p / PC, pc = p - pr * PC;
+                const int gy = gy0 + pr, gx = gx0 + pc;
+                const bool ok = p < PR * PC && gy >= 0 && gy < sa.H && gx >= 0 && gx < sa.W;
+                okp[j] = ok;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (c >= CH) { pv[j][c] = 0.f; continue; }
+                    const bool in0 = ok && c < n0c, in1 = ok && c >= cs1 && c < nch;
+                    const unsigned o0 = in0 ? (unsigned)(((c * sa.H + gy) * sa.W + gx) * es0) : 0x80000000u;
+                    const unsigned o1 = in1 ? (unsigned)((((c - cs1) * sa.H + gy) * sa.W + gx) * es1) : 0x80000000u;
+                    const float v0 = sa.dt0 ? (float)(unsigned)__builtin_amdgcn_raw_buffer_load_b8(r0, o0, 0, 0)
+                                            : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, o0, 0, 0));
+                    const float v1 = sa.dt1 ? (float)(unsigned)__builtin_amdgcn_raw_buffer_load_b8(r1, o1, 0, 0)
+                                            : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, o1, 0, 0));
+                    // raft.py:134: 2 * (x / 255) - 1, the reference's operation order (a true division; 2 q is exact, so the contraction of
+                    // the last two steps into one FMA rounds identically); zero padding is applied to the NORMALISED image: padding stays 0
+                    const float q0 = (sa.norm0 && in0) ? 2.0f * (v0 / 255.0f) - 1.0f : v0;
+                    const float q1 = (sa.norm1 && in1) ? 2.0f * (v1 / 255.0f) - 1.0f : v1;
+                    pv[j][c] = q0 + q1;
+                }
+            }
             }
 #pragma unroll
             for (int j = 0; j < NPX; ++j) {
@@ -2151,16 +2200,38 @@ extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream
     sa.B_src = 0; sa.C_src = d->Cin;
     for (int i = 0; i < 8; ++i) sa.win[i] = 0;
     if (d->n_windows > 0) {
-        BFLOW_REQUIRE(d->n_windows <= 8 && d->window_starts && d->B % d->n_windows == 0 && d->src_channels >= d->Cin, BFLOW_E_ARG,
+        const int wwidth = d->x2 ? d->Cin - d->x2_channels : d->Cin;          // channels a window supplies (the rest comes from x2)
+        BFLOW_REQUIRE(d->n_windows <= 8 && d->window_starts && d->B % d->n_windows == 0 && d->src_channels >= wwidth && wwidth > 0, BFLOW_E_ARG,
                       "conv_stem: bad channel windows");
         sa.B_src = d->B / d->n_windows; sa.C_src = d->src_channels;
         for (int i = 0; i < d->n_windows; ++i) {
-            BFLOW_REQUIRE(d->window_starts[i] >= 0 && d->window_starts[i] + d->Cin <= d->src_channels, BFLOW_E_ARG, "conv_stem: window %d out of range", i);
+            BFLOW_REQUIRE(d->window_starts[i] >= 0 && d->window_starts[i] + wwidth <= d->src_channels, BFLOW_E_ARG, "conv_stem: window %d out of range", i);
             sa.win[i] = d->window_starts[i];
         }
     }
     sa.layout = d->layout;
     BFLOW_REQUIRE(d->layout == 0 || d->layout == 1, BFLOW_E_ARG, "conv_stem: layout must be 0 (im2col tiles) or 1 (row windows)");
+    sa.general = 0; sa.c1 = d->Cin; sa.x2 = nullptr; sa.dt0 = sa.dt1 = sa.norm0 = sa.norm1 = 0;
+    for (int i = 0; i < 8; ++i) sa.xw[i] = d->x;
+    if (d->window_bases || d->x2 || d->x_dtype || d->x_image_norm) {
+        BFLOW_REQUIRE(d->layout == 1, BFLOW_E_ARG, "conv_stem: multi-source / uint8 / normalised input needs the row-window kernel (layout 1)");
+        BFLOW_REQUIRE((d->x_dtype == 0 || d->x_dtype == 1) && (d->x2_dtype == 0 || d->x2_dtype == 1), BFLOW_E_ARG, "conv_stem: element types are 0 (fp32) or 1 (uint8)");
+        BFLOW_REQUIRE(!d->x2 || (d->x2_channels > 0 && d->x2_channels < d->Cin), BFLOW_E_ARG, "conv_stem: x2_channels must be in (0, Cin)");
+        BFLOW_REQUIRE(!d->window_bases || d->n_windows > 0, BFLOW_E_ARG, "conv_stem: window_bases needs n_windows");
+        sa.general = 1;
+        sa.c1 = d->x2 ? d->Cin - d->x2_channels : d->Cin;
+        if (d->n_windows > 0) {
+            BFLOW_REQUIRE(d->src_channels >= sa.c1, BFLOW_E_ARG, "conv_stem: source narrower than the window");
+            for (int i = 0; i < d->n_windows; ++i) {
+                BFLOW_REQUIRE(d->window_starts[i] + sa.c1 <= d->src_channels, BFLOW_E_ARG, "conv_stem: window %d out of range", i);
+                sa.xw[i] = d->window_bases ? (const void*)d->window_bases[i] : (const void*)d->x;
+                BFLOW_REQUIRE(sa.xw[i], BFLOW_E_ARG, "conv_stem: null window base %d", i);
+            }
+        } else {
+            sa.C_src = sa.c1;
+        }
+        sa.x2 = d->x2; sa.dt0 = d->x_dtype; sa.dt1 = d->x2_dtype; sa.norm0 = d->x_image_norm; sa.norm1 = d->x2_image_norm;
+    }
     const int ksteps_row = (d->ksize * sa.chunk + 15) / 16;                       // layout 1: 16-deep steps per filter row
     const int kb_expected = ((d->Cin + sa.chunk - 1) / sa.chunk) * (d->layout == 1 ? (d->ksize * ksteps_row + 1) / 2 : sa.kblocks_per_chunk);
     BFLOW_REQUIRE(d->k_blocks == kb_expected, BFLOW_E_ARG,

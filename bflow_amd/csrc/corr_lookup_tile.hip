@@ -233,8 +233,13 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
             l8[j] = ll;
         }
         const long long o = (((long long)b * CBk + cb) * Prow + n) * 32 + chunk * 8;
+#ifdef CONV_NT_STORES      // tools A/B build (see conv_engine.h)
+        __builtin_nontemporal_store(h8, reinterpret_cast<half8*>(oh + o));
+        __builtin_nontemporal_store(l8, reinterpret_cast<half8*>(ol + o));
+#else
         *reinterpret_cast<half8*>(oh + o) = h8;
         *reinterpret_cast<half8*>(ol + o) = l8;
+#endif
     }
 }
 

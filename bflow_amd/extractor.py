@@ -138,7 +138,7 @@ class BasicEncoder(nn.Module):
         pk0 = cache["stem"].get(self.conv1.weight)
         c0 = self.conv1.out_channels
         h0, w0 = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1
-        xin = x if isinstance(x, S.ChannelWindows) else x.contiguous()
+        xin = x if isinstance(x, (S.ChannelWindows, S.StemInput)) else x.contiguous()
         if kind == "instance":     # the conv bias cancels under InstanceNorm; statistics come out of the epilogue
             st0 = new_stats(c0)
             _, f0 = S.conv_stem(xin, pk0, stats=st0, want_split=False, want_f32=True)

@@ -69,7 +69,9 @@ class StemDesc(ctypes.Structure):
                 ("out_f32", ctypes.c_void_p), ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p), ("out_rows_per_image", ctypes.c_int),
                 ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("act", ctypes.c_int), ("stats", ctypes.c_void_p),
                 ("stats_replicas", ctypes.c_int), ("n_windows", ctypes.c_int), ("src_channels", ctypes.c_int),
-                ("window_starts", ctypes.POINTER(ctypes.c_int)), ("layout", ctypes.c_int)]
+                ("window_starts", ctypes.POINTER(ctypes.c_int)), ("layout", ctypes.c_int),
+                ("window_bases", ctypes.POINTER(ctypes.c_void_p)), ("x2", ctypes.c_void_p), ("x2_channels", ctypes.c_int),
+                ("x_dtype", ctypes.c_int), ("x2_dtype", ctypes.c_int), ("x_image_norm", ctypes.c_int), ("x2_image_norm", ctypes.c_int)]
 
 
 class NormDesc(ctypes.Structure):

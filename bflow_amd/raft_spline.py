@@ -259,10 +259,19 @@ class RAFTSpline(nn.Module):
             assert voxel_grid is not None
             voxel_grid = voxel_grid.contiguous().float()
             grids, context_input = self.gen_voxel_grids(voxel_grid)
+        img_in = ctx_general = None
         if self.fnet_img is not None:
             assert images is not None and len(images) == 2
-            images = [2 * (x.float().contiguous() / 255) - 1 for x in images]   # raft.py:134
-            context_input = images[0] if context_input is None else torch.cat((context_input, images[0]), dim=-3)
+            # raft.py:134-140 without a torch launch: the normalisation 2 * (x / 255) - 1, the stacking of the two images (extractor.py:106-110)
+            # and cat((context_grid, img0)) all happen in the stem kernel's load (S.StemInput); uint8 / fp32 images are read as they are
+            images = [x.contiguous() if x.dtype in (torch.uint8, torch.float32) else x.float().contiguous() for x in images]
+            assert images[0].dtype == images[1].dtype and images[0].shape == images[1].shape
+            img_in = S.StemInput([(images[0], 0), (images[1], 0)], 3, norm=True)
+            if context_input is None:
+                ctx_general = S.StemInput([(images[0], 0)], 3, norm=True)
+            else:
+                ctx_general = S.StemInput([(voxel_grid, voxel_grid.shape[1] - self.nbins_context)], self.nbins_context, extra=images[0], extra_norm=True)
+            context_input = ctx_general          # (only its shape / device are read below)
         assert context_input is not None
         B, _, H, W = context_input.shape
         assert H % 8 == 0 and W % 8 == 0                                       # bezier.py:67-68
@@ -303,7 +312,7 @@ class RAFTSpline(nn.Module):
             if tm: tm.stop("fnet_ev")
         if self.fnet_img is not None:
             if tm: tm.start("fnet_img")
-            corr_img = encode_pair(self.fnet_img, torch.cat(images, dim=0), B, self.img_corr_params["levels"])
+            corr_img = encode_pair(self.fnet_img, img_in, B, self.img_corr_params["levels"])
             if tm: tm.stop("fnet_img")
 
         bezier = torch.zeros((B, 2 * self.bezier_degree, h, w), dtype=torch.float32, device=device)   # raft.py:150

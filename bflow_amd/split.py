@@ -236,22 +236,64 @@ class ChannelWindows:
         return torch.cat([self.source[:, s_:s_ + self.width] for s_ in self.starts], dim=0)
 
 
+class StemInput:
+    """The stem convolution's input assembled IN the kernel's load (bflow_stem_desc_t.window_bases / x2 / *_dtype / *_image_norm) instead of by
+    torch launches: image n = window group n // B, source image n % B; its channels are [window channels | extra channels]:
+      windows : list of (tensor (B, C_src, H, W), first channel) -- the groups, stacked along the batch axis (extractor.py:106-110's torch.cat);
+      width   : channels a window supplies;
+      extra   : optional tensor (B, C_x, H, W) whose channels follow the window's (raft.py:137-140: cat((context_grid, img0)));
+      norm / extra_norm : 2 * (v / 255) - 1 on that part (raft.py:134).
+    Tensors are fp32 or uint8, contiguous, never copied or converted."""
+
+    def __init__(self, windows, width: int, extra: Optional[torch.Tensor] = None, norm: bool = False, extra_norm: bool = False):
+        assert 1 <= len(windows) <= 8
+        t0 = windows[0][0]
+        B, C_src, H, W = t0.shape
+        for t, st in windows:
+            assert t.dim() == 4 and tuple(t.shape) == (B, C_src, H, W) and t.dtype == t0.dtype and t.is_contiguous() and t.device == t0.device
+            assert 0 <= st and st + width <= C_src
+        assert t0.dtype in (torch.float32, torch.uint8)
+        if extra is not None:
+            assert extra.dim() == 4 and extra.shape[0] == B and tuple(extra.shape[2:]) == (H, W) and extra.is_contiguous()
+            assert extra.dtype in (torch.float32, torch.uint8) and extra.device == t0.device
+        self.windows, self.width, self.extra, self.norm, self.extra_norm = [(t, int(st)) for t, st in windows], int(width), extra, bool(norm), bool(extra_norm)
+        self.shape = (len(windows) * B, width + (0 if extra is None else extra.shape[1]), H, W)
+        self.device = t0.device
+
+    def materialize(self) -> torch.Tensor:
+        """The tensor the reference builds with torch ops (tests).  The normalisation runs on the CPU like the reference path does: there
+        `x / 255` is a true fp32 division (torch's GPU kernel multiplies by the reciprocal of a scalar divisor, one ulp off for some values)."""
+        def nrm(t, on):
+            t = t.float()
+            return (2 * (t.cpu() / 255) - 1).to(t.device) if on else t
+        parts = []
+        for t, st in self.windows:
+            w = nrm(t[:, st:st + self.width], self.norm)
+            parts.append(w if self.extra is None else torch.cat((w, nrm(self.extra, self.extra_norm)), dim=1))
+        return torch.cat(parts, dim=0)
+
+
 def conv_stem(x, packed, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = ACT_NONE,
               stats: Optional[torch.Tensor] = None, want_split: bool = True, want_f32: bool = False):
     """7x7 / stride 2 / pad 3 convolution of a few-channel fp32 NCHW tensor or ChannelWindows (BasicEncoder.conv1) -> (split_out or
     None, blocked fp32 or None), epilogue as `conv`.  `packed` = PackedStemWeight.get(weight)."""
     planes, (cout, cin, k_blocks, cout_pad) = packed[0], packed[1]
     windows = x if isinstance(x, ChannelWindows) else None
+    general = x if isinstance(x, StemInput) else None
     B, C, H, W = x.shape
     if windows is not None:
         x = windows.source
-    assert C == cin and x.dtype == torch.float32 and x.is_contiguous()
+    if general is not None:
+        x = general.windows[0][0]
+        assert C == cin
+    else:
+        assert C == cin and x.dtype == torch.float32 and x.is_contiguous()
     Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     dev = x.device
     out_split = SplitTensor.empty(B, Ho, Wo, cout, dev) if want_split else None
     out_f32 = torch.empty((B, (cout + 31) // 32, Ho * Wo, 32), dtype=torch.float32, device=dev) if want_f32 else None
     d = hip.StemDesc()
-    d.x, d.w_hi, d.w_lo = hip._dev(x, name="x"), planes[0].data_ptr(), planes[1].data_ptr()
+    d.x, d.w_hi, d.w_lo = (hip._dev(x, name="x") if general is None else x.data_ptr()), planes[0].data_ptr(), planes[1].data_ptr()
     d.B, d.Cin, d.H, d.W, d.Cout, d.cout_pad, d.k_blocks = B, C, H, W, cout, cout_pad, k_blocks
     d.ksize, d.stride, d.pad = 7, 2, 3
     d.layout = STEM_LAYOUT if len(packed) < 3 else packed[2]
@@ -267,6 +309,16 @@ def conv_stem(x, packed, scale: Optional[torch.Tensor] = None, shift: Optional[t
         d.n_windows, d.src_channels = len(windows.starts), x.shape[1]
         starts = (ctypes.c_int * len(windows.starts))(*windows.starts)
         d.window_starts = starts
+    if general is not None:
+        nw = len(general.windows)
+        d.n_windows, d.src_channels = nw, x.shape[1]
+        starts = (ctypes.c_int * nw)(*[st for _, st in general.windows])
+        bases = (ctypes.c_void_p * nw)(*[t.data_ptr() for t, _ in general.windows])
+        d.window_starts, d.window_bases = starts, bases
+        d.x_dtype, d.x_image_norm = int(x.dtype == torch.uint8), int(general.norm)
+        if general.extra is not None:
+            d.x2, d.x2_channels = general.extra.data_ptr(), general.extra.shape[1]
+            d.x2_dtype, d.x2_image_norm = int(general.extra.dtype == torch.uint8), int(general.extra_norm)
     hip._check(hip.lib().bflow_conv_stem(ctypes.byref(d), hip._stream()), "bflow_conv_stem")
     return out_split, out_f32
 

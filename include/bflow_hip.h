@@ -173,6 +173,20 @@ typedef struct bflow_stem_desc {
                                             each chunk's 7 rows zero padded to a multiple of 32 -- the row-window kernel (round 3): the input
                                             patch is split once and laid out [row][column][channel], a filter row's 7 x chunk values of an
                                             output pixel are contiguous and nothing is gathered                                              */
+    /* General input of the row-window kernel (layout 1; all zero / NULL = the plain fp32 input above).  Replaces the torch element-wise and
+     * concatenation launches of raft.py:131-140: `images = [2 * (x.float() / 255) - 1 ...]`, `fnet_img(images)` (the encoder's torch.cat of the
+     * list, extractor.py:106-110) and `context_input = cat((context_grid, images[0]))`.
+     *   window_bases   : host array of n_windows DEVICE pointers: window group g reads its channels from ITS OWN source tensor (the two images);
+     *                    NULL: every window reads `x`;
+     *   x2, x2_channels: the LAST x2_channels channels of every image come from image n % (B / n_windows) of x2 (x2_channels channels per
+     *                    image); the window then supplies the first Cin - x2_channels;
+     *   x_dtype / x2_dtype        : 0 fp32, 1 uint8 (element type of the window sources / of x2);
+     *   x_image_norm / x2_image_norm: 1 = the element is 2 * (v / 255) - 1 (raft.py:134, the reference's operation order); zero padding is
+     *                    applied to the normalised image.                                                                                   */
+    const void* const* window_bases;
+    const void* x2;
+    int x2_channels;
+    int x_dtype, x2_dtype, x_image_norm, x2_image_norm;
 } bflow_stem_desc_t;
 int bflow_conv_stem(const bflow_stem_desc_t* desc, bflow_stream_t stream);
 int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,

@@ -1420,6 +1420,80 @@ def test_conv_stem_vs_fp64(cin, H, W, B):
     assert float(((gs - want).abs() / (mag * 1.5 + 1.0)).max()) < 1e-6
 
 
+@pytest.mark.parametrize("case", ["two_images_u8", "two_images_f32", "ctx_plus_image_u8", "ctx41_plus_image_f32", "image_only_u8"])
+def test_conv_stem_general_input_equals_materialised(case):
+    """The stem kernel assembles its input in its load (S.StemInput -> bflow_stem_desc_t.window_bases / x2 / *_dtype / *_image_norm): the two
+    images stacked along the batch axis, `2 * (x / 255) - 1` on uint8 or fp32 images, and cat((context_grid, img0)) -- raft.py:131-140 without
+    a torch launch.  Must equal, BIT FOR BIT, the same convolution of the tensor torch builds with exactly those operations (same kernel, same
+    arithmetic: only where the element comes from differs), for channel counts whose 8-channel chunks straddle the two sources (5 + 3 = 8:
+    one mixed chunk; 41 + 3 = 44: the boundary inside the sixth chunk), odd sizes and batch > 1."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(9)
+    B, H, W = 2, 38, 52
+    def img(dt):
+        a = rs.randint(0, 256, (B, 3, H, W))
+        return cu(a.astype(np.uint8)) if dt == "u8" else cu(a.astype(np.float32) + rs.rand(B, 3, H, W).astype(np.float32) * 0.5)
+    if case.startswith("two_images"):
+        dt = case.split("_")[-1]
+        a, b = img(dt), img(dt)
+        gen = S.StemInput([(a, 0), (b, 0)], 3, norm=True)
+    elif case == "ctx_plus_image_u8":
+        vox = cu(rs.standard_normal((B, 9, H, W)).astype(np.float32))
+        gen = S.StemInput([(vox, 4)], 5, extra=img("u8"), extra_norm=True)
+    elif case == "ctx41_plus_image_f32":
+        vox = cu(rs.standard_normal((B, 65, H, W)).astype(np.float32))
+        gen = S.StemInput([(vox, 24)], 41, extra=img("f32"), extra_norm=True)
+    else:
+        gen = S.StemInput([(img("u8"), 0)], 3, norm=True)
+    n, cin = gen.shape[0], gen.shape[1]
+    w = cu((rs.standard_normal((64, cin, 7, 7)) / np.sqrt(cin * 49)).astype(np.float32))
+    pk = S.PackedStemWeight().get(w)
+    mat = gen.materialize().contiguous()
+    assert tuple(mat.shape) == tuple(gen.shape)
+    st_a = torch.zeros((n, 64, 2), dtype=torch.float64, device=DEV)
+    st_b = torch.zeros_like(st_a)
+    _, fa = S.conv_stem(gen, pk, stats=st_a, want_split=False, want_f32=True)
+    _, fb = S.conv_stem(mat, pk, stats=st_b, want_split=False, want_f32=True)
+    assert torch.equal(fa, fb) and torch.isfinite(fa).all()
+    sc, sh = cu(rs.uniform(0.5, 1.5, 64).astype(np.float32)), cu(rs.standard_normal(64).astype(np.float32))
+    oa, _ = S.conv_stem(gen, pk, scale=sc, shift=sh, act=S.ACT_RELU)
+    ob, _ = S.conv_stem(mat, pk, scale=sc, shift=sh, act=S.ACT_RELU)
+    assert torch.equal(oa.planes, ob.planes)
+    # and against fp64 (the materialised tensor is what the reference feeds its conv1)
+    ref = torch.nn.functional.conv2d(mat.cpu().double(), w.cpu().double(), None, stride=2, padding=3)
+    mag = torch.nn.functional.conv2d(mat.cpu().double().abs(), w.cpu().double().abs(), None, stride=2, padding=3) + 1.0
+    got = S.blocked_f32_to_nhwc(fa, ref.shape[2], ref.shape[3], 64).permute(0, 3, 1, 2).cpu().double()
+    assert float(((got - ref).abs() / mag).max()) < 5e-7
+
+
+def test_image_configs_launch_no_torch_elementwise_kernels():
+    """C3-shaped forward (events + images): the image normalisation and both concatenations are part of the stem's load, so the forward must
+    not launch torch's element-wise / cat kernels for them: torch.cat, Tensor.float and the arithmetic operators are poisoned for image-sized
+    tensors during an eager forward."""
+    cfg, m, sd = _model("E_I_LU4_BD2")
+    H, W = 128, 160          # (every pyramid level >= 2 x 2: on a 1 x 1 level the reference's own coordinate normalisation divides by zero)
+    vox = torch.from_numpy(synthetic.voxel_grid(1, 9, H, W, seed=3)).to(DEV)
+    a, b = synthetic.image_pair(1, H, W, seed=5)
+    imgs = [torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)]
+    want_low, want_up = m(voxel_grid=vox, images=imgs, iters=2, test_mode=True)
+    want = want_up.get_params().clone()
+    import unittest.mock as mock
+    real_cat = torch.cat
+
+    def guarded_cat(ts, *a_, **k_):
+        ts = list(ts)
+        assert not any(t.dim() == 4 and t.shape[-2:] == (H, W) for t in ts), "torch.cat on an input-sized tensor"
+        return real_cat(ts, *a_, **k_)
+
+    with mock.patch.object(torch, "cat", guarded_cat), mock.patch.object(torch.Tensor, "__truediv__", lambda *a_: (_ for _ in ()).throw(AssertionError("torch division"))):
+        low, up = m(voxel_grid=vox, images=imgs, iters=2, test_mode=True)
+    assert torch.equal(up.get_params(), want)
+    with torch.inference_mode():
+        _, rup = O.forward(sd, cfg, vox.cpu(), [i.cpu() for i in imgs], iters=2, test_mode=True)
+    e = float(O.epe_masked(up.get_flow_from_reference(1.0).cpu(), O.bezier_flow(rup, 1.0)))
+    assert e < 1e-3, e
+
+
 def test_conv_engine_random_shapes_vs_fp64():
     """Randomised sweep over the conv engine's dispatch space (halo / 8-wave halo / generic / stem kernels; ragged patches, odd sizes,
     channel counts that are not multiples of 32, batch > 1, every epilogue option) against fp64 references."""

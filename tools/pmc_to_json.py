@@ -1,12 +1,14 @@
 #!/usr/bin/env python
 """Folds the rocprofv3 --pmc counter CSVs of tools/collect_profiles.sh (one FETCH_SIZE / WRITE_SIZE / MFMA set per roofline kernel + the
-MFMA calibration launch) into profiles/r03_pmc.json.   usage: pmc_to_json.py <dir with <key>_{FETCH_SIZE,WRITE_SIZE,MFMA}.csv> <out.json>"""
+MFMA calibration launch) into profiles/r04_pmc.json.   usage: pmc_to_json.py <dir with <key>_{FETCH_SIZE,WRITE_SIZE,MFMA}.csv> <out.json>"""
 import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.roofline_kernels import CONV_NAME, K5_NAME, LOOKUP_NAME
+from tools.roofline_kernels import CONV_NAME, HALO8_NAME, K5_NAME, K5_SPLIT_NAME, LOOKUP_NAME
 d, outp = sys.argv[1], sys.argv[2]
-NAMES = {"roofline": (CONV_NAME, "conv_halo_kernel", 196755456.0),
+NAMES = {"roofline": (HALO8_NAME, "conv_halo8_kernel", 4.0 * 4800 * (256 + 192) + 4.0 * 192 * 256 * 9),
+         "roofline_encoder": (CONV_NAME, "conv_halo_kernel", 196755456.0),
          "roofline_corr_build": (K5_NAME, "corr_stream_kernel", 393216000.0),
+         "roofline_corr_build_split": (K5_SPLIT_NAME, "corr_stream_kernel", 393216000.0),
          "roofline_lookup": (LOOKUP_NAME, "corr_lookup_tile_kernel", 24326400.0)}
 
 
@@ -46,7 +48,7 @@ for key, (name, regex, alg) in NAMES.items():
     kern[name] = {"fetch_raw": f, "fetch_corrected": fc, "write": w, "traffic": None if fc is None or w is None else fc + w, "algorithmic_bytes": alg,
                   "mfma": m}
 from bench import kernel_source_hash
-json.dump({"source": "rocprofv3 --pmc on tools/roofline_probe.py (the launchers bench.py times), MI355X, round 3: FETCH_SIZE, WRITE_SIZE and the SQ / GRBM set in "
+json.dump({"source": "rocprofv3 --pmc on tools/roofline_probe.py (the launchers bench.py times), MI355X, round 4: FETCH_SIZE, WRITE_SIZE and the SQ / GRBM set in "
                      "separate passes",
            "kernel_source_hash": kernel_source_hash(),
            "units": "bytes per launch; counters are reported in KB (x1024).  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reads exactly 1/2 of "
