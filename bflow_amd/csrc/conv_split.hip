@@ -19,6 +19,9 @@
 //            2-KB / 4-KB run).
 #include "conv_engine.h"
 
+#ifndef CONV_NT_STORES_ENC
+#define CONV_NT_STORES_ENC 0  // tools A/B: 1 = non-temporal stores in the direct (transposed-accumulator) epilogue of the encoder's 3x3s and stem
+#endif
 #ifndef CONV_SPREAD_DMA
 #define CONV_SPREAD_DMA 0     // tools A/B (tools/build_flag_variant.sh): 1 = the small-grid kernels issue a step's LDS-DMA pieces between its taps
 #endif
@@ -75,7 +78,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (
             if (a.act == 1) v = fmaxf(v, 0.f);
             else if (a.act == 2) v = tanhf(v);
             if (!cok) v = 0.f;                                   // padded channels of the last block are written as zeros
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, offs[r], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, offs[r], 0, CONV_NT_STORES_ENC ? 2 : 0);
             if (offs[r] != 0x80000000u) { s1 += v; s2 += v * v; }
         }
         if (a.stats) {                                           // the other 16 pixels of this channel sit in the other half of the wave
