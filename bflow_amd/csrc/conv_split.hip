@@ -1571,7 +1571,8 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs s
 // for 35; the surplus columns are the next pixels' finite values against ZERO weights), 7 rows per chunk; the weights are an ordinary
 // packed tensor in (chunk, row, window) order, two 16-deep steps per 32-wide k-block, streamed by LDS-DMA as before.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KS, int STRIDE, bool TR>
+template <int KS, int STRIDE, bool TR, bool GEN = false>   // GEN: the general input (StemArgs.general) -- its own instantiation, so that the plain
+                                                          // kernel keeps its 158 registers (3 workgroups per CU; one merged kernel needed 202: 84 -> 110 us)
 __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemArgs sa) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 2, TH = 8, TW = 16;
@@ -1647,7 +1648,7 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
             const long long img = (long long)sa.H * sa.W;
             constexpr int NPX = (PR * PC + CT - 1) / CT;
             float pv[NPX][8];
-            if (!sa.general) {
+            if constexpr (!GEN) {
             const long long x_base = sa.B_src > 0 ? ((long long)(b % sa.B_src) * sa.C_src + sa.win[b / sa.B_src] + c_first) * img
                                                   : ((long long)b * sa.Cin + c_first) * img;
             const rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.x + x_base), 0, (int)(nch * img * 4), 0x00020000);
@@ -1676,14 +1677,12 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
             const char* base1 = reinterpret_cast<const char*>(sa.x2) + ((long long)bi * (sa.Cin - sa.c1) + max(c_first - sa.c1, 0)) * img * es1;
             const rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)base0, 0, (int)(n0c * img * es0), 0x00020000);
             const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.x2 ? base1 : base0), 0, sa.x2 ? (int)(n1c * img * es1) : 0, 0x00020000);
-            bool okp[NPX];
 #pragma unroll
             for (int j = 0; j < NPX; ++j) {
                 const int p = tid + j * CT;
                 const int pr = p / PC, pc = p - pr * PC;
                 const int gy = gy0 + pr, gx = gx0 + pc;
                 const bool ok = p < PR * PC && gy >= 0 && gy < sa.H && gx >= 0 && gx < sa.W;
-                okp[j] = ok;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     if (c >= CH) { pv[j][c] = 0.f; continue; }
@@ -2259,13 +2258,14 @@ extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream
         const bool tr = !no_direct && a.out_f32 && !a.oh;
         const int epi = tr ? 2 * 4 * 64 * 4 : (2 * 4 * 64 + 4 * 2 * 32 * CONV_STG_STRIDE) * 4;
         const int lds1 = body > epi ? body : epi;
-        if (tr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_rows_kernel<7, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-            hipLaunchKernelGGL((conv_stem_rows_kernel<7, 2, true>), grid, dim3(CT), lds1, (hipStream_t)stream, a, sa);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_rows_kernel<7, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-            hipLaunchKernelGGL((conv_stem_rows_kernel<7, 2, false>), grid, dim3(CT), lds1, (hipStream_t)stream, a, sa);
-        }
+#define LAUNCH_STEM_ROWS(TRR, GENN)                                                                                    \
+    {                                                                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_rows_kernel<7, 2, TRR, GENN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1); \
+        hipLaunchKernelGGL((conv_stem_rows_kernel<7, 2, TRR, GENN>), grid, dim3(CT), lds1, (hipStream_t)stream, a, sa); \
+    }
+        if (sa.general) { if (tr) LAUNCH_STEM_ROWS(true, true) else LAUNCH_STEM_ROWS(false, true) }
+        else { if (tr) LAUNCH_STEM_ROWS(true, false) else LAUNCH_STEM_ROWS(false, false) }
+#undef LAUNCH_STEM_ROWS
         return bflow::launch_status("conv_stem(rows)");
     }
     if (!no_direct && a.out_f32 && !a.oh) {     // fp32 (+ statistics) output: transposed accumulators, direct stores (see conv_epilogue_direct)
