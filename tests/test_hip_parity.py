@@ -919,6 +919,44 @@ def test_no_silent_library_paths(monkeypatch):
     assert torch.isfinite(up.get_params()).all()
 
 
+@pytest.mark.parametrize("cin,cout,nin", [(64, 96, False), (96, 96, True), (96, 160, False)])
+def test_conv_halo_half_tile_equals_full_tile(cin, cout, nin, monkeypatch):
+    """Layers whose last 64-channel tile is half empty (Cout % 64 in (0, 32]: the encoder's 96-channel stage): the workgroups of that tile skip the
+    fragment reads and MFMAs of the empty half (conv_halo_kernel<..., HT>; opt-in, BFLOW_CONV_HALF_TILE=1: measured neutral).  Same bits as
+    the default kernel, which multiplies the padding, for the plain fp32 + statistics output and for the normalise-on-load input."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(12)
+    B, H, W = 2, 64, 208                                     # 8 x 13 patches x 2 images x 2 tiles >= 200: the 64-channel-tile grid
+    w = cu((rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
+    pk = S.PackedConvWeight().get(w)
+    x = cu(rs.standard_normal((B, cin, H, W)).astype(np.float32))
+
+    def run():
+        st = torch.zeros((8, B, cout, 2), dtype=torch.float64, device=DEV)
+        if nin:
+            raw = S.from_nchw(x).float_nhwc().permute(0, 3, 1, 2).contiguous()                # any fp32 "previous convolution output"
+            st_in = torch.zeros((8, B, cin, 2), dtype=torch.float64, device=DEV)
+            blocked = torch.empty((B, cin // 32, H * W, 32), device=DEV)
+            blocked.copy_(raw.view(B, cin // 32, 32, H * W).permute(0, 1, 3, 2))
+            st_in[0, :, :, 0] = raw.double().sum(dim=(2, 3))
+            st_in[0, :, :, 1] = (raw.double() ** 2).sum(dim=(2, 3))
+            out = S.conv_norm_in(blocked, (B, H, W, cin), st_in, pk, stats=st)
+        else:
+            _, out = S.conv(S.from_nchw(x), pk, padding=1, want_split=False, want_f32=True, stats=st)
+        return out.clone(), st.sum(0)
+    monkeypatch.setenv("BFLOW_CONV_HALF_TILE", "1")
+    got, st_a = run()
+    monkeypatch.delenv("BFLOW_CONV_HALF_TILE")
+    want, st_b = run()
+    assert torch.equal(got, want)
+    np.testing.assert_allclose(st_a.cpu().numpy(), st_b.cpu().numpy(), rtol=1e-12, atol=1e-9)
+    if not nin:
+        ref = torch.nn.functional.conv2d(x.cpu().double(), w.cpu().double(), None, padding=1)
+        mag = torch.nn.functional.conv2d(x.cpu().double().abs(), w.cpu().double().abs(), None, padding=1) + 1.0
+        g = S.blocked_f32_to_nhwc(got, H, W, cout).permute(0, 3, 1, 2).cpu().double()
+        assert float(((g - ref).abs() / mag).max()) < 5e-7
+
+
 @pytest.mark.parametrize("cin,cout,k,pad,H,W,B,force", [
     (256, 128, (1, 5), (0, 2), 60, 80, 1, None),      # q of the GRU at DSEC size: 160 workgroups of 8x16 patches -> 200 of 6x16 on 12 waves (auto)
     (256, 128, (5, 1), (2, 0), 60, 80, 1, None),
