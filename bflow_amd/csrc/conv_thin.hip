@@ -179,13 +179,14 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(ThinArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same operation on the matrix cores, "taps as output channels" (round 4): for 9 * Cout <= 64 (degree <= 3: the DSEC models) the 3 x 3
-// filter is ONE dense 1 x 1 GEMM  Y[pixel][tap * Cout + co] = sum_c x[pixel][c] w[co][c][tap]  (K = C <= 256, 64 padded output rows)
-// followed by a shifted sum  out[p][co] = sum_tap Y[p + tap][tap * Cout + co].  The vector-ALU kernel above re-reads the nine taps of every
+// The same operation on the matrix cores, "taps as output channels" (round 4): the 3 x 3 filter is a dense 1 x 1 GEMM
+// Y[pixel][tap * Cout + co] = sum_c x[pixel][c] w[co][c][tap]  (K = C <= 256; 9 * Cout output rows, 64 per PASS: one pass at degree 2, three at
+// degree 10; Cout <= 28) followed by a shifted sum  out[p][co] = sum_tap Y[p + tap][tap * Cout + co].  The vector-ALU kernel above re-reads the nine taps of every
 // pixel and the 36 KB of weights of every 8 pixels from L2 (65 MB per launch at DSEC size, 9.6 us in the captured iteration); here a
-// workgroup owns a 2 x 10 pixel patch: its 4 x 12 halo (all C channels, hi + lo: 48 KB) and the packed weights (48 KB) are fetched ONCE by
-// LDS-DMA with every piece in flight at once, 8 waves = 2 pixel tiles (the 48 halo pixels) x 2 output tiles x 2 k-halves run 8 channel
-// blocks x 3 split MFMAs each, Y goes through LDS (over the operands) and 20 x Cout threads do the shifted sum, the bias, P += dP and the
+// workgroup owns a 2 x 10 pixel patch: its 4 x 12 halo (all C channels, hi + lo: 48 KB) is fetched ONCE and the weights of a pass (the units
+// that hold real rows: 48 KB at degree 2) by LDS-DMA with every piece in flight at once, 8 waves = 2 pixel tiles (the 48 halo pixels) x 2 output
+// tiles x 2 k-halves run 8 channel blocks x 3 split MFMAs per pass, Y goes through LDS (the next pass's weights land meanwhile) and 20 x Cout
+// items do the shifted sum (partial sums of the passes in a register), the bias, P += dP and the
 // re-emission of the Bezier channels.  Products are the engine's 3-pass split products (2^-22; the weights are a packed split tensor like
 // any other filter: bflow_conv_pack_weights of the derived 1 x 1 filter).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -223,10 +224,11 @@ __global__ __launch_bounds__(64 * TM_NW, 1) void conv_thin_mfma_kernel(ThinMArgs
     const int b = blockIdx.y;
     const int tiles_x = (a.W + TM_TW - 1) / TM_TW;
     const int ty = blockIdx.x / tiles_x, y0 = ty * TM_TH, x0 = (blockIdx.x - ty * tiles_x) * TM_TW;
-    const int O_W = a.CB * (2 * TM_AU * 1024);                 // weights behind the halo planes
-    const int O_SCR = a.CB * TM_PPB * 1024;                    // 1 KB scratch for dummy pieces
+    // LDS: [halo: CB x (hi 3 KB | lo 3 KB)] [weights of ONE pass: CB x (hi 4 KB | lo 4 KB)] [Y: 2 k-halves x 64 pixels x 68 floats] [1 KB scratch]
+    const int O_W = a.CB * (2 * TM_AU * 1024);
+    const int O_Y = O_W + a.CB * (2 * TM_WU * 1024);
+    const int O_SCR = O_Y + 2 * TM_YR * TM_YS * 4;
 
-    // ---- every operand byte by LDS-DMA, in flight at once: piece p = (block, {halo hi x5, halo lo x5, weights hi x4, weights lo x4}) ----
     const int urow = lane >> 2;
     const int uchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
     const int plane_b = a.P_in * 64;
@@ -235,90 +237,124 @@ __global__ __launch_bounds__(64 * TM_NW, 1) void conv_thin_mfma_kernel(ThinMArgs
     const int wtile_b = a.cout_pad * 64;
     const __amdgpu_buffer_rsrc_t r_wh = __builtin_amdgcn_make_buffer_rsrc((void*)a.wh, 0, a.CB * wtile_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_wl = __builtin_amdgcn_make_buffer_rsrc((void*)a.wl, 0, a.CB * wtile_b, 0x00020000);
-    const int wu_used = (9 * a.Cout + 15) >> 4;                // weight units that hold real rows (3 for degree 2): the rest is never fetched
-    const int npieces = a.CB * TM_PPB;
-    const int niter = (npieces + TM_NW - 1) / TM_NW;           // the same instruction count in every wave
-    for (int i = 0; i < niter; ++i) {
-        const int p = wave_all + TM_NW * i;
-        const bool real = p < npieces;
-        const int cb = real ? p / TM_PPB : 0, r = real ? p - cb * TM_PPB : 0;
-        char* const dst = real ? lds + (r < 2 * TM_AU ? cb * (2 * TM_AU * 1024) + r * 1024 : O_W + cb * (2 * TM_WU * 1024) + (r - 2 * TM_AU) * 1024) : lds + O_SCR;
-        if (r < 2 * TM_AU) {
+    const int nrows = 9 * a.Cout;                              // rows of the derived 1 x 1 filter: tap * Cout + co
+    const int npass = (nrows + 63) >> 6;                       // 64 rows per pass (degree 2: one pass, degree 10: three)
+
+    // ---- the halo (all C channels, hi + lo): fetched ONCE by LDS-DMA; the same instruction count in every wave (dummy pieces -> scratch) ----
+    {
+        const int np = a.CB * 2 * TM_AU, ni = (np + TM_NW - 1) / TM_NW;
+        for (int i = 0; i < ni; ++i) {
+            const int p = wave_all + TM_NW * i;
+            const bool real = p < np;
+            const int cb = real ? p / (2 * TM_AU) : 0, r = real ? p - cb * (2 * TM_AU) : 0;
             const int unit = r < TM_AU ? r : r - TM_AU;
             const int row = unit * 16 + urow;
             const int hy = row / TM_HWD, hx = row - hy * TM_HWD;
             const int py = y0 - 1 + hy, px = x0 - 1 + hx;
             const bool ok = real && row < TM_HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
             const unsigned off = ok ? (unsigned)(((py * a.W + px) * 32 + uchunk) * 2) : 0x80000000u;
+            char* const dst = real ? lds + cb * (2 * TM_AU * 1024) + r * 1024 : lds + O_SCR;
             if (r < TM_AU) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_xh, (lptr_tt)dst, 16, off, cb * plane_b, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(r_xl, (lptr_tt)dst, 16, off, cb * plane_b, 0, 0);
-        } else {
-            const int u = r - 2 * TM_AU, unit = u & 3;
-            const unsigned off = unit < wu_used ? (unsigned)(((unit * 16 + urow) * 32 + uchunk) * 2) : 0x80000000u;   // (unused rows: zeros, no traffic)
+        }
+    }
+    // weights of pass `ps`: rows [64 ps, 64 ps + 64) of every channel block; 16-row units without a real row are never fetched (zeros)
+    auto issue_weights = [&](int ps) {
+        const int np = a.CB * 2 * TM_WU, ni = (np + TM_NW - 1) / TM_NW;
+        for (int i = 0; i < ni; ++i) {
+            const int p = wave_all + TM_NW * i;
+            const bool real = p < np;
+            const int cb = real ? p / (2 * TM_WU) : 0, u = real ? p - cb * (2 * TM_WU) : 0;
+            const int unit = u & 3, row0 = ps * 64 + unit * 16;
+            const unsigned off = (real && row0 < nrows) ? (unsigned)(((row0 + urow) * 32 + uchunk) * 2) : 0x80000000u;
+            char* const dst = real ? lds + O_W + cb * (2 * TM_WU * 1024) + u * 1024 : lds + O_SCR;
             if (u < TM_WU) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wh, (lptr_tt)dst, 16, off, cb * wtile_b, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wl, (lptr_tt)dst, 16, off, cb * wtile_b, 0, 0);
         }
-    }
+    };
+    issue_weights(0);
 
-    // ---- 8 waves: pixel tile (32 of the 64 halo rows; rows >= 48 are never used), output tile (32 of the 64 weight rows), k-half ----
+    // ---- 8 waves: pixel tile (32 of the 64 halo rows; rows >= 48 are never used), output tile (32 of the pass's 64 rows), k-half ----
     const int ptile = wave_all % TM_NPT, ntile = (wave_all / TM_NPT) & 1, khalf = wave_all / (2 * TM_NPT);
     const int kq = khalf * 2 + kh;
     const int hp = ptile * 32 + l31, wr = ntile * 32 + l31;
     const int ao = hp * 64 + ((kq ^ ((hp >> 2) & 3)) * 16);
     const int wo = wr * 64 + ((kq ^ ((wr >> 2) & 3)) * 16);
-    f32x16t hh, x1, x2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) hh[r] = x1[r] = x2[r] = 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int cb = 0; cb < a.CB; ++cb) {
-        const char* ab = lds + cb * (2 * TM_AU * 1024);
-        const char* wb = lds + O_W + cb * (2 * TM_WU * 1024);
-        const half8 xh = *reinterpret_cast<const half8*>(ab + ao);
-        const half8 xl = *reinterpret_cast<const half8*>(ab + TM_AU * 1024 + ao);
-        const half8 wh = *reinterpret_cast<const half8*>(wb + wo);
-        const half8 wl = *reinterpret_cast<const half8*>(wb + TM_WU * 1024 + wo);
-        hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh, 0, 0, 0);     // D[output row][pixel]
-        x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, x1, 0, 0, 0);
-        x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, x2, 0, 0, 0);
-    }
-    __builtin_amdgcn_s_barrier();                              // every wave has read its operands: Y may overwrite them
-    // ---- Y[khalf][halo pixel][64 rows] through LDS: lane = pixel, registers 4j .. 4j+3 = rows 8j + 4 kh + 0..3 of the wave's tile ----
-    float* const Y = reinterpret_cast<float*>(lds);
-    {
-        float* yr = Y + ((khalf * TM_YR + hp) * TM_YS) + ntile * 32 + 4 * kh;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<float4*>(yr + 8 * j) = make_float4(hh[4 * j] + (x1[4 * j] + x2[4 * j]) * bflow::SPLIT_LO_INV,
-                                                                 hh[4 * j + 1] + (x1[4 * j + 1] + x2[4 * j + 1]) * bflow::SPLIT_LO_INV,
-                                                                 hh[4 * j + 2] + (x1[4 * j + 2] + x2[4 * j + 2]) * bflow::SPLIT_LO_INV,
-                                                                 hh[4 * j + 3] + (x1[4 * j + 3] + x2[4 * j + 3]) * bflow::SPLIT_LO_INV);
-    }
-    __syncthreads();
-    // ---- shifted sum + bias + P += dP + the Bezier channels of the GRU input: thread = (output channel, pixel of the 2 x 16 patch) ----
-    const int HW = a.H * a.W;
+    float* const Y = reinterpret_cast<float*>(lds + O_Y);
+    // shifted sum: item = (output channel, pixel of the 2 x 10 patch); an item's partial sums over the passes stay in a register
     constexpr int NPX = TM_TH * TM_TW;                         // 20 output pixels
-    if (tid < NPX * a.Cout) {
-        const int co = tid / NPX, o = tid - co * NPX;
-        const int oy = o / TM_TW, ox = o - oy * TM_TW;
-        const int y = y0 + oy, x = x0 + ox;
-        float sum = 0.f;
+    constexpr int NITEM = (NPX * 28 + 64 * TM_NW - 1) / (64 * TM_NW);   // Cout <= 28: two items per thread at most
+    float part[NITEM];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int hpx = (oy + t / 3) * TM_HWD + ox + t % 3;
-            sum += Y[hpx * TM_YS + t * a.Cout + co] + Y[(TM_YR + hpx) * TM_YS + t * a.Cout + co];
+    for (int k = 0; k < NITEM; ++k) part[k] = 0.f;
+
+    for (int ps = 0; ps < npass; ++ps) {
+        f32x16t hh, x1, x2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hh[r] = x1[r] = x2[r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (first pass: the halo too)
+        __builtin_amdgcn_s_barrier();
+        for (int cb = 0; cb < a.CB; ++cb) {
+            const char* ab = lds + cb * (2 * TM_AU * 1024);
+            const char* wb = lds + O_W + cb * (2 * TM_WU * 1024);
+            const half8 xh = *reinterpret_cast<const half8*>(ab + ao);
+            const half8 xl = *reinterpret_cast<const half8*>(ab + TM_AU * 1024 + ao);
+            const half8 wh = *reinterpret_cast<const half8*>(wb + wo);
+            const half8 wl = *reinterpret_cast<const half8*>(wb + TM_WU * 1024 + wo);
+            hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, hh, 0, 0, 0);     // D[output row][pixel]
+            x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, x1, 0, 0, 0);
+            x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, x2, 0, 0, 0);
         }
-        if (y < a.H && x < a.W) {
-            const int n = y * a.W + x;
-            float* pa = a.acc + ((long long)b * a.Cout + co) * HW + n;
-            const float v = *pa + (a.bias ? a.bias[co] : 0.f) + sum;       // bezier.py:137-139: params += delta (+ the conv bias)
-            *pa = v;
-            if (a.oh) {
-                _Float16 hi, lo;
-                bflow::split1(v, hi, lo);
-                const long long oo = (((long long)b * a.CBo + a.cb_off) * a.P_out + n) * 32 + a.c_off + co;
-                a.oh[oo] = hi;
-                a.ol[oo] = lo;
+        // Y[khalf][halo pixel][64 rows of this pass]: lane = pixel, registers 4j .. 4j+3 = rows 8j + 4 kh + 0..3 of the wave's tile.  (The previous
+        // pass's readers of Y passed the barrier at the top of this pass.)
+        {
+            float* yr = Y + ((khalf * TM_YR + hp) * TM_YS) + ntile * 32 + 4 * kh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(yr + 8 * j) = make_float4(hh[4 * j] + (x1[4 * j] + x2[4 * j]) * bflow::SPLIT_LO_INV,
+                                                                     hh[4 * j + 1] + (x1[4 * j + 1] + x2[4 * j + 1]) * bflow::SPLIT_LO_INV,
+                                                                     hh[4 * j + 2] + (x1[4 * j + 2] + x2[4 * j + 2]) * bflow::SPLIT_LO_INV,
+                                                                     hh[4 * j + 3] + (x1[4 * j + 3] + x2[4 * j + 3]) * bflow::SPLIT_LO_INV);
+        }
+        __syncthreads();                                       // Y complete; every wave has read this pass's weights
+        if (ps + 1 < npass) issue_weights(ps + 1);             // the next pass's weights land under the shifted sum
+#pragma unroll
+        for (int k = 0; k < NITEM; ++k) {
+            const int it = tid + k * 64 * TM_NW;
+            if (it < NPX * a.Cout) {
+                const int co = it / NPX, o = it - co * NPX;
+                const int oy = o / TM_TW, ox = o - oy * TM_TW;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int row = t * a.Cout + co - ps * 64;                  // row of (tap, channel) inside this pass, if it is in it
+                    if (row >= 0 && row < 64) {
+                        const int hpx = (oy + t / 3) * TM_HWD + ox + t % 3;
+                        part[k] += Y[hpx * TM_YS + row] + Y[(TM_YR + hpx) * TM_YS + row];
+                    }
+                }
+            }
+        }
+    }
+    // ---- bias + P += dP + the Bezier channels of the GRU input ----
+    const int HW = a.H * a.W;
+#pragma unroll
+    for (int k = 0; k < NITEM; ++k) {
+        const int it = tid + k * 64 * TM_NW;
+        if (it < NPX * a.Cout) {
+            const int co = it / NPX, o = it - co * NPX;
+            const int y = y0 + o / TM_TW, x = x0 + o % TM_TW;
+            if (y < a.H && x < a.W) {
+                const int n = y * a.W + x;
+                float* pa = a.acc + ((long long)b * a.Cout + co) * HW + n;
+                const float v = *pa + (a.bias ? a.bias[co] : 0.f) + part[k];    // bezier.py:137-139: params += delta (+ the conv bias)
+                *pa = v;
+                if (a.oh) {
+                    _Float16 hi, lo;
+                    bflow::split1(v, hi, lo);
+                    const long long oo = (((long long)b * a.CBo + a.cb_off) * a.P_out + n) * 32 + a.c_off + co;
+                    a.oh[oo] = hi;
+                    a.ol[oo] = lo;
+                }
             }
         }
     }
@@ -333,6 +369,7 @@ __global__ __launch_bounds__(64 * TM_NW, 1) void conv_thin_mfma_kernel(ThinMArgs
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 
@@ -370,8 +407,8 @@ extern "C" int bflow_conv_thin_mfma_acc(const void* x_hi, const void* x_lo, cons
                                         float* acc_nchw, void* out_hi, void* out_lo, int B, int H, int W, int C, int in_rows_per_image, int Cout,
                                         int out_channel_blocks, int out_block, int out_rows_per_image, int out_channel_in_block, bflow_stream_t stream) {
     BFLOW_REQUIRE(x_hi && x_lo && w_hi && w_lo && acc_nchw, BFLOW_E_ARG, "conv_thin_mfma_acc: null pointer");
-    BFLOW_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && C <= 256 && Cout >= 1 && 9 * Cout <= 64 && cout_pad >= 64, BFLOW_E_ARG,
-                  "conv_thin_mfma_acc: needs C %% 32 == 0, C <= 256, 9 * Cout <= 64, cout_pad >= 64 (got C=%d Cout=%d cout_pad=%d)", C, Cout, cout_pad);
+    BFLOW_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && C <= 256 && Cout >= 1 && Cout <= 28 && cout_pad >= (9 * Cout + 63) / 64 * 64, BFLOW_E_ARG,
+                  "conv_thin_mfma_acc: needs C %% 32 == 0, C <= 256, Cout <= 28, cout_pad >= 9 * Cout rounded up to 64 (got C=%d Cout=%d cout_pad=%d)", C, Cout, cout_pad);
     BFLOW_REQUIRE(in_rows_per_image >= H * W && B <= 65535, BFLOW_E_ARG, "conv_thin_mfma_acc: bad row count / batch");
     BFLOW_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), BFLOW_E_ARG, "conv_thin_mfma_acc: out_hi / out_lo go together");
     if (out_hi) BFLOW_REQUIRE(out_block >= 0 && out_block < out_channel_blocks && out_rows_per_image >= H * W && out_channel_in_block >= 0 &&
@@ -381,8 +418,7 @@ extern "C" int bflow_conv_thin_mfma_acc(const void* x_hi, const void* x_lo, cons
     a.cout_pad = cout_pad; a.bias = bias; a.acc = acc_nchw; a.oh = (_Float16*)out_hi; a.ol = (_Float16*)out_lo;
     a.B = B; a.H = H; a.W = W; a.CB = C / 32; a.P_in = in_rows_per_image; a.Cout = Cout;
     a.CBo = out_channel_blocks; a.cb_off = out_block; a.P_out = out_rows_per_image; a.c_off = out_channel_in_block;
-    const int ops = a.CB * TM_PPB * 1024 + 1024, ys = 2 * TM_YR * TM_YS * 4;
-    const int lds = ops > ys ? ops : ys;
+    const int lds = a.CB * TM_PPB * 1024 + 2 * TM_YR * TM_YS * 4 + 1024;      // halo + one pass of weights + Y + scratch: 132 KB at C = 256
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     dim3 grid(bflow::ceil_div(H, TM_TH) * bflow::ceil_div(W, TM_TW), B);
     hipLaunchKernelGGL(conv_thin_mfma_kernel, grid, dim3(64 * TM_NW), lds, (hipStream_t)stream, a);

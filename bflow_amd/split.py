@@ -123,7 +123,7 @@ THIN_MFMA = os.environ.get("BFLOW_NO_THIN_MFMA") is None      # A/B switch (tool
 
 class ThinConvWeight:
     """Weights of a thin-output convolution: fp32 tap-major (KH*KW, Cout, Cin) for bflow_conv_thin_acc, and -- for a 3 x 3 filter with
-    9 * Cout <= 64 -- the derived 1 x 1 filter W'[tap * Cout + co][c] packed as a split tensor for bflow_conv_thin_mfma_acc."""
+    Cout <= 28 -- the derived 1 x 1 filter W'[tap * Cout + co][c] packed as a split tensor for bflow_conv_thin_mfma_acc."""
 
     def __init__(self):
         self._key = None
@@ -138,7 +138,7 @@ class ThinConvWeight:
                 w = weight.detach().float()
                 self.w = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin).contiguous()
                 self.mfma = None
-                if (kh, kw) == (3, 3) and 9 * cout <= 64 and cin % 32 == 0 and cin <= 256 and weight.is_cuda:
+                if (kh, kw) == (3, 3) and cout <= 28 and cin % 32 == 0 and cin <= 256 and weight.is_cuda:
                     taps = self.w.reshape(9 * cout, cin, 1, 1).contiguous()          # row = tap * Cout + co
                     self.mfma = PackedConvWeight().get(taps)
             self._key, self.meta = key, (cout, cin, kh, kw)
@@ -148,7 +148,7 @@ class ThinConvWeight:
 def conv_thin_acc(x: SplitTensor, packed, bias: Optional[torch.Tensor], acc_nchw: torch.Tensor, out_split: Optional[SplitTensor] = None,
                   channel_offset: int = 0, mfma: Optional[bool] = None):
     """acc_nchw (B, cout, H, W) fp32 += conv(x, w) + bias ("same" zero padding, stride 1, cout <= 32); out_split's 32-channel block at
-    `channel_offset` receives the updated values.  3 x 3 with 9 * cout <= 64 (the degree-2 Bezier head): on the matrix cores
+    `channel_offset` receives the updated values.  3 x 3 with cout <= 28 (the Bezier head up to degree 14): on the matrix cores
     (bflow_conv_thin_mfma_acc, taps as output channels); otherwise on the vector ALU in fp32 (bflow_conv_thin_acc).  mfma=False forces the latter."""
     w, (cout, cin, kh, kw) = packed[0], packed[1]
     mf = packed[2] if len(packed) > 2 else None

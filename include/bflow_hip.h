@@ -286,11 +286,11 @@ int bflow_conv_thin_acc(const void* x_hi, const void* x_lo, const float* w_packe
                         int out_channel_blocks, int out_block, int out_rows_per_image, int out_channel_in_block, bflow_stream_t stream);
 
 /* bflow_conv_thin_mfma_acc: the SAME operation as bflow_conv_thin_acc (BezierHead.conv2 + delta_update_params, update.py:12-18,
- * bezier.py:137-139) for a 3 x 3 filter with 9 * Cout <= 64 (degree <= 3) on the matrix cores, "taps as output channels": one dense
- * 1 x 1 GEMM  Y[pixel][tap * Cout + co] = sum_c x[pixel][c] w[co][c][tap]  over a workgroup's 4 x 18 halo patch (operands fetched once
- * by LDS-DMA), then  out[p][co] = sum_tap Y[p + tap][tap * Cout + co]  through LDS.  Products are the engine's three-pass split products.
+ * bezier.py:137-139) for a 3 x 3 filter with Cout <= 28 (degree <= 14) on the matrix cores, "taps as output channels": a dense
+ * 1 x 1 GEMM  Y[pixel][tap * Cout + co] = sum_c x[pixel][c] w[co][c][tap]  over a workgroup's 4 x 12 halo patch (fetched once by LDS-DMA;
+ * 64 output rows per pass), then  out[p][co] = sum_tap Y[p + tap][tap * Cout + co]  through LDS.  Products are the engine's three-pass split products.
  *   w_hi/w_lo : the derived 1 x 1 filter W'[tap * Cout + co][c] = w[co][c][tap / 3][tap % 3] packed by bflow_conv_pack_weights
- *               (KH = KW = 1, Cout' = 9 * Cout, cout_pad >= 64, cin_pad = C): (C/32, cout_pad, 32) fp16 planes;
+ *               (KH = KW = 1, Cout' = 9 * Cout, cout_pad >= Cout' rounded up to 64, cin_pad = C): (C/32, cout_pad, 32) fp16 planes;
  *   everything else as bflow_conv_thin_acc.                                                                                   */
 int bflow_conv_thin_mfma_acc(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, int cout_pad, const float* bias,
                              float* acc_nchw, void* out_hi, void* out_lo, int B, int H, int W, int C, int in_rows_per_image, int Cout,

@@ -1064,7 +1064,7 @@ def test_conv_thin_acc_vs_fp64(cin, cout, k, H, W, B, blocks, blk):
     err = float(((acc.cpu().double() - ref).abs() / mag).max())
     print(f"conv_thin {cin}->{cout} {k}x{k}: err/sum|x||w| {err:.2e}")
     assert err < 3e-7                                              # fp32 FMA accumulation over <= 2304 products
-    if k == 3 and 9 * cout <= 64:
+    if k == 3 and cout <= 28:
         # the matrix-core form (bflow_conv_thin_mfma_acc: taps as output channels, three-pass split products, weights split to 22 bits): same
         # accumulator update, same emitted block, inside another block with its neighbours left alone (the merged Bezier channels of M)
         assert pkw[2] is not None
