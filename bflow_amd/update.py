@@ -26,7 +26,7 @@ from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backwa
 
 # head2 (Conv2d(256, 2*deg, 3)): the vector-ALU kernel takes 5 us per 4800 pixels, the MFMA halo kernel 17 us at 4800 pixels but only
 # 40 us at 38400 (batch 8) where its grid fills the chip -- measured cross-over near 24000 pixels.
-THIN_HEAD_MAX_PIXELS = 20000
+THIN_HEAD_MAX_PIXELS = int(os.environ.get("BFLOW_THIN_HEAD_MAX_PIXELS", "20000"))     # (env: A/B of the cross-over, tools/)
 MERGE_BEZIER_BLOCK = os.environ.get("BFLOW_NO_MERGED_BEZIER") is None     # A/B switch (tools/): see SplitWorkspace
 
 
