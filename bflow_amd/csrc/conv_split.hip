@@ -2036,10 +2036,11 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         const int nt = (a.xraw || (long long)patches * d->B * bflow::ceil_div(d->Cout, 64) >= 200) ? 2 : 1;
         a.n_tiles = bflow::ceil_div(d->Cout, 32 * nt);
         dim3 hgrid((patches + 7) / 8 * 8 * a.n_tiles, 1, d->B);
+        static const int halo_lds_pad = [] { const char* e = getenv("BFLOW_HALO_LDS_PAD"); return e ? atoi(e) : 0; }();   // tools: forces 1 workgroup per CU
 #define LAUNCH_HALO(N, KHH, KWW)                                                                                       \
     {                                                                                                                  \
         constexpr int units_ = (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16 + 1) / 2 * 2;                           \
-        const int lds = 2 * 2 * units_ * 1024 + 4 * (N) * 4096;                                                        \
+        const int lds = 2 * 2 * units_ * 1024 + 4 * (N) * 4096 + halo_lds_pad;   /* (pad: occupancy probe, tools) */       \
         if ((N) == 2 && (KHH) == 3 && a.xraw && half_tile) {   /* ... a half-empty last channel tile (96-channel layers) */ \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 3, 3, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             hipLaunchKernelGGL((conv_halo_kernel<2, 3, 3, true, true, true>), hgrid, dim3(CT), lds, s, a);             \
