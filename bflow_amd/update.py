@@ -28,6 +28,7 @@ from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backwa
 # 40 us at 38400 (batch 8) where its grid fills the chip -- measured cross-over near 24000 pixels.
 THIN_HEAD_MAX_PIXELS = int(os.environ.get("BFLOW_THIN_HEAD_MAX_PIXELS", "20000"))     # (env: A/B of the cross-over, tools/)
 MERGE_BEZIER_BLOCK = os.environ.get("BFLOW_NO_MERGED_BEZIER") is None     # A/B switch (tools/): see SplitWorkspace
+MASK_TILE = int(os.environ["BFLOW_MASK_TILE"]) if "BFLOW_MASK_TILE" in os.environ else None   # tools A/B: channel tile of the mask head's 1x1 (None: pick_tile)
 
 
 class BezierHead(nn.Module):
@@ -241,7 +242,10 @@ class BasicUpdateBlock(nn.Module):
         with hip.Branch(ws.overlap and need_mask) as mask_branch:
             if need_mask:
                 m1, _ = S.conv(ws.H, self._pk("mask0", lambda a=self.mask[0].weight: a), padding=1, shift=self.mask[0].bias, act=S.ACT_RELU)
-                m2, _ = S.conv(m1, self._pk("mask2", lambda a=self.mask[2].weight: a), shift=self.mask[2].bias)
+                m2, _ = S.conv(m1, self._pk("mask2", lambda a=self.mask[2].weight: a), shift=self.mask[2].bias,
+                               tile=MASK_TILE if MASK_TILE is not None else (96 if m1.shape[0] * m1.H * m1.W <= THIN_HEAD_MAX_PIXELS else None))
+                # (batch 1: 96-channel tiles = 228 workgroups, one round, 229 KB of operands each, instead of 342 of 64 channels:
+                #  3.643-3.647 vs 3.648-3.668 ms per frame over three alternating pairs)
                 mask = m2.to_nchw()
         bh = self.bezier_head
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
