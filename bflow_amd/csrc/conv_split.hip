@@ -1856,6 +1856,7 @@ struct NormArgs {
     int B, HW, C, CB, P; float eps;
     int tiles_per_block;   // consecutive 64-pixel tiles walked by one block (amortises the coefficient set-up on big grids)
     int stats_reps;        // replicas of the statistics tables (summed here)
+    int act_b;             // 1: the second branch is relu(norm_b(b)) (a residual that was never materialised), 0: norm_b(b)
 };
 
 
@@ -1918,7 +1919,10 @@ __global__ __launch_bounds__(256) void norm_act_split_kernel(NormArgs p) {
             const int c = cb * 32 + c8 + k;
             float x = fmaf(v[k], coef[0][c8 + k], coef[1][c8 + k]);   // (explicit fma: the NIN halo kernel applies the same expression, bit for bit)
             if (p.act_a == 1) x = fmaxf(x, 0.f);
-            if (p.b) x += fmaf(bv[k], coef[2][c8 + k], coef[3][c8 + k]);
+            if (p.b) {
+                const float yb = fmaf(bv[k], coef[2][c8 + k], coef[3][c8 + k]);
+                x += p.act_b == 1 ? fmaxf(yb, 0.f) : yb;
+            }
             if (p.rh) x += (float)rh8[k] + (float)rl8[k] * LO_INV;
             if (p.act_out == 1) x = fmaxf(x, 0.f);
             else if (p.act_out == 2) x = tanhf(x);
@@ -2195,6 +2199,7 @@ extern "C" int bflow_norm_act_split(const bflow_norm_desc_t* d, bflow_stream_t s
     BFLOW_REQUIRE(!(d->b && d->a_is_nchw), BFLOW_E_ARG, "norm_act_split: second branch requires blocked inputs");
     NormArgs p;
     p.a = d->a; p.stats_a = d->stats_a; p.scale_a = d->scale_a; p.shift_a = d->shift_a; p.a_nchw = d->a_is_nchw; p.act_a = d->act_a;
+    p.act_b = d->act_b;
     p.b = d->b; p.stats_b = d->stats_b; p.rh = (const _Float16*)d->res_hi; p.rl = (const _Float16*)d->res_lo; p.act_out = d->act_out;
     p.oh = (_Float16*)d->out_hi; p.ol = (_Float16*)d->out_lo; p.out_f32 = d->out_f32; p.B = d->B; p.HW = d->HW; p.C = d->C;
     p.CB = (d->C + 31) / 32; p.P = d->rows_per_image > 0 ? d->rows_per_image : d->HW; p.eps = d->eps;

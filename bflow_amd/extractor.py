@@ -21,6 +21,9 @@ from .norm_train import norm_act  # [relu](norm(x)): hand-written forward / back
 
 STATS_R = 8
 FUSE_NORM_IN = os.environ.get("BFLOW_NO_NORM_IN") is None     # A/B switch (tools/): conv2 of a residual block normalises its input on load
+# round 4: the stem's norm + ReLU is never materialised either (layer1.0.conv1 normalises on load, the block-end kernel takes the residual as
+# relu(norm_b(b))): 3.581 / 3.597 / 3.614 vs 3.604 / 3.632 / 3.626 ms per frame over three alternating pairs.  BFLOW_NO_NORM_IN_STEM for A/B.
+FUSE_NORM_IN_STEM = os.environ.get("BFLOW_NO_NORM_IN_STEM") is None
 
 
 def _make_norm(kind: str, channels: int) -> nn.Module:
@@ -139,10 +142,17 @@ class BasicEncoder(nn.Module):
         c0 = self.conv1.out_channels
         h0, w0 = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1
         xin = x if isinstance(x, (S.ChannelWindows, S.StemInput)) else x.contiguous()
+        raw0 = None                # (f0, st0): the stem's pre-normalisation output when relu(norm1(conv1)) is never materialised
         if kind == "instance":     # the conv bias cancels under InstanceNorm; statistics come out of the epilogue
             st0 = new_stats(c0)
             _, f0 = S.conv_stem(xin, pk0, stats=st0, want_split=False, want_f32=True)
-            cur, _ = S.norm_act(f0, (n, h0, w0, c0), stats_a=st0, act_a=S.ACT_RELU)
+            if FUSE_NORM_IN and FUSE_NORM_IN_STEM and c0 <= 128 and c0 % 32 == 0 and self.layer1[0].conv1.stride[0] == 1:
+                # extractor.py:113 `x = relu(norm1(conv1(x)))` has two consumers: layer1.0.conv1 normalises it on load (x_raw), and the
+                # block's residual `x + y` (extractor.py:55) takes it as relu(norm_b(b)) inside the block-end kernel: one launch and one
+                # read + write of the half-resolution map less
+                raw0, cur = (f0, st0), None
+            else:
+                cur, _ = S.norm_act(f0, (n, h0, w0, c0), stats_a=st0, act_a=S.ACT_RELU)
         else:                      # folded BatchNorm + ReLU in the epilogue: the stem is ONE launch
             sc, sh = self._bn_affine(self.norm1, self.conv1.bias)
             cur, _ = S.conv_stem(xin, pk0, scale=sc, shift=sh, act=S.ACT_RELU)
@@ -184,8 +194,13 @@ class BasicEncoder(nn.Module):
                 if kind == "instance" and FUSE_NORM_IN and blk.conv1.out_channels <= 128 and blk.conv1.out_channels % 32 == 0:
                     # relu(norm1(conv1(x))) is never materialised: conv2 normalises conv1's fp32 output while it stages its halo
                     # (bflow_conv_desc_t.x_raw): the same arithmetic, one read + write of the activation and one launch less
-                    f1, st1 = conv_norm(pre + ".conv1", blk.conv1, blk.norm1, cur, stride, True)
-                    ho, wo = out_hw(cur, blk.conv1, stride)
+                    if raw0 is not None and li == 1 and bi == 0:
+                        st1 = new_stats(blk.conv1.out_channels)
+                        f1 = S.conv_norm_in(raw0[0], (n, h0, w0, c0), raw0[1], self._packed(pre + ".conv1", blk.conv1), stats=st1, eps=self.norm1.eps)
+                        ho, wo = h0, w0
+                    else:
+                        f1, st1 = conv_norm(pre + ".conv1", blk.conv1, blk.norm1, cur, stride, True)
+                        ho, wo = out_hw(cur, blk.conv1, stride)
                     st2 = new_stats(blk.conv2.out_channels)
                     c2 = S.conv_norm_in(f1, (n, ho, wo, blk.conv1.out_channels), st1, self._packed(pre + ".conv2", blk.conv2), stats=st2,
                                         eps=blk.norm1.eps)
@@ -194,7 +209,10 @@ class BasicEncoder(nn.Module):
                     a1 = conv_norm_relu_split(pre + ".conv1", blk.conv1, blk.norm1, cur, stride)
                     c2, st2 = conv_norm(pre + ".conv2", blk.conv2, blk.norm2, a1, 1, True)
                     shape = (n, a1.H, a1.W, blk.conv2.out_channels)
-                if blk.downsample is None:
+                if blk.downsample is None and raw0 is not None and li == 1 and bi == 0:
+                    # relu(x + relu(norm2(conv2))) with x = relu(norm1(stem)) taken from the stem's raw output
+                    cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU, b=raw0[0], stats_b=raw0[1], act_b=S.ACT_RELU, act_out=S.ACT_RELU)
+                elif blk.downsample is None:
                     # relu(x + relu(norm2(conv2)))          (extractor.py:50-55)
                     cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU if kind == "instance" else S.ACT_NONE, res=cur,
                                         act_out=S.ACT_RELU)

@@ -81,7 +81,7 @@ class NormDesc(ctypes.Structure):
                 ("res_hi", ctypes.c_void_p), ("res_lo", ctypes.c_void_p), ("act_out", ctypes.c_int),
                 ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p), ("out_f32", ctypes.c_void_p),
                 ("B", ctypes.c_int), ("HW", ctypes.c_int), ("C", ctypes.c_int), ("eps", ctypes.c_float), ("rows_per_image", ctypes.c_int),
-                ("stats_replicas", ctypes.c_int)]
+                ("stats_replicas", ctypes.c_int), ("act_b", ctypes.c_int)]
 
 
 _lib = None

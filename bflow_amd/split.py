@@ -519,8 +519,8 @@ def norm_act(a: torch.Tensor, shape_bhwc, a_is_nchw: bool = False, stats_a: Opti
              scale_a: Optional[torch.Tensor] = None, shift_a: Optional[torch.Tensor] = None, act_a: int = ACT_NONE,
              b: Optional[torch.Tensor] = None, stats_b: Optional[torch.Tensor] = None, res: Optional[SplitTensor] = None,
              act_out: int = ACT_NONE, eps: float = 1e-5, out: Optional[SplitTensor] = None, out_f32: Optional[torch.Tensor] = None,
-             want_split: bool = True) -> Tuple[Optional[SplitTensor], Optional[torch.Tensor]]:
-    """out = act_out(res + act_a(norm_a(a)))  (see bflow_norm_act_split).  a / b: blocked fp32 (B, C/32, H*W, 32), or a: NCHW."""
+             want_split: bool = True, act_b: int = ACT_NONE) -> Tuple[Optional[SplitTensor], Optional[torch.Tensor]]:
+    """out = act_out(res + act_a(norm_a(a)) + act_b(norm_b(b)))  (see bflow_norm_act_split).  a / b: blocked fp32 (B, C/32, H*W, 32), or a: NCHW."""
     B, H, W, C = shape_bhwc
     if out is None and want_split:
         out = SplitTensor.empty(B, H, W, C, a.device)
@@ -544,6 +544,7 @@ def norm_act(a: torch.Tensor, shape_bhwc, a_is_nchw: bool = False, stats_a: Opti
     ra, rb = _stats_replicas(stats_a, B, C), _stats_replicas(stats_b, B, C)
     assert not (ra and rb) or ra == rb, "both statistics tables must use the same number of replicas"
     d.stats_replicas = max(ra, rb)
+    d.act_b = act_b
     hip._check(hip.lib().bflow_norm_act_split(ctypes.byref(d), hip._stream()), "bflow_norm_act_split")
     return out, out_f32
 

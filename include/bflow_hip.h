@@ -312,6 +312,8 @@ typedef struct bflow_norm_desc {
     int B, HW, C; float eps;
     int rows_per_image;               /* pixel rows per image of the blocked tensors; 0 = HW                     */
     int stats_replicas;               /* stats_a / stats_b are (R, B, C, 2) tables to be summed; 0 = 1           */
+    int act_b;                        /* 1: the b branch is relu(norm_b(b)) -- a residual relu(norm(conv)) that was never materialised
+                                         (extractor.py:113 feeding the first block's `x + y`, extractor.py:55); 0: norm_b(b)               */
 } bflow_norm_desc_t;
 int bflow_plane_stats(const float* x, double* stats, long long planes, int HW, bflow_stream_t stream);
 int bflow_norm_act_split(const bflow_norm_desc_t* desc, bflow_stream_t stream);
