@@ -191,7 +191,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
             // gate operands (h as hi/lo halves, z) of the four row groups: same idea, one latency instead of four
             const int cbk = (n0 >> 5) + n;
             const bool r_half = a.gate == 1 && cbk >= a.CBo;
-            const bool need_h = a.gate == 2 || r_half;
+            const bool need_h = a.gate == 2 || a.gate == 3 || r_half;
             const long long gbase = (((long long)b * a.CBo + (r_half ? cbk - a.CBo : cbk)) * a.P_out) * 32 + ch;
             half4v g_hh[NIT], g_hl[NIT];
             float4 g_z[NIT];
@@ -248,7 +248,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&hh)[NT
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float h = (float)hh4[k] + (float)hl4[k] * LO_INV;
-                            const float o = (a.gate == 1) ? bflow::gate_sigmoid(v[k]) * h : (1.f - zz[k]) * h + zz[k] * bflow::gate_tanh(v[k]);
+                            const float o = (a.gate == 1) ? bflow::gate_sigmoid(v[k]) * h
+                                          : (a.gate == 2) ? (1.f - zz[k]) * h + zz[k] * bflow::gate_tanh(v[k])
+                                                          : fmaxf(v[k] + h, 0.f);          // gate 3: the residual block's relu(x + y), extractor.py:55
                             _Float16 x1, x2;
                             split1(o, x1, x2);
                             h4[k] = x1;

@@ -2020,10 +2020,11 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
     a.xraw = d->x_raw; a.xstats = d->x_stats; a.xstats_reps = d->x_stats_replicas > 0 ? d->x_stats_replicas : 1; a.xeps = d->x_eps;
     a.gate = d->gate; a.gh = (const _Float16*)d->gate_h_hi; a.gl = (const _Float16*)d->gate_h_lo; a.gz = d->gate_z;
     if (d->gate) {
-        BFLOW_REQUIRE((d->gate == 1 || d->gate == 2) && d->gate_h_hi && d->gate_h_lo && d->out_hi && d->out_lo && !d->stats && d->act == 0 &&
+        BFLOW_REQUIRE(d->gate >= 1 && d->gate <= 3 && d->gate_h_hi && d->gate_h_lo && d->out_hi && d->out_lo && !d->stats && (d->act == 0 || d->gate == 3) &&
                           d->out_channel_offset == 0 && d->Cout % 32 == 0, BFLOW_E_ARG, "conv_split: bad gate arguments");
-        BFLOW_REQUIRE(d->gate == 1 ? (d->out_f32 && d->Cout == 2 * out_c) : (d->gate_z && d->Cout == out_c), BFLOW_E_ARG,
-                      "conv_split: gate buffers must hold Cout/2 (zr) or Cout (blend) channels");
+        BFLOW_REQUIRE(d->gate == 1 ? (d->out_f32 && d->Cout == 2 * out_c) : ((d->gate_z || d->gate == 3) && d->Cout == out_c), BFLOW_E_ARG,
+                      "conv_split: gate buffers must hold Cout/2 (zr) or Cout (blend, residual) channels");
+        BFLOW_REQUIRE(d->gate != 3 || (!d->out_f32 && !d->acc_nchw), BFLOW_E_ARG, "conv_split: the residual epilogue writes the split output only");
     }
     a.n_tiles = bflow::ceil_div(d->Cout, d->tile_n);
     const int m_tiles8 = (bflow::ceil_div((long long)Ho * Wo, CBM) + 7) / 8 * 8;   // pixel tiles, padded to the 8 XCDs

@@ -24,6 +24,9 @@ FUSE_NORM_IN = os.environ.get("BFLOW_NO_NORM_IN") is None     # A/B switch (tool
 # round 4: the stem's norm + ReLU is never materialised either (layer1.0.conv1 normalises on load, the block-end kernel takes the residual as
 # relu(norm_b(b))): 3.581 / 3.597 / 3.614 vs 3.604 / 3.632 / 3.626 ms per frame over three alternating pairs.  BFLOW_NO_NORM_IN_STEM for A/B.
 FUSE_NORM_IN_STEM = os.environ.get("BFLOW_NO_NORM_IN_STEM") is None
+# round 4: BatchNorm encoders (the context encoder) take relu(x + y) as conv2's epilogue (bflow_conv_desc_t.gate = 3): six block-end launches
+# less; 3.581 / 3.569 / 3.593 vs 3.606 / 3.656 / 3.619 ms per frame over three alternating pairs.  BFLOW_NO_FUSE_RESIDUAL for A/B.
+FUSE_RESIDUAL = os.environ.get("BFLOW_NO_FUSE_RESIDUAL") is None
 
 
 def _make_norm(kind: str, channels: int) -> nn.Module:
@@ -205,6 +208,22 @@ class BasicEncoder(nn.Module):
                     c2 = S.conv_norm_in(f1, (n, ho, wo, blk.conv1.out_channels), st1, self._packed(pre + ".conv2", blk.conv2), stats=st2,
                                         eps=blk.norm1.eps)
                     shape = (n, ho, wo, blk.conv2.out_channels)
+                elif kind == "batch" and FUSE_RESIDUAL and blk.conv2.out_channels % 32 == 0:
+                    # folded BatchNorm (the context encoder): relu(x + relu(bn2(conv2(y)))) (extractor.py:49-55) is conv2's epilogue -- the
+                    # residual x (or the folded-BatchNorm down-sampling branch, written as a split tensor) enters as `gate_h` (GATE_RES):
+                    # no block-end launch, no fp32 round trip of conv2's output
+                    a1 = conv_norm_relu_split(pre + ".conv1", blk.conv1, blk.norm1, cur, stride)
+                    resid = cur
+                    if blk.downsample is not None:
+                        scd, shd = self._bn_affine(blk.norm3, blk.downsample[0].bias)
+                        resid, _ = S.conv(cur, self._packed(pre + ".downsample.0", blk.downsample[0]), stride=stride, padding=blk.downsample[0].padding,
+                                          scale=scd, shift=shd)
+                    sc2, sh2 = self._bn_affine(blk.norm2, blk.conv2.bias)
+                    out_new = S.SplitTensor.empty(n, a1.H, a1.W, blk.conv2.out_channels, dev)
+                    S.conv(a1, self._packed(pre + ".conv2", blk.conv2), padding=blk.conv2.padding, scale=sc2, shift=sh2, act=S.ACT_RELU,
+                           gate=S.GATE_RES, gate_h=resid, out_split=out_new)
+                    cur = out_new
+                    continue
                 else:
                     a1 = conv_norm_relu_split(pre + ".conv1", blk.conv1, blk.norm1, cur, stride)
                     c2, st2 = conv_norm(pre + ".conv2", blk.conv2, blk.norm2, a1, 1, True)

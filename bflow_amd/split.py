@@ -15,7 +15,7 @@ import torch
 from . import hip
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-GATE_NONE, GATE_ZR, GATE_BLEND = 0, 1, 2
+GATE_NONE, GATE_ZR, GATE_BLEND, GATE_RES = 0, 1, 2, 3     # GATE_RES: split(relu(act(conv) + gate_h)), the residual block's relu(x + y)
 LO_INV = 1.0 / 2048.0
 
 

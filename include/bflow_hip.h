@@ -114,6 +114,10 @@ typedef struct bflow_conv_desc {
                                          1 = "zr": Cout = 2*Ch.  channels [0, Ch): out_f32[c] = sigmoid(v) (the update gate z);
                                              channels [Ch, 2Ch): out_hi/lo[c - Ch] = split(sigmoid(v) * h[c - Ch])  (r * h);
                                          2 = "blend": Cout = Ch.  out_hi/lo[c] = split((1 - z[c]) * h[c] + z[c] * tanh(v));
+                                         3 = "residual" (round 4; not a GRU gate, the same operand path): Cout = Ch.
+                                             out_hi/lo[c] = split(relu(act(v) + h[c])): `relu(x + y)` of ResidualBlock.forward
+                                             (extractor.py:55) with y = act(scale * conv + shift) = the folded-BatchNorm convolution and
+                                             x = h; `act` may be 1 (relu) here;
                                          h = gate_h_hi/lo, z = gate_z; every gate buffer is blocked (B, Ch/32, P_out, 32) like the
                                          outputs (out_channel_stride = Ch, offset 0); out may alias h (blend, in place).       */
     const void *gate_h_hi, *gate_h_lo;
