@@ -373,8 +373,20 @@ class CorrBlockParallelMultiTarget:
         hip.corr_lookup_conv1x1(self._table, params, coef, packed, bias, act, out.planes, channel_offset)
         return out
 
-    def lookup_bezier_split(self, params: torch.Tensor, coef: np.ndarray, out):
-        """lookup_bezier writing the conv engine's blocked split layout directly (no NCHW intermediate)."""
+    def lookup_bezier_split(self, params: torch.Tensor, coef: np.ndarray, out, im2col=None):
+        """lookup_bezier writing the conv engine's blocked split layout directly (no NCHW intermediate).
+        im2col = (SplitTensor, kh, kw, (ph, pw)) (tiled pyramids): the same launch also writes the kh x kw filter windows of `params` -- the
+        input of the motion encoder's 7x7 `convf1` (update.py:91) -- into that tensor (bflow_corr_lookup_im2col)."""
         assert coef.shape[0] == self._num_targets_base
-        hip.corr_lookup_bezier_split(self._table, params, coef, out.planes, tiled=self._tiled, f16_planes=self._f16)
+        rider = None
+        if im2col is not None:
+            col, kh, kw, pad = im2col
+            ph, pw = (pad, pad) if isinstance(pad, int) else pad
+            rider = (col.planes, kh, kw, ph, pw)
+        hip.corr_lookup_bezier_split(self._table, params, coef, out.planes, tiled=self._tiled, f16_planes=self._f16, im2col=rider)
         return out
+
+    @property
+    def im2col_rider(self) -> bool:
+        """True when lookup_bezier_split can carry the im2col of the Bezier parameters in its launch (the tiled look-up kernel)."""
+        return self._tiled

@@ -47,6 +47,43 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((xs - h) * SPLIT_LO_SCALE);
 }
 
+// 2-D neighbourhood gather of a few-channel fp32 NCHW tensor into a blocked split tensor (bflow_im2col_small, and the rider of the look-up
+// launch): item e = ((b * CBk + kb) * P + pix) * 4 + g produces the 8 channels kk = kb * 32 + g * 8 .. + 7 of pixel pix, kk = tap * C + c,
+// out[b, kb, pix, kk % 32] = x[b, c, y + r - pad_h, x + q - pad_w] (zero outside the image and for kk >= KH * KW * C).
+struct Im2colArgs {
+    const float* x;
+    _Float16 *oh, *ol;
+    int C, H, W, KH, KW, pad_h, pad_w, CBk, P;
+};
+__device__ __forceinline__ void im2col_small_item(const Im2colArgs& m, long long e) {
+    typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
+    const int K = m.KH * m.KW * m.C;
+    const int g = (int)(e & 3);
+    const long long row = e >> 2;                        // (b*CBk + kb)*P + pix
+    const long long bkb = row / m.P;
+    const int pix = (int)(row - bkb * m.P);
+    const int b = (int)(bkb / m.CBk), kb = (int)(bkb - (long long)b * m.CBk);
+    half8_ h8, l8;
+    const int y = pix / m.W, xx0 = pix - y * m.W;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int kk = kb * 32 + g * 8 + k;
+        float v = 0.f;
+        if (kk < K && pix < m.H * m.W) {
+            const int t = kk / m.C, c = kk - t * m.C;
+            const int r = t / m.KW, q = t - r * m.KW;
+            const int yy = y + r - m.pad_h, xx = xx0 + q - m.pad_w;
+            if (yy >= 0 && yy < m.H && xx >= 0 && xx < m.W) v = m.x[((long long)b * m.C + c) * m.H * m.W + yy * m.W + xx];
+        }
+        _Float16 a, d;
+        split1(v, a, d);
+        h8[k] = a;
+        l8[k] = d;
+    }
+    *reinterpret_cast<half8_*>(m.oh + row * 32 + g * 8) = h8;
+    *reinterpret_cast<half8_*>(m.ol + row * 32 + g * 8) = l8;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Gate non-linearities of the fused GRU epilogues (conv_engine.h) on the transcendental unit: v_exp_f32 / v_rcp_f32 (1 ulp each) instead

@@ -116,8 +116,10 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x16 (
 //   KG = k-groups per workgroup: with KG = 2 the workgroup has 8 waves; waves 0-3 and 4-7 own the same output tile but alternate
 //        k-tiles (each group with its own LDS ring) and are summed through LDS at the end.  A small grid then runs 2 waves per
 //        SIMD, so one group's LDS/issue latency hides behind the other's MFMAs (intra-workgroup split-K).
+//   `bx` = the workgroup's index in ITS convolution's 1-D grid (blockIdx.x of a plain launch; a pair launch, below, subtracts the
+//        first convolution's grid).
 template <int NT, int S, int KG>
-__global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_split_body(const ConvArgs& a, const int bx) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the body uses device-only builtins (buffer resources); the host pass only needs the stub
     constexpr int CSTAGES = S;
     constexpr int BN = 32 * NT;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
     int m0, n0;
     {
         const int ntn = a.n_tiles;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = bx & 7, slot = bx >> 3;
         const int mt = (slot / ntn) * 8 + xcd;
         m0 = mt * CBM;
         n0 = (slot - (slot / ntn) * ntn) * BN;
@@ -292,6 +294,24 @@ __global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
     conv_epilogue<NT, 4 * KG, KG>(a, hh, xx, b, [=](int row) { return mw + row < HoWo ? mw + row : -1; }, n0, lane, wave, tid, writer,
                                   reinterpret_cast<float*>(lds), grp);
 #endif
+}
+
+template <int NT, int S, int KG>
+__global__ __launch_bounds__(CT * KG, 2) void conv_split_kernel(ConvArgs a) {
+    conv_split_body<NT, S, KG>(a, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PAIR launches (round 4).  Two INDEPENDENT convolutions that resolve to the same small-grid kernel run as ONE grid: workgroups
+// [0, n0) are the first convolution's, [n0, n0 + n1) the second's (both counts are multiples of 8, so the XCD decode of either body is
+// unchanged).  The batch-1 motion encoder (update.py:88-97) has two such pairs -- convc1 | convf1 and convc2 | convf2 -- that used
+// to sit on two hardware queues: every cross-queue edge of the captured graph cost the main chain 5-7 us (profiles/r04_iteration_launches.txt:
+// the 6.7 us hole before `conv`, the 4.6 us one after the Bezier head), more than the overlap saved at this size.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, int S, int KG>
+__global__ __launch_bounds__(CT * KG, 2) void conv_split_pair_kernel(ConvArgs a0, ConvArgs a1, int n0) {
+    if ((int)blockIdx.x < n0) conv_split_body<NT, S, KG>(a0, (int)blockIdx.x);
+    else conv_split_body<NT, S, KG>(a1, (int)blockIdx.x - n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -817,7 +837,7 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 //     (lanes 0-31 or 32-63 active).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KH, int KW>
-__global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_halo8_body(const ConvArgs& a, const int bx) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 8, TW = 16;
     constexpr int HWD = TW + KW - 1, HR = HWD * (TH + KH - 1);
@@ -846,7 +866,7 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
     int y0, x0, n0;
     {
         const int ntn = a.n_tiles;
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = bx & 7, slot = bx >> 3;
         const int mt = (slot / ntn) * 8 + xcd;
         if (mt >= tiles_x * tiles_y) return;
         n0 = (slot - (slot / ntn) * ntn) * 32;
@@ -989,6 +1009,17 @@ __global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
 #endif
     H8STAMP(6) H8STAMP_RT(15)
 #endif
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(2 * CT, 2) void conv_halo8_kernel(ConvArgs a) {
+    conv_halo8_body<KH, KW>(a, (int)blockIdx.x);
+}
+
+template <int KH, int KW>     // two independent convolutions as one grid (see conv_split_pair_kernel)
+__global__ __launch_bounds__(2 * CT, 2) void conv_halo8_pair_kernel(ConvArgs a0, ConvArgs a1, int n0) {
+    if ((int)blockIdx.x < n0) conv_halo8_body<KH, KW>(a0, (int)blockIdx.x);
+    else conv_halo8_body<KH, KW>(a1, (int)blockIdx.x - n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1971,7 +2002,15 @@ __global__ __launch_bounds__(256) void split_to_nchw_kernel(const _Float16* __re
 
 }  // namespace
 
-extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t stream) {
+// A convolution that a PAIR launch (bflow_conv_split_pair) can take: its resolved kernel arguments and grid instead of a launch.
+struct PairPlan {
+    int kind = 0;        // 0 = launched on its own (no pair variant of its kernel); 1 = conv_split_kernel<2, 3, 2>; 2 = conv_halo8_kernel<3, 3>
+    ConvArgs a;
+    unsigned gx = 0;     // workgroups (a multiple of 8)
+    int lds = 0;
+};
+
+static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, PairPlan* plan) {
     BFLOW_REQUIRE(d && ((d->x_hi && d->x_lo) || (d->x_raw && d->x_stats)) && d->w_hi && d->w_lo, BFLOW_E_ARG, "conv_split: null operand");
     if (d->x_raw)
         BFLOW_REQUIRE(d->x_stats && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && !d->x2_hi && d->out_f32 && !d->out_hi &&
@@ -2084,6 +2123,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
 #define LAUNCH_HALO8(KHH, KWW)                                                                                         \
     {                                                                                                                  \
         const int lds = 2 * 2 * (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16) * 1024 + 2 * 3 * 4096;                   \
+        if (plan && (KHH) == 3 && (KWW) == 3 && !a.stats) { plan->kind = 2; plan->a = a; plan->gx = hgrid.x; plan->lds = lds; return 0; } \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo8_kernel<KHH, KWW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((conv_halo8_kernel<KHH, KWW>), hgrid, dim3(2 * CT), lds, s, a);                             \
     }
@@ -2101,6 +2141,8 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         const long long wg8 = (long long)patches * d->B * a.n_tiles, wg10 = (long long)patches10 * d->B * a.n_tiles;
         // (6 x 16 patches = 3 slabs on SIX waves, two k-groups, were measured in round 3: q 12.2 vs 11.9 us -- 2 / 2 / 1 / 1 waves per SIMD)
         const bool forced_variant = force && strncmp(force, "halo", 4) == 0 && force[4];
+        // (a pair of 3x3s on 10 x 16 patches -- convc2 | convf2 at 60 x 80 as 180 + 60 workgroups, one per CU, instead of 240 + 80 of 8 x 16 -- was
+        //  built and measured in round 4: 22.3 vs 19.2 us for the launch, 3.587-3.614 vs 3.570-3.597 ms per frame; removed)
         const bool ten = small8 && (forced_variant ? strcmp(force, "halo10") == 0 : (wg8 > 256 && wg10 <= 256));
         // 6 x 16 patches on 12 waves (conv_halo_bp_kernel: four k-groups) when the 8 x 16 grid leaves more than a quarter of the chip idle and
         // the 6 x 16 grid still fits one round: the <= 128-channel convolutions at 60 x 80 (160 -> 200 workgroups carrying 3 instead of 4
@@ -2108,7 +2150,7 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         const int patches6 = bflow::ceil_div(d->H, 6) * bflow::ceil_div(d->W, 16);
         const long long wg6 = (long long)patches6 * d->B * a.n_tiles;
         static const bool no_h12 = getenv("BFLOW_CONV_NO_HALO12") != nullptr;
-        const bool twelve = small8 && !ten && (forced_variant ? strcmp(force, "halo12") == 0 : (!no_h12 && wg8 <= 192 && wg6 <= 256 && wg6 > wg8));
+        const bool twelve = small8 && !ten && !plan && (forced_variant ? strcmp(force, "halo12") == 0 : (!no_h12 && wg8 <= 192 && wg6 <= 256 && wg6 > wg8));
         if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (ten) LAUNCH_HALO10(3, 3) else if (twelve) LAUNCH_HALO12(3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }
         else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else if (ten) LAUNCH_HALO10(1, 5) else if (twelve) LAUNCH_HALO12(1, 5) else if (small8) LAUNCH_HALO8(1, 5) else LAUNCH_HALO(1, 1, 5) }
         else { if (nt == 2) LAUNCH_HALO(2, 5, 1) else if (ten) LAUNCH_HALO10(5, 1) else if (twelve) LAUNCH_HALO12(5, 1) else if (small8) LAUNCH_HALO8(5, 1) else LAUNCH_HALO(1, 5, 1) }
@@ -2160,11 +2202,54 @@ extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t strea
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_kernel<N, SS, KGG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((conv_split_kernel<N, SS, KGG>), grid, dim3(CT * (KGG)), lds, s, a);                        \
     }
+    if (plan && NT == 2 && deep && !a.stats && a.w_sets == 1) {
+        plan->kind = 1; plan->a = a; plan->gx = grid.x; plan->lds = 2 * 3 * (2 * CBM * 64 + 2 * 4 * 1024);
+        return 0;
+    }
     if (NT == 2) { if (deep) LAUNCH(2, 3, 2) else LAUNCH(2, 3, 1) }
     else if (NT == 3) { if (deep) LAUNCH(3, 5, 1) else LAUNCH(3, 3, 1) }
     else { if (deep) LAUNCH(4, 5, 1) else LAUNCH(4, 3, 1) }
 #undef LAUNCH
     return bflow::launch_status("conv_split");
+}
+
+extern "C" int bflow_conv_split(const bflow_conv_desc_t* d, bflow_stream_t stream) { return conv_split_impl(d, stream, nullptr); }
+
+// Two independent convolutions (neither reads what the other writes; disjoint outputs; same batch) on one stream.  When both resolve to the
+// same small-grid kernel that has a pair variant -- the generic split-k kernel (1x1 / im2col GEMMs) or the 8-wave 3x3 halo kernel -- they
+// are ONE launch (conv_split_pair_kernel / conv_halo8_pair_kernel); otherwise two consecutive launches.  Results are those of two
+// bflow_conv_split calls bit for bit (same kernel bodies, same tiles).  *fused (optional) receives 1 when one launch was made.
+extern "C" int bflow_conv_split_pair(const bflow_conv_desc_t* d0, const bflow_conv_desc_t* d1, int* fused, bflow_stream_t stream) {
+    if (fused) *fused = 0;
+    BFLOW_REQUIRE(d0 && d1 && d0->B == d1->B, BFLOW_E_ARG, "conv_split_pair: two descriptors of the same batch size expected");
+    static const bool no_pair = getenv("BFLOW_CONV_NO_PAIR") != nullptr;      // tools A/B: always two launches
+    if (no_pair) {
+        const int rc = conv_split_impl(d0, stream, nullptr);
+        return rc != 0 ? rc : conv_split_impl(d1, stream, nullptr);
+    }
+    PairPlan p0, p1;
+    int rc = conv_split_impl(d0, stream, &p0);
+    if (rc != 0) return rc;
+    rc = conv_split_impl(d1, stream, &p1);
+    if (rc != 0) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (p0.kind && p0.kind == p1.kind) {
+        const int lds = p0.lds > p1.lds ? p0.lds : p1.lds;
+        dim3 grid(p0.gx + p1.gx, 1, d0->B);
+        if (p0.kind == 1) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_pair_kernel<2, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((conv_split_pair_kernel<2, 3, 2>), grid, dim3(CT * 2), lds, s, p0.a, p1.a, (int)p0.gx);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo8_pair_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((conv_halo8_pair_kernel<3, 3>), grid, dim3(2 * CT), lds, s, p0.a, p1.a, (int)p0.gx);
+        }
+        if (fused) *fused = 1;
+        return bflow::launch_status("conv_split_pair");
+    }
+    // no common pair kernel: whatever was only planned is launched on its own, through the ordinary route
+    if (p0.kind) { rc = conv_split_impl(d0, stream, nullptr); if (rc != 0) return rc; }
+    if (p1.kind) { rc = conv_split_impl(d1, stream, nullptr); if (rc != 0) return rc; }
+    return 0;
 }
 
 extern "C" int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW, int cout_pad, int cin_pad,

@@ -316,7 +316,8 @@ extern "C" int bflow_corr_lookup_bezier(const bflow_plane_t* planes, int P, cons
 namespace bflow {
 int pool_tiled_launch(const void* in, void* out, long long planes, int h, int w, bool f16, hipStream_t stream);
 int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg, void* out_hi, void* out_lo,
-                       int channel_blocks, int rows_per_image, int B, int h1, int w1, bool f16_planes, hipStream_t stream);
+                       int channel_blocks, int rows_per_image, int B, int h1, int w1, bool f16_planes, hipStream_t stream,
+                       const Im2colArgs* rider = nullptr);
 }
 
 extern "C" int bflow_corr_pool2x2_tiled(const float* in, float* out, long long planes, int h, int w, bflow_stream_t stream) {
@@ -339,6 +340,19 @@ extern "C" int bflow_corr_lookup_bezier_split_tiled(const bflow_plane_t* planes,
                                                     bflow_stream_t stream) {
     return bflow::lookup_tile_launch(planes, P, params, coef, T, deg, out_hi, out_lo, channel_blocks, rows_per_image, B, h1, w1, false,
                                      (hipStream_t)stream);
+}
+
+// Look-up (tiled planes, fp32 or fp16) + bflow_im2col_small of the same Bezier parameters as ONE launch: the two first kernels of an update
+// iteration (update.py:117 / corr.py look-up and the 7x7 `convf1` input of update.py:91) both read `params` and nothing of each other.
+extern "C" int bflow_corr_lookup_im2col(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg, void* out_hi,
+                                        void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1, int f16_planes, void* col_hi,
+                                        void* col_lo, int KH, int KW, int pad_h, int pad_w, int col_rows_per_image, bflow_stream_t stream) {
+    BFLOW_REQUIRE(col_hi && col_lo && KH > 0 && KW > 0 && deg >= 1 && h1 > 0 && w1 > 0, BFLOW_E_ARG, "corr_lookup_im2col: bad im2col arguments");
+    const int Pc = col_rows_per_image > 0 ? col_rows_per_image : h1 * w1;
+    BFLOW_REQUIRE(Pc >= h1 * w1, BFLOW_E_ARG, "corr_lookup_im2col: col_rows_per_image < h1*w1");
+    bflow::Im2colArgs m{params, (_Float16*)col_hi, (_Float16*)col_lo, 2 * deg, h1, w1, KH, KW, pad_h, pad_w, (KH * KW * 2 * deg + 31) / 32, Pc};
+    return bflow::lookup_tile_launch(planes, P, params, coef, T, deg, out_hi, out_lo, channel_blocks, rows_per_image, B, h1, w1, f16_planes != 0,
+                                     (hipStream_t)stream, &m);
 }
 
 extern "C" int bflow_corr_lookup_bezier_split(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,

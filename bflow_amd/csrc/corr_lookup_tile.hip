@@ -64,7 +64,8 @@ __device__ __forceinline__ int tiled_index(int y, int x, int tw) {
 
 template <typename VT, int TP, int THREADS>
 __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args, const float* __restrict__ params, _Float16* __restrict__ oh,
-                                                                 _Float16* __restrict__ ol, int CBk, int Prow, int h1, int w1, int abl) {
+                                                                 _Float16* __restrict__ ol, int CBk, int Prow, int h1, int w1, int abl,
+                                                                 bflow::Im2colArgs rider, int rider_blocks) {
     constexpr int EPU = 16 / (int)sizeof(VT);          // elements per 16-B unit: 4 (fp32) / 8 (fp16)
     constexpr int UPR = sizeof(VT) == 4 ? 4 : 3;       // units per patch row: columns [ox_al, ox_al + UPR*EPU) cover ox .. ox+11 for any alignment
     constexpr int PCOLS = UPR * EPU;                   // 16 / 24
@@ -75,7 +76,17 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     const int N = h1 * w1;
     const int P = args.P;
     const int b = blockIdx.y;
-    const int n0 = blockIdx.x * TP;
+    // Rider (bflow_corr_lookup_im2col): the first `rider_blocks` workgroups of every image expand the 7x7 windows of the SAME Bezier parameters
+    // for the motion encoder's convf1 (update.py:91) -- the other first kernel of an update iteration, 5-8 us of its own on a second queue
+    // before -- and leave; they are dispatched first and gone long before the gather tiles finish (as the LAST workgroups of the grid
+    // instead: 3.425-3.439 vs 3.412-3.432 ms per frame, three alternating pairs).
+    if ((int)blockIdx.x < rider_blocks) {
+        const long long per_image = (long long)rider.CBk * rider.P * 4;
+        for (long long e = (long long)blockIdx.x * THREADS + tid; e < per_image; e += (long long)rider_blocks * THREADS)
+            bflow::im2col_small_item(rider, (long long)b * per_image + e);
+        return;
+    }
+    const int n0 = ((int)blockIdx.x - rider_blocks) * TP;
     const int npair = P * TP;                 // pair = plane * TP + pixel of the tile
     const bool swz_on = !(abl & 16);
     const int cstride = ((P * NCH + 31) >> 5) * 32;   // staged channels per pixel (whole channel blocks)
@@ -274,7 +285,8 @@ __global__ __launch_bounds__(256) void corr_pool2x2_tiled_kernel(const VT* __res
 namespace bflow {
 
 int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg, void* out_hi, void* out_lo,
-                       int channel_blocks, int rows_per_image, int B, int h1, int w1, bool f16_planes, hipStream_t stream) {
+                       int channel_blocks, int rows_per_image, int B, int h1, int w1, bool f16_planes, hipStream_t stream,
+                       const Im2colArgs* rider) {
     BFLOW_REQUIRE(planes && P > 0 && T > 0, BFLOW_E_ARG, "corr_lookup: bad plane table");
     BFLOW_REQUIRE(P <= BFLOW_MAX_PLANES, BFLOW_E_LIMIT, "corr_lookup: %d planes > %d", P, BFLOW_MAX_PLANES);
     BFLOW_REQUIRE(T <= BFLOW_MAX_TARGETS, BFLOW_E_LIMIT, "corr_lookup: %d targets > %d", T, BFLOW_MAX_TARGETS);
@@ -305,10 +317,18 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
     const int tp = (tp_env == 2 || tp_env == 4 || tp_env == 8) ? tp_env : 2;
     const int cstride = ((P * NCH + 31) >> 5) * 32;
     const int lds = 16 * BFLOW_MAX_PLANES + P * tp * (4 + 18 + 36) * 4 + P * tp * PATCH * 16 * (f16_planes ? 3 : 4) + tp * cstride * 4 + 1024;
-    dim3 grid(ceil_div((long long)h1 * w1, tp), B);
+    Im2colArgs m = {};
+    int rider_blocks = 0;
+    if (rider) {
+        m = *rider;
+        rider_blocks = (int)ceil_div((long long)m.CBk * m.P * 4, 256);      // one 8-channel group per thread
+        if (rider_blocks > 1024) rider_blocks = 1024;
+    }
+    dim3 grid(ceil_div((long long)h1 * w1, tp) + rider_blocks, B);
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, params, (_Float16*)out_hi, (_Float16*)out_lo, channel_blocks, rows_per_image, h1, w1, abl);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, params, (_Float16*)out_hi, (_Float16*)out_lo, channel_blocks, rows_per_image, h1, w1, abl,
+                           m, rider_blocks);
     };
     if (f16_planes) {
         if (tp == 2) go(corr_lookup_tile_kernel<_Float16, 2, 256>);

@@ -85,36 +85,9 @@ namespace {
 // 2-D neighbourhood gather of a few-channel fp32 NCHW tensor into a blocked split tensor: out[b, pix, tap*C + c] =
 // x[b, c, y + r - pad, x + q - pad] (zero outside), K = KH*KW*C padded to a multiple of 32 with zeros.  Turns the 7x7
 // convolution over the 2*deg Bezier channels (update.py:62,91) into a dense 1x1 GEMM instead of 49 mostly-empty k-tiles.
-__global__ __launch_bounds__(256) void im2col_small_kernel(const float* __restrict__ x, _Float16* __restrict__ oh, _Float16* __restrict__ ol,
-                                                           int B, int C, int H, int W, int KH, int KW, int pad_h, int pad_w, int CBk, int P) {
-    const int K = KH * KW * C;
-    const long long total = (long long)B * CBk * P * 4;     // 8-channel groups
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(e & 3);
-        const long long row = e >> 2;                        // (b*CBk + kb)*P + pix
-        const long long bkb = row / P;
-        const int pix = (int)(row - bkb * P);
-        const int b = (int)(bkb / CBk), kb = (int)(bkb - (long long)b * CBk);
-        half8 h8, l8;
-        const int y = pix / W, xx0 = pix - y * W;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int kk = kb * 32 + g * 8 + k;
-            float v = 0.f;
-            if (kk < K && pix < H * W) {
-                const int t = kk / C, c = kk - t * C;
-                const int r = t / KW, q = t - r * KW;
-                const int yy = y + r - pad_h, xx = xx0 + q - pad_w;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[((long long)b * C + c) * H * W + yy * W + xx];
-            }
-            _Float16 a, d;
-            split1(v, a, d);
-            h8[k] = a;
-            l8[k] = d;
-        }
-        *reinterpret_cast<half8*>(oh + row * 32 + g * 8) = h8;
-        *reinterpret_cast<half8*>(ol + row * 32 + g * 8) = l8;
-    }
+__global__ __launch_bounds__(256) void im2col_small_kernel(bflow::Im2colArgs m, int B) {
+    const long long total = (long long)B * m.CBk * m.P * 4;     // 8-channel groups (bflow::im2col_small_item, common.h)
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) bflow::im2col_small_item(m, e);
 }
 }  // namespace
 
@@ -124,7 +97,7 @@ extern "C" int bflow_im2col_small(const float* x, void* out_hi, void* out_lo, in
     const int P = rows_per_image > 0 ? rows_per_image : H * W;
     const int CBk = (KH * KW * C + 31) / 32;
     const long long total = (long long)B * CBk * P * 4;
-    hipLaunchKernelGGL(im2col_small_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)out_hi,
-                       (_Float16*)out_lo, B, C, H, W, KH, KW, pad_h, pad_w, CBk, P);
+    bflow::Im2colArgs m{x, (_Float16*)out_hi, (_Float16*)out_lo, C, H, W, KH, KW, pad_h, pad_w, CBk, P};
+    hipLaunchKernelGGL(im2col_small_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, m, B);
     return bflow::launch_status("im2col_small");
 }

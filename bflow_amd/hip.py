@@ -30,7 +30,7 @@ EXPORTS = (
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
     "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_scatter_rectified", "bflow_maxabs_diff",
     "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
-    "bflow_l1_masked_grad",
+    "bflow_l1_masked_grad", "bflow_conv_split_pair", "bflow_corr_lookup_im2col",
 )
 
 
@@ -122,6 +122,8 @@ def lib() -> ctypes.CDLL:
         "bflow_conv_pack_weights_adjoint": [vp, vp, vp, i, i, i, i, i, i, vp],
         "bflow_conv_stem": [ctypes.POINTER(StemDesc), vp],
         "bflow_conv_split": [ctypes.POINTER(ConvDesc), vp],
+        "bflow_conv_split_pair": [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_int), vp],
+        "bflow_corr_lookup_im2col": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_conv_thin_acc": [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, vp],
         "bflow_conv_thin_mfma_acc": [vp, vp, vp, vp, i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, vp],
         "bflow_wgrad_pack": [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, i, i, i, vp, vp],
@@ -386,7 +388,7 @@ def corr_lookup_bezier(table, params: torch.Tensor, coef: np.ndarray, out: torch
 
 
 def corr_lookup_bezier_split(table, params: torch.Tensor, coef: np.ndarray, out_planes: torch.Tensor, tiled: bool = False,
-                             f16_planes: bool = False):
+                             f16_planes: bool = False, im2col=None):
     """out_planes: (2, B, CBk, rows, 32) fp16 (hi, lo), zero-initialised once by the caller (pad channels are never written by the row-major
     kernel).  tiled: the plane table describes tiled planes (bflow_corr_build_split_tiled / bflow_corr_pool2x2_tiled)."""
     B, C2, h1, w1 = params.shape
@@ -396,6 +398,16 @@ def corr_lookup_bezier_split(table, params: torch.Tensor, coef: np.ndarray, out_
     assert out_planes.dtype == torch.float16 and out_planes.is_contiguous() and out_planes.shape[0] == 2 and out_planes.shape[1] == B \
         and out_planes.shape[4] == 32 and out_planes.shape[2] * 32 >= P * 81 and out_planes.shape[3] >= h1 * w1
     assert tiled or not f16_planes
+    if im2col is not None:
+        # + the filter windows of the same parameters (bflow_im2col_small) as the first workgroups of the look-up launch
+        col_planes, kh, kw, ph, pw = im2col
+        assert tiled and col_planes.dtype == torch.float16 and col_planes.is_contiguous() and col_planes.shape[0] == 2 and col_planes.shape[1] == B \
+            and col_planes.shape[2] == (kh * kw * C2 + 31) // 32 and col_planes.shape[3] >= h1 * w1 and col_planes.shape[4] == 32
+        _check(lib().bflow_corr_lookup_im2col(table, P, _dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), T, deg,
+                                              out_planes[0].data_ptr(), out_planes[1].data_ptr(), out_planes.shape[2], out_planes.shape[3], B, h1, w1,
+                                              int(f16_planes), col_planes[0].data_ptr(), col_planes[1].data_ptr(), kh, kw, ph, pw, col_planes.shape[3],
+                                              _stream()), "bflow_corr_lookup_im2col")
+        return
     fn = lib().bflow_corr_lookup_bezier_split_tiled_f16 if f16_planes else lib().bflow_corr_lookup_bezier_split_tiled if tiled \
         else lib().bflow_corr_lookup_bezier_split
     _check(fn(table, P, _dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),

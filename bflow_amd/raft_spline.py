@@ -33,7 +33,7 @@ from .bezier import BezierCurves, polynomial_coefficients
 from .corr import CorrBlockParallelMultiTarget, CorrComputation
 from .extractor import BasicEncoder
 from .timers import StageTimer
-from .update import BasicUpdateBlock, FusedLookup
+from .update import BasicUpdateBlock, FusedLookup, SplitLookup
 
 
 
@@ -347,8 +347,7 @@ class RAFTSpline(nn.Module):
             need_mask = (not test_mode) or itr == iters - 1
             if tm is None:
                 # the look-up runs inside the step, next to the (independent) Bezier branch of the motion encoder
-                mask = ub.step_split(ws, fused if fused is not None else (lambda: corr_block.lookup_bezier_split(bezier, coef, out=corr_feat)),
-                                     bezier, need_mask)
+                mask = ub.step_split(ws, fused if fused is not None else SplitLookup(corr_block, bezier, coef, corr_feat), bezier, need_mask)
             else:
                 # stage timing (eager): the same kernels, the look-up timed on its own, no side-stream overlap
                 tm.start("1 iter")

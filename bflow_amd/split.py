@@ -329,7 +329,7 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
          want_split: bool = True, want_f32: bool = False, out_rows: Optional[int] = None, zero_rows: bool = False,
          x2: Optional[SplitTensor] = None, addend: Optional[torch.Tensor] = None, tile: Optional[int] = None,
          gate: int = GATE_NONE, gate_h: Optional[SplitTensor] = None, gate_z: Optional[torch.Tensor] = None,
-         acc_nchw: Optional[torch.Tensor] = None, weight_sets: int = 1, keep_pad: bool = False):
+         acc_nchw: Optional[torch.Tensor] = None, weight_sets: int = 1, keep_pad: bool = False, _desc_only: bool = False):
     """Implicit-GEMM convolution.  `packed` = PackedConvWeight.get(weight).  Returns (split_out or None, f32_out or None);
     f32_out is blocked fp32 (B, Cs/32, P_out, 32).  When out_* buffers are given the result is written at channel
     `channel_offset` (a multiple of 32) of their channel dimension (free concatenation).  out_rows > Ho*Wo allocates
@@ -392,8 +392,21 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
         d.gate_z = None if gate_z is None else gate_z.data_ptr()
     d.weight_sets = weight_sets
     d.keep_pad_channels = int(keep_pad)     # the pad channels of the last output block belong to another producer: do not zero them
+    if _desc_only:                          # conv_pair: the resolved descriptor instead of a launch
+        return d, out_split, out_f32
     hip._check(hip.lib().bflow_conv_split(ctypes.byref(d), hip._stream()), "bflow_conv_split")
     return out_split, out_f32
+
+
+def conv_pair(first: dict, second: dict):
+    """Two INDEPENDENT convolutions (keyword arguments of `conv` each; neither reads the other's output) through bflow_conv_split_pair: ONE
+    launch when both resolve to the same small-grid kernel (the batch-1 motion encoder's convc1 | convf1 and convc2 | convf2), else two.
+    Returns ((split, f32) of the first, (split, f32) of the second, fused: bool); results bit-identical to two `conv` calls."""
+    d0, s0, f0 = conv(**first, _desc_only=True)
+    d1, s1, f1 = conv(**second, _desc_only=True)
+    fused = ctypes.c_int(0)
+    hip._check(hip.lib().bflow_conv_split_pair(ctypes.byref(d0), ctypes.byref(d1), ctypes.byref(fused), hip._stream()), "bflow_conv_split_pair")
+    return (s0, f0), (s1, f1), bool(fused.value)
 
 
 def conv_norm_in(raw: torch.Tensor, shape_bhwc, x_stats: torch.Tensor, packed, stats: Optional[torch.Tensor] = None, eps: float = 1e-5,

@@ -81,6 +81,19 @@ class FusedLookup:
         self.corr_block, self.bezier, self.coef = corr_block, bezier, coef
 
 
+class SplitLookup:
+    """`corr` argument of `step_split` for the ordinary look-up (CorrBlockParallelMultiTarget.lookup_bezier_split into `out`): a callable the
+    step invokes where the look-up belongs.  With im2col = (SplitTensor, kh, kw, padding) the same launch also writes the filter windows of the
+    Bezier parameters (`im2col_rider`: the pyramid's look-up kernel can carry them)."""
+
+    def __init__(self, corr_block, bezier: torch.Tensor, coef, out):
+        self.corr_block, self.bezier, self.coef, self.out = corr_block, bezier, coef, out
+        self.im2col_rider = bool(getattr(corr_block, "im2col_rider", False))
+
+    def __call__(self, im2col=None):
+        return self.corr_block.lookup_bezier_split(self.bezier, self.coef, out=self.out, im2col=im2col)
+
+
 class SplitWorkspace:
     """Buffers of one forward when the update block runs on the split-fp16 engine (blocked channels-last split tensors)."""
 
@@ -101,8 +114,13 @@ class SplitWorkspace:
         self.INP = None                                                          # relu(context) split, set by set_context
         self.corbez = S.SplitTensor.empty(batch, h, w, 256, device)
         self.C1 = None                                                           # relu(convc1(look-up)) of the fused look-up launch
+        self.COL = None                                                          # 7x7 windows of the Bezier parameters (one-queue path)
         self.inp_terms = None
         self.overlap = True                                                      # independent branches on a side stream
+
+
+ITER_BRANCH = os.environ.get("BFLOW_NO_OVERLAP") is None    # tools A/B: the two motion-encoder branches on one queue
+ONE_QUEUE = os.environ.get("BFLOW_NO_ONE_QUEUE") is None     # tools A/B: off = the side-stream form of the batch-1 motion encoder
 
 
 class BasicUpdateBlock(nn.Module):
@@ -207,7 +225,25 @@ class BasicUpdateBlock(nn.Module):
         # The correlation branch (look-up -> 1x1 -> 3x3) and the Bezier branch (7x7 as im2col + 1x1 GEMM -> 3x3) are independent.
         # The LONGER one is issued on the side stream: the graph keeps the captured stream's nodes on one hardware queue, and a
         # cross-queue join costs ~10 us unless the other side finished long before (measured both ways).
-        with hip.Branch(ws.overlap) as corr_branch:
+        kh, kw = enc.convf1.kernel_size
+        if ws.overlap and ONE_QUEUE and callable(corr) and getattr(corr, "im2col_rider", False) and ws.H.shape[0] * ws.H.H * ws.H.W <= THIN_HEAD_MAX_PIXELS:
+            # Small grids (batch 1 at DSEC size): the two branches as PAIR launches on ONE queue -- look-up | im2col, convc1 | convf1,
+            # convc2 | convf2 -- instead of two queues: every cross-queue edge of the captured graph cost the chain 5-7 us
+            # (profiles/r04_iteration_launches.txt), about what the overlap saved.
+            if ws.COL is None:
+                ws.COL = S.SplitTensor.empty(ws.H.shape[0], ws.H.H, ws.H.W, kh * kw * bezier.shape[1], bezier.device)
+            cs = corr(im2col=(ws.COL, kh, kw, enc.convf1.padding))
+            (c1, _), (f1, _), _ = S.conv_pair(
+                dict(x=cs, packed=self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU),
+                dict(x=ws.COL, packed=self._pk("convf1_cols", lambda a=enc.convf1.weight: a.permute(0, 2, 3, 1).reshape(a.shape[0], -1, 1, 1)),
+                     shift=enc.convf1.bias, act=S.ACT_RELU))
+            S.conv_pair(
+                dict(x=c1, packed=self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
+                     out_split=ws.corbez, channel_offset=0),
+                dict(x=f1, packed=self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
+                     out_split=ws.corbez, channel_offset=192))
+            return self._step_tail(ws, bezier, need_mask)
+        with hip.Branch(ws.overlap and ITER_BRANCH) as corr_branch:
             if isinstance(corr, FusedLookup):
                 # look-up + convc1 + ReLU as ONE launch (bflow_corr_lookup_conv1x1): the correlation features stay in the CU
                 if ws.C1 is None:
@@ -221,13 +257,17 @@ class BasicUpdateBlock(nn.Module):
                 c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
             S.conv(c1, self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
                    out_split=ws.corbez, channel_offset=0)
-        kh, kw = enc.convf1.kernel_size
         col = S.im2col_small(bezier, kh, kw, enc.convf1.padding)
         f1, _ = S.conv(col, self._pk("convf1_cols", lambda a=enc.convf1.weight: a.permute(0, 2, 3, 1).reshape(a.shape[0], -1, 1, 1)),
                        shift=enc.convf1.bias, act=S.ACT_RELU)
         S.conv(f1, self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
                out_split=ws.corbez, channel_offset=192)
         corr_branch.join()
+        return self._step_tail(ws, bezier, need_mask)
+
+    def _step_tail(self, ws: SplitWorkspace, bezier: torch.Tensor, need_mask: bool):
+        """The rest of the iteration behind the two motion-encoder branches: `conv`, the separable conv-GRU, the heads."""
+        enc = self.encoder
         S.conv(ws.corbez, self._pk("conv", lambda a=enc.conv.weight: a), padding=1, shift=enc.conv.bias, act=S.ACT_RELU,
                out_split=ws.M, channel_offset=0, keep_pad=ws.merged)     # merged: the pad channels of the last block hold the Bezier parameters
         # ---- separable conv-GRU (update.py:33-48)

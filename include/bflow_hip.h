@@ -200,6 +200,13 @@ int bflow_conv_pack_weights(const float* w, void* w_hi, void* w_lo, int Cout, in
 int bflow_conv_pack_weights_adjoint(const float* w, void* w_hi, void* w_lo, int Cout, int Cin, int KH, int KW,
                             int cout_pad, int cin_pad, bflow_stream_t stream);
 int bflow_conv_split(const bflow_conv_desc_t* desc, bflow_stream_t stream);
+/* Two INDEPENDENT convolutions of the same batch (neither reads what the other writes; disjoint outputs) issued on one stream.  When both
+ * resolve to the same small-grid kernel that has a pair variant -- the generic split-k kernel (1x1 filters / im2col GEMMs on <= 320
+ * workgroups) or the 8-wave 3x3 halo kernel -- they are ONE launch whose grid is the two grids back to back (the batch-1 motion encoder,
+ * update.py:88-97: convc1 | convf1 and convc2 | convf2, which the reference leaves to the stream scheduler); otherwise two consecutive
+ * launches.  The results are those of two bflow_conv_split calls bit for bit.  *fused (may be null) receives 1 for one launch, else 0.
+ * BFLOW_CONV_NO_PAIR (environment, tools A/B) forces two launches. */
+int bflow_conv_split_pair(const bflow_conv_desc_t* desc0, const bflow_conv_desc_t* desc1, int* fused, bflow_stream_t stream);
 
 /* Training convolutions (bflow_amd/conv_train.py): the adjoints of Conv2d that the reference gets from autograd over
  * torch.nn.Conv2d (extractor.py / update.py convolutions) run on bflow_conv_split; these are the helpers around it.
@@ -431,6 +438,13 @@ int bflow_corr_build_tiled(const void* f1_hi, const void* f1_second, const void*
 int bflow_corr_lookup_bezier_split_tiled_f16(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
                                              void* out_hi, void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1,
                                              bflow_stream_t stream);
+/* bflow_corr_lookup_bezier_split_tiled (f16_planes = 0) / _tiled_f16 (1)  +  bflow_im2col_small(params, C = 2 deg, H = h1, W = w1, KH, KW, pads)
+ * as ONE launch: the first workgroups of the look-up grid expand the filter windows of the same Bezier parameters into (col_hi, col_lo)
+ * (B, ceil(KH KW 2 deg / 32), col_rows_per_image, 32) -- the two kernels an update iteration starts with (the look-up of raft.py:181-183 and the
+ * input of the 7x7 `convf1`, update.py:91) read `params` and nothing of each other.  Outputs bit-identical to the two separate calls. */
+int bflow_corr_lookup_im2col(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg, void* out_hi,
+                             void* out_lo, int channel_blocks, int rows_per_image, int B, int h1, int w1, int f16_planes, void* col_hi,
+                             void* col_lo, int KH, int KW, int pad_h, int pad_w, int col_rows_per_image, bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K8  Bezier polynomial coefficients C(deg,i) (1-t)^(deg-i) t^i, i = 1..deg, computed in fp64 on the HOST

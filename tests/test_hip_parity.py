@@ -235,6 +235,78 @@ def test_lookup_tiled_split_vs_oracle(deg, B, h, w, levels):
     assert (sp2.float_nhwc() - sp.float_nhwc()).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("deg,B,h,w,levels,f16", [(2, 1, 60, 80, [1, 1, 1, 4], False), (10, 2, 15, 20, [1, 1, 3], False), (2, 2, 18, 22, [1, 2, 4], True),
+                                                  (1, 1, 7, 9, [1], False)])
+def test_lookup_with_im2col_rider_equals_separate_launches(deg, B, h, w, levels, f16):
+    """bflow_corr_lookup_im2col (look-up + the 7x7 windows of the Bezier parameters as the first workgroups of the same launch) against
+    bflow_corr_lookup_bezier_split_tiled(_f16) and bflow_im2col_small on their own: both outputs bit for bit, including the pad
+    channels of the last window block; the windows also against a plain unfold of the parameters (split to 2^-22)."""
+    from bflow_amd import split as S
+    T, D = len(levels), 128
+    rs = np.random.RandomState(15)
+    f1, f2 = cu(rs.standard_normal((B, D, h, w)).astype(np.float32)), cu(rs.standard_normal((T, B, D, h, w)).astype(np.float32))
+    params = cu((rs.standard_normal((B, 2 * deg, h, w)) * 3).astype(np.float32))
+    coef = hip.bezier_coeffs([(i + 1) / T for i in range(T)], deg)
+    blk = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, levels), layout="tiled", precision="f16" if f16 else "split")
+    assert blk.im2col_rider
+    ref_feat = blk.lookup_bezier_split(params, coef, blk.new_output_split())
+    ref_col = S.im2col_small(params, 7, 7, 3)
+    col = S.SplitTensor.empty(B, h, w, 49 * 2 * deg, DEV)
+    col.planes.fill_(7.0)                                            # every element must be overwritten (pad channels included)
+    feat = blk.lookup_bezier_split(params, coef, blk.new_output_split(), im2col=(col, 7, 7, 3))
+    assert torch.equal(feat.planes, ref_feat.planes)
+    assert torch.equal(col.planes, ref_col.planes)
+    unf = torch.nn.functional.unfold(params.cpu(), 7, padding=3).reshape(B, 2 * deg, 49, h, w).permute(0, 3, 4, 2, 1).reshape(B, h, w, -1)   # k = tap*C + c
+    assert float((col.float_nhwc()[..., :unf.shape[-1]].cpu() - unf).abs().max()) < 1e-5
+    if unf.shape[-1] % 32:
+        assert float(col.planes[:, :, -1, :, unf.shape[-1] % 32:].abs().max()) == 0.0      # pad channels of the last window block
+
+
+@pytest.mark.parametrize("case", ["gemm", "halo8", "mixed", "big"])
+def test_conv_pair_equals_two_launches(case, monkeypatch):
+    """bflow_conv_split_pair: two independent convolutions as ONE grid (conv_split_pair_kernel / conv_halo8_pair_kernel: the batch-1 motion
+    encoder's convc1 | convf1 and convc2 | convf2, update.py:88-97) give the bits of two bflow_conv_split launches -- also into channel
+    ranges of one shared output (the free concatenation) -- and shapes without a common pair kernel fall back to two launches."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(16)
+    H, W, B = (60, 80, 1) if case != "big" else (64, 96, 4)
+    def mk(cin, cout, k):
+        x = S.from_nchw(cu(rs.standard_normal((B, cin, H, W)).astype(np.float32)))
+        pk = S.PackedConvWeight().get(cu((rs.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)))
+        return x, pk, cu(rs.standard_normal(cout).astype(np.float32))
+    if case == "gemm":        # 1x1 GEMMs on <= 320 workgroups: the generic split-k kernel (324 -> 256 look-up features, 224 -> 128 window columns)
+        (xa, pa, ba), (xb, pb, bb), k, expect = mk(352, 256, 1), mk(224, 128, 1), 1, True
+    elif case == "halo8":     # 3x3 on 40 patches: 256 -> 192 and 128 -> 64 into one 256-channel tensor at offsets 0 / 192
+        (xa, pa, ba), (xb, pb, bb), k, expect = mk(256, 192, 3), mk(128, 64, 3), 3, True
+    elif case == "mixed":     # 256 output channels take the 10x16 kernel, 64 the 8x16 one: no common kernel
+        (xa, pa, ba), (xb, pb, bb), k, expect = mk(128, 256, 3), mk(128, 64, 3), 3, False
+    else:                     # grids that fill the chip: the 4-wave halo kernel, two launches
+        (xa, pa, ba), (xb, pb, bb), k, expect = mk(128, 192, 3), mk(64, 64, 3), 3, False
+    pad = k // 2
+    ca, cb_ = pa[1][0], pb[1][0]
+    tot = (ca + 31) // 32 * 32 + (cb_ + 31) // 32 * 32
+    def outs():
+        t = S.SplitTensor.empty(B, H, W, tot, DEV)
+        t.planes.fill_(3.0)
+        return t
+    if case == "halo8":       # on its own the 64-channel convolution takes the 6x16 / 12-wave kernel (another summation order): the pair is
+        monkeypatch.setenv("BFLOW_CONV_KERNEL", "halo8x16")    # compared with the kernel it runs, forced for the single launches
+    ref = outs()
+    S.conv(xa, pa, padding=pad, shift=ba, act=S.ACT_RELU, out_split=ref, channel_offset=0)
+    S.conv(xb, pb, padding=pad, shift=bb, act=S.ACT_RELU, out_split=ref, channel_offset=(ca + 31) // 32 * 32)
+    got = outs()
+    _, _, fused = S.conv_pair(dict(x=xa, packed=pa, padding=pad, shift=ba, act=S.ACT_RELU, out_split=got, channel_offset=0),
+                              dict(x=xb, packed=pb, padding=pad, shift=bb, act=S.ACT_RELU, out_split=got, channel_offset=(ca + 31) // 32 * 32))
+    assert fused == expect
+    assert torch.equal(got.planes, ref.planes)
+    # separate outputs (allocated by the call), the second convolution first
+    (sb, _), (sa, _), fused2 = S.conv_pair(dict(x=xb, packed=pb, padding=pad, shift=bb), dict(x=xa, packed=pa, padding=pad, shift=ba))
+    assert fused2 == expect
+    ra, _ = S.conv(xa, pa, padding=pad, shift=ba)
+    rb, _ = S.conv(xb, pb, padding=pad, shift=bb)
+    assert torch.equal(sa.planes, ra.planes) and torch.equal(sb.planes, rb.planes)
+
+
 @pytest.mark.parametrize("deg,B,h,w,levels,cout", [(2, 1, 60, 80, [1, 1, 1, 4], 256), (2, 2, 18, 22, [1, 2, 4], 256), (10, 1, 15, 20, [1, 1, 3], 96),
                                                    (2, 3, 9, 11, [3], 64), (3, 1, 20, 33, [4], 256), (2, 1, 12, 16, [2, 2, 4], 128), (2, 1, 8, 8, [1], 32), (2, 2, 9, 11, [1, 2, 3], 160), (2, 1, 16, 9, [2], 256)])
 def test_lookup_conv1x1_fused_vs_separate_and_fp64(deg, B, h, w, levels, cout, monkeypatch):

@@ -74,7 +74,7 @@ python "$REPO/tools/corr_precision_probe.py" --c5 2>/dev/null | grep corr_precis
 python - "$OUT" <<'PY'
 import csv, sys, os
 d = sys.argv[1]
-for key, rx in (("roofline", "conv_halo8_kernel"), ("roofline_encoder", "conv_halo_kernel"), ("roofline_corr_build", "corr_stream_kernel"),
+for key, rx in (("roofline", "conv_halo8_pair_kernel"), ("roofline_encoder", "conv_halo_kernel"), ("roofline_corr_build", "corr_stream_kernel"),
                 ("roofline_corr_build_split", "corr_stream_kernel"), ("roofline_lookup", "corr_lookup_tile_kernel"), ("calib", "rate_kernel")):
     for c in ("FETCH_SIZE", "WRITE_SIZE", "MFMA"):
         p = os.path.join(d, f"{key}_{c}.csv")

@@ -51,7 +51,8 @@ while the sources still hash to the same value.
 | `r04_lookup_conv_probe.txt` | `python tools/lookup_conv_probe.py --shapes c2,c4`, `... --stamps` on the `tools/lookup_conv_stamps.sh` build, `BFLOW_LOOKUP_CONV=1 python bench.py` vs default | the fused look-up + convc1 launch (opt-in): in-graph duration against the two separate launches, per-wave cycle stamps of its phases, and the A/B inside the captured forward |
 | `r04_gru_conv_probe.txt` | `python tools/gru_conv_probe.py` | a batch-1 GRU gate convolution: plain fp32 output vs fused gate epilogue, full input [h \| M] vs one half — the numbers behind the input-split experiment |
 | `r04_halo12_ab.txt`, `r04_spread_dma_ab.txt`, `r04_thin_head.txt`, `r04_half_tile_ab.txt`, `r04_nt_stores_ab.txt` | `tools/r04_h12.sh`, `tools/r04_thin.sh`, `tools/r04_thin2.sh`, `tools/r04_ht.sh`, `tools/r04_nt.sh`, `tools/r04_nt2.sh` (alternating runs on one box each) | this round's A/B experiments: the 12-wave small-grid kernel, LDS-DMA pieces spread over a step's taps, the thin head on the matrix cores (2×16 vs 2×10 patches vs the vector-ALU kernel), the half-tile variant of the encoder's 96-channel layers, non-temporal stores (look-up: adopted; conv epilogues / encoder: neutral) |
-| `r04_iteration_launches.txt` | `tools/trace_iteration.py` on the `--kernel-trace` of `bench.py --no-extras` | one steady-state update iteration launch by launch: kernel, queue, workgroups, threads, µs |
+| `r04_iteration_launches.txt` | `tools/trace_iteration.py` on the `--kernel-trace` of `bench.py --no-extras` | one steady-state update iteration launch by launch: kernel, queue, workgroups, threads, µs — the two-queue form of rounds 2–3 (`BFLOW_NO_ONE_QUEUE=1` now) |
+| `r04_iteration_launches_one_queue.txt`, `r04_one_queue_pairs_ab.txt` | `tools/r04_pair.sh` | the same iteration as ten launches on ONE queue (look-up ‖ im2col rider, `conv_split_pair_kernel`, `conv_halo8_pair_kernel`: DESIGN §8 item 11) and its alternating same-box A/B against the side-stream form (−1.0…−1.5 % per frame), the 10×16 pair variant and the rider placement |
 | `r04_k5_balanced_split.txt` | `tools/r04_k5bal.sh` on the variant with a chip-wide equal work split (not in the tree) | K5: balanced split vs the lockstep split — durations per arithmetic, per-workgroup cycle stamps, bench A/B: slower |
 | `r04_stem_norm_in_ab.txt`, `r04_residual_epilogue_ab.txt`, `r04_halo_occupancy_probe.txt`, `r04_thin_head_crossover.txt` | `tools/r04_stemnin.sh`, `tools/r04_res.sh`, `tools/r04_occ.sh`, `tools/r04_thinmax.sh` | encoder launch / traffic reductions that paid (the stem's norm never materialised: −0.65 %; the context encoder's `relu(x + y)` as conv2's epilogue: −1.3 %), the occupancy probe of the halo kernel (1 vs 2 workgroups per CU), the thin-head cross-over at batch 8 (neutral) |
 | `r04_k7_ablation.txt` | `BFLOW_LOOKUP_ABL=<bits> python tools/k7_abl_probe.py` | K7 with phases switched off (timing only): the phases add up to the total at C2 and on the C4 shard |
@@ -74,7 +75,7 @@ while the sources still hash to the same value.
 
 | Kernel (as `bench.py` launches it) | bound | achieved | peak | frac | launch | PMC traffic vs algorithmic | MFMA utilisation (PMC) |
 |---|---|---|---|---|---|---|---|
-| `roofline`: `conv_halo8_kernel<3,3>` on convc2 (3×3, 256→192, 1×60×80) — the kernel with the largest total time of the frame | fp16 MFMA / 3 | {r["achieved"]:.0f} TFLOP/s-equiv. | 833 | **{r["frac"]:.2f}** | {r["avg_launch_ms"]*1e3:.1f} µs | {tr(r)} | {mf(r)} |
+| `roofline`: `conv_halo8_pair_kernel<3,3>` on convc2 ‖ convf2 (3×3, 256→192 and 128→64, 1×60×80, one launch) — the small-grid 3×3 family has the largest total time of the frame | fp16 MFMA / 3 | {r["achieved"]:.0f} TFLOP/s-equiv. | 833 | **{r["frac"]:.2f}** | {r["avg_launch_ms"]*1e3:.1f} µs | {tr(r)} | {mf(r)} |
 | `roofline_encoder`: `conv_halo_kernel<2,3,3,TR>` encoder layer1 3×3 (rounds 1–3 reported this one as `roofline`) | fp16 MFMA / 3 | {re_["achieved"]:.0f} TFLOP/s-equiv. | 833 | **{re_["frac"]:.2f}** (round 3: 0.36, round 2: 0.31) | {re_["avg_launch_ms"]*1e3:.0f} µs | {tr(re_)} | {mf(re_)} |
 | `roofline_corr_build`: K5, the product launch (split8: hi·hi fp16 + fp8 cross terms, tiled planes) | HBM (2nd roof: matrix, 2 units / product) | {rk["achieved"]/1e3:.2f} TB/s; {rk.get("tflops_equivalent", 0):.0f} TFLOP/s-equiv. | 8 TB/s; 1250 | **{rk["frac"]:.2f}**; {rk.get("frac_of_store_ceiling", 0):.2f} of the best pure store stream measured in the same process ({rk.get("store_ceiling_gbs", 0)/1e3:.2f} TB/s); matrix {rk.get("frac_mfma", 0):.2f} | {rk["avg_launch_ms"]*1e3:.0f} µs | {tr(rk)} | {mf(rk)} |
 | `roofline_corr_build_split`: K5 with three fp16 passes (the fp32-class number) | HBM / matrix (3 units / product) | {rks["achieved"]/1e3:.2f} TB/s | 8 TB/s; 833 | **{rks["frac"]:.2f}**; matrix {rks.get("frac_mfma", 0):.2f} | {rks["avg_launch_ms"]*1e3:.0f} µs | {tr(rks)} | {mf(rks)} |

@@ -3,13 +3,13 @@
 MFMA calibration launch) into profiles/r04_pmc.json.   usage: pmc_to_json.py <dir with <key>_{FETCH_SIZE,WRITE_SIZE,MFMA}.csv> <out.json>"""
 import csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.roofline_kernels import CONV_NAME, HALO8_NAME, K5_NAME, K5_SPLIT_NAME, LOOKUP_NAME
+from tools.roofline_kernels import CONV_NAME, HALO8_NAME, HALO8_REGEX, K5_NAME, K5_SPLIT_NAME, LOOKUP_NAME
 d, outp = sys.argv[1], sys.argv[2]
-NAMES = {"roofline": (HALO8_NAME, "conv_halo8_kernel", 4.0 * 4800 * (256 + 192) + 4.0 * 192 * 256 * 9),
+NAMES = {"roofline": (HALO8_NAME, HALO8_REGEX, 4.0 * 4800 * (256 + 192 + 128 + 64) + 4.0 * 9 * (192 * 256 + 64 * 128)),
          "roofline_encoder": (CONV_NAME, "conv_halo_kernel", 196755456.0),
          "roofline_corr_build": (K5_NAME, "corr_stream_kernel", 393216000.0),
          "roofline_corr_build_split": (K5_SPLIT_NAME, "corr_stream_kernel", 393216000.0),
-         "roofline_lookup": (LOOKUP_NAME, "corr_lookup_tile_kernel", 24326400.0)}
+         "roofline_lookup": (LOOKUP_NAME, "corr_lookup_tile_kernel", 24326400.0 + 4.0 * 4800 * (4 + 7 * 32))}
 
 
 def rows_of(path, regex):

@@ -5,7 +5,7 @@ kernel on torch's current stream.  bench.py times them with hipEvents; tools/roo
 `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex <regex>` to produce profiles/r04_pmc.json.
 
   roofline                 the kernel with the largest TotalDurationNs in the C2-only kernel trace (profiles/r0x_rocprofv3_kernel_stats_c2only.csv):
-                           conv_halo8_kernel<3,3>, the batch-1 small-grid 3x3 -- on its largest launch, the motion encoder's convc2
+                           the batch-1 small-grid 3x3 family on its largest launch: conv_halo8_pair_kernel<3,3>, the motion encoder's convc2 | convf2
   roofline_encoder         conv_halo_kernel<2,3,3> on the encoder's layer-1 launch (rounds 1-3 reported this one as `roofline`)
   roofline_corr_build      K5, the product launch (split8) ;  roofline_corr_build_split: the 3-pass fp32-class arithmetic on the same operands
   roofline_lookup          K7 at C2 (batch 1) ;  roofline_lookup_c4_shard: K7 on C4's per-GPU shard (batch 8)
@@ -18,7 +18,9 @@ from bflow_amd import hip, split as S
 from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
 
 CONV_NAME = "conv_halo_kernel<2,3,3> (encoder layer1 3x3 64->64, 5x240x320)"
-HALO8_NAME = "conv_halo8_kernel<3,3> (motion encoder convc2 3x3 256->192 + bias + ReLU, 1x60x80: the kernel with the largest total time of the frame)"
+HALO8_NAME = ("conv_halo8_pair_kernel<3,3> (motion encoder convc2 | convf2 as ONE launch: 3x3 256->192 and 3x3 128->64, + bias + ReLU, 1x60x80 -- the 8-wave "
+              "small-grid 3x3 kernel on its largest launch; the small-grid 3x3 / 1x5 / 5x1 family has the largest total time of the frame)")
+HALO8_REGEX = "conv_halo8_pair_kernel"
 K5_SPLIT_NAME = "corr_stream_kernel<8, true, 0, false> (bflow_corr_build_tiled: 3-pass split arithmetic = fp32 class, fp32 tiled volume, D = 256)"
 LOOKUP_C4_NAME = "corr_lookup_tile_kernel<float, 2, 256> (C4 per-GPU shard: batch 8)"
 K5_C5_NAME = "corr_stream_kernel (BASELINE configs[4]: 1024x1024, 5 event targets + 1 image target, f16/w = fp16 operands, one MFMA pass, fp32 tiled volume)"
@@ -69,7 +71,7 @@ def frame_flops(model, B, H, W, iters):
     frame = sum(v for k, v in parts.items() if k != "update_iteration") + iters * it
     return frame, it, parts
 K5_NAME = "corr_stream_kernel<8, true, 2, false> (bflow_corr_build_tiled: split8 arithmetic, fp32 tiled volume, D = 256 -- the product launch)"
-LOOKUP_NAME = "corr_lookup_tile_kernel<float, 2, 256> (fused bezier, tiled planes, split out)"
+LOOKUP_NAME = "corr_lookup_tile_kernel<float, 2, 256> (fused bezier, tiled planes, split out; + the im2col rider of bflow_corr_lookup_im2col)"
 
 
 def build(model, vox, cfg, low_params=None):
@@ -94,12 +96,18 @@ def build(model, vox, cfg, low_params=None):
         h8_, w8_ = H // 8, W // 8
         c1 = S.from_nchw(torch.relu(torch.randn(B, ub.encoder.convc1.out_channels, h8_, w8_, device=dev)))
         pk2 = ub._pk("convc2", lambda a=ub.encoder.convc2.weight: a)
+        pkf2 = ub._pk("convf2", lambda a=ub.encoder.convf2.weight: a)
+        f1_ = S.from_nchw(torch.relu(torch.randn(B, ub.encoder.convf1.out_channels, h8_, w8_, device=dev)))
         corbez = S.SplitTensor.empty(B, h8_, w8_, 256, dev)
-        out.append(dict(key="roofline", name=HALO8_NAME, regex="conv_halo8_kernel", bound="mfma",
-                        launch=lambda: S.conv(c1, pk2, padding=1, shift=ub.encoder.convc2.bias, act=S.ACT_RELU, out_split=corbez, channel_offset=0),
-                        flops=conv_flops(ub.encoder.convc2, h8_, w8_, B),
-                        bytes=4.0 * B * h8_ * w8_ * (256 + 192) + 4.0 * 192 * 256 * 9,
-                        note="batch 1: 240 workgroups (one per CU on 240 of 256 CUs), a chain of dependent launches -- occupancy- and latency-bound, not matrix-bound"))
+        # the product launch (update.py step_split, one-queue form): bflow_conv_split_pair of the two 3x3s of the motion encoder
+        out.append(dict(key="roofline", name=HALO8_NAME, regex=HALO8_REGEX, bound="mfma",
+                        launch=lambda: S.conv_pair(dict(x=c1, packed=pk2, padding=1, shift=ub.encoder.convc2.bias, act=S.ACT_RELU, out_split=corbez, channel_offset=0),
+                                                   dict(x=f1_, packed=pkf2, padding=1, shift=ub.encoder.convf2.bias, act=S.ACT_RELU, out_split=corbez,
+                                                        channel_offset=192)),
+                        flops=conv_flops(ub.encoder.convc2, h8_, w8_, B) + conv_flops(ub.encoder.convf2, h8_, w8_, B),
+                        bytes=4.0 * B * h8_ * w8_ * (256 + 192 + 128 + 64) + 4.0 * 9 * (192 * 256 + 64 * 128),
+                        note="batch 1: 240 + 80 workgroups on 256 CUs, a link of a chain of dependent launches -- bound by the operand fill of a CU and launch "
+                             "latency, not by the matrix cores"))
         out.append(dict(key="roofline_encoder", name=CONV_NAME, regex="conv_halo_kernel<", bound="mfma",
                         launch=lambda: S.conv(cur, pk, stride=1, padding=1, want_split=False, out_f32=o32, stats=st),
                         flops=2.0 * n5 * h0 * w0 * 64 * 64 * 9,
@@ -137,10 +145,16 @@ def build(model, vox, cfg, low_params=None):
         params = (torch.randn(B, 2 * model.bezier_degree, h8, w8, device=dev) * 4 if low_params is None else low_params.clone())
         feat = cblk.new_output_split()
         coef = model._coefficients()
+        # the product launch at batch 1 carries the 7x7 windows of the Bezier parameters for convf1 as its first workgroups
+        # (bflow_corr_lookup_im2col): their bytes (2 deg x 4 B read, ceil(49 x 2 deg / 32) x 32 x 4 B written per pixel) are part of the launch
+        ck = (49 * 2 * model.bezier_degree + 31) // 32
+        col = S.SplitTensor.empty(B, h8, w8, 49 * 2 * model.bezier_degree, dev)
+        rider_bytes = 4.0 * B * N * (2 * model.bezier_degree + ck * 32)
         out.append(dict(key="roofline_lookup", name=LOOKUP_NAME, regex="corr_lookup_tile_kernel", bound="hbm",
-                        launch=lambda: cblk.lookup_bezier_split(params, coef, feat),
-                        flops=None, bytes=4.0 * B * N * cblk.num_planes * (100 + 81), keep=(cblk, vol, planes, x8),
-                        line_bytes=lookup_line_bytes(cblk, B)))
+                        launch=lambda: cblk.lookup_bezier_split(params, coef, feat, im2col=(col, 7, 7, 3)),
+                        flops=None, bytes=4.0 * B * N * cblk.num_planes * (100 + 81) + rider_bytes, keep=(cblk, vol, planes, x8),
+                        line_bytes=lookup_line_bytes(cblk, B) + rider_bytes,
+                        note=f"incl. the im2col rider of the same launch ({rider_bytes / 1e6:.2f} MB of the algorithmic bytes)"))
     return out
 
 
