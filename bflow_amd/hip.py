@@ -30,7 +30,7 @@ EXPORTS = (
     "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
     "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_scatter_rectified", "bflow_maxabs_diff",
     "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
-    "bflow_l1_masked_grad", "bflow_conv_split_pair", "bflow_corr_lookup_im2col",
+    "bflow_l1_masked_grad", "bflow_conv_split_pair", "bflow_corr_lookup_im2col", "bflow_cvx_upsample_blocked",
 )
 
 
@@ -155,6 +155,7 @@ def lib() -> ctypes.CDLL:
         "bflow_bezier_coeffs": [ctypes.POINTER(ctypes.c_double), i, i, ctypes.POINTER(ctypes.c_float)],
         "bflow_bezier_eval": [vp, ctypes.POINTER(ctypes.c_float), i, i, i, i, i, i, vp, vp],
         "bflow_cvx_upsample": [vp, vp, vp, f, vp, i, i, i, i, vp],
+        "bflow_cvx_upsample_blocked": [vp, vp, f, vp, i, i, i, i, i, vp],
         "bflow_voxel_scatter_f32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
         "bflow_voxel_scatter_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
         "bflow_voxel_scatter_i32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
@@ -459,6 +460,17 @@ def bezier_eval(params: torch.Tensor, coef: np.ndarray, add_coords0: bool = Fals
 
 
 # ------------------------------------------------------------------------------------------------ K13
+def cvx_upsample_blocked(data: torch.Tensor, mask_blocked: torch.Tensor, mask_scale: float = 1.0) -> torch.Tensor:
+    """cvx_upsample on the mask in the conv engine's blocked fp32 layout (B, 18, rows, 32) (bias included)."""
+    B, C, h, w = data.shape
+    assert mask_blocked.dtype == torch.float32 and mask_blocked.is_contiguous() and mask_blocked.shape[:2] == (B, 18) and mask_blocked.shape[3] == 32 \
+        and mask_blocked.shape[2] >= h * w
+    out = torch.empty((B, C, 8 * h, 8 * w), dtype=torch.float32, device=data.device)
+    _check(lib().bflow_cvx_upsample_blocked(_dev(data, name="data"), _dev(mask_blocked, name="mask"), float(mask_scale), _dev(out), B, C, h, w,
+                                            mask_blocked.shape[2], _stream()), "bflow_cvx_upsample_blocked")
+    return out
+
+
 def cvx_upsample(data: torch.Tensor, mask: torch.Tensor, mask_bias: Optional[torch.Tensor] = None, mask_scale: float = 1.0) -> torch.Tensor:
     B, C, h, w = data.shape
     assert mask.shape == (B, 576, h, w)

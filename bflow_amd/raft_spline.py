@@ -58,6 +58,7 @@ class EncodedFrame:
 
 
 # layer of the event feature encoder behind which the context encoder is forked (0: at the start); BFLOW_CNET_FORK_LAYER for A/B
+MASK_BLOCKED = os.environ.get("BFLOW_MASK_NCHW") is None     # the up-sampling reads the mask head's blocked fp32 output (no NCHW copy); env: tools A/B
 CNET_FORK_LAYER = int(os.environ.get("BFLOW_CNET_FORK_LAYER", "0"))     # measured: 0 -> 272.8 / 272.3, 1 -> 271.9 / 271.3, 2 -> 263.2 / 263.6 frames/s
 
 
@@ -289,6 +290,7 @@ class RAFTSpline(nn.Module):
             with hip.Branch(tm is None) as br:
                 if pr: pr("cnet.begin")
                 ws_ = ub.new_split_workspace(B, h, w, device)
+                state["bezier0"] = torch.zeros((B, 2 * self.bezier_degree, h, w), dtype=torch.float32, device=device)   # raft.py:150
                 ws_.overlap = tm is None and hip.BRANCHING
                 ctx_in = context_input
                 if self.fnet_img is None:      # the context bins are the LAST channels of the voxel grid: one window, read in place
@@ -315,10 +317,12 @@ class RAFTSpline(nn.Module):
             corr_img = encode_pair(self.fnet_img, img_in, B, self.img_corr_params["levels"])
             if tm: tm.stop("fnet_img")
 
-        bezier = torch.zeros((B, 2 * self.bezier_degree, h, w), dtype=torch.float32, device=device)   # raft.py:150
         if flow_init is not None:
+            bezier = torch.zeros((B, 2 * self.bezier_degree, h, w), dtype=torch.float32, device=device)   # raft.py:150
             assert flow_init.shape == bezier.shape
             bezier += flow_init                                               # raft.py:152-153
+        else:
+            bezier = state["bezier0"]                                          # zeros, filled on the context branch (off the critical chain)
 
         if pr: pr("fnet.end")
         if tm: tm.start("corr computation")
@@ -331,7 +335,8 @@ class RAFTSpline(nn.Module):
         if pr: pr("joined")
 
         corr_feat = corr_block.new_output_split()
-        S.bezier_update(bezier, None, ws.M, ws.bez_channel // 32, channel_in_block=ws.bez_channel % 32)     # emit the initial Bezier channels
+        if flow_init is not None:     # (zero parameters: their channels of M are the zeros the workspace was allocated with -- no launch)
+            S.bezier_update(bezier, None, ws.M, ws.bez_channel // 32, channel_in_block=ws.bez_channel % 32)     # emit the initial Bezier channels
         return EncodedFrame(corr_block, ws, bezier, corr_feat)
 
     def _iterate(self, fr: "EncodedFrame", iters: int, test_mode: bool):
@@ -347,7 +352,8 @@ class RAFTSpline(nn.Module):
             need_mask = (not test_mode) or itr == iters - 1
             if tm is None:
                 # the look-up runs inside the step, next to the (independent) Bezier branch of the motion encoder
-                mask = ub.step_split(ws, fused if fused is not None else SplitLookup(corr_block, bezier, coef, corr_feat), bezier, need_mask)
+                mask = ub.step_split(ws, fused if fused is not None else SplitLookup(corr_block, bezier, coef, corr_feat), bezier, need_mask,
+                                     mask_blocked=MASK_BLOCKED)
             else:
                 # stage timing (eager): the same kernels, the look-up timed on its own, no side-stream overlap
                 tm.start("1 iter")
@@ -359,7 +365,7 @@ class RAFTSpline(nn.Module):
                 tm.stop("update (per iter)")
                 tm.stop("1 iter")
             if need_mask:
-                ups.append(hip.cvx_upsample(bezier, mask, None, 0.25))
+                ups.append(hip.cvx_upsample_blocked(bezier, mask, 0.25) if (tm is None and MASK_BLOCKED) else hip.cvx_upsample(bezier, mask, None, 0.25))
         if tm: tm.stop("all iters")
         if pr: pr("iters.end")
         return bezier, ups

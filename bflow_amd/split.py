@@ -42,10 +42,15 @@ class SplitTensor:
         self.C = planes.shape[2] * 32 if C is None else C
 
     @classmethod
-    def empty(cls, B: int, H: int, W: int, C: int, device, rows: Optional[int] = None, zero: bool = False) -> "SplitTensor":
+    def empty(cls, B: int, H: int, W: int, C: int, device, rows: Optional[int] = None, zero: bool = False, zero_tail: bool = False) -> "SplitTensor":
+        """zero: every element; zero_tail: only the pad rows [H*W, rows) -- what a producer that writes all H*W pixel rows of every channel
+        block leaves undefined (one small strided fill instead of a pass over the whole tensor)."""
         rows = H * W if rows is None else rows
         alloc = torch.zeros if zero else torch.empty
-        return cls(alloc((2, B, (C + 31) // 32, rows, 32), dtype=torch.float16, device=device), H, W, C)
+        t = alloc((2, B, (C + 31) // 32, rows, 32), dtype=torch.float16, device=device)
+        if zero_tail and not zero and rows > H * W:
+            t[:, :, :, H * W:].zero_()
+        return cls(t, H, W, C)
 
     @property
     def shape(self) -> Tuple[int, int, int, int]:
@@ -349,7 +354,7 @@ def conv(x: SplitTensor, packed, stride: int = 1, padding=(0, 0), scale: Optiona
     if tile is None:
         tile = pick_tile(cout, B * ((Ho * Wo + 127) // 128))
     if out_split is None and want_split:
-        out_split = SplitTensor.empty(B, Ho, Wo, cout, dev, rows=rows, zero=zero_rows or rows != Ho * Wo)
+        out_split = SplitTensor.empty(B, Ho, Wo, cout, dev, rows=rows, zero_tail=zero_rows or rows != Ho * Wo)     # the kernel writes every pixel row (pad channels as zeros)
     if out_f32 is None and want_f32:
         out_f32 = torch.empty((B, (cout + 31) // 32, rows, 32), dtype=torch.float32, device=dev)
     cs = None

@@ -216,10 +216,11 @@ class BasicUpdateBlock(nn.Module):
             terms.append((t_zr, t_q))
         ws.inp_terms = terms
 
-    def step_split(self, ws: SplitWorkspace, corr, bezier: torch.Tensor, need_mask: bool):
+    def step_split(self, ws: SplitWorkspace, corr, bezier: torch.Tensor, need_mask: bool, mask_blocked: bool = False):
         """One iteration of update.py:116-126 on the split-fp16 engine.  corr: (B, P*81, h, w) fp32 (look-up output), the same as a blocked SplitTensor, a
         callable producing either (then the look-up itself overlaps with the Bezier branch), or a FusedLookup (look-up + convc1 in one launch), bezier: (B, 2*deg, h, w) fp32 updated IN PLACE.
-        Returns the mask logits incl. bias (B, 576, h, w) fp32 or None."""
+        Returns the mask logits incl. bias (B, 576, h, w) fp32 -- mask_blocked: as the last convolution writes them, blocked fp32
+        (B, 18, h*w, 32), for hip.cvx_upsample_blocked -- or None."""
         enc = self.encoder
         # ---- motion encoder (update.py:88-97); every bias + relu lives in a conv epilogue, every cat is a channel offset
         # The correlation branch (look-up -> 1x1 -> 3x3) and the Bezier branch (7x7 as im2col + 1x1 GEMM -> 3x3) are independent.
@@ -242,7 +243,7 @@ class BasicUpdateBlock(nn.Module):
                      out_split=ws.corbez, channel_offset=0),
                 dict(x=f1, packed=self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
                      out_split=ws.corbez, channel_offset=192))
-            return self._step_tail(ws, bezier, need_mask)
+            return self._step_tail(ws, bezier, need_mask, mask_blocked)
         with hip.Branch(ws.overlap and ITER_BRANCH) as corr_branch:
             if isinstance(corr, FusedLookup):
                 # look-up + convc1 + ReLU as ONE launch (bflow_corr_lookup_conv1x1): the correlation features stay in the CU
@@ -263,9 +264,9 @@ class BasicUpdateBlock(nn.Module):
         S.conv(f1, self._pk("convf2", lambda a=enc.convf2.weight: a), padding=1, shift=enc.convf2.bias, act=S.ACT_RELU,
                out_split=ws.corbez, channel_offset=192)
         corr_branch.join()
-        return self._step_tail(ws, bezier, need_mask)
+        return self._step_tail(ws, bezier, need_mask, mask_blocked)
 
-    def _step_tail(self, ws: SplitWorkspace, bezier: torch.Tensor, need_mask: bool):
+    def _step_tail(self, ws: SplitWorkspace, bezier: torch.Tensor, need_mask: bool, mask_blocked: bool = False):
         """The rest of the iteration behind the two motion-encoder branches: `conv`, the separable conv-GRU, the heads."""
         enc = self.encoder
         S.conv(ws.corbez, self._pk("conv", lambda a=enc.conv.weight: a), padding=1, shift=enc.conv.bias, act=S.ACT_RELU,
@@ -282,11 +283,12 @@ class BasicUpdateBlock(nn.Module):
         with hip.Branch(ws.overlap and need_mask) as mask_branch:
             if need_mask:
                 m1, _ = S.conv(ws.H, self._pk("mask0", lambda a=self.mask[0].weight: a), padding=1, shift=self.mask[0].bias, act=S.ACT_RELU)
-                m2, _ = S.conv(m1, self._pk("mask2", lambda a=self.mask[2].weight: a), shift=self.mask[2].bias,
-                               tile=MASK_TILE if MASK_TILE is not None else (96 if m1.shape[0] * m1.H * m1.W <= THIN_HEAD_MAX_PIXELS else None))
+                m2, m2f = S.conv(m1, self._pk("mask2", lambda a=self.mask[2].weight: a), shift=self.mask[2].bias, want_split=not mask_blocked,
+                                 want_f32=mask_blocked,
+                                 tile=MASK_TILE if MASK_TILE is not None else (96 if m1.shape[0] * m1.H * m1.W <= THIN_HEAD_MAX_PIXELS else None))
                 # (batch 1: 96-channel tiles = 228 workgroups, one round, 229 KB of operands each, instead of 342 of 64 channels:
                 #  3.643-3.647 vs 3.648-3.668 ms per frame over three alternating pairs)
-                mask = m2.to_nchw()
+                mask = m2f if mask_blocked else m2.to_nchw()     # blocked: the up-sampling kernel reads the convolution's own layout
         bh = self.bezier_head
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
         # bezier += delta (bezier.py:137-139) and the new Bezier channel block of M are produced by the epilogue

@@ -465,6 +465,10 @@ int bflow_bezier_eval(const float* params, const float* coef, int T, int deg, in
  *   data : (B, C, h, w)   mask : (B, 576, h, w)   out : (B, C, 8h, 8w)                                  */
 int bflow_cvx_upsample(const float* data, const float* mask, const float* mask_bias, float mask_scale,
                        float* out, int B, int C, int h, int w, bflow_stream_t stream);
+/* The same operator reading the mask as the conv engine writes it: blocked fp32 (B, 18, mask_rows_per_image, 32) = the out_f32 of the mask
+ * head's last convolution (update.py:120-125), bias included (no mask_bias here); equal masks give the bits of bflow_cvx_upsample. */
+int bflow_cvx_upsample_blocked(const float* data, const float* mask_blocked, float mask_scale, float* out, int B, int C, int h, int w,
+                               int mask_rows_per_image, bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K1  event voxel grid: signed tri-linear (float x/y) or temporal-linear (integer x/y) scatter-add.

@@ -523,6 +523,21 @@ def test_bezier_golden(golden_dir, deg):
     np.testing.assert_array_equal(hip.bezier_coeffs(ts, deg), O.bezier_coeffs(ts, deg).astype(np.float32))
 
 
+@pytest.mark.parametrize("B,C,h,w,rows", [(1, 4, 60, 80, None), (2, 20, 9, 13, 128), (1, 2, 1, 1, None)])
+def test_cvx_upsample_blocked_equals_nchw(B, C, h, w, rows):
+    """bflow_cvx_upsample_blocked (mask in the conv engine's blocked fp32 layout, as the mask head's last convolution writes it) gives the
+    bits of bflow_cvx_upsample on the same mask values."""
+    rs = np.random.RandomState(17)
+    data = cu(rs.standard_normal((B, C, h, w)).astype(np.float32) * 3)
+    mask = cu(rs.standard_normal((B, 576, h, w)).astype(np.float32) * 4)
+    P = h * w if rows is None else rows
+    blocked = torch.full((B, 18, P, 32), 9.0, device=DEV)
+    blocked[:, :, :h * w] = mask.reshape(B, 18, 32, h * w).permute(0, 1, 3, 2)
+    ref = hip.cvx_upsample(data, mask, None, 0.25)
+    got = hip.cvx_upsample_blocked(data, blocked.contiguous(), 0.25)
+    assert torch.equal(got, ref)
+
+
 def test_cvx_upsample_golden(golden_dir):
     d = g(golden_dir, "cvx_upsample")
     out = BezierCurves(cu(d["data"])).create_upsampled(cu(d["mask"])).get_params()
