@@ -10,8 +10,10 @@ checkpoints load through `load_state_dict`.  What differs is how the hot path is
     pyramid             bflow_corr_pool2x2                                                                   (K6)
     per iteration       bflow_corr_lookup_bezier_split (Bezier evaluation + coords0 + 9x9 gather fused, written in the conv
                         engine's layout), 10 engine convolutions with bias / activation / concatenation / GRU gates /
-                        parameter update in their epilogues (K7-K12)
-    last iteration      mask head + bflow_cvx_upsample                                                       (K13)
+                        parameter update in their epilogues (K7-K12); at batch 1 ten launches on one queue: the look-up
+                        carries the im2col of the Bezier parameters (bflow_corr_lookup_im2col) and the motion encoder's
+                        two branches are pair launches (bflow_conv_split_pair)
+    last iteration      mask head + bflow_cvx_upsample_blocked (the mask in the convolution's own layout)    (K13)
 
 The whole forward is free of host synchronisation, so `enable_hipgraph()` captures it once per input signature into
 a hipGraph (bflow_amd/graph.py) and replays it; eager execution stays available for debugging and stage timing.
