@@ -31,7 +31,7 @@ python "$REPO/bench.py" --steps 30 --warmup 5 > "$OUT/r04_bench.json" 2> "$OUT/b
 rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o c2 -- python "$REPO/bench.py" --steps 30 --warmup 5 --no-extras > /tmp/kt.log 2>&1
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); head -40 "$f" > "$OUT/r04_rocprofv3_kernel_stats_c2only.csv"
 # one steady-state update iteration, launch by launch (workgroups, threads, us) from the same trace
-f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); python "$REPO/tools/trace_iteration.py" "$f" > "$OUT/r04_iteration_launches.txt" 2>&1
+f=$(find /tmp/kt -name "*kernel_trace.csv" | head -1); python "$REPO/tools/trace_iteration.py" "$f" > "$OUT/r04_iteration_launches_one_queue.txt" 2>&1
 rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o bench -- python "$REPO/bench.py" --steps 30 --warmup 5 --no-cpu-baseline > /tmp/kt.log 2>&1
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); head -46 "$f" > "$OUT/r04_rocprofv3_kernel_stats.csv"
 # stage boundaries INSIDE the captured graph, no tracer attached (the tracer serialises the two queues)

@@ -53,7 +53,7 @@ while the sources still hash to the same value.
 | `r04_halo12_ab.txt`, `r04_spread_dma_ab.txt`, `r04_thin_head.txt`, `r04_half_tile_ab.txt`, `r04_nt_stores_ab.txt` | `tools/r04_h12.sh`, `tools/r04_thin.sh`, `tools/r04_thin2.sh`, `tools/r04_ht.sh`, `tools/r04_nt.sh`, `tools/r04_nt2.sh` (alternating runs on one box each) | this round's A/B experiments: the 12-wave small-grid kernel, LDS-DMA pieces spread over a step's taps, the thin head on the matrix cores (2×16 vs 2×10 patches vs the vector-ALU kernel), the half-tile variant of the encoder's 96-channel layers, non-temporal stores (look-up: adopted; conv epilogues / encoder: neutral) |
 | `r04_iteration_launches.txt` | `tools/trace_iteration.py` on the `--kernel-trace` of `bench.py --no-extras` | one steady-state update iteration launch by launch: kernel, queue, workgroups, threads, µs — the two-queue form of rounds 2–3 (`BFLOW_NO_ONE_QUEUE=1` now) |
 | `r04_frame_encoder_launches.txt`, `r04_frame_tail_launches.txt` | `tools/trace_frame.py <kernel_trace.csv> encoder\|tail` (`tools/r04_frame.sh`, `tools/r04_tail.sh`) | every launch of one steady-state frame OUTSIDE the update loop: encoders + K5 + pooling on the two queues (before item 12's trims), and the last iteration + mask head + up-sampling (after them) |
-| `r04_iteration_launches_one_queue.txt`, `r04_one_queue_pairs_ab.txt` | `tools/r04_pair.sh` | the same iteration as ten launches on ONE queue (look-up ‖ im2col rider, `conv_split_pair_kernel`, `conv_halo8_pair_kernel`: DESIGN §8 item 11) and its alternating same-box A/B against the side-stream form (−1.0…−1.5 % per frame), the 10×16 pair variant and the rider placement |
+| `r04_iteration_launches_one_queue.txt` (`tools/collect_profiles.sh`: the product), `r04_one_queue_pairs_ab.txt` | `tools/r04_pair.sh` | the same iteration as ten launches on ONE queue (look-up ‖ im2col rider, `conv_split_pair_kernel`, `conv_halo8_pair_kernel`: DESIGN §8 item 11) and its alternating same-box A/B against the side-stream form (−1.0…−1.5 % per frame), the 10×16 pair variant and the rider placement |
 | `r04_k5_balanced_split.txt` | `tools/r04_k5bal.sh` on the variant with a chip-wide equal work split (not in the tree) | K5: balanced split vs the lockstep split — durations per arithmetic, per-workgroup cycle stamps, bench A/B: slower |
 | `r04_stem_norm_in_ab.txt`, `r04_residual_epilogue_ab.txt`, `r04_halo_occupancy_probe.txt`, `r04_thin_head_crossover.txt` | `tools/r04_stemnin.sh`, `tools/r04_res.sh`, `tools/r04_occ.sh`, `tools/r04_thinmax.sh` | encoder launch / traffic reductions that paid (the stem's norm never materialised: −0.65 %; the context encoder's `relu(x + y)` as conv2's epilogue: −1.3 %), the occupancy probe of the halo kernel (1 vs 2 workgroups per CU), the thin-head cross-over at batch 8 (neutral) |
 | `r04_k7_ablation.txt` | `BFLOW_LOOKUP_ABL=<bits> python tools/k7_abl_probe.py` | K7 with phases switched off (timing only): the phases add up to the total at C2 and on the C4 shard |
