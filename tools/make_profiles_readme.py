@@ -52,6 +52,7 @@ while the sources still hash to the same value.
 | `r04_gru_conv_probe.txt` | `python tools/gru_conv_probe.py` | a batch-1 GRU gate convolution: plain fp32 output vs fused gate epilogue, full input [h \| M] vs one half — the numbers behind the input-split experiment |
 | `r04_halo12_ab.txt`, `r04_spread_dma_ab.txt`, `r04_thin_head.txt`, `r04_half_tile_ab.txt`, `r04_nt_stores_ab.txt` | `tools/r04_h12.sh`, `tools/r04_thin.sh`, `tools/r04_thin2.sh`, `tools/r04_ht.sh`, `tools/r04_nt.sh`, `tools/r04_nt2.sh` (alternating runs on one box each) | this round's A/B experiments: the 12-wave small-grid kernel, LDS-DMA pieces spread over a step's taps, the thin head on the matrix cores (2×16 vs 2×10 patches vs the vector-ALU kernel), the half-tile variant of the encoder's 96-channel layers, non-temporal stores (look-up: adopted; conv epilogues / encoder: neutral) |
 | `r04_iteration_launches.txt` | `tools/trace_iteration.py` on the `--kernel-trace` of `bench.py --no-extras` | one steady-state update iteration launch by launch: kernel, queue, workgroups, threads, µs — the two-queue form of rounds 2–3 (`BFLOW_NO_ONE_QUEUE=1` now) |
+| `r04_encoder_conv_probes.txt` | `tools/enc_conv_probe.py` with probe builds of `conv_split.hip` (flags quoted in the file; not in the tree) | the encoder's 3×3 convolutions alone, product vs a third fewer LDS fragment reads vs no weight streaming: −0…4 % / −5…10 % |
 | `r04_frame_encoder_launches.txt`, `r04_frame_tail_launches.txt` | `tools/trace_frame.py <kernel_trace.csv> encoder\|tail` (`tools/r04_frame.sh`, `tools/r04_tail.sh`) | every launch of one steady-state frame OUTSIDE the update loop: encoders + K5 + pooling on the two queues (before item 12's trims), and the last iteration + mask head + up-sampling (after them) |
 | `r04_iteration_launches_one_queue.txt` (`tools/collect_profiles.sh`: the product), `r04_one_queue_pairs_ab.txt` | `tools/r04_pair.sh` | the same iteration as ten launches on ONE queue (look-up ‖ im2col rider, `conv_split_pair_kernel`, `conv_halo8_pair_kernel`: DESIGN §8 item 11) and its alternating same-box A/B against the side-stream form (−1.0…−1.5 % per frame), the 10×16 pair variant and the rider placement |
 | `r04_k5_balanced_split.txt` | `tools/r04_k5bal.sh` on the variant with a chip-wide equal work split (not in the tree) | K5: balanced split vs the lockstep split — durations per arithmetic, per-workgroup cycle stamps, bench A/B: slower |
