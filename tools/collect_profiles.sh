@@ -68,7 +68,9 @@ python "$REPO/tools/corr_precision_probe.py" --c5 2>/dev/null | grep corr_precis
     python "$REPO/bench.py" --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench, separate launches (default):', d['value'], 'frames/s,', d['ms_per_gru_iter'], 'ms per iteration')"
   done; } > "$OUT/r04_lookup_conv_probe.txt" 2>&1
 { python "$REPO/tools/gru_conv_probe.py" 2>/dev/null | grep Cin
-  BFLOW_CONV_NO_HALO12=1 BFLOW_HIP_LIB="$REPO/bflow_amd/lib/ab/libbflow_hip_h8stamps.so" python "$REPO/tools/gru_conv_probe.py" --stamps 2>/dev/null | grep -vE "Cin=|amdgpu"; } > "$OUT/r04_gru_conv_probe.txt"
+  BFLOW_CONV_NO_HALO12=1 BFLOW_HIP_LIB="$REPO/bflow_amd/lib/ab/libbflow_hip_h8stamps.so" python "$REPO/tools/gru_conv_probe.py" --stamps 2>/dev/null | grep -vE "Cin=|amdgpu"
+  echo; echo "# the ten launches of one steady-state update iteration of the frame (rocprofv3 --kernel-trace of bench.py; = r04_iteration_launches_one_queue.txt):"
+  cat "$OUT/r04_iteration_launches_one_queue.txt"; } > "$OUT/r04_gru_conv_probe.txt"
 
 # keep only the rows of the three kernels in the committed counter CSVs
 python - "$OUT" <<'PY'
