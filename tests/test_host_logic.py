@@ -402,3 +402,28 @@ def test_lightning_checkpoint_loads_strictly(tmp_path):
     other = bflow_amd.RAFTSpline(configs.model_config("E_LU4_BD2"))
     with pytest.raises(RuntimeError):
         load_lightning_checkpoint(other, path, strict=True)
+
+
+def test_split_tensor_pad_rows_and_the_lookup_callable():
+    """Host logic of round 4's launch trims: `SplitTensor.empty(zero_tail=True)` zeroes exactly the pad rows [H*W, rows) (what K5's 128-row operand
+    padding reads; the convolution writes every pixel row), and `SplitLookup` hands the im2col request through to the pyramid's look-up."""
+    from bflow_amd import split as S
+    from bflow_amd.update import SplitLookup
+    t = S.SplitTensor.empty(2, 3, 5, 40, "cpu", rows=24, zero_tail=True)
+    assert t.planes.shape == (2, 2, 2, 24, 32) and float(t.planes[:, :, :, 15:].abs().max()) == 0.0
+    t.planes[:, :, :, :15] = 1.0                       # (the pixel rows are left to the producer)
+    assert S.SplitTensor.empty(1, 2, 2, 32, "cpu", zero=True).planes.abs().max() == 0
+    assert S.SplitTensor.empty(1, 2, 2, 32, "cpu", zero_tail=True).planes.shape == (2, 1, 1, 4, 32)   # no pad rows: nothing to do
+
+    class Block:
+        im2col_rider = True
+        def lookup_bezier_split(self, params, coef, out, im2col=None):
+            self.seen = (params, coef, out, im2col)
+            return out
+    blk = Block()
+    call = SplitLookup(blk, "bezier", "coef", "feat")
+    assert call.im2col_rider and call() == "feat" and blk.seen == ("bezier", "coef", "feat", None)
+    assert call(im2col=("col", 7, 7, 3)) == "feat" and blk.seen[3] == ("col", 7, 7, 3)
+    class Rows:                                        # a row-major pyramid has no rider
+        def lookup_bezier_split(self, *a, **k): return None
+    assert not SplitLookup(Rows(), 0, 0, 0).im2col_rider
