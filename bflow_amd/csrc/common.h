@@ -49,36 +49,41 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
 
 // 2-D neighbourhood gather of a few-channel fp32 NCHW tensor into a blocked split tensor (bflow_im2col_small, and the rider of the look-up
 // launch): item e = ((b * CBk + kb) * P + pix) * 4 + g produces the 8 channels kk = kb * 32 + g * 8 .. + 7 of pixel pix, kk = tap * C + c,
-// out[b, kb, pix, kk % 32] = x[b, c, y + r - pad_h, x + q - pad_w] (zero outside the image and for kk >= KH * KW * C).
+// out[b, kb, pix, kk % 32] = x[b, c, y + r - pad_h, x + q - pad_w] (zero outside the image and for kk >= KH * KW * C).  The item index is per image
+// and 32-bit (CBk * P * 4 < 2^32, checked by the callers): a 64-bit division per item cost more than the gather.
 struct Im2colArgs {
     const float* x;
     _Float16 *oh, *ol;
     int C, H, W, KH, KW, pad_h, pad_w, CBk, P;
 };
-__device__ __forceinline__ void im2col_small_item(const Im2colArgs& m, long long e) {
+__device__ __forceinline__ void im2col_small_item(const Im2colArgs& m, int b, unsigned e) {   // e = (kb * P + pix) * 4 + g inside image b (32-bit)
     typedef _Float16 half8_ __attribute__((ext_vector_type(8)));
     const int K = m.KH * m.KW * m.C;
     const int g = (int)(e & 3);
-    const long long row = e >> 2;                        // (b*CBk + kb)*P + pix
-    const long long bkb = row / m.P;
-    const int pix = (int)(row - bkb * m.P);
-    const int b = (int)(bkb / m.CBk), kb = (int)(bkb - (long long)b * m.CBk);
+    const unsigned rowi = e >> 2;                         // kb * P + pix
+    const int kb = (int)(rowi / (unsigned)m.P), pix = (int)(rowi - (unsigned)kb * (unsigned)m.P);
+    const long long row = ((long long)b * m.CBk + kb) * m.P + pix;
     half8_ h8, l8;
     const int y = pix / m.W, xx0 = pix - y * m.W;
+    // (tap row r, tap column q, channel c) of the item's first channel by division, of the other seven by carrying: the divisions by the
+    // run-time C and KW were most of this kernel's instructions (16 per item)
+    const int kk0 = kb * 32 + g * 8;
+    int t = kk0 / m.C, c = kk0 - t * m.C;
+    int r = t / m.KW, q = t - r * m.KW;
+    const bool pix_ok = pix < m.H * m.W;
+    const float* xb = m.x + (long long)b * m.C * m.H * m.W;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int kk = kb * 32 + g * 8 + k;
         float v = 0.f;
-        if (kk < K && pix < m.H * m.W) {
-            const int t = kk / m.C, c = kk - t * m.C;
-            const int r = t / m.KW, q = t - r * m.KW;
+        if (kk0 + k < K && pix_ok) {
             const int yy = y + r - m.pad_h, xx = xx0 + q - m.pad_w;
-            if (yy >= 0 && yy < m.H && xx >= 0 && xx < m.W) v = m.x[((long long)b * m.C + c) * m.H * m.W + yy * m.W + xx];
+            if (yy >= 0 && yy < m.H && xx >= 0 && xx < m.W) v = xb[((long long)c * m.H + yy) * m.W + xx];
         }
         _Float16 a, d;
         split1(v, a, d);
         h8[k] = a;
         l8[k] = d;
+        if (++c == m.C) { c = 0; if (++q == m.KW) { q = 0; ++r; } }
     }
     *reinterpret_cast<half8_*>(m.oh + row * 32 + g * 8) = h8;
     *reinterpret_cast<half8_*>(m.ol + row * 32 + g * 8) = l8;

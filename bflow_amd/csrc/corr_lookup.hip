@@ -350,6 +350,7 @@ extern "C" int bflow_corr_lookup_im2col(const bflow_plane_t* planes, int P, cons
     BFLOW_REQUIRE(col_hi && col_lo && KH > 0 && KW > 0 && deg >= 1 && h1 > 0 && w1 > 0, BFLOW_E_ARG, "corr_lookup_im2col: bad im2col arguments");
     const int Pc = col_rows_per_image > 0 ? col_rows_per_image : h1 * w1;
     BFLOW_REQUIRE(Pc >= h1 * w1, BFLOW_E_ARG, "corr_lookup_im2col: col_rows_per_image < h1*w1");
+    BFLOW_REQUIRE((long long)((KH * KW * 2 * deg + 31) / 32) * Pc * 4 < (1LL << 31), BFLOW_E_LIMIT, "corr_lookup_im2col: image too large for 32-bit item indices");
     bflow::Im2colArgs m{params, (_Float16*)col_hi, (_Float16*)col_lo, 2 * deg, h1, w1, KH, KW, pad_h, pad_w, (KH * KW * 2 * deg + 31) / 32, Pc};
     return bflow::lookup_tile_launch(planes, P, params, coef, T, deg, out_hi, out_lo, channel_blocks, rows_per_image, B, h1, w1, f16_planes != 0,
                                      (hipStream_t)stream, &m);

@@ -81,9 +81,8 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     // before -- and leave; they are dispatched first and gone long before the gather tiles finish (as the LAST workgroups of the grid
     // instead: 3.425-3.439 vs 3.412-3.432 ms per frame, three alternating pairs).
     if ((int)blockIdx.x < rider_blocks) {
-        const long long per_image = (long long)rider.CBk * rider.P * 4;
-        for (long long e = (long long)blockIdx.x * THREADS + tid; e < per_image; e += (long long)rider_blocks * THREADS)
-            bflow::im2col_small_item(rider, (long long)b * per_image + e);
+        const unsigned per_image = (unsigned)rider.CBk * (unsigned)rider.P * 4u;
+        for (unsigned e = blockIdx.x * THREADS + tid; e < per_image; e += (unsigned)rider_blocks * THREADS) bflow::im2col_small_item(rider, b, e);
         return;
     }
     const int n0 = ((int)blockIdx.x - rider_blocks) * TP;

@@ -85,9 +85,9 @@ namespace {
 // 2-D neighbourhood gather of a few-channel fp32 NCHW tensor into a blocked split tensor: out[b, pix, tap*C + c] =
 // x[b, c, y + r - pad, x + q - pad] (zero outside), K = KH*KW*C padded to a multiple of 32 with zeros.  Turns the 7x7
 // convolution over the 2*deg Bezier channels (update.py:62,91) into a dense 1x1 GEMM instead of 49 mostly-empty k-tiles.
-__global__ __launch_bounds__(256) void im2col_small_kernel(bflow::Im2colArgs m, int B) {
-    const long long total = (long long)B * m.CBk * m.P * 4;     // 8-channel groups (bflow::im2col_small_item, common.h)
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) bflow::im2col_small_item(m, e);
+__global__ __launch_bounds__(256) void im2col_small_kernel(bflow::Im2colArgs m) {
+    const unsigned per_image = (unsigned)m.CBk * (unsigned)m.P * 4u;     // 8-channel groups (bflow::im2col_small_item, common.h); image = blockIdx.y
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < per_image; e += gridDim.x * blockDim.x) bflow::im2col_small_item(m, (int)blockIdx.y, e);
 }
 }  // namespace
 
@@ -96,8 +96,8 @@ extern "C" int bflow_im2col_small(const float* x, void* out_hi, void* out_lo, in
     BFLOW_REQUIRE(x && out_hi && out_lo && B > 0 && C > 0 && H > 0 && W > 0 && KH > 0 && KW > 0, BFLOW_E_ARG, "im2col_small: bad arguments");
     const int P = rows_per_image > 0 ? rows_per_image : H * W;
     const int CBk = (KH * KW * C + 31) / 32;
-    const long long total = (long long)B * CBk * P * 4;
+    BFLOW_REQUIRE((long long)CBk * P * 4 < (1LL << 31) && B <= 65535, BFLOW_E_LIMIT, "im2col_small: image too large for 32-bit item indices");
     bflow::Im2colArgs m{x, (_Float16*)out_hi, (_Float16*)out_lo, C, H, W, KH, KW, pad_h, pad_w, CBk, P};
-    hipLaunchKernelGGL(im2col_small_kernel, dim3(bflow::stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, m, B);
+    hipLaunchKernelGGL(im2col_small_kernel, dim3(bflow::stream_grid((long long)CBk * P * 4, 256), B), dim3(256), 0, (hipStream_t)stream, m);
     return bflow::launch_status("im2col_small");
 }

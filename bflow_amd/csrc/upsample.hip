@@ -79,9 +79,16 @@ __global__ __launch_bounds__(256) void cvx_upsample_blocked_kernel(const float* 
     const long long total = (long long)B * 2 * N * 8;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(idx & 7);
-        const long long r = idx >> 3;
-        const int n = (int)(r % N);
-        const int bi = (int)(r / N);
+        int n, bi;
+        if (total < (1LL << 31)) {                       // (uniform) 32-bit index arithmetic: a 64-bit division costs more than the softmax
+            const unsigned r = (unsigned)idx >> 3;
+            bi = (int)(r / (unsigned)N);
+            n = (int)(r - (unsigned)bi * (unsigned)N);
+        } else {
+            const long long r = idx >> 3;
+            n = (int)(r % N);
+            bi = (int)(r / N);
+        }
         const int ihi = bi & 1, b = bi >> 1;
         const int i = ihi * 4 + (q >> 1), j0 = (q & 1) * 4;
         const int y = n / w, x = n - y * w;
