@@ -1,54 +1,300 @@
 // K1 / K2: event voxel grid (reference: VoxelGrid.convert + norm_voxel_grid, data/utils/representations.py:9-18,64-111).
 //
-// K1 is an atomic-scatter kernel: one event per lane, 8 (float x/y) or 2 (integer x/y) fp32 hardware atomic adds
-// (global_atomic_add_f32) into the (C,H,W) grid; the event arrays are read with fully coalesced loads.  The order of
-// accumulation differs from the reference's sequential put_(accumulate=True), so K1 is checked to a stated fp32
-// tolerance, not bit-exactly.
+// K1 (round 5) bins the events by grid tile, accumulates every tile in LDS in 64-bit fixed point and writes it once: no global
+// atomics, no zero fill, run-to-run bit-identical (see the block comment above the kernels).
 // K2 is three streaming passes (sum+count of non-zeros, sum of squared deviations, apply) with wavefront-shuffle +
 // one fp64 atomic per block reductions; the scalar results stay on the device (graph-capture safe).
 #include "common.h"
 
 namespace {
 
-template <class XY>
-__global__ __launch_bounds__(256) void voxel_scatter_kernel(const XY* __restrict__ xs, const XY* __restrict__ ys,
-                                                            const signed char* __restrict__ pol, const long long* __restrict__ ts,
-                                                            long long n, long long t0c, long long t1c, float* __restrict__ grid, int C,
-                                                            int H, int W) {
-    constexpr bool INT_XY = !__is_floating_point(XY);
-    const float denom = (float)(t1c - t0c);
-    const float cm1 = (float)(C - 1);
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-        // representations.py:58: int64 tensor / python int -> float32 true division, then * (C-1)
-        const float t_norm = (float)(ts[e] - t0c) / denom * cm1;
-        const float tf = floorf(t_norm);
-        const float tcl = fminf(fmaxf(tf, -4.f), (float)C + 4.f);
-        const int t0 = (int)tcl;
-        const float value = 2.f * (float)pol[e] - 1.f;
+// ---- K1: tile-binned, LDS-accumulated, deterministic ----------------------------------------------------------------------------------
+// The grid is cut into BINS of CG channels x TH rows x 32 columns (one bin = one workgroup's LDS accumulator and one set of whole 128-B
+// output rows).  An event belongs to every bin one of its 8 (float x/y) or 2 (integer x/y) neighbour cells lies in: 1 bin for most,
+// 2 / 4 / 8 for events on a bin's upper borders (+24 % records at 15 x 480 x 640).  Four launches, no global atomics, no zero fill:
+//   count    workgroup b owns the contiguous event chunk b: LDS histogram over the bins -> counts[b][bin]
+//   scan     per bin the exclusive prefix over the chunks (in place) and the bin totals
+//   place    workgroup b scans the totals (bin bases), adds its own prefix row = its private cursor per bin, and writes a 16-B record
+//            (x, y, t_norm, value) per (event, bin) -- the rectification gather (f-1) happens here and in `count`
+//   gather   workgroup = bin: its records add their contributions into 64-bit FIXED-POINT LDS cells (ds_add_u64, 2^-40 units), the
+//            bin is converted (one rounding per cell) and stored once, as whole rows, zeros included.
+// Integer addition is associative, so the result does not depend on the order in which records meet (run-to-run bit-identical,
+// whatever `place` did), and it is the correctly rounded EXACT sum of the reference's own fp32 contributions (each product is formed
+// with the reference's operations in the reference's order; a contribution below 2^-16 is truncated at 2^-40 absolute) -- closer to
+// the real sum than the reference's sequential fp32 accumulation, from which it differs by that accumulation's round-off.
+// Range: |cell sum| < 2^23 (8 M same-sign events on ONE cell).
+enum { SRC_F32 = 0, SRC_I16 = 1, SRC_I32 = 2, SRC_RECT = 3 };
+
+struct VoxGeo {
+    int C, H, W;
+    int cg_shift;      // channels per bin = 1 << cg_shift when ng > 1; ng == 1: the bin holds all C channels
+    int CG;            // channels per bin
+    int th_shift, TH;  // rows per bin (8 / 16 / 32); 32 columns per bin
+    int ntx, nty;      // spatial bins
+    int g_lo, g_cnt;   // channel groups of this slab
+    int nbins;         // ntx * nty * g_cnt
+    float denom, cm1;
+    long long t0c;
+};
+
+struct VoxSrc {
+    const void *x, *y, *pol;
+    const long long* t;
+    const float* rect;
+    long long n;
+};
+
+struct VoxRec {        // 16 bytes
+    union { float fx; int qm; };
+    union { float fy; int qd; };
+    float tn, value;
+};
+
+// the (up to) 2 x 2 x 2 bins of an event: per axis the first bin and, if the upper neighbour lies in another one, the second (-1 = none)
+struct VoxBins { int tx[2], ty[2], tg[2]; };
+
+__device__ __forceinline__ int vox_bin_index(const VoxGeo& g, int tg, int ty, int tx) { return ((tg - g.g_lo) * g.nty + ty) * g.ntx + tx; }
+
+__device__ __forceinline__ void vox_axis(int lo, int limit, int shift, int out[2]) {
+    const int a = (lo >= 0 && lo < limit) ? (lo >> shift) : -1;
+    int b = (lo + 1 >= 0 && lo + 1 < limit) ? ((lo + 1) >> shift) : -1;
+    if (b == a) b = -1;
+    out[0] = a;
+    out[1] = b;
+}
+
+__device__ __forceinline__ void vox_groups(const VoxGeo& g, int p0, int p1, bool v0, bool v1, int out[2]) {   // channel planes -> groups of this slab
+    int a = v0 ? (p0 >> g.cg_shift) : -1, b = v1 ? (p1 >> g.cg_shift) : -1;
+    if (a >= 0 && (a < g.g_lo || a >= g.g_lo + g.g_cnt)) a = -1;
+    if (b >= 0 && (b < g.g_lo || b >= g.g_lo + g.g_cnt)) b = -1;
+    if (b == a) b = -1;
+    out[0] = a;
+    out[1] = b;
+}
+
+// representations.py:58: int64 tensor - python int -> int64; / python int -> float32 true division; * (C - 1)
+__device__ __forceinline__ float vox_tnorm(const VoxGeo& g, long long t) { return (float)(t - g.t0c) / g.denom * g.cm1; }
+
+// Loads event e and classifies it: the record and the bins it belongs to.  Returns false if it contributes nothing (in this slab).
+template <int SRC>
+__device__ __forceinline__ bool vox_event(const VoxGeo& g, const VoxSrc& s, long long e, VoxRec& r, VoxBins& b, int* bad) {
+    r.tn = vox_tnorm(g, s.t[e]);
+    const float tf = floorf(r.tn);
+    const float tcl = fminf(fmaxf(tf, -4.f), (float)g.C + 4.f);
+    const int t0 = (int)tcl;
+    const bool t_sane = tf == tcl;
+    if (SRC == SRC_I16 || SRC == SRC_I32) {
+        // representations.py:85-94: only the time bin is masked; x / y enter through the FLAT index ht*wd*t + wd*y + x handed to Tensor.put_,
+        // which accepts [-numel, numel) (negative = from the end) and raises outside: an index put_ would accept lands where put_ puts it,
+        // one it would raise on is dropped.  With q = wd*y + x = qd * HW + qm (0 <= qm < HW) the index of time bin tl is (tl + qd) * HW + qm:
+        // pixel qm of plane p = tl + qd (+ C if negative), accepted iff -C <= tl + qd < C.
+        r.value = 2.f * (float)reinterpret_cast<const signed char*>(s.pol)[e] - 1.f;
+        const long long x = SRC == SRC_I16 ? (long long)reinterpret_cast<const short*>(s.x)[e] : (long long)reinterpret_cast<const int*>(s.x)[e];
+        const long long y = SRC == SRC_I16 ? (long long)reinterpret_cast<const short*>(s.y)[e] : (long long)reinterpret_cast<const int*>(s.y)[e];
+        const long long HW = (long long)g.H * g.W, q = y * g.W + x;
+        long long qd = q / HW, qm = q - qd * HW;
+        if (qm < 0) { qm += HW; --qd; }
+        qd = qd < -(1 << 20) ? -(1 << 20) : (qd > (1 << 20) ? (1 << 20) : qd);
+        r.qm = (int)qm;
+        r.qd = (int)qd;
+        int p0 = t0 + r.qd, p1 = t0 + 1 + r.qd;
+        const bool v0 = t_sane && t0 >= 0 && t0 < g.C && p0 >= -g.C && p0 < g.C;
+        const bool v1 = t_sane && t0 + 1 >= 0 && t0 + 1 < g.C && p1 >= -g.C && p1 < g.C;
+        p0 += p0 < 0 ? g.C : 0;
+        p1 += p1 < 0 ? g.C : 0;
+        vox_groups(g, p0, p1, v0, v1, b.tg);
+        const int py = r.qm / g.W, px = r.qm - py * g.W;
+        b.tx[0] = px >> 5; b.tx[1] = -1;
+        b.ty[0] = py >> g.th_shift; b.ty[1] = -1;
+        return (b.tg[0] & b.tg[1]) >= 0;
+    } else {
+        if (SRC == SRC_RECT) {
+            // BaseSubSequence._rectify_events (data/dsec/subsequence/base.py:137-143): rectify_map[y, x] -> (x', y')
+            const int xr = reinterpret_cast<const unsigned short*>(s.x)[e], yr = reinterpret_cast<const unsigned short*>(s.y)[e];
+            if (xr >= g.W || yr >= g.H) {
+                if (bad) atomicAdd(bad, 1);
+                return false;
+            }
+            const float2 xy = *reinterpret_cast<const float2*>(s.rect + ((long long)yr * g.W + xr) * 2);
+            r.fx = xy.x;
+            r.fy = xy.y;
+            r.value = 2.f * (float)reinterpret_cast<const unsigned char*>(s.pol)[e] - 1.f;
+        } else {
+            r.fx = reinterpret_cast<const float*>(s.x)[e];
+            r.fy = reinterpret_cast<const float*>(s.y)[e];
+            r.value = 2.f * (float)reinterpret_cast<const signed char*>(s.pol)[e] - 1.f;
+        }
+        const float xf = floorf(r.fx), yf = floorf(r.fy);
+        const float xcl = fminf(fmaxf(xf, -4.f), (float)g.W + 4.f), ycl = fminf(fmaxf(yf, -4.f), (float)g.H + 4.f);
+        if (!(t_sane && xf == xcl && yf == ycl)) return false;      // NaN / far outside: no neighbour cell is in the grid
+        vox_axis((int)xcl, g.W, 5, b.tx);
+        vox_axis((int)ycl, g.H, g.th_shift, b.ty);
+        vox_groups(g, t0, t0 + 1, t0 >= 0 && t0 < g.C, t0 + 1 >= 0 && t0 + 1 < g.C, b.tg);
+        return (b.tx[0] & b.tx[1]) >= 0 && (b.ty[0] & b.ty[1]) >= 0 && (b.tg[0] & b.tg[1]) >= 0;   // -1 = none: any bin on every axis
+    }
+}
+
+template <class F>
+__device__ __forceinline__ void vox_for_bins(const VoxGeo& g, const VoxBins& b, F f) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (b.tg[k] >= 0 && b.ty[j] >= 0 && b.tx[i] >= 0) f(vox_bin_index(g, b.tg[k], b.ty[j], b.tx[i]));
+}
+
+// chunk b of the events: [lo, hi)
+__device__ __forceinline__ void vox_chunk(long long n, int nb, int b, long long& lo, long long& hi) {
+    const long long per = ((n + nb - 1) / nb + 255) & ~255LL;
+    lo = per * b;
+    hi = lo + per < n ? lo + per : n;
+    if (lo > n) lo = n;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void voxel_count_kernel(VoxGeo g, VoxSrc s, int* __restrict__ counts, int* __restrict__ bad) {
+    extern __shared__ int hist[];
+    for (int i = threadIdx.x; i < g.nbins; i += 256) hist[i] = 0;
+    __syncthreads();
+    long long lo, hi;
+    vox_chunk(s.n, gridDim.x, blockIdx.x, lo, hi);
+    for (long long e = lo + threadIdx.x; e < hi; e += 256) {
+        VoxRec r;
+        VoxBins b;
+        if (vox_event<SRC>(g, s, e, r, b, bad)) vox_for_bins(g, b, [&](int bin) { atomicAdd(&hist[bin], 1); });
+    }
+    __syncthreads();
+    int* row = counts + (long long)blockIdx.x * g.nbins;
+    for (int i = threadIdx.x; i < g.nbins; i += 256) row[i] = hist[i];
+}
+
+// counts[b][bin] -> exclusive prefix over b (in place); totals[bin].  Workgroup = 64 bins x 16 segments of the chunk axis (a wave = one
+// segment: coalesced rows), every thread holds its <= 32 values in registers.
+__global__ __launch_bounds__(1024) void voxel_scan_kernel(int* __restrict__ counts, int* __restrict__ totals, int nb, int nbins) {
+    __shared__ int seg_tot[16][64];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int bin = blockIdx.x * 64 + lane;
+    const int per = (nb + 15) >> 4;                    // <= 32
+    const int b0 = seg * per;
+    int v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = (k < per && b0 + k < nb && bin < nbins) ? counts[(long long)(b0 + k) * nbins + bin] : 0;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int c = v[k];
+        v[k] = sum;
+        sum += c;
+    }
+    seg_tot[seg][lane] = sum;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = seg_tot[k][lane];
+        off += k < seg ? c : 0;
+        tot += c;
+    }
+    if (bin < nbins) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < per && b0 + k < nb) counts[(long long)(b0 + k) * nbins + bin] = off + v[k];
+        if (seg == 0) totals[bin] = tot;
+    }
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void voxel_place_kernel(VoxGeo g, VoxSrc s, const int* __restrict__ prefix, const int* __restrict__ totals,
+                                                          int* __restrict__ bin_base, VoxRec* __restrict__ recs) {
+    extern __shared__ int cursor[];
+    __shared__ int wave_tot[4];
+    // exclusive scan of the bin totals: thread i owns the run [i * per, (i + 1) * per)
+    const int per = (g.nbins + 255) >> 8;
+    const int i0 = threadIdx.x * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k) sum += (i0 + k < g.nbins) ? totals[i0 + k] : 0;
+    int incl = sum;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wv; ++w) base += wave_tot[w];
+    const int* row = prefix + (long long)blockIdx.x * g.nbins;
+    for (int k = 0; k < per; ++k) {
+        if (i0 + k < g.nbins) {
+            cursor[i0 + k] = base + row[i0 + k];
+            if (blockIdx.x == 0) bin_base[i0 + k] = base;
+            base += totals[i0 + k];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 255) bin_base[g.nbins] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    long long lo, hi;
+    vox_chunk(s.n, gridDim.x, blockIdx.x, lo, hi);
+    for (long long e = lo + threadIdx.x; e < hi; e += 256) {
+        VoxRec r;
+        VoxBins b;
+        if (vox_event<SRC>(g, s, e, r, b, nullptr))
+            vox_for_bins(g, b, [&](int bin) {
+                const int slot = atomicAdd(&cursor[bin], 1);
+                *reinterpret_cast<uint4*>(recs + slot) = *reinterpret_cast<const uint4*>(&r);
+            });
+    }
+}
+
+// fp32 -> signed fixed point, 2^-40 units, truncated toward zero below the unit (deterministic; exact for |w| >= 2^-16)
+__device__ __forceinline__ long long vox_fixed(float w) {
+    const int bits = __float_as_int(w);
+    const int ex = (bits >> 23) & 255;
+    const long long m = (long long)((bits & 0x7fffff) | (ex ? 0x800000 : 0));
+    int sh = (ex ? ex : 1) - 110;                       // value = m * 2^(ex - 150); * 2^40
+    sh = sh > 38 ? 38 : sh;                             // inf / NaN / absurd magnitudes: garbage in, bounded shift
+    const long long mag = sh >= 0 ? (m << sh) : (sh > -24 ? (m >> -sh) : 0);
+    return bits < 0 ? -mag : mag;
+}
+
+template <bool INT_XY>
+__global__ __launch_bounds__(256) void voxel_gather_kernel(VoxGeo g, const int* __restrict__ bin_base, const VoxRec* __restrict__ recs,
+                                                           float* __restrict__ grid) {
+    extern __shared__ unsigned long long acc[];         // [CG][TH][32]
+    const int cells = g.CG << (g.th_shift + 5);
+    for (int i = threadIdx.x; i < cells; i += 256) acc[i] = 0ull;
+    const int bin = blockIdx.x;
+    const int tx = bin % g.ntx, ty = (bin / g.ntx) % g.nty, tg = bin / (g.ntx * g.nty) + g.g_lo;
+    const int x_lo = tx << 5, y_lo = ty << g.th_shift, c_lo = tg * g.CG;   // ng == 1: tg = 0
+    const int r_lo = bin_base[bin], r_hi = bin_base[bin + 1];
+    __syncthreads();
+    auto add = [&](int tl, int yl, int xl, float w) {
+        const unsigned c = (unsigned)(tl - c_lo), yy = (unsigned)(yl - y_lo), xx = (unsigned)(xl - x_lo);
+        if (c < (unsigned)g.CG && yy < (unsigned)g.TH && xx < 32u)
+            atomicAdd(&acc[((c << g.th_shift) + yy) * 32 + xx], (unsigned long long)vox_fixed(w));
+    };
+    for (int i = r_lo + (int)threadIdx.x; i < r_hi; i += 256) {
+        VoxRec r;
+        *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(recs + i);
+        const float tf = floorf(r.tn);
+        const int t0 = (int)tf;                         // classified sane by `place`
         if (INT_XY) {
-            // representations.py:85-94: only the time bin is masked; x / y enter through the FLAT index ht*wd*t + wd*y + x handed to
-            // Tensor.put_, which accepts [-numel, numel) (negative = from the end) and raises outside.  The same rule here: an index
-            // put_ would accept lands where put_ puts it, one it would raise on is dropped -- never an out-of-bounds write.
-            const long long x = (long long)xs[e], y = (long long)ys[e];
-            const long long numel = (long long)C * H * W;
+            const int py = r.qm / g.W, px = r.qm - py * g.W;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int tl = t0 + dt;
-                if (tl >= 0 && tl < C && tf == tcl) {
-                    long long idx = ((long long)tl * H + y) * W + x;
-                    if (idx < 0) idx += numel;
-                    if (idx >= 0 && idx < numel) {
-                        const float wgt = value * (1.f - fabsf((float)tl - t_norm));
-                        atomicAdd(grid + idx, wgt);
-                    }
+                int p = tl + r.qd;
+                if (tl >= 0 && tl < g.C && p >= -g.C && p < g.C) {
+                    p += p < 0 ? g.C : 0;
+                    add(p, py, px, r.value * (1.f - fabsf((float)tl - r.tn)));           // representations.py:87
                 }
             }
         } else {
-            const float x = (float)xs[e], y = (float)ys[e];
-            const float xf = floorf(x), yf = floorf(y);
-            const float xcl = fminf(fmaxf(xf, -4.f), (float)W + 4.f), ycl = fminf(fmaxf(yf, -4.f), (float)H + 4.f);
-            const bool sane = (xf == xcl) && (yf == ycl) && (tf == tcl);
-            const int x0 = (int)xcl, y0 = (int)ycl;
+            const float x = r.fx, y = r.fy;
+            const int x0 = (int)floorf(x), y0 = (int)floorf(y);
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
@@ -56,56 +302,17 @@ __global__ __launch_bounds__(256) void voxel_scatter_kernel(const XY* __restrict
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
                         const int xl = x0 + dx, yl = y0 + dy, tl = t0 + dt;
-                        if (sane && xl < W && xl >= 0 && yl < H && yl >= 0 && tl >= 0 && tl < C) {
+                        if (xl < g.W && xl >= 0 && yl < g.H && yl >= 0 && tl >= 0 && tl < g.C)
                             // representations.py:103: value * (1-|xlim-x|) * (1-|ylim-y|) * (1-|tlim-t_norm|), left to right
-                            const float wgt = value * (1.f - fabsf((float)xl - x)) * (1.f - fabsf((float)yl - y)) *
-                                              (1.f - fabsf((float)tl - t_norm));
-                            atomicAdd(grid + ((long long)tl * H + yl) * W + xl, wgt);
-                        }
+                            add(tl, yl, xl, r.value * (1.f - fabsf((float)xl - x)) * (1.f - fabsf((float)yl - y)) * (1.f - fabsf((float)tl - r.tn)));
                     }
         }
     }
-}
-
-// f-1: DSEC sample assembly.  Raw sensor events (uint16 x / y, 0/1 polarity) are rectified through the per-sequence
-// map (BaseSubSequence._rectify_events, data/dsec/subsequence/base.py:137-143: rectify_map[y, x] -> (x', y') float32) and
-// scattered tri-linearly in the same kernel: the rectified coordinate arrays are never materialised.  Events whose raw
-// coordinates fall outside the map (the reference asserts on them) are skipped and counted in *bad.
-__global__ __launch_bounds__(256) void voxel_scatter_rect_kernel(const unsigned short* __restrict__ xs, const unsigned short* __restrict__ ys,
-                                                                 const unsigned char* __restrict__ pol, const long long* __restrict__ ts,
-                                                                 long long n, const float* __restrict__ rect, long long t0c, long long t1c,
-                                                                 float* __restrict__ grid, int C, int H, int W, int* __restrict__ bad) {
-    const float denom = (float)(t1c - t0c);
-    const float cm1 = (float)(C - 1);
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-        const int xr = xs[e], yr = ys[e];
-        if (xr >= W || yr >= H) {
-            if (bad) atomicAdd(bad, 1);
-            continue;
-        }
-        const float2 xy = *reinterpret_cast<const float2*>(rect + ((long long)yr * W + xr) * 2);
-        const float t_norm = (float)(ts[e] - t0c) / denom * cm1;
-        const float tf = floorf(t_norm);
-        const float tcl = fminf(fmaxf(tf, -4.f), (float)C + 4.f);
-        const int t0 = (int)tcl;
-        const float value = 2.f * (float)pol[e] - 1.f;
-        const float x = xy.x, y = xy.y;
-        const float xf = floorf(x), yf = floorf(y);
-        const float xcl = fminf(fmaxf(xf, -4.f), (float)W + 4.f), ycl = fminf(fmaxf(yf, -4.f), (float)H + 4.f);
-        const bool sane = (xf == xcl) && (yf == ycl) && (tf == tcl);
-        const int x0 = (int)xcl, y0 = (int)ycl;
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx)
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int xl = x0 + dx, yl = y0 + dy, tl = t0 + dt;
-                    if (sane && xl < W && xl >= 0 && yl < H && yl >= 0 && tl >= 0 && tl < C) {
-                        const float wgt = value * (1.f - fabsf((float)xl - x)) * (1.f - fabsf((float)yl - y)) * (1.f - fabsf((float)tl - t_norm));
-                        atomicAdd(grid + ((long long)tl * H + yl) * W + xl, wgt);
-                    }
-                }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cells; i += 256) {
+        const int xx = i & 31, yy = (i >> 5) & (g.TH - 1), c = i >> (5 + g.th_shift);
+        const int xl = x_lo + xx, yl = y_lo + yy, tl = c_lo + c;
+        if (xl < g.W && yl < g.H && tl < g.C) grid[((long long)tl * g.H + yl) * g.W + xl] = __ll2float_rn((long long)acc[i]) * 0x1p-40f;
     }
 }
 
@@ -177,33 +384,105 @@ __global__ __launch_bounds__(256) void norm_pass3(float* __restrict__ g, long lo
     }
 }
 
-template <class XY>
-int scatter(const XY* x, const XY* y, const signed char* pol, const long long* t, long long n, long long t0c, long long t1c, float* grid,
-            int C, int H, int W, bflow_stream_t stream, const char* what) {
-    BFLOW_REQUIRE(grid && C > 1 && H > 1 && W > 1, BFLOW_E_ARG, "%s: bad grid", what);
+struct VoxPlan {
+    VoxGeo geo;          // g_lo / g_cnt / nbins are per slab
+    int ng, groups_per_slab, nb;
+    size_t off_totals, off_base, off_recs, bytes;
+};
+
+constexpr int VOX_MAX_BINS = 8192;
+
+// Bin shape and workspace layout.  max_dup = the most bins one event can belong to.
+static int vox_plan(long long n, int C, int H, int W, bool float_xy, VoxPlan& p, const char* what) {
+    BFLOW_REQUIRE(C > 1 && H > 1 && W > 1, BFLOW_E_ARG, "%s: bad grid", what);
+    BFLOW_REQUIRE(n >= 0 && n <= (1LL << 27), BFLOW_E_ARG, "%s: at most 2^27 events per call", what);
+    BFLOW_REQUIRE((long long)C * H * W < (1LL << 31) && (long long)H * W <= (1LL << 24), BFLOW_E_ARG, "%s: grid too large", what);
+    VoxGeo& g = p.geo;
+    g.C = C; g.H = H; g.W = W;
+    g.cg_shift = 3;
+    g.CG = C <= 8 ? C : 8;
+    p.ng = C <= 8 ? 1 : (C + 7) / 8;
+    g.ntx = (W + 31) / 32;
+    g.th_shift = 3;
+    while (g.th_shift < 5 && (long long)g.ntx * ((H + (1 << g.th_shift) - 1) >> g.th_shift) * p.ng > VOX_MAX_BINS) ++g.th_shift;
+    g.TH = 1 << g.th_shift;
+    g.nty = (H + g.TH - 1) >> g.th_shift;
+    const int spatial = g.ntx * g.nty;
+    BFLOW_REQUIRE(spatial <= VOX_MAX_BINS, BFLOW_E_ARG, "%s: grid too large", what);
+    p.groups_per_slab = VOX_MAX_BINS / spatial;
+    if (p.groups_per_slab > p.ng) p.groups_per_slab = p.ng;
+    const int slab_bins = spatial * p.groups_per_slab;
+    // chunks: 4096 events each at 2 M events; fewer, larger ones when the count matrix (chunks x bins) would outgrow the event arrays
+    long long nb = (n + 4095) / 4096;
+    const long long cap = slab_bins > 4096 ? 256 : 512;
+    nb = nb < 1 ? 1 : (nb > cap ? cap : nb);
+    p.nb = (int)nb;
+    const int max_dup = (float_xy ? 4 : 1) * (p.ng > 1 ? 2 : 1);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    p.off_totals = up((size_t)p.nb * slab_bins * 4);
+    p.off_base = p.off_totals + up((size_t)slab_bins * 4);
+    p.off_recs = p.off_base + up((size_t)(slab_bins + 1) * 4);
+    p.bytes = p.off_recs + up((size_t)(n > 0 ? n : 1) * max_dup * sizeof(VoxRec));
+    return 0;
+}
+
+template <int SRC>
+int vox_run(const VoxSrc& s, long long t0c, long long t1c, float* grid, int C, int H, int W, void* ws, long long ws_bytes, int* bad,
+            bflow_stream_t stream, const char* what) {
+    constexpr bool FLOAT_XY = SRC == SRC_F32 || SRC == SRC_RECT;
+    VoxPlan p;
+    if (int rc = vox_plan(s.n, C, H, W, FLOAT_XY, p, what)) return rc;
+    BFLOW_REQUIRE(grid, BFLOW_E_ARG, "%s: bad grid", what);
     BFLOW_REQUIRE(t1c > t0c, BFLOW_E_ARG, "%s: t1_center must be > t0_center", what);
-    if (n == 0) return 0;
-    BFLOW_REQUIRE(x && y && pol && t && n > 0, BFLOW_E_ARG, "%s: bad event arrays", what);
-    hipLaunchKernelGGL(voxel_scatter_kernel<XY>, dim3(bflow::stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, pol, t, n,
-                       t0c, t1c, grid, C, H, W);
+    BFLOW_REQUIRE(s.n == 0 || (s.x && s.y && s.pol && s.t), BFLOW_E_ARG, "%s: bad event arrays", what);
+    BFLOW_REQUIRE(ws && ((uintptr_t)ws & 15) == 0 && ws_bytes >= (long long)p.bytes, BFLOW_E_ARG,
+                  "%s: workspace of %lld bytes needed (bflow_voxel_workspace_bytes), 16-byte aligned", what, (long long)p.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    VoxGeo g = p.geo;
+    g.t0c = t0c;
+    g.denom = (float)(t1c - t0c);
+    g.cm1 = (float)(C - 1);
+    char* w = (char*)ws;
+    int* counts = (int*)w;
+    int* totals = (int*)(w + p.off_totals);
+    int* base = (int*)(w + p.off_base);
+    VoxRec* recs = (VoxRec*)(w + p.off_recs);
+    for (int g_lo = 0; g_lo < p.ng; g_lo += p.groups_per_slab) {
+        g.g_lo = g_lo;
+        g.g_cnt = p.ng - g_lo < p.groups_per_slab ? p.ng - g_lo : p.groups_per_slab;
+        g.nbins = g.ntx * g.nty * g.g_cnt;
+        hipLaunchKernelGGL(voxel_count_kernel<SRC>, dim3(p.nb), dim3(256), (size_t)g.nbins * 4, st, g, s, counts, g_lo == 0 ? bad : nullptr);
+        hipLaunchKernelGGL(voxel_scan_kernel, dim3((g.nbins + 63) / 64), dim3(1024), 0, st, counts, totals, p.nb, g.nbins);
+        hipLaunchKernelGGL(voxel_place_kernel<SRC>, dim3(p.nb), dim3(256), (size_t)g.nbins * 4, st, g, s, counts, totals, base, recs);
+        hipLaunchKernelGGL(voxel_gather_kernel<!FLOAT_XY>, dim3(g.nbins), dim3(256), (size_t)g.CG * g.TH * 32 * 8, st, g, base, recs, grid);
+    }
     return bflow::launch_status(what);
 }
 
 }  // namespace
 
-extern "C" int bflow_voxel_scatter_f32xy(const float* x, const float* y, const signed char* pol, const long long* t, long long n,
-                                         long long t0c, long long t1c, float* grid, int C, int H, int W, bflow_stream_t stream) {
-    return scatter<float>(x, y, pol, t, n, t0c, t1c, grid, C, H, W, stream, "voxel_scatter_f32xy");
+extern "C" long long bflow_voxel_workspace_bytes(long long n_events, int C, int H, int W, int float_xy) {
+    VoxPlan p;
+    if (vox_plan(n_events, C, H, W, float_xy != 0, p, "voxel_workspace_bytes")) return -1;
+    return (long long)p.bytes;
 }
 
-extern "C" int bflow_voxel_scatter_i16xy(const short* x, const short* y, const signed char* pol, const long long* t, long long n,
-                                         long long t0c, long long t1c, float* grid, int C, int H, int W, bflow_stream_t stream) {
-    return scatter<short>(x, y, pol, t, n, t0c, t1c, grid, C, H, W, stream, "voxel_scatter_i16xy");
+extern "C" int bflow_voxel_grid_f32xy(const float* x, const float* y, const signed char* pol, const long long* t, long long n,
+                                      long long t0c, long long t1c, float* grid, int C, int H, int W, void* ws, long long ws_bytes,
+                                      bflow_stream_t stream) {
+    return vox_run<SRC_F32>(VoxSrc{x, y, pol, t, nullptr, n}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_f32xy");
 }
 
-extern "C" int bflow_voxel_scatter_i32xy(const int* x, const int* y, const signed char* pol, const long long* t, long long n,
-                                         long long t0c, long long t1c, float* grid, int C, int H, int W, bflow_stream_t stream) {
-    return scatter<int>(x, y, pol, t, n, t0c, t1c, grid, C, H, W, stream, "voxel_scatter_i32xy");
+extern "C" int bflow_voxel_grid_i16xy(const short* x, const short* y, const signed char* pol, const long long* t, long long n,
+                                      long long t0c, long long t1c, float* grid, int C, int H, int W, void* ws, long long ws_bytes,
+                                      bflow_stream_t stream) {
+    return vox_run<SRC_I16>(VoxSrc{x, y, pol, t, nullptr, n}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_i16xy");
+}
+
+extern "C" int bflow_voxel_grid_i32xy(const int* x, const int* y, const signed char* pol, const long long* t, long long n,
+                                      long long t0c, long long t1c, float* grid, int C, int H, int W, void* ws, long long ws_bytes,
+                                      bflow_stream_t stream) {
+    return vox_run<SRC_I32>(VoxSrc{x, y, pol, t, nullptr, n}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_i32xy");
 }
 
 extern "C" int bflow_voxel_norm(float* grid, long long n, double* ws, bflow_stream_t stream) {
@@ -221,17 +500,12 @@ extern "C" int bflow_voxel_norm(float* grid, long long n, double* ws, bflow_stre
     return bflow::launch_status("voxel_norm");
 }
 
-extern "C" int bflow_voxel_scatter_rectified(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,
-                                             long long n, const float* rectify_map, long long t0c, long long t1c, float* grid, int C, int H,
-                                             int W, int* bad_count, bflow_stream_t stream) {
-    BFLOW_REQUIRE(grid && rectify_map && C > 1 && H > 1 && W > 1, BFLOW_E_ARG, "voxel_scatter_rectified: bad grid / map");
-    BFLOW_REQUIRE(t1c > t0c, BFLOW_E_ARG, "voxel_scatter_rectified: t1_center must be > t0_center");
-    BFLOW_REQUIRE(((uintptr_t)rectify_map & 7) == 0, BFLOW_E_ARG, "voxel_scatter_rectified: the map must be 8-byte aligned");
-    if (n == 0) return 0;
-    BFLOW_REQUIRE(x && y && pol && t && n > 0, BFLOW_E_ARG, "voxel_scatter_rectified: bad event arrays");
-    hipLaunchKernelGGL(voxel_scatter_rect_kernel, dim3(bflow::stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, pol, t, n,
-                       rectify_map, t0c, t1c, grid, C, H, W, bad_count);
-    return bflow::launch_status("voxel_scatter_rectified");
+extern "C" int bflow_voxel_grid_rectified(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,
+                                          long long n, const float* rectify_map, long long t0c, long long t1c, float* grid, int C, int H,
+                                          int W, int* bad_count, void* ws, long long ws_bytes, bflow_stream_t stream) {
+    BFLOW_REQUIRE(rectify_map && ((uintptr_t)rectify_map & 7) == 0, BFLOW_E_ARG, "voxel_grid_rectified: the map must be 8-byte aligned");
+    return vox_run<SRC_RECT>(VoxSrc{x, y, pol, t, rectify_map, n}, t0c, t1c, grid, C, H, W, ws, ws_bytes, bad_count, stream,
+                             "voxel_grid_rectified");
 }
 
 extern "C" int bflow_maxabs_diff(const float* a, const float* b, long long n, float* out, bflow_stream_t stream) {

@@ -5,7 +5,7 @@ CPU DataLoader worker per sample -- pick the current / previous flow interval, c
 either side), rectify the raw sensor coordinates through the sequence's map, build two voxel grids, drop the temporal slice they
 share, normalise -- with the arithmetic in HIP kernels:
 
-    raw events (uint16 x / y, 0/1 polarity, int64 us)  --bflow_voxel_scatter_rectified-->  grid_prev, grid_cur   (K1 + map gather)
+    raw events (uint16 x / y, 0/1 polarity, int64 us)  --bflow_voxel_grid_rectified-->  grid_prev, grid_cur   (K1 + map gather)
     max |grid_prev[-1] - grid_cur[0]| < 0.5             --bflow_maxabs_diff-->              the reference's consistency assert
     [grid_prev | grid_cur[1:]]                          --bflow_voxel_norm-->               (2*bins - 1, H, W) network input (K2)
 
@@ -115,9 +115,9 @@ class TwoStepAssembler:
         x, y, p, t = events.window(t_start, t_end)
         if t0c is None:                                                                     # version 0: centres = first / last event
             t0c, t1c = int(t[0]), int(t[-1])
-        grid = torch.zeros((self.num_bins, self.height, self.width), dtype=torch.float32, device=self.device)
+        grid = torch.empty((self.num_bins, self.height, self.width), dtype=torch.float32, device=self.device)   # K1 writes every cell
         dev = lambda a, dt: a.to(device=self.device, dtype=dt).contiguous()
-        hip.voxel_scatter_rectified(dev(x, torch.uint16), dev(y, torch.uint16), dev(p, torch.uint8), dev(t, torch.int64),
+        hip.voxel_grid_rectified(dev(x, torch.uint16), dev(y, torch.uint16), dev(p, torch.uint8), dev(t, torch.int64),
                                     self.rectify_events_map, t0c, t1c, grid, self._bad)
         return grid
 

@@ -27,8 +27,8 @@ EXPORTS = (
     "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_build_tiled", "bflow_split_to_x8", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_conv_thin_mfma_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_rows_to_split", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_norm_train_finalize", "bflow_norm_train_apply", "bflow_norm_train_bwd_stats", "bflow_norm_train_bwd_finalize", "bflow_norm_train_bwd_apply", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_corr_lookup_conv1x1", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
-    "bflow_voxel_scatter_f32xy", "bflow_voxel_scatter_i16xy", "bflow_voxel_scatter_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
-    "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_scatter_rectified", "bflow_maxabs_diff",
+    "bflow_voxel_workspace_bytes", "bflow_voxel_grid_f32xy", "bflow_voxel_grid_i16xy", "bflow_voxel_grid_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
+    "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_grid_rectified", "bflow_maxabs_diff",
     "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
     "bflow_l1_masked_grad", "bflow_conv_split_pair", "bflow_corr_lookup_im2col", "bflow_cvx_upsample_blocked",
 )
@@ -156,11 +156,12 @@ def lib() -> ctypes.CDLL:
         "bflow_bezier_eval": [vp, ctypes.POINTER(ctypes.c_float), i, i, i, i, i, i, vp, vp],
         "bflow_cvx_upsample": [vp, vp, vp, f, vp, i, i, i, i, vp],
         "bflow_cvx_upsample_blocked": [vp, vp, f, vp, i, i, i, i, i, vp],
-        "bflow_voxel_scatter_f32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
-        "bflow_voxel_scatter_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
-        "bflow_voxel_scatter_i32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp],
+        "bflow_voxel_workspace_bytes": [ll, i, i, i, i],
+        "bflow_voxel_grid_f32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp, ll, vp],
+        "bflow_voxel_grid_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp, ll, vp],
+        "bflow_voxel_grid_i32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp, ll, vp],
         "bflow_voxel_norm": [vp, ll, vp, vp],
-        "bflow_voxel_scatter_rectified": [vp, vp, vp, vp, ll, vp, ll, ll, vp, i, i, i, vp, vp],
+        "bflow_voxel_grid_rectified": [vp, vp, vp, vp, ll, vp, ll, ll, vp, i, i, i, vp, vp, ll, vp],
         "bflow_maxabs_diff": [vp, vp, ll, vp, vp],
         "bflow_epe_accumulate": [vp, vp, vp, i, i, ll, vp, vp],
         "bflow_flow_metrics_accumulate": [vp, vp, vp, i, i, ll, f, f, f, vp, vp],
@@ -175,7 +176,7 @@ def lib() -> ctypes.CDLL:
     }
     for name, args in sig.items():
         fn = getattr(L, name)
-        fn.restype = i
+        fn.restype = ll if name == "bflow_voxel_workspace_bytes" else i
         fn.argtypes = args
     _lib = L
     return L
@@ -481,33 +482,48 @@ def cvx_upsample(data: torch.Tensor, mask: torch.Tensor, mask_bias: Optional[tor
 
 
 # ------------------------------------------------------------------------------------------------ K1 / K2
-def voxel_scatter(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.Tensor, t0_center: int, t1_center: int,
-                  grid: torch.Tensor):
+def _voxel_workspace(n: int, C: int, H: int, W: int, float_xy: bool, device) -> torch.Tensor:
+    nbytes = int(lib().bflow_voxel_workspace_bytes(n, C, H, W, int(float_xy)))
+    if nbytes < 0:
+        raise BflowHipError("voxel grid: " + lib().bflow_last_error_string().decode("utf-8", "replace"))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def voxel_grid(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.Tensor, t0_center: int, t1_center: int,
+               grid: torch.Tensor, workspace: Optional[torch.Tensor] = None):
+    """K1: `grid` (C, H, W) is written whole (it need not be zeroed)."""
     C, H, W = grid.shape
     n = x.numel()
     ppol = _dev(pol, torch.int8, "pol")
     pt = _dev(t, torch.int64, "time")
     if x.dtype == torch.float32:
-        fn, px, py = lib().bflow_voxel_scatter_f32xy, _dev(x, torch.float32, "x"), _dev(y, torch.float32, "y")
+        fn, px, py = lib().bflow_voxel_grid_f32xy, _dev(x, torch.float32, "x"), _dev(y, torch.float32, "y")
     elif x.dtype == torch.int16:
-        fn, px, py = lib().bflow_voxel_scatter_i16xy, _dev(x, torch.int16, "x"), _dev(y, torch.int16, "y")
+        fn, px, py = lib().bflow_voxel_grid_i16xy, _dev(x, torch.int16, "x"), _dev(y, torch.int16, "y")
     elif x.dtype == torch.int32:
-        fn, px, py = lib().bflow_voxel_scatter_i32xy, _dev(x, torch.int32, "x"), _dev(y, torch.int32, "y")
+        fn, px, py = lib().bflow_voxel_grid_i32xy, _dev(x, torch.int32, "x"), _dev(y, torch.int32, "y")
     else:
-        raise BflowHipError(f"voxel_scatter: x/y dtype {x.dtype} unsupported (float32, int16 or int32)")
-    _check(fn(px, py, ppol, pt, n, int(t0_center), int(t1_center), _dev(grid, name="grid"), C, H, W, _stream()), "bflow_voxel_scatter")
+        raise BflowHipError(f"voxel_grid: x/y dtype {x.dtype} unsupported (float32, int16 or int32)")
+    if workspace is None:
+        workspace = _voxel_workspace(n, C, H, W, x.dtype == torch.float32, grid.device)
+    _check(fn(px, py, ppol, pt, n, int(t0_center), int(t1_center), _dev(grid, name="grid"), C, H, W, _dev(workspace, torch.uint8, "workspace"),
+              workspace.numel(), _stream()), "bflow_voxel_grid")
 
 
-def voxel_scatter_rectified(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.Tensor, rectify_map: torch.Tensor,
-                            t0_center: int, t1_center: int, grid: torch.Tensor, bad_count: Optional[torch.Tensor] = None):
-    """Raw uint16 sensor coordinates -> rectify_map[y, x] -> tri-linear scatter (f-1)."""
+def voxel_grid_rectified(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.Tensor, rectify_map: torch.Tensor,
+                         t0_center: int, t1_center: int, grid: torch.Tensor, bad_count: Optional[torch.Tensor] = None,
+                         workspace: Optional[torch.Tensor] = None):
+    """Raw uint16 sensor coordinates -> rectify_map[y, x] -> tri-linear accumulation (f-1); `grid` is written whole."""
     C, H, W = grid.shape
     assert tuple(rectify_map.shape) == (H, W, 2)
-    _check(lib().bflow_voxel_scatter_rectified(_dev(x, torch.uint16, "x"), _dev(y, torch.uint16, "y"), _dev(pol, torch.uint8, "pol"),
-                                               _dev(t, torch.int64, "time"), x.numel(), _dev(rectify_map, name="rectify_map"), int(t0_center),
-                                               int(t1_center), _dev(grid, name="grid"), C, H, W,
-                                               None if bad_count is None else _dev(bad_count, torch.int32, "bad_count"), _stream()),
-           "bflow_voxel_scatter_rectified")
+    if workspace is None:
+        workspace = _voxel_workspace(x.numel(), C, H, W, True, grid.device)
+    _check(lib().bflow_voxel_grid_rectified(_dev(x, torch.uint16, "x"), _dev(y, torch.uint16, "y"), _dev(pol, torch.uint8, "pol"),
+                                            _dev(t, torch.int64, "time"), x.numel(), _dev(rectify_map, name="rectify_map"), int(t0_center),
+                                            int(t1_center), _dev(grid, name="grid"), C, H, W,
+                                            None if bad_count is None else _dev(bad_count, torch.int32, "bad_count"),
+                                            _dev(workspace, torch.uint8, "workspace"), workspace.numel(), _stream()),
+           "bflow_voxel_grid_rectified")
 
 
 def maxabs_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

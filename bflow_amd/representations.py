@@ -1,8 +1,9 @@
 """Event voxel grid on the GPU -- drop-in for data/utils/representations.py:9-111 (VoxelGrid.convert, norm_voxel_grid).
 
 The reference runs `convert` on the CPU inside DataLoader workers (24 masked put_ passes per grid, single-threaded by
-its own torch.set_num_threads(1)); here the events are scattered with fp32 hardware atomics by one HIP kernel (K1) and
-normalised by a three-pass reduction (K2).  Inputs must be GPU tensors."""
+its own torch.set_num_threads(1)); here the events are binned by grid tile, accumulated per tile in LDS in 64-bit fixed point and
+written once (K1: deterministic, no atomics on memory, no zero fill), then normalised by a three-pass reduction (K2).  Inputs must be
+GPU tensors."""
 from __future__ import annotations
 
 import math
@@ -61,6 +62,6 @@ class VoxelGrid(EventRepresentation):
                 lim = 2 ** 31 - 1
                 x, y = x.clamp(-lim, lim), y.clamp(-lim, lim)      # int64 outliers saturate (and are then dropped by the flat-index rule)
             xs, ys = x.to(xy_dtype).contiguous(), y.to(xy_dtype).contiguous()
-        grid = torch.zeros((self.nb_channels, self.height, self.width), dtype=torch.float32, device=x.device)
-        hip.voxel_scatter(xs, ys, pol.to(torch.int8).contiguous(), time.to(torch.int64).contiguous(), int(t0_center), int(t1_center), grid)
+        grid = torch.empty((self.nb_channels, self.height, self.width), dtype=torch.float32, device=x.device)   # K1 writes every cell
+        hip.voxel_grid(xs, ys, pol.to(torch.int8).contiguous(), time.to(torch.int64).contiguous(), int(t0_center), int(t1_center), grid)
         return grid

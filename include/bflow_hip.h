@@ -471,37 +471,41 @@ int bflow_cvx_upsample_blocked(const float* data, const float* mask_blocked, flo
                                int mask_rows_per_image, bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * K1  event voxel grid: signed tri-linear (float x/y) or temporal-linear (integer x/y) scatter-add.
- * Replaces VoxelGrid.convert, data/utils/representations.py:64-111.  `grid` (C,H,W) must be zeroed by the
- * caller (hipMemsetAsync); accumulation uses fp32 hardware atomics (order is not deterministic).
- *   x,y : fp32 (f32xy), int16 (i16xy) or int32 (i32xy);  pol : int8 in {0,1};  t : int64 microseconds.
+ * K1  event voxel grid: signed tri-linear (float x/y) or temporal-linear (integer x/y) accumulation of events.
+ * Replaces VoxelGrid.convert, data/utils/representations.py:64-111.  `grid` (C,H,W) is WRITTEN WHOLE (no zero fill by the caller).
+ * Tile-binned: the events are counted and placed per grid tile (two passes, deterministic prefix sums, no global atomics), every tile
+ * is accumulated in LDS in 64-bit fixed point (2^-40 units) and stored once: the result is bit-identical from run to run and equals the
+ * correctly rounded exact sum of the reference's fp32 contributions (|cell sum| < 2^23).  `workspace`: device memory, 16-byte
+ * aligned, >= bflow_voxel_workspace_bytes(n_events, C, H, W, float_xy) bytes (returns -1 for an unsupported size), any contents.
+ *   x,y : fp32 (f32xy), int16 (i16xy) or int32 (i32xy);  pol : int8 in {0,1};  t : int64 microseconds;  n_events <= 2^27.
  * Integer x/y follow the reference's FLAT index ht*wd*t + wd*y + x into Tensor.put_ (representations.py:85-94: only the time bin
  * is masked): an index in [-C*H*W, C*H*W) lands where put_ puts it (negative = from the end), one put_ would raise on is dropped;
  * no coordinate can cause an out-of-bounds write.                                                      */
-int bflow_voxel_scatter_f32xy(const float* x, const float* y, const signed char* pol, const long long* t,
-                              long long n_events, long long t0_center, long long t1_center,
-                              float* grid, int C, int H, int W, bflow_stream_t stream);
-int bflow_voxel_scatter_i16xy(const short* x, const short* y, const signed char* pol, const long long* t,
-                              long long n_events, long long t0_center, long long t1_center,
-                              float* grid, int C, int H, int W, bflow_stream_t stream);
-int bflow_voxel_scatter_i32xy(const int* x, const int* y, const signed char* pol, const long long* t,
-                              long long n_events, long long t0_center, long long t1_center,
-                              float* grid, int C, int H, int W, bflow_stream_t stream);
+long long bflow_voxel_workspace_bytes(long long n_events, int C, int H, int W, int float_xy);
+int bflow_voxel_grid_f32xy(const float* x, const float* y, const signed char* pol, const long long* t,
+                           long long n_events, long long t0_center, long long t1_center,
+                           float* grid, int C, int H, int W, void* workspace, long long workspace_bytes, bflow_stream_t stream);
+int bflow_voxel_grid_i16xy(const short* x, const short* y, const signed char* pol, const long long* t,
+                           long long n_events, long long t0_center, long long t1_center,
+                           float* grid, int C, int H, int W, void* workspace, long long workspace_bytes, bflow_stream_t stream);
+int bflow_voxel_grid_i32xy(const int* x, const int* y, const signed char* pol, const long long* t,
+                           long long n_events, long long t0_center, long long t1_center,
+                           float* grid, int C, int H, int W, void* workspace, long long workspace_bytes, bflow_stream_t stream);
 
 /* K2  in-place normalisation over the NON-ZERO entries: (v - mean) / std (unbiased), or v - mean if std == 0.
  * Replaces norm_voxel_grid, representations.py:9-18.  workspace: device, >= 4 doubles, any contents.    */
 int bflow_voxel_norm(float* grid, long long n, double* workspace, bflow_stream_t stream);
 
 /* DSEC sample assembly: BaseSubSequence._rectify_events + _events_to_voxel_grid (data/dsec/subsequence/base.py:121-143)
- * in one kernel.  x, y: raw sensor coordinates (uint16, as stored in events.h5), pol: 0/1, t: int64 us;
- * rectify_map (H, W, 2) float32: rectify_map[y, x] = (x', y'), the rectified sub-pixel position, scattered tri-linearly
- * like bflow_voxel_scatter_f32xy.  Events with x >= W or y >= H are skipped and counted in *bad_count (may be NULL;
- * the reference asserts on them).
+ * inside K1's binning passes.  x, y: raw sensor coordinates (uint16, as stored in events.h5), pol: 0/1, t: int64 us;
+ * rectify_map (H, W, 2) float32: rectify_map[y, x] = (x', y'), the rectified sub-pixel position, accumulated tri-linearly
+ * like bflow_voxel_grid_f32xy (workspace: float_xy = 1).  Events with x >= W or y >= H are skipped and counted in *bad_count
+ * (may be NULL; the reference asserts on them).
  * bflow_maxabs_diff: *out = max(*out, max_i |a[i] - b[i]|) (out zeroed by the caller) -- the agreement check of the temporal
  * slice shared by the previous and the current grid (data/dsec/subsequence/twostep.py:83).                                  */
-int bflow_voxel_scatter_rectified(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,
-                                  long long n, const float* rectify_map, long long t0_center, long long t1_center, float* grid,
-                                  int C, int H, int W, int* bad_count, bflow_stream_t stream);
+int bflow_voxel_grid_rectified(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,
+                               long long n, const float* rectify_map, long long t0_center, long long t1_center, float* grid,
+                               int C, int H, int W, int* bad_count, void* workspace, long long workspace_bytes, bflow_stream_t stream);
 int bflow_maxabs_diff(const float* a, const float* b, long long n, float* out, bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------

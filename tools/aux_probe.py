@@ -23,10 +23,10 @@ for n_ev in (500_000, 2_000_000):
     p = torch.from_numpy(rs.randint(0, 2, n_ev).astype(np.int8)).to(dev)
     t = torch.from_numpy(np.sort(rs.randint(0, 100_000, n_ev)).astype(np.int64)).to(dev)
     grid = torch.zeros((C, H, W), device=dev)
-    timed(lambda: hip.voxel_scatter(x, y, p, t, 0, 100_000, grid), f"K1 voxel_scatter f32xy, {n_ev/1e6:.1f} M events", n_ev * (17 + 8 * 8),
+    timed(lambda: hip.voxel_grid(x, y, p, t, 0, 100_000, grid), f"K1 voxel_scatter f32xy, {n_ev/1e6:.1f} M events", n_ev * (17 + 8 * 8),
           note=f"{n_ev/1e6:.1f} M events -> {n_ev*8/1e9:.3f} G atomics")
     xi, yi = x.round().to(torch.int16), y.round().to(torch.int16)
-    timed(lambda: hip.voxel_scatter(xi, yi, p, t, 0, 100_000, grid), f"K1 voxel_scatter i16xy, {n_ev/1e6:.1f} M events", n_ev * (13 + 2 * 8))
+    timed(lambda: hip.voxel_grid(xi, yi, p, t, 0, 100_000, grid), f"K1 voxel_scatter i16xy, {n_ev/1e6:.1f} M events", n_ev * (13 + 2 * 8))
 grid = torch.from_numpy((rs.standard_normal((C, H, W)) * (rs.uniform(size=(C, H, W)) < 0.3)).astype(np.float32)).to(dev)
 ws = torch.empty(4, dtype=torch.float64, device=dev)
 timed(lambda: hip.voxel_norm(grid, ws), "K2 voxel_norm 9x480x640", 4.0 * grid.numel() * 4, note="(3 reads + 1 write)")
