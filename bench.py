@@ -40,7 +40,8 @@ H, W, ITERS, CFG = 480, 640, 12, "E_LU4_BD2"
 GLOBAL_BATCH, MICRO_BATCH = 64, 8          # BASELINE configs[3]
 PEAK_SPLIT_TFLOPS = round(2500.0 / 3, 1)   # fp16 dense MFMA peak (~2.5 PFLOP/s) / 3 MFMA passes per fp32-class product
 PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-PMC_FILE = "r04_pmc.json"                  # rocprofv3 --pmc evidence of this round (tools/collect_profiles.sh)
+K5_SUSTAINED_GHZ = 1.7                     # shader clock of K5 under load (cycle stamps / wall clock per workgroup: profiles/r0x_k5_stamps_split8.txt, 1.66-1.8)
+PMC_FILE = "r05_pmc.json"                  # rocprofv3 --pmc evidence of this round (tools/collect_profiles.sh)
 
 
 def kernel_source_hash() -> str:
@@ -54,6 +55,20 @@ def kernel_source_hash() -> str:
             h.update(f.encode())
             h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
+
+
+def micro_batch_plan(global_batch: int, rank: int, world: int, graph: bool = True):
+    """The frames rank `rank` of `world` runs per step of BASELINE configs[3]: its contiguous shard of the global batch cut into micro-batches of
+    at most MICRO_BATCH frames, but at least two per rank when graphs are on (two forwards in flight fill the chip better than one: 8 frames
+    at N = 8 as two concurrent micro-batches of 4 = 358 frames/s, one of 8 = 332; tools/two_frame_probe.py).
+    Returns (micro, [(first_sample, n), ...])."""
+    from bflow_amd import dist as bdist
+    s0, s1 = bdist.shard_range(global_batch, rank, world)
+    micro = min(MICRO_BATCH, max(1, (s1 - s0) // 2)) if graph else min(MICRO_BATCH, s1 - s0)
+    n_micro = (s1 - s0) // micro
+    # every frame of the shard must be run: frames/s counts s1 - s0 frames per step (a remainder micro-batch would be counted, not run)
+    assert n_micro * micro == s1 - s0, f"the rank's {s1 - s0} frames do not split into micro-batches of {micro}: use a world size that divides {global_batch} into even shards"
+    return micro, [(s0 + k * micro, micro) for k in range(n_micro)]
 
 
 def free_port() -> int:
@@ -77,6 +92,9 @@ def relaunch(args) -> int:
     """--gpus N > 1 without a torchrun environment: become the launcher of N ranks on this node."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL needs dmabuf IPC on this driver stack
+    # host-thread policy, stated (torchrun would otherwise set OMP_NUM_THREADS=1 silently): the ranks share the box's usable cores evenly;
+    # a rank's host work is launch enqueueing on one thread, the rest only serves torch's CPU ops outside the timed loop
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -104,6 +122,8 @@ def main():
                          f"or `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}`")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    host_threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or max(1, usable_cores() // max(world, 1))
+    torch.set_num_threads(host_threads)
 
     def barrier():
         if world > 1:
@@ -165,18 +185,14 @@ def main():
     # ---- workload B: C4, global batch 64 -> contiguous shard of this rank, micro-batches of 8 (one captured graph, replayed per micro-batch)
     assert GLOBAL_BATCH % (world * MICRO_BATCH) == 0 or world * MICRO_BATCH > GLOBAL_BATCH, "global batch 64 must split into micro-batches of 8"
     s0, s1 = bdist.shard_range(GLOBAL_BATCH, rank, world)
-    # micro-batches of 8 (C4's per-GPU batch), but always at least two per rank: two forwards in flight fill the chip better than one
-    # (8 frames at N = 8: two concurrent micro-batches of 4 = 358 frames/s, one of 8 = 332; tools/two_frame_probe.py)
-    micro = min(MICRO_BATCH, max(1, (s1 - s0) // 2)) if not args.no_graph else min(MICRO_BATCH, s1 - s0)
-    n_micro = (s1 - s0) // micro
-    # every frame of the shard must be run: frames/s counts s1 - s0 frames per step (a remainder micro-batch would be counted, not run)
-    assert n_micro * micro == s1 - s0, f"the rank's {s1 - s0} frames do not split into micro-batches of {micro}: use a world size that divides {GLOBAL_BATCH} into even shards"
+    micro, plan = micro_batch_plan(GLOBAL_BATCH, rank, world, graph=not args.no_graph)
+    n_micro = len(plan)
     vox8 = None
 
     def setup_c4():
         nonlocal vox8
         # the shard's micro-batches share one resident buffer set: every micro-batch replays the same graph on its own frames
-        vox8 = [torch.from_numpy(synthetic.voxel_grid(micro, 9, H, W, seed=1234, first_sample=s0 + k * micro)).to(dev) for k in range(n_micro)]
+        vox8 = [torch.from_numpy(synthetic.voxel_grid(n, 9, H, W, seed=1234, first_sample=first)).to(dev) for first, n in plan]
 
     # micro-batches are independent: two of them run as parallel branches of one captured graph (bflow_amd/pipeline.py) -- same frames,
     # same arithmetic (bit-identical outputs), the second forward fills the CUs the first one's GRU loop leaves idle
@@ -215,6 +231,10 @@ def main():
     e = epe_masked(up.get_flow_from_reference(1.0).contiguous(), gt)
     epe_mean, epe_sum, epe_cnt = bdist.reduce_epe(e.double(), torch.ones((), dtype=torch.float64, device=dev))
 
+    # LOCAL_RANK -> device of every rank (one process per GPU), gathered with the same 16-B-per-rank exchange
+    rec = bdist.all_gather_records(torch.tensor([float(rank), float(local), float(torch.cuda.current_device())], dtype=torch.float64, device=dev))
+    rank_devices = [[int(v) for v in row] for row in rec.cpu().tolist()]
+
     out = None
     if rank == 0:
         wl_c2 = (f"raft-spline {CFG} events-only, DSEC-shaped voxel grid (9x{H}x{W}), batch 1/GPU, {ITERS} GRU iters (BASELINE configs[1]), "
@@ -235,6 +255,9 @@ def main():
                                          "the timed region (measured: no difference to a zero-copy hand-over, 277-279 frames/s either way)"},
             "c2_weak": dict(res_c2, unit="frames/s", workload=wl_c2, scaling="weak"),
             "epe_vs_synthetic_gt": round(float(epe_mean), 4), "epe_ranks_gathered": int(epe_cnt),
+            "dist_backend": backend if world > 1 else None,
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if (world > 1 and backend == "nccl") else None,
+            "rank_devices": rank_devices, "host_threads_per_rank": host_threads,
         }
         if res_c4 is not None:
             out["c4_strong"] = dict(res_c4, unit="frames/s", workload=wl_c4, scaling="strong", frames_per_rank_per_step=s1 - s0, micro_batch=micro,
@@ -343,7 +366,14 @@ def main():
             k.clear()
 
         for k in roofline_kernels(model, vox1, cfg, low.get_params()):
+            rider_bytes = k.get("rider_bytes")
             price(k)
+            if rider_bytes is not None:      # the batch-1 product launch = look-up + im2col rider: reported inside roofline_lookup, never in its frac
+                w = out.pop("_lookup_with_rider")
+                out["roofline_lookup"]["product_launch_with_rider"] = {
+                    "avg_launch_ms": w["avg_launch_ms"], "rider_bytes": rider_bytes,
+                    "rider_extra_us": round((w["avg_launch_ms"] - out["roofline_lookup"]["avg_launch_ms"]) * 1e3, 2),
+                    "note": "bflow_corr_lookup_im2col: the 7x7 windows of the Bezier parameters for convf1 written by the first workgroups of the look-up launch"}
         torch.cuda.empty_cache()
         for k in build_big(model, cfg, dev):
             price(k)
@@ -366,20 +396,59 @@ def main():
                         ceil["lockstep_4B_nt_gbs"] = float(line.split("us")[1].split("GB/s")[0])
             except Exception as e:       # a tools binary: its absence or failure must not take the bench line down
                 ceil["store_patterns_error"] = repr(e)[:200]
-        for key in ("roofline_corr_build", "roofline_corr_build_split"):
+        for key, units in (("roofline_corr_build", 2.0), ("roofline_corr_build_split", 3.0)):
             if key in out:
+                r = out[key]
                 best = max(v for k_, v in ceil.items() if k_.endswith("_gbs"))
-                out[key]["store_ceiling_gbs"] = best
-                out[key]["store_ceilings"] = ceil
-                out[key]["frac_of_store_ceiling"] = round(out[key]["achieved"] / best, 4)
+                r["store_ceiling_gbs"] = best
+                r["store_ceilings"] = ceil
+                r["frac_of_store_ceiling"] = round(r["achieved"] / best, 4)
+                # the bound this arithmetic can reach: the matrix pipes at the clock the chip sustains under this load (32 cycles per
+                # v_mfma_f32_32x32x16_f16 per SIMD, 16 k-steps x `units` per 32x32x256 block, 1024 SIMDs) NEXT TO the store stream at the
+                # measured ceiling of a pure store stream of K5's own shape; perfectly overlapped = the slower of the two
+                blocks = r["flop_per_launch"] / (2.0 * 32 * 32 * 256)
+                t_mfma = blocks * 16 * units * 32 / 1024 / (K5_SUSTAINED_GHZ * 1e9)
+                k5_store = ceil.get("k5_shape_4B_nt_gbs", ceil["hipMemsetAsync_gbs"])
+                t_store = r["algorithmic_bytes_per_launch"] / (k5_store * 1e9)
+                r["model_cap"] = {"frac": round(r["algorithmic_bytes_per_launch"] / max(t_mfma, t_store) / 1e9 / PEAK_HBM_GBS, 4),
+                                  "frac_if_additive": round(r["algorithmic_bytes_per_launch"] / (t_mfma + t_store) / 1e9 / PEAK_HBM_GBS, 4),
+                                  "t_mfma_us": round(t_mfma * 1e6, 1), "t_store_us": round(t_store * 1e6, 1), "sustained_clock_ghz": K5_SUSTAINED_GHZ,
+                                  "store_stream_gbs": k5_store,
+                                  "note": "cap of this arithmetic = max(matrix pipes at the sustained clock, store stream of K5's shape); "
+                                          "frac is measured against 8 TB/s, which no arithmetic with matrix work can reach here"}
         if world == 1:
             out["gpu_stage_ms"] = gpu_stage_ms(cfg, sd, vox1, dev)
             out["voxel_kernels"] = voxel_kernels(dev)
+            out["pipeline_from_events"] = pipeline_from_events(model, cfg, dev)
+            torch.cuda.empty_cache()
+            out.update(other_baseline_configs(dev, max(3, min(args.steps, 10))))
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, torch.from_numpy(vox1_np[:1]))
             out["gpu_over_cpu"] = round(out["c2_weak"]["value"] / out["cpu_baseline"]["value"], 1)
 
     if rank == 0:
+        # the scalars a reader needs, LAST: a driver that keeps the tail of a long line keeps these
+        def g(*path):
+            d = out
+            for k in path:
+                if not isinstance(d, dict) or k not in d:
+                    return None
+                d = d[k]
+            return d
+        fr = {k: out[k].get("frac") for k in out if k.startswith("roofline") and isinstance(out[k], dict)}
+        out["summary"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "ms_per_gru_iter": out.get("ms_per_gru_iter"),
+                          "ms_fixed_part": out.get("ms_fixed_part"), "value_split": g("value_split", "value"),
+                          "c4_strong": g("c4_strong", "value"), "c2_two_in_flight": g("c2_two_in_flight", "value"),
+                          "c4_rank_shape_at_n8": g("c4_rank_shape_at_n8", "value"), "c3_batch8": g("c3_batch8", "value"), "c5": g("c5", "value"),
+                          "pipeline_from_events": g("pipeline_from_events", "value"),
+                          "k1_float_xy_ms": g("voxel_kernels", "k1_float_xy", "ms"), "k1_float_xy_frac": g("voxel_kernels", "k1_float_xy", "frac"),
+                          "k1_int_xy_frac": g("voxel_kernels", "k1_int_xy", "frac"), "k2_frac": g("voxel_kernels", "k2_norm", "frac"),
+                          "frac": fr, "lookup_frac_of_line_cap": g("roofline_lookup", "frac_of_line_granular_cap"),
+                          "lookup_c4_frac_of_line_cap": g("roofline_lookup_c4_shard", "frac_of_line_granular_cap"),
+                          "k5_model_cap": g("roofline_corr_build", "model_cap", "frac"), "cpu_frames_s": g("cpu_baseline", "value"),
+                          "gpu_stage_ms": {k: v for k, v in (out.get("gpu_stage_ms") or {}).items() if isinstance(v, (int, float))},
+                          "epe_ranks_gathered": out.get("epe_ranks_gathered"), "rccl": out.get("rccl_version")}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
@@ -453,65 +522,176 @@ def cpu_baseline(cfg, sd, vox_cpu, budget_s=32.0):
 
 
 def gpu_stage_ms(cfg, sd, vox, dev):
-    """Per-stage milliseconds of the HIP path under the reference's hook names: EAGER launches (a hipGraph replay has no place to record
-    events) bracketed by hipEvents on the launch stream (bflow_amd/timers.py), 2 warm-ups + 5 forwards.  Eager mode pays the host's
-    enqueue latency per launch, so these are upper bounds of the stage times inside the graph replay that `value` measures."""
+    """Per-stage milliseconds of the HIP path under the reference's hook names, read from INSIDE the hipGraph replay `value` is measured
+    on: one-thread bflow_clock_stamp launches (100 MHz device wall clock) at the stage boundaries of a captured forward
+    (bflow_amd/timers.py StampTimer), mean of 5 replays after 3 warm-ups.  `cnet` runs on its own branch next to `fnet_ev`."""
+    import numpy as np
     import bflow_amd
+    from bflow_amd.timers import StampTimer
     m = bflow_amd.RAFTSpline(cfg).eval()
     m.load_state_dict(sd)
     m.to(dev)
-    m.enable_stage_timing()
-    for _ in range(7):
+    m.enable_hipgraph()
+    st = StampTimer(dev)
+    m._probe = st
+    acc = {}
+    for k in range(8):
         m(voxel_grid=vox, iters=ITERS, test_mode=True)
-    per = {"1 iter": ITERS, "corr lookup (per iter)": ITERS, "update (per iter)": ITERS, "get_flow (per iter)": ITERS}
-    out = {k: round(v, 4) for k, v in m.stage_timer.summary_ms(per).items()}
-    out["note"] = "eager launches + hipEvents (upper bounds: host enqueue latency included); 'get_flow (per iter)' is fused into the look-up kernel"
+        if k >= 3:
+            for name, v in st.stage_ms().items():
+                acc.setdefault(name, []).append(v)
+    out = {k: round(float(np.mean(v)), 4) for k, v in acc.items()}
+    out["note"] = ("in-graph clock stamps (each a one-thread launch on the chain: ~1-2 us per boundary, 2 per iteration); 'get_flow (per iter)' is fused into "
+                   "the look-up kernel; 'corr lookup (per iter)' includes the im2col rider of the same launch")
     return out
 
 
 def voxel_kernels(dev):
-    """K1 / K2 on synthetic DSEC-shaped events: 2 M events per 100 ms window into the 15-bin 480x640 grid the two-step
-    assembly uses; algorithmic bytes per SURVEY 8(d): 16 B per event + 8 (float xy) or 2 (int xy) fp32 atomic read-modify-writes +
-    the zero-initialisation of the grid; K2: four passes over the grid."""
+    """K1 / K2 on synthetic DSEC-shaped events: 2 M events per 100 ms window into the 15-bin 480x640 grid; algorithmic
+    bytes per SURVEY 8(d): 16 B per event + 8 (float xy) or 2 (int xy) fp32 read-modify-writes (8 B each) + the grid once; K2: four passes
+    over the grid.  Graph-timed whole calls (K1 = four launches: count, scan, place, gather) with a resident workspace."""
     import numpy as np
     import torch
-    from bflow_amd import synthetic
-    from bflow_amd.representations import VoxelGrid, norm_voxel_grid
+    from bflow_amd import hip, synthetic
     C, Hh, Ww, n_ev = 15, H, W, 2_000_000
     out = {}
+
+    def graph_ms(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) / reps)
+        return best
+
     for tag, int_xy in (("float_xy", False), ("int_xy", True)):
         ev = synthetic.events(n_ev, Hh, Ww, 0, 100_000, seed=7, int_xy=int_xy)
         x, y, p, t = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in ev)
-        vg = VoxelGrid(C, Hh, Ww)
-        for _ in range(3):
-            g = vg.convert(x, y, p, t, 0, 100_000)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(10):
-            g = vg.convert(x, y, p, t, 0, 100_000)
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / 10
+        grid = torch.empty((C, Hh, Ww), device=dev)
+        ws = hip._voxel_workspace(n_ev, C, Hh, Ww, not int_xy, dev)
+        ms = graph_ms(lambda: hip.voxel_grid(x, y, p, t, 0, 100_000, grid, ws))
+        a = grid.clone()
+        hip.voxel_grid(x, y, p, t, 0, 100_000, grid, ws)
         atom = 2 if int_xy else 8
         by = n_ev * (16 + atom * 8) + C * Hh * Ww * 4
-        out["k1_" + tag] = {"ms": round(ms, 4), "events_per_s": round(n_ev / ms * 1e3), "atomics_per_s": round(n_ev * atom / ms * 1e3),
-                            "algorithmic_gb_s": round(by / ms / 1e6, 1), "events": n_ev, "grid": [C, Hh, Ww],
-                            "note": "whole VoxelGrid.convert call (dtype conversions + zero fill + scatter kernel)"}
+        out["k1_" + tag] = {"ms": round(ms, 4), "events_per_s": round(n_ev / ms * 1e3), "algorithmic_gb_s": round(by / ms / 1e6, 1),
+                            "frac": round(by / ms / 1e6 / PEAK_HBM_GBS, 4), "bound": "hbm", "events": n_ev, "grid": [C, Hh, Ww],
+                            "bit_identical_run_to_run": bool(torch.equal(a, grid)), "workspace_mb": round(ws.numel() / 1e6, 1),
+                            "kernel": "voxel_count / scan / place / gather (tile-binned, LDS fixed-point accumulation, no global atomics)"}
     g = torch.randn(9, Hh, Ww, device=dev) * (torch.rand(9, Hh, Ww, device=dev) < 0.3)
-    for _ in range(3):
-        norm_voxel_grid(g.clone())
-    gs = [g.clone() for _ in range(10)]
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for q in gs:
-        norm_voxel_grid(q)
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / 10
-    out["k2_norm"] = {"ms": round(ms, 4), "algorithmic_gb_s": round(4 * g.numel() * 4 / ms / 1e6, 1), "grid": [9, Hh, Ww],
-                      "note": "three reading passes + one writing pass over the 11-MB grid"}
+    wsn = torch.empty(4, dtype=torch.float64, device=dev)
+    q = g.clone()
+    ms = graph_ms(lambda: hip.voxel_norm(q, wsn))
+    by = 4 * g.numel() * 4
+    out["k2_norm"] = {"ms": round(ms, 4), "algorithmic_gb_s": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / PEAK_HBM_GBS, 4), "bound": "hbm",
+                      "grid": [9, Hh, Ww], "note": "three reading passes + one writing pass over the 11-MB grid"}
+    return out
+
+
+def pipeline_from_events(model, cfg, dev, steps=10):
+    """Frames/s of the chain from RAW events (SURVEY 8(f-1) + a-1/a-2 + the forward): per frame two windows of ~2 M raw DSEC-style events
+    (uint16 x / y, rectification-map gather inside K1) -> two 5-bin grids -> merge -> K2 -> the C2 forward (graph replay).  Events, map
+    and weights resident in HBM; the assembly is eager launches (K1's grid size depends on the window's event count)."""
+    import numpy as np
+    import torch
+    from bflow_amd.dsec import EventStream, TwoStepAssembler
+    bins = cfg["num_bins"]["correlation"]
+    rs = np.random.RandomState(21)
+    n = 5_200_000                                                   # 260 ms of stream at 20 M events/s: 2 M per 100-ms window
+    ev = dict(x=rs.randint(0, W, n).astype(np.uint16), y=rs.randint(0, H, n).astype(np.uint16), p=rs.randint(0, 2, n).astype(np.uint8),
+              t=np.sort(rs.randint(1_000_000, 1_260_000, n)).astype(np.int64))
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    rect = np.stack([xx * 1.01 - 3 + np.sin(yy / 40.0), yy * 0.99 + 2 + np.cos(xx / 50.0)], -1).astype(np.float32)
+    ts = np.array([[1_030_000, 1_130_000], [1_130_000, 1_230_000]], dtype=np.int64)
+    stream = EventStream(**ev, device=dev)
+    asm = TwoStepAssembler(bins, H, W, rect, device=dev)
+
+    def frame():
+        vox = asm.assemble(stream, ts, 1, check=False)
+        return model(voxel_grid=vox[None], iters=ITERS, test_mode=True)
+
+    def assemble_only():
+        return asm.assemble(stream, ts, 1, check=False)
+
+    def timed(fn, k):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+
+    t_frame, t_asm = timed(frame, steps), timed(assemble_only, steps)
+    return {"value": round(1.0 / t_frame, 2), "unit": "frames/s", "ms_per_frame": round(t_frame * 1e3, 4), "ms_assembly": round(t_asm * 1e3, 4),
+            "events_per_window": int(n * 100_000 / 260_000), "steps": steps,
+            "workload": "raw events -> 2 x K1 (rectified, 5 bins) -> merge -> K2 -> C2 forward (12 iters); wall clock incl. the host's eager enqueue of the assembly"}
+
+
+def other_baseline_configs(dev, steps):
+    """Frames/s of the BASELINE configurations `value` is NOT quoted on (parity-tested at full size in tests/test_hip_parity.py): configs[2]
+    (C3: events + images, batch 8), configs[4] (C5: 1024 x 1024, degree 10, 20 iterations, f16/w correlation) and the per-rank shape of
+    configs[3] at N = 8 (8 frames as two micro-batches of 4 in flight).  Synthetic inputs, deterministic random-init weights, graph replay."""
+    import torch
+    import bflow_amd
+    from bflow_amd import configs, synthetic
+    from bflow_amd.pipeline import ConcurrentRunner
+    from bflow_amd.weights import deterministic_state_dict
+    out = {}
+
+    def run(fn, frames, k):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / k
+        return {"value": round(frames / el, 2), "unit": "frames/s", "ms_per_step": round(el * 1e3, 3), "frames_per_step": frames, "steps": k}
+
+    for key, idx in (("c3_batch8", 2), ("c5", 4)):
+        e = configs.baseline_config(idx)
+        cfg = e["model"]
+        m = bflow_amd.RAFTSpline(cfg).eval()
+        m.load_state_dict(deterministic_state_dict(m, seed=0))
+        m.to(dev)
+        m.enable_hipgraph()
+        C = cfg["num_bins"]["context"] + cfg["num_bins"]["correlation"] - 1
+        B, hh, ww = e["batch"], e["height"], e["width"]
+        vox = torch.from_numpy(synthetic.voxel_grid(B, C, hh, ww, seed=7)).to(dev)
+        imgs = None
+        if cfg["use_boundary_images"]:
+            a, b = synthetic.image_pair(B, hh, ww, seed=8)
+            imgs = [torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)]
+        r = run(lambda: m(voxel_grid=vox, images=imgs, iters=e["iters"], test_mode=True), B, steps if idx == 2 else max(3, steps // 2))
+        r["workload"] = f"BASELINE configs[{idx}]: raft-spline {e['experiment']}, {C}x{hh}x{ww} voxel grid" + (" + 2 RGB images" if imgs else "") + \
+                        f", batch {B}, {e['iters']} iters" + (f", correlation.precision = {cfg['correlation'].get('precision')}" if cfg["correlation"].get("precision") else "")
+        out[key] = r
+        del m, vox, imgs
+        torch.cuda.empty_cache()
+    cfg = configs.model_config(CFG)
+    m = bflow_amd.RAFTSpline(cfg).eval()
+    m.load_state_dict(deterministic_state_dict(m, seed=0))
+    m.to(dev)
+    m.enable_hipgraph()
+    pair = ConcurrentRunner(m, ITERS, streams=2)
+    v = [torch.from_numpy(synthetic.voxel_grid(4, 9, H, W, seed=1234, first_sample=4 * k)).to(dev) for k in range(2)]
+    r = run(lambda: pair(v), 8, steps)
+    r["workload"] = "what ONE rank runs per step of configs[3] at N = 8: its 8 frames as two micro-batches of 4, both in flight in one graph"
+    out["c4_rank_shape_at_n8"] = r
     return out
 
 

@@ -28,6 +28,16 @@ extern "C" int bflow_version(void) { return BFLOW_ABI_VERSION; }
 
 extern "C" const char* bflow_last_error_string(void) { return bflow::g_err; }
 
+namespace {
+__global__ void clock_stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+}  // namespace
+
+extern "C" int bflow_clock_stamp(unsigned long long* slot, bflow_stream_t stream) {
+    BFLOW_REQUIRE(slot, BFLOW_E_ARG, "clock_stamp: null slot");
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+    return bflow::launch_status("clock_stamp");
+}
+
 // models/raft_spline/bezier.py:141-180: binom(deg, i) * (1-t)^(deg-i) * t^i in float64, then cast to fp32.
 extern "C" int bflow_bezier_coeffs(const double* times, int T, int deg, float* coef_out) {
     BFLOW_REQUIRE(times && coef_out && T > 0 && deg >= 1, BFLOW_E_ARG, "bezier_coeffs: bad arguments");

@@ -27,7 +27,7 @@ EXPORTS = (
     "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_build_tiled", "bflow_split_to_x8", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_conv_thin_mfma_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_rows_to_split", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_norm_train_finalize", "bflow_norm_train_apply", "bflow_norm_train_bwd_stats", "bflow_norm_train_bwd_finalize", "bflow_norm_train_bwd_apply", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_corr_lookup_conv1x1", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
-    "bflow_voxel_workspace_bytes", "bflow_voxel_grid_f32xy", "bflow_voxel_grid_i16xy", "bflow_voxel_grid_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
+    "bflow_clock_stamp", "bflow_voxel_workspace_bytes", "bflow_voxel_grid_f32xy", "bflow_voxel_grid_i16xy", "bflow_voxel_grid_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
     "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_grid_rectified", "bflow_maxabs_diff",
     "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
     "bflow_l1_masked_grad", "bflow_conv_split_pair", "bflow_corr_lookup_im2col", "bflow_cvx_upsample_blocked",
@@ -156,6 +156,7 @@ def lib() -> ctypes.CDLL:
         "bflow_bezier_eval": [vp, ctypes.POINTER(ctypes.c_float), i, i, i, i, i, i, vp, vp],
         "bflow_cvx_upsample": [vp, vp, vp, f, vp, i, i, i, i, vp],
         "bflow_cvx_upsample_blocked": [vp, vp, f, vp, i, i, i, i, i, vp],
+        "bflow_clock_stamp": [vp, vp],
         "bflow_voxel_workspace_bytes": [ll, i, i, i, i],
         "bflow_voxel_grid_f32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp, ll, vp],
         "bflow_voxel_grid_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp, ll, vp],
@@ -479,6 +480,12 @@ def cvx_upsample(data: torch.Tensor, mask: torch.Tensor, mask_bias: Optional[tor
     _check(lib().bflow_cvx_upsample(_dev(data, name="data"), _dev(mask, name="mask"), _opt(mask_bias, "mask_bias"), float(mask_scale),
                                     _dev(out), B, C, h, w, _stream()), "bflow_cvx_upsample")
     return out
+
+
+def clock_stamp(slots: torch.Tensor, index: int):
+    """Writes the device's 100 MHz wall clock into slots[index] (int64) on the current stream (capture-safe measurement hook)."""
+    assert slots.dtype == torch.int64 and 0 <= index < slots.numel()
+    _check(lib().bflow_clock_stamp(_dev(slots, torch.int64, "slots") + 8 * index, _stream()), "bflow_clock_stamp")
 
 
 # ------------------------------------------------------------------------------------------------ K1 / K2

@@ -268,7 +268,10 @@ class RAFTSpline(nn.Module):
             # raft.py:134-140 without a torch launch: the normalisation 2 * (x / 255) - 1, the stacking of the two images (extractor.py:106-110)
             # and cat((context_grid, img0)) all happen in the stem kernel's load (S.StemInput); uint8 / fp32 images are read as they are
             images = [x.contiguous() if x.dtype in (torch.uint8, torch.float32) else x.float().contiguous() for x in images]
-            assert images[0].dtype == images[1].dtype and images[0].shape == images[1].shape
+            if images[0].dtype != images[1].dtype:      # the reference calls .float() on each image (raft.py:134): a mixed pair is legal
+                images = [x.float() for x in images]
+            if images[0].shape != images[1].shape or images[0].dim() != 4 or images[0].shape[1] != 3:
+                raise hip.BflowHipError(f"images: two (B, 3, H, W) tensors of equal shape expected, got {tuple(images[0].shape)} and {tuple(images[1].shape)}")
             img_in = S.StemInput([(images[0], 0), (images[1], 0)], 3, norm=True)
             if context_input is None:
                 ctx_general = S.StemInput([(images[0], 0)], 3, norm=True)
@@ -352,10 +355,13 @@ class RAFTSpline(nn.Module):
         if tm: tm.start("all iters")
         for itr in range(iters):
             need_mask = (not test_mode) or itr == iters - 1
+            if pr: pr(f"iter{itr}.begin")
             if tm is None:
                 # the look-up runs inside the step, next to the (independent) Bezier branch of the motion encoder
-                mask = ub.step_split(ws, fused if fused is not None else SplitLookup(corr_block, bezier, coef, corr_feat), bezier, need_mask,
-                                     mask_blocked=MASK_BLOCKED)
+                look = fused if fused is not None else SplitLookup(corr_block, bezier, coef, corr_feat)
+                if pr and fused is None:
+                    look.after = lambda k=itr: pr(f"iter{k}.lookup_end")
+                mask = ub.step_split(ws, look, bezier, need_mask, mask_blocked=MASK_BLOCKED)
             else:
                 # stage timing (eager): the same kernels, the look-up timed on its own, no side-stream overlap
                 tm.start("1 iter")

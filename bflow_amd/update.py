@@ -89,9 +89,13 @@ class SplitLookup:
     def __init__(self, corr_block, bezier: torch.Tensor, coef, out):
         self.corr_block, self.bezier, self.coef, self.out = corr_block, bezier, coef, out
         self.im2col_rider = bool(getattr(corr_block, "im2col_rider", False))
+        self.after = None          # measurement hook (timers.StampTimer): called right behind the look-up launch
 
     def __call__(self, im2col=None):
-        return self.corr_block.lookup_bezier_split(self.bezier, self.coef, out=self.out, im2col=im2col)
+        out = self.corr_block.lookup_bezier_split(self.bezier, self.coef, out=self.out, im2col=im2col)
+        if self.after is not None:
+            self.after()
+        return out
 
 
 class SplitWorkspace:

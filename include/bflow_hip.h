@@ -44,6 +44,10 @@ typedef void* bflow_stream_t;   /* hipStream_t */
 
 int         bflow_version(void);
 const char* bflow_last_error_string(void);
+/* Measurement hook (no counterpart in the reference; its CudaTimer, utils/timers.py:11-33, synchronises the device instead): one
+ * one-thread launch that writes the device's 100 MHz wall clock into *slot.  Capture-safe, so the stage boundaries of a hipGraph
+ * replay can be read back without a tracer (bflow_amd/timers.py StampTimer; bench.py `gpu_stage_ms`).                           */
+int         bflow_clock_stamp(unsigned long long* slot, bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K5  all-pairs correlation volume ("feature_dot_product").

@@ -176,10 +176,27 @@ def test_bench_self_launches_its_ranks(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert int(seen["env"]["OMP_NUM_THREADS"]) >= 1            # the per-rank host-thread policy is stated by the launcher, not left to torchrun
     # the global batch of configs[3] splits into micro-batches of 8 for every N of the scaling curve
     for n in (1, 2, 4, 8):
         a, b = bdist.shard_range(bench.GLOBAL_BATCH, 0, n)
         assert (b - a) % min(bench.MICRO_BATCH, b - a) == 0 and (b - a) * n == bench.GLOBAL_BATCH
+
+
+def test_micro_batch_plan_covers_the_global_batch_exactly_once():
+    """bench.py's C4 leg: for every N of the scaling curve the ranks' micro-batches tile the 64 frames exactly once; at N = 8 a rank runs
+    its 8 frames as two micro-batches of 4 (both in flight in one graph)."""
+    import bench
+    for world in (1, 2, 4, 8):
+        seen = []
+        for r in range(world):
+            micro, plan = bench.micro_batch_plan(bench.GLOBAL_BATCH, r, world)
+            assert len(plan) >= 2 and all(n == micro <= bench.MICRO_BATCH for _, n in plan)
+            seen += [f for first, n in plan for f in range(first, first + n)]
+        assert sorted(seen) == list(range(bench.GLOBAL_BATCH))
+    assert bench.micro_batch_plan(bench.GLOBAL_BATCH, 3, 8) == (4, [(24, 4), (28, 4)])
+    assert bench.micro_batch_plan(bench.GLOBAL_BATCH, 0, 1)[0] == 8 and len(bench.micro_batch_plan(bench.GLOBAL_BATCH, 0, 1)[1]) == 8
+    assert bench.micro_batch_plan(bench.GLOBAL_BATCH, 1, 8, graph=False) == (8, [(8, 8)])
 
 
 def test_shard_ranges_cover_the_global_batch():

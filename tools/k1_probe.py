@@ -21,8 +21,11 @@ def timed(fn, reps=20):
     return best
 
 
-for C, H, W, n_ev in ((15, 480, 640, 2_000_000), (5, 480, 640, 2_000_000), (5, 480, 640, 500_000), (65, 384, 384, 2_000_000), (65, 1024, 1024, 4_000_000)):
-    for int_xy in (False, True):
+CASES = ((15, 480, 640, 2_000_000), (5, 480, 640, 2_000_000), (5, 480, 640, 500_000), (65, 384, 384, 2_000_000), (65, 1024, 1024, 4_000_000))
+if len(sys.argv) > 1:
+    CASES = CASES[int(sys.argv[1]):int(sys.argv[1]) + 1]
+for C, H, W, n_ev in CASES:
+    for int_xy in ((False,) if len(sys.argv) > 2 else (False, True)):
         ev = synthetic.events(n_ev, H, W, 0, 100_000, seed=7, int_xy=int_xy)
         x, y, p, t = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in ev)
         grid = torch.empty((C, H, W), device=dev)

@@ -5,8 +5,9 @@ kernel on torch's current stream.  bench.py times them with hipEvents; tools/roo
 `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-include-regex <regex>` to produce profiles/r04_pmc.json.
 
   roofline                 the kernel with the largest TotalDurationNs in the C2-only kernel trace (profiles/r0x_rocprofv3_kernel_stats_c2only.csv):
-                           the batch-1 small-grid 3x3 family on its largest launch: conv_halo8_pair_kernel<3,3>, the motion encoder's convc2 | convf2
-  roofline_encoder         conv_halo_kernel<2,3,3> on the encoder's layer-1 launch (rounds 1-3 reported this one as `roofline`)
+                           conv_halo_kernel<2,3,3,...> on its largest launch, the feature encoder's layer-1 3x3 (64 -> 64 on 5 x 240 x 320)
+  roofline_update_conv     the batch-1 small-grid 3x3 family on its largest launch: conv_halo8_pair_kernel<3,3>, the motion encoder's convc2 | convf2
+                           (round 4 reported this one as `roofline`)
   roofline_corr_build      K5, the product launch (split8) ;  roofline_corr_build_split: the 3-pass fp32-class arithmetic on the same operands
   roofline_lookup          K7 at C2 (batch 1) ;  roofline_lookup_c4_shard: K7 on C4's per-GPU shard (batch 8)
   roofline_corr_build_c5   K5 at BASELINE configs[4]'s size (1024 x 1024, 5 event targets + 1 image target) with the arithmetic that config selects ("f16/w")
@@ -100,7 +101,7 @@ def build(model, vox, cfg, low_params=None):
         f1_ = S.from_nchw(torch.relu(torch.randn(B, ub.encoder.convf1.out_channels, h8_, w8_, device=dev)))
         corbez = S.SplitTensor.empty(B, h8_, w8_, 256, dev)
         # the product launch (update.py step_split, one-queue form): bflow_conv_split_pair of the two 3x3s of the motion encoder
-        out.append(dict(key="roofline", name=HALO8_NAME, regex=HALO8_REGEX, bound="mfma",
+        out.append(dict(key="roofline_update_conv", name=HALO8_NAME, regex=HALO8_REGEX, bound="mfma",
                         launch=lambda: S.conv_pair(dict(x=c1, packed=pk2, padding=1, shift=ub.encoder.convc2.bias, act=S.ACT_RELU, out_split=corbez, channel_offset=0),
                                                    dict(x=f1_, packed=pkf2, padding=1, shift=ub.encoder.convf2.bias, act=S.ACT_RELU, out_split=corbez,
                                                         channel_offset=192)),
@@ -108,11 +109,12 @@ def build(model, vox, cfg, low_params=None):
                         bytes=4.0 * B * h8_ * w8_ * (256 + 192 + 128 + 64) + 4.0 * 9 * (192 * 256 + 64 * 128),
                         note="batch 1: 240 + 80 workgroups on 256 CUs, a link of a chain of dependent launches -- bound by the operand fill of a CU and launch "
                              "latency, not by the matrix cores"))
-        out.append(dict(key="roofline_encoder", name=CONV_NAME, regex="conv_halo_kernel<", bound="mfma",
+        out.insert(0, dict(key="roofline", name=CONV_NAME, regex="conv_halo_kernel<", bound="mfma",
                         launch=lambda: S.conv(cur, pk, stride=1, padding=1, want_split=False, out_f32=o32, stats=st),
                         flops=2.0 * n5 * h0 * w0 * 64 * 64 * 9,
                         # split input (4 B/elem) + fp32 output (4 B/elem) + packed weights
-                        bytes=4.0 * n5 * h0 * w0 * 64 * 2 + 4.0 * 64 * 64 * 9))
+                        bytes=4.0 * n5 * h0 * w0 * 64 * 2 + 4.0 * 64 * 64 * 9,
+                        note="the kernel with the largest total time in the C2-only kernel trace; the frame's critical path (feature encoder)"))
         # (2) K5 correlation build on the same engine (HBM-write-bound by design): 393.2 MB algorithmic per sample
         D = model.fnet_ev.conv2.out_channels
         h8, w8 = H // 8, W // 8
@@ -150,11 +152,15 @@ def build(model, vox, cfg, low_params=None):
         ck = (49 * 2 * model.bezier_degree + 31) // 32
         col = S.SplitTensor.empty(B, h8, w8, 49 * 2 * model.bezier_degree, dev)
         rider_bytes = 4.0 * B * N * (2 * model.bezier_degree + ck * 32)
-        out.append(dict(key="roofline_lookup", name=LOOKUP_NAME, regex="corr_lookup_tile_kernel", bound="hbm",
+        # 4 B N P (100 + 81) bytes -- the look-up alone.  The product launch at batch 1 also carries the im2col rider: timed
+        # separately (`_lookup_with_rider`, folded into roofline_lookup.product_launch_with_rider by bench.py), its bytes never enter `frac`
+        out.append(dict(key="roofline_lookup", name=LOOKUP_NAME.split(";")[0] + ")", regex="corr_lookup_tile_kernel", bound="hbm",
+                        launch=lambda: cblk.lookup_bezier_split(params, coef, feat),
+                        flops=None, bytes=4.0 * B * N * cblk.num_planes * (100 + 81), keep=(cblk, vol, planes, x8),
+                        line_bytes=lookup_line_bytes(cblk, B)))
+        out.append(dict(key="_lookup_with_rider", name=LOOKUP_NAME, regex="corr_lookup_tile_kernel", bound="hbm",
                         launch=lambda: cblk.lookup_bezier_split(params, coef, feat, im2col=(col, 7, 7, 3)),
-                        flops=None, bytes=4.0 * B * N * cblk.num_planes * (100 + 81) + rider_bytes, keep=(cblk, vol, planes, x8),
-                        line_bytes=lookup_line_bytes(cblk, B) + rider_bytes,
-                        note=f"incl. the im2col rider of the same launch ({rider_bytes / 1e6:.2f} MB of the algorithmic bytes)"))
+                        flops=None, bytes=4.0 * B * N * cblk.num_planes * (100 + 81) + rider_bytes, rider_bytes=rider_bytes, keep=(cblk, col)))
     return out
 
 
