@@ -822,6 +822,8 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 #endif
 }
 
+#include "conv_stream.h"
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Small-grid halo variant (batch-1 update block: 40 patches x Cout/32 workgroups <= one per CU).  With one 4-wave workgroup
 // per CU every SIMD holds a single wave and each (wait, barrier, fragment reads, 6 MFMAs) step is a serial latency chain
@@ -2151,6 +2153,22 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
         const long long wg6 = (long long)patches6 * d->B * a.n_tiles;
         static const bool no_h12 = getenv("BFLOW_CONV_NO_HALO12") != nullptr;
         const bool twelve = small8 && !ten && !plan && (forced_variant ? strcmp(force, "halo12") == 0 : (!no_h12 && wg8 <= 192 && wg6 <= 256 && wg6 > wg8));
+        // the persistent form (conv_stream.h) for the feature encoder's 3x3s on grids of more than two rounds: fp32 (+ statistics) output
+        static const bool no_stream = getenv("BFLOW_CONV_NO_STREAM") != nullptr;      // A/B timing (tools/)
+        const long long items = (long long)patches * d->B * a.n_tiles;
+        if (shape == 1 && nt == 2 && direct && !a.xraw && !a.x2h && a.act != 2 && !no_stream && !force && a.CB == 2 && items >= 1024 && items < (1LL << 30)) {
+            const int per = (int)((items + 511) / 512), g = (int)((items + per - 1) / per);
+            const int lds = 2 * 2 * 12 * 1024 + 4 * 2 * 4096;
+            const int tiles_x = bflow::ceil_div(d->W, 16);
+#define LAUNCH_STREAM(CBB)                                                                                             \
+    {                                                                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_stream_kernel<CBB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((conv_halo_stream_kernel<CBB>), dim3(g), dim3(CT), lds, s, a, per, patches, tiles_x, (int)items); \
+    }
+            if (a.CB == 2) LAUNCH_STREAM(2) else if (a.CB == 3) LAUNCH_STREAM(3) else LAUNCH_STREAM(4)
+#undef LAUNCH_STREAM
+            return bflow::launch_status("conv_split(stream)");
+        }
         if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (ten) LAUNCH_HALO10(3, 3) else if (twelve) LAUNCH_HALO12(3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }
         else if (shape == 2) { if (nt == 2) LAUNCH_HALO(2, 1, 5) else if (ten) LAUNCH_HALO10(1, 5) else if (twelve) LAUNCH_HALO12(1, 5) else if (small8) LAUNCH_HALO8(1, 5) else LAUNCH_HALO(1, 1, 5) }
         else { if (nt == 2) LAUNCH_HALO(2, 5, 1) else if (ten) LAUNCH_HALO10(5, 1) else if (twelve) LAUNCH_HALO12(5, 1) else if (small8) LAUNCH_HALO8(5, 1) else LAUNCH_HALO(1, 5, 1) }

@@ -1032,6 +1032,46 @@ def test_conv_fp32_stats_and_direct_kernels_vs_fp64(cin, cout, k, stride, pad, H
         assert not bool(o_f32.view(B, -1, Ho * Wo, 32)[:, -1, :, cout % 32:].any())
 
 
+@pytest.mark.parametrize("cin,cout,H,W,B,relu", [
+    (64, 64, 240, 320, 2, False),     # encoder layer 1 at its own size: 1200 items, whole patches
+    (64, 64, 100, 150, 10, True),     # ragged patches on both edges; 130 patches per image: ranges of 3 items cross image boundaries
+    (64, 96, 104, 160, 8, False),     # two channel tiles per image, the second half empty (Cout = 96)
+])
+def test_conv_stream_kernel_vs_fp64_and_halo_kernel(cin, cout, H, W, B, relu, monkeypatch):
+    """conv_halo_stream_kernel (round 5: persistent workgroups, the store drain of item i between the MFMAs of item i + 1, statistics kept
+    in registers per range) against fp64 and, bit for bit, against conv_halo_kernel<2, 3, 3, TR> (same products, same summation order)."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(cout + H)
+    x = rs.standard_normal((B, cin, H, W)).astype(np.float32)
+    w = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    bias = rs.standard_normal(cout).astype(np.float32)
+    xs, pk = S.from_nchw(cu(x)), S.PackedConvWeight().get(cu(w))
+    act = S.ACT_RELU if relu else S.ACT_NONE
+
+    def run():
+        st = torch.zeros((8, B, cout, 2), dtype=torch.float64, device=DEV)
+        _, o = S.conv(xs, pk, padding=1, shift=cu(bias), act=act, want_split=False, want_f32=True, stats=st)
+        return o, st.sum(0)
+    o1, st1 = run()
+    o1b, st1b = run()
+    assert torch.equal(o1, o1b)
+    monkeypatch.setenv("BFLOW_CONV_KERNEL", "halo")            # the per-item kernel
+    o0, st0 = run()
+    monkeypatch.delenv("BFLOW_CONV_KERNEL")
+    assert torch.equal(o1, o0)
+    np.testing.assert_allclose(st1.cpu().numpy(), st0.cpu().numpy(), rtol=2e-6, atol=1e-3)
+    xd, wd = cu(x).double(), cu(w).double()
+    ref = torch.nn.functional.conv2d(xd, wd, cu(bias).double(), padding=1)
+    ref = ref.clamp(min=0) if relu else ref
+    mag = torch.nn.functional.conv2d(xd.abs(), wd.abs(), None, padding=1) + 1.0 + cu(bias).double().abs().view(1, -1, 1, 1)
+    got = S.blocked_f32_to_nhwc(o1, H, W, cout).permute(0, 3, 1, 2).double()
+    assert float(((got - ref).abs() / mag).max()) < 5e-7
+    np.testing.assert_allclose(st1[..., 0].cpu().numpy(), ref.sum(dim=(2, 3)).cpu().numpy(), rtol=1e-5, atol=5e-3)
+    np.testing.assert_allclose(st1[..., 1].cpu().numpy(), (ref * ref).sum(dim=(2, 3)).cpu().numpy(), rtol=1e-5, atol=5e-3)
+    if cout % 32:
+        assert not bool(o1.view(B, -1, H * W, 32)[:, -1, :, cout % 32:].any())
+
+
 # (grids of >= 200 workgroups, as in the encoder: both forms then run the SAME 64-channel-tile halo kernel, hence the same summation order)
 @pytest.mark.parametrize("c1,c2,H,W,B", [(64, 64, 117, 150, 2), (96, 96, 99, 150, 1), (128, 128, 60, 80, 3)])
 def test_conv_norm_in_equals_normalise_then_convolve(c1, c2, H, W, B):
