@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds libbflow_hip.so (gfx950 only) in-tree: bflow_amd/lib/libbflow_hip.so
-#   build.sh          incremental (objects older than their source, common.h or the ABI header are rebuilt)
+#   build.sh          incremental (objects older than their source, any header of csrc/ or the ABI header are rebuilt)
 #   build.sh --force  rebuild every object (what __graft_entry__.build() runs: a real "does it build" check)
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
@@ -12,7 +12,9 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -munsafe-f
 OBJS=(); PIDS=()
 for f in "$HERE"/*.hip; do
   o="$OUT/$(basename "${f%.hip}").o"
-  if [ $FORCE = 1 ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/conv_engine.h" -nt "$o" ] || [ "$HERE/../../include/bflow_hip.h" -nt "$o" ]; then
+  stale=0
+  for h in "$HERE"/*.h "$HERE/../../include/bflow_hip.h"; do [ "$h" -nt "$o" ] && stale=1; done
+  if [ $FORCE = 1 ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
     rm -f "$o"
     "$HIPCC" $FLAGS -c "$f" -o "$o" &
     PIDS+=($!)

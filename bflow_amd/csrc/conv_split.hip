@@ -2153,20 +2153,25 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
         const long long wg6 = (long long)patches6 * d->B * a.n_tiles;
         static const bool no_h12 = getenv("BFLOW_CONV_NO_HALO12") != nullptr;
         const bool twelve = small8 && !ten && !plan && (forced_variant ? strcmp(force, "halo12") == 0 : (!no_h12 && wg8 <= 192 && wg6 <= 256 && wg6 > wg8));
-        // the persistent form (conv_stream.h) for the feature encoder's 3x3s on grids of more than two rounds: fp32 (+ statistics) output
-        static const bool no_stream = getenv("BFLOW_CONV_NO_STREAM") != nullptr;      // A/B timing (tools/)
+        // the persistent form (conv_stream.h) for the feature encoder's 3x3s on grids of more than two rounds: fp32 (+ statistics) output.
+        // Measured per shape (tools/enc_stream_probe.py, profiles/r05_enc_stream_ab.txt): 64 -> 64 (two input blocks, one channel tile): -5...-9 %;
+        // 96 -> 96 / 128 -> 128 (27 / 36 k-steps per item, two channel tiles, the 96-channel one half empty): +-0 at batch 40, +3 % at batch 5
+        // (ranges of 3 patches) -- the kernel runs any block count >= 2 (tested), the dispatch takes it where it wins.  BFLOW_CONV_STREAM=all
+        // (tests, A/B) takes it wherever it can run.
+        static const int stream_mode = [] { const char* e = getenv("BFLOW_CONV_STREAM"); return !e ? 1 : !strcmp(e, "0") ? 0 : !strcmp(e, "all") ? 2 : 1; }();
         const long long items = (long long)patches * d->B * a.n_tiles;
-        if (shape == 1 && nt == 2 && direct && !a.xraw && !a.x2h && a.act != 2 && !no_stream && !force && a.CB == 2 && items >= 1024 && items < (1LL << 30)) {
-            const int per = (int)((items + 511) / 512), g = (int)((items + per - 1) / per);
+        if (shape == 1 && nt == 2 && direct && !a.xraw && !a.x2h && a.act != 2 && stream_mode && !force && a.CB >= 2 && (a.CB == 2 || stream_mode == 2) &&
+            items >= 1024 && items < (1LL << 30)) {
+            // ranges of `per` patches x one channel tile; <= 512 of them (two workgroups per CU), a multiple of 8 x n_tiles (whole XCDs of
+            // whole patch ranges; a few trailing workgroups may own no patch)
+            const long long bp = (long long)patches * d->B;
+            const int per = (int)bflow::ceil_div(bp * a.n_tiles, 512);
+            int g = (int)bflow::ceil_div(bp, per) * a.n_tiles;
+            g = bflow::ceil_div(g, 8 * a.n_tiles) * 8 * a.n_tiles;
             const int lds = 2 * 2 * 12 * 1024 + 4 * 2 * 4096;
             const int tiles_x = bflow::ceil_div(d->W, 16);
-#define LAUNCH_STREAM(CBB)                                                                                             \
-    {                                                                                                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_stream_kernel<CBB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((conv_halo_stream_kernel<CBB>), dim3(g), dim3(CT), lds, s, a, per, patches, tiles_x, (int)items); \
-    }
-            if (a.CB == 2) LAUNCH_STREAM(2) else if (a.CB == 3) LAUNCH_STREAM(3) else LAUNCH_STREAM(4)
-#undef LAUNCH_STREAM
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL(conv_halo_stream_kernel, dim3(g), dim3(CT), lds, s, a, per, patches, tiles_x, (int)bp);
             return bflow::launch_status("conv_split(stream)");
         }
         if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (ten) LAUNCH_HALO10(3, 3) else if (twelve) LAUNCH_HALO12(3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }

@@ -1,5 +1,5 @@
 // Persistent ("streaming") form of the 3 x 3 halo convolution for outputs that are pre-normalisation fp32 (+ InstanceNorm statistics):
-// every 3 x 3 of the feature encoder (extractor.py:47-55,103-125) on grids that fill the chip more than once.  Included by
+// every 3 x 3 of the feature encoder (extractor.py:47-55,103-125) on grids that fill the chip more than twice.  Included by
 // conv_split.hip inside its anonymous namespace (uses ConvArgs, slab_row / slab_col, the LDS image of conv_halo_kernel<2, 3, 3, TR>).
 //
 // Why: conv_halo_kernel's workgroups live for CB x 9 k-steps only; a third of a workgroup's life is its prologue (first halo + weight
@@ -7,21 +7,28 @@
 // reduction), during which its SIMDs have no matrix work of their own: the layer-1 launch ran at 0.33-0.36 of the split format's matrix
 // peak for three rounds ("the lever that is left is a persistent kernel that overlaps tile i's store drain with
 // tile i+1's first halo under counted vmcnt over loads AND stores -- the structure K5 has").  This is that kernel:
-//   * <= 2 x 256 persistent workgroups; a workgroup owns a CONTIGUOUS range of the item list (image, channel tile, 8 x 16 patch) and walks
+//   * <= 2 x 256 persistent workgroups; a workgroup owns ONE channel tile of a CONTIGUOUS range of the (image, 8 x 16 patch) list and walks
 //     it as ONE k-loop: the halo double buffer and the 4-slot weight ring run on across item boundaries, so item i+1's first halo and
 //     weight tiles land under item i's last taps (the prologue exists once per workgroup);
 //   * the accumulators are transposed (D[pixel][channel]: one register of a wave = two complete 128-B rows of the blocked fp32 output);
 //     at an item boundary they are folded into 32 "drain" registers (hi + lo 2^-11) and the first MFMAs of the next item start from a
 //     zero C operand; the drain registers are scaled, added into the lane's statistics and STORED between the MFMAs of item i+1's
-//     k-steps, 1-2 per step -- no store phase, no LDS, no barrier of its own;
+//     first two channel blocks, 2-3 per k-step -- no store phase, no LDS, no barrier of its own;
 //   * vmcnt counts LDS-DMA pieces and stores alike and retires them in order (gfx9): every step issues a compile-time number of both
 //     (out-of-range stores of edge patches / of the empty drain of the first item are dropped by the buffer bounds check, not skipped),
-//     so "the weight tile of the next step has landed" stays a fixed s_waitcnt immediate.  The last two steps of an item issue no
-//     stores, which makes the prologue's counts equal to the steady state's;
+//     so "the weight tile of the next step has landed" stays a fixed s_waitcnt immediate.  The last two taps of a channel block issue no
+//     stores, which makes every block's counts -- and the prologue's -- independent of its neighbours;
 //   * a range never leaves its (image, channel tile) group without a flush, so the InstanceNorm sums stay in two registers per lane
 //     and channel block for the whole range: ONE reduction + 128 fp64 atomics per workgroup instead of one per item.
-// Template: CBT = input channel blocks (2, 3, 4: 64 / 96 / 128 channels); 64-channel output tiles (NT = 2).
-template <int CBT>
+// The k-loop of an item is three instantiations of one 9-tap body -- channel block 0 (zero C operand, drains output block 0 of the previous
+// item), block 1 (drains output block 1), blocks >= 2 (no drain) -- so the number of input channel blocks is a run-time value (>= 2) and
+// the unrolled code (and its register pressure) does not grow with it.  64-channel output tiles (NT = 2).
+//
+// CSTREAM_ABL (tools/enc_stream_ablate.sh only; timing builds with WRONG results): 1 no stores, 2 no in-loop LDS-DMA, 4 no fragment reads,
+// 5 no barrier / vmcnt wait.
+#ifndef CSTREAM_ABL
+#define CSTREAM_ABL 0
+#endif
 __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int per, int n_patches, int tiles_x, int total) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 2, KH = 3, KW = 3, NW = 4;
@@ -35,15 +42,13 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
     constexpr int NBP = 4 * NT / NW;
     constexpr int SB = 4, LA = 2;
     constexpr int O_B = 2 * A_BUF;
-    constexpr int NSTEPS = CBT * NTAPS;
-    constexpr int NDR = NT * 16;                       // drain registers = stores per item and lane
-    constexpr int DSTEPS = NSTEPS - 2;                 // steps that carry stores (the last two of an item carry none)
-    static_assert(NDR <= 2 * DSTEPS, "at most two stores per step");
+    constexpr int DTAPS = NTAPS - 2;                   // taps of a channel block that carry stores (its last two carry none)
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
+    const int CB = a.CB;
 
     // ---- per-lane constants of the LDS-DMA pieces (independent of the item)
     const int urow = lane >> 2;
@@ -51,27 +56,34 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
     const int plane_b = a.P_in * 64;
     const bool lo_a = wave & 1, lo_w = wave / (NW / 2);
     const int wtile_b = a.cout_pad * 64;
-    const rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(lo_w ? a.wl : a.wh), 0, NTAPS * CBT * wtile_b, 0x00020000);
+    const rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)(lo_w ? a.wl : a.wh), 0, NTAPS * CB * wtile_b, 0x00020000);
     char* const a_dst = lds + (lo_a ? A_PLANE : 0) + (wave >> 1) * 1024;
     char* const w_dst = lds + O_B + (lo_w ? B_PLANE : 0);
     const int R0 = (wave * 2 + slab_row(l31)) * HWD + slab_col(l31);
     const int wsw = (l31 >> 2) & 3;
     const long long oplane = (long long)a.P_out * 32;  // floats of one channel block of one output image
-    const float act_floor = a.act == 1 ? 0.f : -__builtin_inff();      // (tanh epilogues stay on conv_halo_kernel: see the dispatch)
+    const float act_floor = a.act == 1 ? 0.f : -__builtin_inff();      // act 0 / 1 (tanh epilogues stay on conv_halo_kernel: see the dispatch)
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    int q = blockIdx.x * per;
+    // workgroup -> range.  A range = `per` consecutive patches of the (image, patch) list x ONE channel tile; the ranges are numbered with
+    // the channel tile fastest, and workgroup w (which runs on XCD w % 8) takes range (w % 8) G/8 + w / 8: an XCD owns CONSECUTIVE ranges,
+    // i.e. both channel tiles of the same patches -- walked at the same time by neighbouring workgroups, so that the halo they share is
+    // fetched into that XCD's L2 once (as conv_halo_kernel's "all channel tiles of a patch on one XCD, back to back") -- and a band of
+    // ~19 patch rows of an image at the layer-1 size, whose vertically adjacent patches share halo rows
+    const int nwg = gridDim.x;
+    const int chunk = (nwg & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3);
+    const int n0 = (chunk % a.n_tiles) * (32 * NT);
+    int q = (chunk / a.n_tiles) * per;
     const int q_end = q + per < total ? q + per : total;
     while (q < q_end) {
-        // ---- one segment: items q .. seg_end - 1, all in one (image, channel tile) group
-        const int group = q / n_patches;
-        int mt = q - group * n_patches;
-        const int seg_end = (group + 1) * n_patches < q_end ? (group + 1) * n_patches : q_end;
+        // ---- one segment: patches q .. seg_end - 1 of ONE image
+        const int b = q / n_patches;
+        int mt = q - b * n_patches;
+        const int seg_end = (b + 1) * n_patches < q_end ? (b + 1) * n_patches : q_end;
         int left = seg_end - q;                         // items still to start
         q = seg_end;
-        const int b = group / a.n_tiles, n0 = (group - b * a.n_tiles) * (32 * NT);
 
-        const rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_a ? a.xl : a.xh) + (long long)b * CBT * a.P_in * 32), 0, CBT * plane_b, 0x00020000);
+        const rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc((void*)((lo_a ? a.xl : a.xh) + (long long)b * CB * a.P_in * 32), 0, CB * plane_b, 0x00020000);
         unsigned wvo[NBP];
 #pragma unroll
         for (int j = 0; j < NBP; ++j) {
@@ -116,21 +128,20 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
             const int ty = m / tiles_x;
             const int y0 = ty * TH, x0 = (m - ty * tiles_x) * TW;
             const int yw = y0 + wave * 2;
-            // register r of lane (channel, kh): column x0 + r, slab row (popcount(r >> 2) + kh) & 1: dbase[p] = row p ^ kh ... indexed by popcount parity
+            // register r of lane (channel, kh): column x0 + r, slab row (popcount(r >> 2) + kh) & 1 -> dbase[parity of popcount(r >> 2)]
             const int ya = yw + kh, yb = yw + (kh ^ 1);
             dbase[0] = ya < a.H ? (unsigned)((ya * a.W + x0) * 128 + l31 * 4) : 0x80000000u;
             dbase[1] = yb < a.H ? (unsigned)((yb * a.W + x0) * 128 + l31 * 4) : 0x80000000u;
             dxlim = a.W - x0;
         };
-        // the q-th store of the drained item: channel block q / 16, register q % 16
-        auto drain_store = [&](auto qc) __attribute__((always_inline)) {
-            constexpr int qq = decltype(qc)::value;
-            constexpr int n = qq / 16, r = qq % 16;
+        // store of register r of output block n of the drained item
+        auto drain_store = [&](auto nc, auto rc) __attribute__((always_inline)) {
+            constexpr int n = decltype(nc)::value, r = decltype(rc)::value;
             constexpr int par = __builtin_popcount((unsigned)(r >> 2)) & 1;
-            float v = fmaxf(fmaf(dr[n][r], sc[n], sh[n]), act_floor);      // act 0 / 1 (ReLU): a clamp from below, no branch between the MFMAs
+            float v = fmaxf(fmaf(dr[n][r], sc[n], sh[n]), act_floor);      // ReLU = a clamp from below: no branch between the MFMAs
             if (!cok[n]) v = 0.f;
             const unsigned off = r < dxlim ? dbase[par] : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_o[n], off, r * 128, CONV_NT_STORES_ENC ? 2 : 0);
+            if (CSTREAM_ABL != 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_o[n], off, r * 128, CONV_NT_STORES_ENC ? 2 : 0);
             if (off != 0x80000000u) { s1[n] += v; s2[n] = fmaf(v, v, s2[n]); }
         };
 
@@ -140,11 +151,11 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
         const int y0_ = ty_ * TH, x0_ = ((M) - ty_ * tiles_x) * TW;                                                      \
         _Pragma("unroll") for (int i = 0; i < AP; ++i)                                                                   \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (lptr_t)(a_dst + (BUF) * A_BUF + i * (NW / 2) * 1024), 16,     \
-                                                     halo_offset(i, y0_, x0_, (EXISTS)), (CBI) * PLANE_STRIDE, 0, 0);         \
+                                                     halo_offset(i, y0_, x0_, (EXISTS)), (CBI) * plane_b, 0, 0);         \
     }
 #define STREAM_ISSUE_B(CBI, TAP, SLOT)                                                                                   \
     {                                                                                                                    \
-        const int so_ = ((TAP) * CBT + (CBI)) * WTILE_STRIDE;                                                            \
+        const int so_ = ((TAP) * CB + (CBI)) * wtile_b;                                                                  \
         _Pragma("unroll") for (int j = 0; j < NBP; ++j)                                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (SLOT) * B_SLOT + ((wave * NBP + j) % (2 * NT)) * 1024), 16, \
                                                      wvo[j], so_, 0, 0);                                                 \
@@ -157,19 +168,21 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
         const int R_ = R0 + ((TAP) / KW) * HWD + ((TAP) % KW);                                                           \
         const int sw_ = (R_ >> 2) & 3;                                                                                   \
         const int ao_ = R_ * 64 + ((((KS) * 2 + kh) ^ sw_) * 16);                                                        \
-        XH = *reinterpret_cast<const half8*>((ABUF) + ao_);                                                              \
-        XL = *reinterpret_cast<const half8*>((ABUF) + A_PLANE + ao_);                                                    \
         const int co_ = (((KS) * 2 + kh) ^ wsw) * 16;                                                                    \
-        _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                                 \
-            const int wo_ = (n * 32 + l31) * 64 + co_;                                                                   \
-            WH[n] = *reinterpret_cast<const half8*>((WSLOT) + wo_);                                                      \
-            WL[n] = *reinterpret_cast<const half8*>((WSLOT) + B_PLANE + wo_);                                            \
+        if (CSTREAM_ABL == 4) {                                                                                          \
+            asm volatile("" : "+v"(XH), "+v"(XL), "+v"(WH[0]), "+v"(WL[0]), "+v"(WH[1]), "+v"(WL[1]));                    \
+        } else {                                                                                                         \
+            XH = *reinterpret_cast<const half8*>((ABUF) + ao_);                                                          \
+            XL = *reinterpret_cast<const half8*>((ABUF) + A_PLANE + ao_);                                                \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                             \
+                const int wo_ = (n * 32 + l31) * 64 + co_;                                                               \
+                WH[n] = *reinterpret_cast<const half8*>((WSLOT) + wo_);                                                  \
+                WL[n] = *reinterpret_cast<const half8*>((WSLOT) + B_PLANE + wo_);                                        \
+            }                                                                                                            \
         }                                                                                                                \
     }
 
         // ---- prologue of the segment: first halo, first LA + 1 weight tiles
-#define PLANE_STRIDE plane_b
-#define WTILE_STRIDE wtile_b
         STREAM_ISSUE_A(mt, true, 0, 0)
 #pragma unroll
         for (int t = 0; t <= LA; ++t) STREAM_ISSUE_B(0, t, t)
@@ -179,44 +192,40 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         STREAM_READ(xh0, xl0, wh0, wl0, lds, lds + O_B, 0, 0)
-        int islot = LA + 1, rslot = 0;                  // rslot: ring slot of the tap being computed
-        int hbuf = 0;                                   // halo buffer of the phase (item, cb) being computed
+        int islot = LA + 1, rslot = 0;                  // ring slot to fill next / of the tap being computed
+        int hbuf = 0;                                   // halo buffer of the phase (item, channel block) being computed
 
-#undef PLANE_STRIDE
-#undef WTILE_STRIDE
-#define PLANE_STRIDE plane_v
-#define WTILE_STRIDE wtile_v
-        while (left > 0) {
-            --left;
-            // (opaque copies: hipcc otherwise hoists every (tap, block) * stride product and every LDS destination out of this loop --
-            //  ~100 loop-invariant SGPRs, spilled into VGPR lanes and, at 3-4 channel blocks, into scratch, whose loads would break the
-            //  counted vmcnt waits)
-            int wtile_v = wtile_b, plane_v = plane_b;
-            asm volatile("" : "+s"(wtile_v), "+s"(plane_v));
-            static_for<0, NSTEPS>([&](auto sc_) __attribute__((always_inline)) {
-                constexpr int st = decltype(sc_)::value;
-                constexpr int cb = st / NTAPS, t = st % NTAPS;
-                // stores of this step: NDR spread over the first DSTEPS steps
-                constexpr int q_lo = st < DSTEPS ? (st * NDR + DSTEPS - 1) / DSTEPS : NDR;
-                constexpr int q_hi = st + 1 < DSTEPS ? ((st + 1) * NDR + DSTEPS - 1) / DSTEPS : NDR;
-                // ops younger than the weight tile of step st + 1 (issued in step st - 2): the stores of steps st - 2 and st - 1, the tile of
-                // step st - 1 and, when that was tap 1, the next phase's halo
-                constexpr int sp2 = (st + NSTEPS - 2) % NSTEPS, sp1 = (st + NSTEPS - 1) % NSTEPS;
-                constexpr int n2 = (sp2 + 1 < DSTEPS ? ((sp2 + 1) * NDR + DSTEPS - 1) / DSTEPS : NDR) - (sp2 < DSTEPS ? (sp2 * NDR + DSTEPS - 1) / DSTEPS : NDR);
-                constexpr int n1 = (sp1 + 1 < DSTEPS ? ((sp1 + 1) * NDR + DSTEPS - 1) / DSTEPS : NDR) - (sp1 < DSTEPS ? (sp1 * NDR + DSTEPS - 1) / DSTEPS : NDR);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + n2 + n1 + (t == 2 ? AP : 0)) : "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                if (t == 1) {
-                    if (cb + 1 < CBT) {
-                        STREAM_ISSUE_A(mt, true, cb + 1, hbuf ^ 1)
-                    } else {                            // the next item's first block (or nothing: out-of-range pieces, the counts stay)
-                        STREAM_ISSUE_A(mt + 1, left > 0, 0, hbuf ^ 1)
-                    }
+        // The 9 taps of channel block `cb` of the current item.  KIND 0: cb == 0 (zero C operand at tap 0; drains output block 0 of the
+        // previous item), 1: cb == 1 (drains output block 1), 2: cb >= 2 (no drain).  Stores per tap (KIND < 2): 16 over the first DTAPS taps.
+        auto block9 = [&](auto kind_c, const int cb) __attribute__((always_inline)) {
+            constexpr int KIND = decltype(kind_c)::value;
+            const bool last_cb = cb + 1 == CB;
+            static_for<0, NTAPS>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value;
+                // drain registers of this tap: r_lo .. r_hi - 1 of output block KIND
+                constexpr int r_lo = (KIND < 2 && t < DTAPS) ? (t * 16 + DTAPS - 1) / DTAPS : 16;
+                constexpr int r_hi = (KIND < 2 && t + 1 < DTAPS) ? ((t + 1) * 16 + DTAPS - 1) / DTAPS : 16;
+                // ops younger than the weight tile of tap t + 1 (issued two steps ago): the stores of the last two steps, the tile issued one step
+                // ago and, when that step was tap 1, the next phase's halo.  Taps DTAPS .. NTAPS - 1 carry no stores, so steps -2 / -1 of a
+                // block contribute none whatever block preceded it.
+                constexpr int tm2 = (t + NTAPS - 2) % NTAPS, tm1 = (t + NTAPS - 1) % NTAPS;
+                constexpr int n2 = (KIND < 2 && t >= 2 && tm2 < DTAPS) ? ((tm2 + 1 < DTAPS ? ((tm2 + 1) * 16 + DTAPS - 1) / DTAPS : 16) - (tm2 * 16 + DTAPS - 1) / DTAPS) : 0;
+                constexpr int n1 = (KIND < 2 && t >= 1 && tm1 < DTAPS) ? ((tm1 + 1 < DTAPS ? ((tm1 + 1) * 16 + DTAPS - 1) / DTAPS : 16) - (tm1 * 16 + DTAPS - 1) / DTAPS) : 0;
+                if (CSTREAM_ABL != 5 && CSTREAM_ABL != 1 && CSTREAM_ABL != 2) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + n2 + n1 + (t == 2 ? AP : 0)) : "memory");
                 }
-                {
+                if (CSTREAM_ABL != 5) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (CSTREAM_ABL != 2) {
+                    if (t == 1) {
+                        if (!last_cb) {
+                            STREAM_ISSUE_A(mt, true, cb + 1, hbuf ^ 1)
+                        } else {                        // the next item's first block (or nothing: out-of-range pieces, the counts stay)
+                            STREAM_ISSUE_A(mt + 1, left > 0, 0, hbuf ^ 1)
+                        }
+                    }
                     constexpr int tn = (t + LA + 1) % NTAPS;
-                    constexpr int cbn = (cb + (t + LA + 1) / NTAPS) % CBT;
+                    const int cbn = (t + LA + 1 < NTAPS) ? cb : (last_cb ? 0 : cb + 1);
                     STREAM_ISSUE_B(cbn, tn, islot)
                 }
                 if (++islot == SB) islot = 0;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
                 const char* wcur = lds + O_B + rslot * B_SLOT;
                 if (++rslot == SB) rslot = 0;
                 const char* wnext = lds + O_B + rslot * B_SLOT;
-                constexpr bool first = st == 0;
+                constexpr bool first = KIND == 0 && t == 0;
                 // second half of THIS tap -> set 1, first half's matrix work (set 0, read half a step ago), the drain of the previous item,
                 // first half of the NEXT tap -> set 0 (its tile landed before this step's barrier), second half's matrix work
                 STREAM_READ(xh1, xl1, wh1, wl1, abuf, wcur, t, 1)
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
                 for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh0, wl0[n], first ? zero16 : xx[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl0, wh0[n], xx[n], 0, 0, 0);
-                static_for<q_lo, q_hi>([&](auto qc) __attribute__((always_inline)) { drain_store(qc); });
+                static_for<r_lo, r_hi>([&](auto rc) __attribute__((always_inline)) { drain_store(std::integral_constant<int, (KIND < 2 ? KIND : 0)>{}, rc); });
                 if (t + 1 < NTAPS) {
                     STREAM_READ(xh0, xl0, wh0, wl0, abuf, wnext, (t + 1) % NTAPS, 0)
                 } else {
@@ -247,11 +256,17 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
                 for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh1, wl1[n], xx[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl1, wh1[n], xx[n], 0, 0, 0);
-                // (the reads of set 0 above must be ISSUED before the next step's barrier releases the slot they read to the DMA two steps on;
-                //  the counted wait below is in program order behind them)
-                if (t == NTAPS - 1) hbuf ^= 1;
             });
-            // ---- item boundary: fold the accumulators into the drain registers (the next item's first MFMAs start from zero)
+            hbuf ^= 1;
+        };
+
+        while (left > 0) {
+            --left;
+            block9(std::integral_constant<int, 0>{}, 0);
+            block9(std::integral_constant<int, 1>{}, 1);
+#pragma nounroll
+            for (int cb = 2; cb < CB; ++cb) block9(std::integral_constant<int, 2>{}, cb);
+            // ---- item boundary: fold the accumulators into the drain registers (the next item's first MFMAs start from a zero C operand)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -262,10 +277,10 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
 #undef STREAM_READ
 #undef STREAM_ISSUE_A
 #undef STREAM_ISSUE_B
-#undef PLANE_STRIDE
-#undef WTILE_STRIDE
         // ---- the last item of the segment has nobody to ride on: plain store sequence, then the statistics of the whole segment
-        static_for<0, NDR>([&](auto qc) __attribute__((always_inline)) { drain_store(qc); });
+        static_for<0, NT>([&](auto nc) __attribute__((always_inline)) {
+            static_for<0, 16>([&](auto rc) __attribute__((always_inline)) { drain_store(nc, rc); });
+        });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // also: the look-ahead pieces must not land in LDS that `red` re-uses
         __builtin_amdgcn_s_barrier();
         if (a.stats) {
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
                     double sum = 0.0;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) sum += (double)p[w * BN];
-                    atomicAdd(a.stats + (long long)(blockIdx.x % a.stats_reps) * a.stats_rep_stride + ((long long)b * a.Cout + col) * 2 + which, sum);
+                    atomicAdd(a.stats + (long long)(chunk % a.stats_reps) * a.stats_rep_stride + ((long long)b * a.Cout + col) * 2 + which, sum);
                 }
             }
             __syncthreads();                                        // `red` is LDS the next segment's prologue refills

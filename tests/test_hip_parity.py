@@ -1036,11 +1036,16 @@ def test_conv_fp32_stats_and_direct_kernels_vs_fp64(cin, cout, k, stride, pad, H
     (64, 64, 240, 320, 2, False),     # encoder layer 1 at its own size: 1200 items, whole patches
     (64, 64, 100, 150, 10, True),     # ragged patches on both edges; 130 patches per image: ranges of 3 items cross image boundaries
     (64, 96, 104, 160, 8, False),     # two channel tiles per image, the second half empty (Cout = 96)
+    (96, 96, 120, 160, 5, False),     # encoder layer 2 at its own size: three input channel blocks (the third runs the no-drain body)
+    (128, 128, 60, 80, 16, True),     # four input channel blocks, a ragged last patch row (60 = 7.5 x 8)
+    (160, 64, 72, 112, 24, False),    # five
 ])
 def test_conv_stream_kernel_vs_fp64_and_halo_kernel(cin, cout, H, W, B, relu, monkeypatch):
     """conv_halo_stream_kernel (round 5: persistent workgroups, the store drain of item i between the MFMAs of item i + 1, statistics kept
     in registers per range) against fp64 and, bit for bit, against conv_halo_kernel<2, 3, 3, TR> (same products, same summation order)."""
     from bflow_amd import split as S
+    if cin != 64 and os.environ.get("BFLOW_CONV_STREAM") != "all":
+        pytest.skip("the dispatch takes the persistent kernel for two input channel blocks only; run with BFLOW_CONV_STREAM=all for the others")
     rs = np.random.RandomState(cout + H)
     x = rs.standard_normal((B, cin, H, W)).astype(np.float32)
     w = (rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)

@@ -21,7 +21,10 @@ def timed(fn, reps=20):
     return best
 
 
-for cin, cout, H, W, B in ((64, 64, 240, 320, 5), (96, 96, 120, 160, 5), (128, 128, 60, 80, 5), (64, 64, 240, 320, 40), (96, 96, 120, 160, 40)):
+SHAPES = ((64, 64, 240, 320, 5), (96, 96, 120, 160, 5), (128, 128, 60, 80, 5), (64, 64, 240, 320, 40), (96, 96, 120, 160, 40))
+if os.environ.get("ENC_PROBE_ONLY"):
+    SHAPES = [SHAPES[int(i)] for i in os.environ["ENC_PROBE_ONLY"].split(",")]
+for cin, cout, H, W, B in SHAPES:
     x = S.from_nchw(torch.relu(torch.randn(B, cin, H, W, device=dev)))
     pk = S.PackedConvWeight().get(torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5)
     st = torch.zeros((8, B, cout, 2), dtype=torch.float64, device=dev)
