@@ -85,6 +85,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel rooflines and the secondary workloads")
+    ap.add_argument("--frame-only", action="store_true", help="value, c4_strong, ms/GRU-iter only: no per-kernel rooflines, stage tables or other configs (tools/ab_bench.sh)")
     return ap.parse_args()
 
 
@@ -311,7 +312,7 @@ def main():
                                        "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": round(fi / (out["ms_per_gru_iter"] * 1e-3) / 1e12 / PEAK_SPLIT_TFLOPS, 4),
                                        "note": "one pass of raft.py:166-195 at batch 1: ten dependent launches on <= 240 workgroups each"}
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and not args.no_extras and not args.frame_only:
         # rooflines of the hand-written kernels (tools/roofline_kernels.py), each timed with hipEvents on the launch stream on the operands
         # of the C2 workload (the timed region above is graph replays, inside which events cannot be recorded)
         from tools.roofline_kernels import build as roofline_kernels, build_big
