@@ -2156,11 +2156,12 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
         // the persistent form (conv_stream.h) for the feature encoder's 3x3s on grids of more than two rounds: fp32 (+ statistics) output.
         // Measured per shape (tools/enc_stream_probe.py, profiles/r05_enc_stream_ab.txt): 64 -> 64 (two input blocks, one channel tile): -5...-9 %;
         // 96 -> 96 / 128 -> 128 (27 / 36 k-steps per item, two channel tiles, the 96-channel one half empty): +-0 at batch 40, +3 % at batch 5
-        // (ranges of 3 patches) -- the kernel runs any block count >= 2 (tested), the dispatch takes it where it wins.  BFLOW_CONV_STREAM=all
-        // (tests, A/B) takes it wherever it can run.
+        // (ranges of 3 patches); with the input normalised on load (x_raw: conv2 of every residual block, 3 of the 4 layer-1 launches) 64 -> 64
+        // 114 -> 96 us / 900 -> 749 us (-16 %), 96 -> 96 72 -> 67 / 533 -> 468 us -- the kernel runs any block count >= 2 (tested), the dispatch
+        // takes it where it wins: x_raw always, else two input blocks.  BFLOW_CONV_STREAM=all (tests, A/B) takes it wherever it can run, =0 never.
         static const int stream_mode = [] { const char* e = getenv("BFLOW_CONV_STREAM"); return !e ? 1 : !strcmp(e, "0") ? 0 : !strcmp(e, "all") ? 2 : 1; }();
         const long long items = (long long)patches * d->B * a.n_tiles;
-        if (shape == 1 && nt == 2 && direct && !a.xraw && !a.x2h && a.act != 2 && stream_mode && !force && a.CB >= 2 && (a.CB == 2 || stream_mode == 2) &&
+        if (shape == 1 && nt == 2 && direct && (!a.xraw || a.CB <= 4) && !a.x2h && a.act != 2 && stream_mode && !force && a.CB >= 2 && (a.CB == 2 || a.xraw || stream_mode == 2) &&
             items >= 1024 && items < (1LL << 30)) {
             // ranges of `per` patches x one channel tile; <= 512 of them (two workgroups per CU), a multiple of 8 x n_tiles (whole XCDs of
             // whole patch ranges; a few trailing workgroups may own no patch)
@@ -2170,8 +2171,13 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
             g = bflow::ceil_div(g, 8 * a.n_tiles) * 8 * a.n_tiles;
             const int lds = 2 * 2 * 12 * 1024 + 4 * 2 * 4096;
             const int tiles_x = bflow::ceil_div(d->W, 16);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipLaunchKernelGGL(conv_halo_stream_kernel, dim3(g), dim3(CT), lds, s, a, per, patches, tiles_x, (int)bp);
+            if (a.xraw) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(conv_halo_stream_kernel<true>, dim3(g), dim3(CT), lds, s, a, per, patches, tiles_x, (int)bp, d->B);
+            } else {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(conv_halo_stream_kernel<false>, dim3(g), dim3(CT), lds, s, a, per, patches, tiles_x, (int)bp, d->B);
+            }
             return bflow::launch_status("conv_split(stream)");
         }
         if (shape == 1) { if (nt == 2) LAUNCH_HALO(2, 3, 3) else if (ten) LAUNCH_HALO10(3, 3) else if (twelve) LAUNCH_HALO12(3, 3) else if (small8) LAUNCH_HALO8(3, 3) else LAUNCH_HALO(1, 3, 3) }

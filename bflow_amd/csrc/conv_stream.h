@@ -29,7 +29,12 @@
 #ifndef CSTREAM_ABL
 #define CSTREAM_ABL 0
 #endif
-__global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int per, int n_patches, int tiles_x, int total) {
+// NIN (as conv_halo_kernel<..., NIN>): the input is the previous convolution's PRE-NORMALISATION fp32 output + its InstanceNorm statistics
+// (ConvArgs.xraw / xstats); a thread loads 4 channels of a halo row as a float4, applies relu((x - mean) * rstd) with the coefficients the
+// normalisation kernel would use, splits and writes the halo buffer by ds_write -- the LDS image the LDS-DMA path produces.  The six loads
+// of a channel block go in three thirds (taps 1, 3, 5 of the block before; written at taps 3, 5, 7): eight registers, not twenty-four.
+template <bool NIN>
+__global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int per, int n_patches, int tiles_x, int total, int n_images) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 2, KH = 3, KW = 3, NW = 4;
     constexpr int TH = 2 * NW, TW = 16;
@@ -43,6 +48,8 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
     constexpr int SB = 4, LA = 2;
     constexpr int O_B = 2 * A_BUF;
     constexpr int DTAPS = NTAPS - 2;                   // taps of a channel block that carry stores (its last two carry none)
+    constexpr int NHL = (HR + 31) / 32, NHH = NHL / 3; // NIN: halo loads per thread and channel block, per third
+    static_assert(NHL == 3 * NHH && NHH == 2 && (A_UNITS * 16 - HR) * 64 >= 128 * 4, "NIN: two equal halves; room for the coefficient tables behind the halo rows");
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -105,6 +112,61 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
                                                        blk ? (int)(oplane * 4) : 0, 0x00020000);
         }
         float s1[NT] = {0.f, 0.f}, s2[NT] = {0.f, 0.f};
+        // NIN: mul / add per input channel of image b in the rows HR .. 16 A_UNITS of halo buffer 0 that no tap ever reads (hi plane: mul, lo: add)
+        float* const nmul = reinterpret_cast<float*>(lds + HR * 64);
+        float* const nadd = reinterpret_cast<float*>(lds + A_PLANE + HR * 64);
+        const int ng = tid & 7;
+        rsrc_t r_raw = r_w;
+        if constexpr (NIN) {
+            r_raw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xraw + (long long)b * CB * a.P_in * 32), 0, CB * a.P_in * 128, 0x00020000);
+            for (int c = tid; c < CB * 32; c += CT) {
+                float m_, a_;
+                norm_coeffs(a.xstats, nullptr, nullptr, b, c, CB * 32, a.H * a.W, a.xeps, m_, a_, a.xstats_reps, (long long)n_images * CB * 32 * 2);
+                nmul[c] = m_;
+                nadd[c] = a_;
+            }
+        }
+        float4 nv[NHH];                                 // the third of a channel block's raw halo that is in flight
+        unsigned nval = 0;                              // bit i: row i of that third lies inside the image
+        // loads of third `hf` of block `cbi` of patch m (zeros when there is no such item); written to halo buffer `buf` by nin_write
+        auto nin_load = [&](int m, bool exists, int cbi, auto hfc) __attribute__((always_inline)) {
+            constexpr int hf = decltype(hfc)::value;
+            const int ty = m / tiles_x;
+            const int y0 = ty * TH, x0 = (m - ty * tiles_x) * TW;
+            nval = 0;
+#pragma unroll
+            for (int i = 0; i < NHH; ++i) {
+                const int row = (tid >> 3) + 32 * (hf * NHH + i);
+                const int hy = row / HWD, hx = row - hy * HWD;
+                const int py = y0 - 1 + hy, px = x0 - 1 + hx;
+                const bool ok = exists && row < HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
+                nval |= ok ? (1u << i) : 0u;
+                nv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_raw, ok ? (unsigned)(((py * a.W + px) * 32 + ng * 4) * 4) : 0x80000000u,
+                                                                                      cbi * a.P_in * 128, 0));
+            }
+        };
+        auto nin_write = [&](int cbi, int buf, auto hfc, auto ic) __attribute__((always_inline)) {
+            constexpr int hf = decltype(hfc)::value, i = decltype(ic)::value;
+            const float4 m4 = *reinterpret_cast<const float4*>(nmul + cbi * 32 + ng * 4);
+            const float4 a4 = *reinterpret_cast<const float4*>(nadd + cbi * 32 + ng * 4);
+            const int row = (tid >> 3) + 32 * (hf * NHH + i);
+            if (row < HR) {
+                const bool in_ = (nval >> i) & 1;      // zero padding applies to the NORMALISED activation
+                const float v_[4] = {in_ ? fmaxf(fmaf(nv[i].x, m4.x, a4.x), 0.f) : 0.f, in_ ? fmaxf(fmaf(nv[i].y, m4.y, a4.y), 0.f) : 0.f,
+                                     in_ ? fmaxf(fmaf(nv[i].z, m4.z, a4.z), 0.f) : 0.f, in_ ? fmaxf(fmaf(nv[i].w, m4.w, a4.w), 0.f) : 0.f};
+                half4v h4_, l4_;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    _Float16 x1_, x2_;
+                    split1(v_[k], x1_, x2_);
+                    h4_[k] = x1_;
+                    l4_[k] = x2_;
+                }
+                char* d_ = lds + buf * A_BUF + row * 64 + ((((ng >> 1) ^ ((row >> 2) & 3))) << 4) + ((ng & 1) << 3);
+                *reinterpret_cast<half4v*>(d_) = h4_;
+                *reinterpret_cast<half4v*>(d_ + A_PLANE) = l4_;
+            }
+        };
 
         // LDS-DMA source offsets of the halo of patch m (all out of range when there is no such item: the pieces are issued all the same,
         // the counts stay); formed where the pieces are issued -- twelve registers that would otherwise live through the whole k-loop
@@ -183,7 +245,16 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
     }
 
         // ---- prologue of the segment: first halo, first LA + 1 weight tiles
-        STREAM_ISSUE_A(mt, true, 0, 0)
+        if constexpr (NIN) {
+            __syncthreads();                                        // coefficient tables complete
+            static_for<0, 3>([&](auto hfc) __attribute__((always_inline)) {
+                nin_load(mt, true, 0, hfc);
+                static_for<0, NHH>([&](auto ic) __attribute__((always_inline)) { nin_write(0, 0, hfc, ic); });
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible to the other waves at the barrier below
+        } else {
+            STREAM_ISSUE_A(mt, true, 0, 0)
+        }
 #pragma unroll
         for (int t = 0; t <= LA; ++t) STREAM_ISSUE_B(0, t, t)
         f32x16 hh[NT], xx[NT];
@@ -212,12 +283,24 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
                 constexpr int n2 = (KIND < 2 && t >= 2 && tm2 < DTAPS) ? ((tm2 + 1 < DTAPS ? ((tm2 + 1) * 16 + DTAPS - 1) / DTAPS : 16) - (tm2 * 16 + DTAPS - 1) / DTAPS) : 0;
                 constexpr int n1 = (KIND < 2 && t >= 1 && tm1 < DTAPS) ? ((tm1 + 1 < DTAPS ? ((tm1 + 1) * 16 + DTAPS - 1) / DTAPS : 16) - (tm1 * 16 + DTAPS - 1) / DTAPS) : 0;
                 if (CSTREAM_ABL != 5 && CSTREAM_ABL != 1 && CSTREAM_ABL != 2) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + n2 + n1 + (t == 2 ? AP : 0)) : "memory");
+                    // (NIN: the raw loads of taps 1, 3 and 5 stand where the halo pieces of tap 1 stand)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + n2 + n1 + (NIN ? ((t == 2 || t == 4 || t == 6) ? NHH : 0) : (t == 2 ? AP : 0))) : "memory");
                 }
                 if (CSTREAM_ABL != 5) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (CSTREAM_ABL != 2) {
-                    if (t == 1) {
+                    if constexpr (NIN) {
+                        // next phase = block cb + 1 of this item, or block 0 of the next one (or nothing: out-of-range loads, the counts stay)
+                        const int m_n = last_cb ? mt + 1 : mt, cb_n = last_cb ? 0 : cb + 1;
+                        const bool ex_n = !last_cb || left > 0;
+                        // third k: written at tap 2k + 3 (its loads, issued two taps before, have landed behind that tap's counted wait), then the
+                        // next third is requested into the same registers; the buffer is read from tap NTAPS - 1 on
+                        if (t == 3 || t == 5 || t == 7) {
+                            static_for<0, NHH>([&](auto ic) __attribute__((always_inline)) { nin_write(cb_n, hbuf ^ 1, std::integral_constant<int, (t - 3) / 2>{}, ic); });
+                            if (t == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible at the barrier of tap NTAPS - 1
+                        }
+                        if (t == 1 || t == 3 || t == 5) nin_load(m_n, ex_n, cb_n, std::integral_constant<int, (t - 1) / 2>{});
+                    } else if (t == 1) {
                         if (!last_cb) {
                             STREAM_ISSUE_A(mt, true, cb + 1, hbuf ^ 1)
                         } else {                        // the next item's first block (or nothing: out-of-range pieces, the counts stay)
@@ -303,12 +386,14 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
             if (tid < 2 * BN) {
                 const int which = tid / BN, c = tid - which * BN;
                 const int col = n0 + c;
+                int rep = chunk % a.stats_reps;
+                asm volatile("" : "+s"(rep));               // (formed here: hoisted to the kernel's top the address costs four registers for its whole life)
                 if (col < a.Cout) {
                     const float* p = red + which * NW * BN + c;
                     double sum = 0.0;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) sum += (double)p[w * BN];
-                    atomicAdd(a.stats + (long long)(chunk % a.stats_reps) * a.stats_rep_stride + ((long long)b * a.Cout + col) * 2 + which, sum);
+                    atomicAdd(a.stats + (long long)rep * a.stats_rep_stride + ((long long)b * a.Cout + col) * 2 + which, sum);
                 }
             }
             __syncthreads();                                        // `red` is LDS the next segment's prologue refills

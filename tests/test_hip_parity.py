@@ -1077,6 +1077,33 @@ def test_conv_stream_kernel_vs_fp64_and_halo_kernel(cin, cout, H, W, B, relu, mo
         assert not bool(o1.view(B, -1, H * W, 32)[:, -1, :, cout % 32:].any())
 
 
+@pytest.mark.parametrize("c1,c2,H,W,B", [(64, 64, 240, 320, 2), (64, 64, 100, 150, 9), (128, 96, 72, 112, 24)])
+def test_conv_stream_kernel_norm_in_equals_halo_kernel(c1, c2, H, W, B, monkeypatch):
+    """conv_halo_stream_kernel<NIN> (normalise-on-load inside the persistent kernel: raw fp32 halo thirds loaded two taps ahead, written by
+    ds_write between the MFMAs) == conv_halo_kernel<2, 3, 3, TR, NIN> bit for bit, statistics to summation order."""
+    from bflow_amd import split as S
+    if c1 != 64 and os.environ.get("BFLOW_CONV_STREAM") != "all":
+        pytest.skip("the dispatch takes the persistent kernel for two input channel blocks only; run with BFLOW_CONV_STREAM=all for the others")
+    rs = np.random.RandomState(c1 + H)
+    raw = cu((rs.standard_normal((B, c1 // 32, H * W, 32)) * 3 + 0.5).astype(np.float32))
+    pk = S.PackedConvWeight().get(cu((rs.standard_normal((c2, c1, 3, 3)) / np.sqrt(c1 * 9)).astype(np.float32)))
+    nchw = S.blocked_f32_to_nhwc(raw, H, W, c1).permute(0, 3, 1, 2).double()
+    st_in = torch.zeros((8, B, c1, 2), dtype=torch.float64, device=DEV)
+    st_in[2, :, :, 0] = nchw.sum(dim=(2, 3))
+    st_in[6, :, :, 1] = (nchw * nchw).sum(dim=(2, 3))
+
+    def run():
+        st = torch.zeros((8, B, c2, 2), dtype=torch.float64, device=DEV)
+        return S.conv_norm_in(raw, (B, H, W, c1), st_in, pk, stats=st), st.sum(0)
+    o1, s1 = run()
+    monkeypatch.setenv("BFLOW_CONV_KERNEL", "halo")            # the per-item kernel
+    o0, s0 = run()
+    monkeypatch.delenv("BFLOW_CONV_KERNEL")
+    assert torch.equal(o1, o0)
+    np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-6, atol=1e-3)
+    assert float(o1.abs().max()) > 1.0
+
+
 # (grids of >= 200 workgroups, as in the encoder: both forms then run the SAME 64-channel-tile halo kernel, hence the same summation order)
 @pytest.mark.parametrize("c1,c2,H,W,B", [(64, 64, 117, 150, 2), (96, 96, 99, 150, 1), (128, 128, 60, 80, 3)])
 def test_conv_norm_in_equals_normalise_then_convolve(c1, c2, H, W, B):

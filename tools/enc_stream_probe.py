@@ -30,6 +30,12 @@ for cin, cout, H, W, B in SHAPES:
     st = torch.zeros((8, B, cout, 2), dtype=torch.float64, device=dev)
     o32 = torch.empty((B, (cout + 31) // 32, H * W, 32), dtype=torch.float32, device=dev)
     fn = lambda: S.conv(x, pk, stride=1, padding=1, want_split=False, out_f32=o32, stats=st)
+    if os.environ.get("ENC_PROBE_NIN"):     # the normalise-on-load form (x_raw): conv2 of a residual block
+        raw = torch.randn(B, cin // 32, H * W, 32, device=dev) * 3 + 0.5
+        st_in = torch.zeros((8, B, cin, 2), dtype=torch.float64, device=dev)
+        st_in[0, :, :, 0] = raw.double().sum(dim=2).reshape(B, cin) * 0 + H * W * 0.5
+        st_in[0, :, :, 1] = H * W * 9.25
+        fn = lambda: S.conv_norm_in(raw, (B, H, W, cin), st_in, pk, stats=st, out_f32=o32)
     res = {}
     for rnd in range(2):
         for tag in ("stream", "halo"):
