@@ -57,12 +57,6 @@ def check_precision(name: str) -> str:
 # panels of the pooled target ~40 %, and those panels sit on two XCDs, which then set the kernel's time.  Off by default, so that the
 # product's K5 launch is the plain streaming kernel; BFLOW_FUSED_POOL=1 (or corr.FUSE_POOL1 = True) enables it.
 FUSE_POOL1 = os.environ.get("BFLOW_FUSED_POOL") is not None
-# Look-up + convc1 + ReLU as ONE launch (bflow_corr_lookup_conv1x1): built, parity-tested and measured (round 3).  Alone it
-# takes 26.0 us against 13.3 + 14.2 us for the two launches at C2, but inside the captured iteration it is 2-5 us SLOWER per iteration
-# (0.165-0.168 vs 0.162-0.163 ms over three A/B pairs): one 512-thread, ~150-KB-LDS workgroup per CU leaves no room for the Bezier branch that
-# runs next to the two separate launches, and per CU the work is the same.  Off by default; BFLOW_LOOKUP_CONV=1 (or
-# corr.FUSE_LOOKUP_CONV = True) enables it.
-FUSE_LOOKUP_CONV = os.environ.get("BFLOW_LOOKUP_CONV") is not None
 
 
 def _x8_planes(p1: torch.Tensor, p2: torch.Tensor):
@@ -362,16 +356,6 @@ class CorrBlockParallelMultiTarget:
         h, w = self._hw
         # the tiled look-up writes every channel of the last block itself (pads as zeros): only the row-major kernel needs a zeroed buffer
         return SplitTensor.empty(self._batch, h, w, self.num_planes * 81, self._pyramid[0][0].device, zero=not self._tiled)
-
-    def conv1x1_fusable(self, cout: int) -> bool:
-        """True when look-up + 1x1 convolution can run as ONE launch (bflow_corr_lookup_conv1x1) on this pyramid."""
-        return FUSE_LOOKUP_CONV and hip.lookup_conv_fusable(self.num_planes, cout, self._tiled, self._f16)
-
-    def lookup_bezier_conv1x1(self, params: torch.Tensor, coef: np.ndarray, packed, bias, act: int, out, channel_offset: int = 0):
-        """relu(convc1(look-up)) of update.py:88 without materialising the look-up features; `out` is a SplitTensor."""
-        assert coef.shape[0] == self._num_targets_base
-        hip.corr_lookup_conv1x1(self._table, params, coef, packed, bias, act, out.planes, channel_offset)
-        return out
 
     def lookup_bezier_split(self, params: torch.Tensor, coef: np.ndarray, out, im2col=None):
         """lookup_bezier writing the conv engine's blocked split layout directly (no NCHW intermediate).

@@ -1,4 +1,4 @@
-// Shared pieces of the split-fp16 MFMA conv engine (conv_split.hip, lookup_conv.hip): vector types, the argument block of a convolution
+// Shared pieces of the split-fp16 MFMA conv engine (conv_split.hip, conv_stream.h): vector types, the argument block of a convolution
 // and the LDS-transposing epilogue.  Internal to the library; every including translation unit gets its own (anonymous-namespace) copy.
 #pragma once
 #include <cstdlib>

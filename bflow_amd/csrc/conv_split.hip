@@ -518,10 +518,10 @@ __device__ __forceinline__ int slab_col(int n) { return ((n >> 3) & 3) * 4 + (n 
 // by ds_write -- the same LDS image the LDS-DMA path produces from a normalised split tensor, so everything downstream is unchanged and
 // the result is bit-identical to "normalise, then convolve", without the normalisation pass over the activation (38 us per 64-channel
 // half-resolution map of the 5 event windows).
-// HT (round 4, opt-in: see the dispatch): the last channel tile may be HALF empty (Cout % 64 in (0, 32]: the 96-channel layers of the encoder) --
-// its workgroups skip the fragment reads and MFMAs of the empty 32-channel half (wave-uniform) instead of multiplying padding: a quarter of such
-// a layer's matrix work.  A separate instantiation, so that the kernels of the other layers are unchanged.  Measured neutral.
-template <int NT, int KH, int KW, bool TR = false, bool NIN = false, bool HT = false>    // TR: transposed accumulators D[pixel][channel] + the direct epilogue
+// (Round 4's HT instantiation -- the workgroups of a half-empty last channel tile, Cout % 64 in (0, 32], skip the empty half's fragment reads and
+// MFMAs: a quarter of the 96-channel layers' matrix work -- was bit-identical and neutral in three alternating pairs
+// (profiles/r04_half_tile_ab.txt); removed in round 5.)
+template <int NT, int KH, int KW, bool TR = false, bool NIN = false>    // TR: transposed accumulators D[pixel][channel] + the direct epilogue
 __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = 4;
@@ -557,7 +557,6 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
         y0 = ty * TH;
         x0 = (mt - ty * tiles_x) * TW;
     }
-    const bool second_half = !HT || NT < 2 || n0 + 32 < a.Cout;   // HT: false for the workgroups of a half-empty last tile (wave-uniform)
 
     // ---- LDS-DMA sources ------------------------------------------------------------------------------------------
     const int urow = lane >> 2;
@@ -693,12 +692,6 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
     // Register pipelining: the fragments of tap s+1 are read from LDS while the MFMAs of tap s run (one wave per SIMD and
     // workgroup: nothing else hides the ds_read latency).  `cur` is consumed, `nxt` is in flight.
     half8 cxh[2], cxl[2], cwh[2][NT], cwl[2][NT], nxh[2], nxl[2], nwh[2][NT], nwl[2][NT];
-    if constexpr (HT) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) cwh[ks][n] = cwl[ks][n] = nwh[ks][n] = nwl[ks][n] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
 #define HALO_READ(XH, XL, WH, WL, ABUF, WSLOT, TAP)                                                                      \
     {                                                                                                                    \
         const int R_ = R0 + ((TAP) / KW) * HWD + ((TAP) % KW);                                                           \
@@ -708,7 +701,7 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
             XH[ks] = *reinterpret_cast<const half8*>((ABUF) + ao_);                                                      \
             XL[ks] = *reinterpret_cast<const half8*>((ABUF) + A_PLANE + ao_);                                            \
             const int co_ = ((ks * 2 + kh) ^ wsw) * 16;                                                                  \
-            _Pragma("unroll") for (int n = 0; n < NT; ++n) if (n == 0 || second_half) {                                  \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                             \
                 const int wo_ = (n * 32 + l31) * 64 + co_;                                                               \
                 WH[ks][n] = *reinterpret_cast<const half8*>((WSLOT) + wo_);                                              \
                 WL[ks][n] = *reinterpret_cast<const half8*>((WSLOT) + B_PLANE + wo_);                                    \
@@ -762,14 +755,7 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_kernel(ConvArgs a) {
             else if (!last_cb) HALO_READ(nxh, nxl, nwh, nwl, abuf_next, wnext, 0)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if constexpr (TR && HT) {  // half-empty last tile: the second 32 channels are skipped (wave-uniform branch)
-                    hh[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxh[ks], cwh[ks][0], hh[0], 0, 0, 0);
-                    if (second_half) hh[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxh[ks], cwh[ks][NT - 1], hh[NT - 1], 0, 0, 0);
-                    xx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxh[ks], cwl[ks][0], xx[0], 0, 0, 0);
-                    if (second_half) xx[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxh[ks], cwl[ks][NT - 1], xx[NT - 1], 0, 0, 0);
-                    xx[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxl[ks], cwh[ks][0], xx[0], 0, 0, 0);
-                    if (second_half) xx[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxl[ks], cwh[ks][NT - 1], xx[NT - 1], 0, 0, 0);
-                } else if constexpr (TR) {        // D[pixel][channel]
+                if constexpr (TR) {        // D[pixel][channel]
 #pragma unroll
                     for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cxh[ks], cwh[ks][n], hh[n], 0, 0, 0);
 #pragma unroll
@@ -2087,15 +2073,9 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
     {                                                                                                                  \
         constexpr int units_ = (((16 + (KWW) - 1) * (8 + (KHH) - 1) + 15) / 16 + 1) / 2 * 2;                           \
         const int lds = 2 * 2 * units_ * 1024 + 4 * (N) * 4096 + halo_lds_pad;   /* (pad: occupancy probe, tools) */       \
-        if ((N) == 2 && (KHH) == 3 && a.xraw && half_tile) {   /* ... a half-empty last channel tile (96-channel layers) */ \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 3, 3, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((conv_halo_kernel<2, 3, 3, true, true, true>), hgrid, dim3(CT), lds, s, a);             \
-        } else if ((N) == 2 && (KHH) == 3 && a.xraw) {   /* ... and the input normalised on its way into LDS */         \
+        if ((N) == 2 && (KHH) == 3 && a.xraw) {   /* ... and the input normalised on its way into LDS */         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 3, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             hipLaunchKernelGGL((conv_halo_kernel<2, 3, 3, true, true>), hgrid, dim3(CT), lds, s, a);                   \
-        } else if ((N) == 2 && (KHH) == 3 && direct && half_tile) {                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 3, 3, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-            hipLaunchKernelGGL((conv_halo_kernel<2, 3, 3, true, false, true>), hgrid, dim3(CT), lds, s, a);            \
         } else if ((N) == 2 && (KHH) == 3 && direct) {   /* fp32 (+ statistics) output: transposed accumulators, stores without an LDS transpose */ \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<2, 3, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             hipLaunchKernelGGL((conv_halo_kernel<2, 3, 3, true>), hgrid, dim3(CT), lds, s, a);                         \
@@ -2131,12 +2111,6 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
     }
         static const bool no_direct = getenv("BFLOW_CONV_NO_DIRECT") != nullptr;      // A/B timing (tools/)
         const bool direct = !no_direct && a.out_f32 && !a.oh && !a.addend && !a.gate && !a.acc;
-        // Half-empty last tile (the encoder's 96-channel stage): conv_halo_kernel<..., HT> skips the empty half's fragment reads and MFMAs -- a
-        // quarter of those layers' matrix work.  Built, bit-identical (test_conv_halo_half_tile_equals_full_tile), measured on one box over three
-        // alternating pairs: 271.8 / 272.8 / 273.4 frames/s with, 273.9 / 274.5 / 273.5 without (fixed part 1.736-1.743 vs 1.718-1.745 ms) -- the
-        // matrix work is not what these launches wait for, and the variant costs 48 more registers.  OFF by default; BFLOW_CONV_HALF_TILE=1 enables it.
-        const bool want_ht = getenv("BFLOW_CONV_HALF_TILE") != nullptr;
-        const bool half_tile = want_ht && (d->Cout % 64) > 0 && (d->Cout % 64) <= 32;    // the last 64-channel tile is half empty
         const bool small8 = nt == 1 && !(force && strcmp(force, "halo4") == 0);   // small grids: the 8-wave split-k variant
         // 10 x 16 patches when the 8 x 16 grid needs a second workgroup on some CUs and the 10 x 16 grid does not
         const int patches10 = bflow::ceil_div(d->H, 10) * bflow::ceil_div(d->W, 16);
@@ -2252,7 +2226,16 @@ extern "C" int bflow_conv_split_pair(const bflow_conv_desc_t* d0, const bflow_co
     if (fused) *fused = 0;
     BFLOW_REQUIRE(d0 && d1 && d0->B == d1->B, BFLOW_E_ARG, "conv_split_pair: two descriptors of the same batch size expected");
     static const bool no_pair = getenv("BFLOW_CONV_NO_PAIR") != nullptr;      // tools A/B: always two launches
-    if (no_pair) {
+    // the pair runs as ONE grid in no particular order: a convolution that reads what the other writes (or writes the same channel blocks of
+    // the same buffer) is not a pair -- two ordered launches instead
+    auto reads = [](const bflow_conv_desc_t* r, const void* p) { return p && (p == r->x_hi || p == r->x_lo || p == r->x2_hi || p == r->x2_lo || p == (const void*)r->x_raw ||
+                                                                             p == (const void*)r->addend || p == r->gate_h_hi || p == (const void*)r->gate_z); };
+    auto writes_into = [&](const bflow_conv_desc_t* w, const bflow_conv_desc_t* r) { return reads(r, w->out_hi) || reads(r, w->out_lo) || reads(r, (const void*)w->out_f32) ||
+                                                                                           reads(r, (const void*)w->acc_nchw); };
+    const bool same_out = (d0->out_hi && d0->out_hi == d1->out_hi) || (d0->out_f32 && d0->out_f32 == d1->out_f32);
+    const bool overlap = same_out && d0->out_channel_offset < d1->out_channel_offset + (d1->Cout + 31) / 32 * 32 &&
+                         d1->out_channel_offset < d0->out_channel_offset + (d0->Cout + 31) / 32 * 32;
+    if (no_pair || writes_into(d0, d1) || writes_into(d1, d0) || overlap) {
         const int rc = conv_split_impl(d0, stream, nullptr);
         return rc != 0 ? rc : conv_split_impl(d1, stream, nullptr);
     }

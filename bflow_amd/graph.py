@@ -90,7 +90,7 @@ class GraphCache:
 
     def run(self, voxel_grid, images, iters: int, flow_init, test_mode: bool):
         key = (self._sig(voxel_grid), None if images is None else tuple(self._sig(x) for x in images), int(iters),
-               self._sig(flow_init), bool(test_mode), self.model.resolved_corr_precision(), _corr.FUSE_POOL1, _corr.FUSE_LOOKUP_CONV)
+               self._sig(flow_init), bool(test_mode), self.model.resolved_corr_precision(), _corr.FUSE_POOL1)
         wkey = self._weights_signature()
         if wkey != self._weights_key:
             self.clear()                         # destroyed here, outside any capture

@@ -25,7 +25,7 @@ ACT_NONE, ACT_RELU = 0, 1
 
 EXPORTS = (
     "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_build_tiled", "bflow_split_to_x8", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_conv_thin_mfma_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_rows_to_split", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_norm_train_finalize", "bflow_norm_train_apply", "bflow_norm_train_bwd_stats", "bflow_norm_train_bwd_finalize", "bflow_norm_train_bwd_apply", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
-    "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_corr_lookup_conv1x1", "bflow_bezier_coeffs", "bflow_bezier_eval", 
+    "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
     "bflow_clock_stamp", "bflow_voxel_workspace_bytes", "bflow_voxel_grid_f32xy", "bflow_voxel_grid_i16xy", "bflow_voxel_grid_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
     "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_grid_rectified", "bflow_maxabs_diff",
@@ -117,7 +117,6 @@ def lib() -> ctypes.CDLL:
         "bflow_split_to_x8": [vp, vp, vp, ll, vp],
         "bflow_corr_lookup_bezier_split_tiled_f16": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
         "bflow_corr_lookup_bezier_split_tiled": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, i, i, vp],
-        "bflow_corr_lookup_conv1x1": [ctypes.POINTER(PlaneDesc), i, vp, ctypes.POINTER(ctypes.c_float), i, i, vp, vp, i, i, i, vp, i, vp, vp, i, i, i, i, i, i, vp],
         "bflow_conv_pack_weights": [vp, vp, vp, i, i, i, i, i, i, vp],
         "bflow_conv_pack_weights_adjoint": [vp, vp, vp, i, i, i, i, i, i, vp],
         "bflow_conv_stem": [ctypes.POINTER(StemDesc), vp],
@@ -418,30 +417,6 @@ def corr_lookup_bezier_split(table, params: torch.Tensor, coef: np.ndarray, out_
               out_planes.shape[3], B, h1, w1, _stream()), "bflow_corr_lookup_bezier_split" + ("_tiled" if tiled else ""))
 
 
-def lookup_conv_fusable(num_planes: int, cout: int, tiled: bool, f16_planes: bool) -> bool:
-    """Shapes bflow_corr_lookup_conv1x1 takes (fp32 tiled planes, <= 8 planes = two gather passes of four, Cout <= 256)."""
-    return tiled and not f16_planes and 1 <= num_planes <= 8 and cout <= 256
-
-
-def corr_lookup_conv1x1(table, params: torch.Tensor, coef: np.ndarray, packed, bias: Optional[torch.Tensor], act: int,
-                        out_planes: torch.Tensor, channel_offset: int = 0):
-    """Look-up + 1x1 convolution in one launch.  packed = PackedConvWeight.get(weight (Cout, P*81, 1, 1)); out_planes (2, B, CBo, rows, 32) fp16."""
-    B, C2, h1, w1 = params.shape
-    T, deg = coef.shape
-    P = len(table)
-    planes, (cout, cin_pad, kh, kw, cout_pad) = packed
-    assert C2 == 2 * deg and coef.dtype == np.float32 and coef.flags["C_CONTIGUOUS"]
-    assert kh == 1 and kw == 1 and cin_pad == (P * 81 + 31) // 32 * 32, f"weights packed for {cin_pad} input channels, {P} planes need {(P * 81 + 31) // 32 * 32}"
-    assert out_planes.dtype == torch.float16 and out_planes.is_contiguous() and out_planes.shape[0] == 2 and out_planes.shape[1] == B \
-        and out_planes.shape[4] == 32 and out_planes.shape[3] >= h1 * w1 and channel_offset % 32 == 0
-    _check(lib().bflow_corr_lookup_conv1x1(table, P, _dev(params, name="params"), coef.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), T, deg,
-                                           planes[0].data_ptr(), planes[1].data_ptr(), cout, cout_pad, cin_pad // 32,
-                                           None if bias is None else _dev(bias, name="bias"), act, out_planes[0].data_ptr(), out_planes[1].data_ptr(),
-                                           out_planes.shape[2], channel_offset // 32, out_planes.shape[3], B, h1, w1, _stream()),
-           "bflow_corr_lookup_conv1x1")
-
-
-# ------------------------------------------------------------------------------------------------ K8
 def bezier_coeffs(times: Sequence[float], degree: int) -> np.ndarray:
     ts = np.ascontiguousarray(np.asarray(times, dtype=np.float64).reshape(-1))
     out = np.empty((ts.size, degree), dtype=np.float32)

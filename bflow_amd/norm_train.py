@@ -98,9 +98,14 @@ def _norm_elementwise(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
                     n = xf.numel() // xf.shape[1]
                     if module.num_batches_tracked is not None:
                         module.num_batches_tracked.add_(1)
-                    f = (1.0 / float(module.num_batches_tracked)) if module.momentum is None else float(module.momentum)
-                    module.running_mean.mul_(1 - f).add_(mean.detach(), alpha=f)
-                    module.running_var.mul_(1 - f).add_(var.detach() * (n / max(n - 1, 1)), alpha=f)
+                    if module.momentum is None:      # cumulative average: the factor stays on the device (no host read: capturable)
+                        f = 1.0 / module.num_batches_tracked.to(mean.dtype)
+                        module.running_mean.add_((mean.detach() - module.running_mean) * f)
+                        module.running_var.add_((var.detach() * (n / max(n - 1, 1)) - module.running_var) * f)
+                    else:
+                        f = float(module.momentum)
+                        module.running_mean.mul_(1 - f).add_(mean.detach(), alpha=f)
+                        module.running_var.mul_(1 - f).add_(var.detach() * (n / max(n - 1, 1)), alpha=f)
         else:
             mean, var = module.running_mean.float(), module.running_var.float()
         scale = torch.rsqrt(var + module.eps)

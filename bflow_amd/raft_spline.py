@@ -35,7 +35,7 @@ from .bezier import BezierCurves, polynomial_coefficients
 from .corr import CorrBlockParallelMultiTarget, CorrComputation
 from .extractor import BasicEncoder
 from .timers import StageTimer
-from .update import BasicUpdateBlock, FusedLookup, SplitLookup
+from .update import BasicUpdateBlock, SplitLookup
 
 
 
@@ -351,15 +351,14 @@ class RAFTSpline(nn.Module):
         corr_block, ws, bezier, corr_feat = fr.corr_block, fr.ws, fr.bezier, fr.corr_feat
         coef = self._coefficients()
         ups: List[torch.Tensor] = []
-        fused = FusedLookup(corr_block, bezier, coef) if corr_block.conv1x1_fusable(ub.encoder.convc1.out_channels) else None
         if tm: tm.start("all iters")
         for itr in range(iters):
             need_mask = (not test_mode) or itr == iters - 1
             if pr: pr(f"iter{itr}.begin")
             if tm is None:
                 # the look-up runs inside the step, next to the (independent) Bezier branch of the motion encoder
-                look = fused if fused is not None else SplitLookup(corr_block, bezier, coef, corr_feat)
-                if pr and fused is None:
+                look = SplitLookup(corr_block, bezier, coef, corr_feat)
+                if pr:
                     look.after = lambda k=itr: pr(f"iter{k}.lookup_end")
                 mask = ub.step_split(ws, look, bezier, need_mask, mask_blocked=MASK_BLOCKED)
             else:

@@ -593,6 +593,14 @@ class GraphedTrainStep:
                 self._graph, self._static, self._out, self._times = hit
                 self._sig = sig
             else:
+                if self._sig is not None and not getattr(self, "_recapture_noted", False):
+                    self._recapture_noted = True            # once: a run whose batch signature alternates pays two warm-up steps + a capture per change
+                    import warnings
+                    warnings.warn(f"GraphedTrainStep: a new batch signature forces a re-capture (max_graphs = {self.max_graphs}; the graph of the previous "
+                                  "signature is " + ("destroyed to make room" if len(self._lru) >= self.max_graphs else "parked") +
+                                  "); max_graphs = 2 or 3 keeps alternating shapes captured at 2-3x the activation memory")
+                # every graph owns all activations of a step: the oldest parked graph has to go BEFORE the new capture allocates its pool (with
+                # max_graphs = 1 that is the graph that was current a moment ago: a capture that then fails leaves no graph at all, see below)
                 while len(self._lru) >= self.max_graphs:    # destroyed here, outside any capture
                     torch.cuda.synchronize()
                     self._lru.popitem(last=False)

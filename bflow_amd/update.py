@@ -26,7 +26,12 @@ from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backwa
 
 # head2 (Conv2d(256, 2*deg, 3)): the vector-ALU kernel takes 5 us per 4800 pixels, the MFMA halo kernel 17 us at 4800 pixels but only
 # 40 us at 38400 (batch 8) where its grid fills the chip -- measured cross-over near 24000 pixels.
-THIN_HEAD_MAX_PIXELS = int(os.environ.get("BFLOW_THIN_HEAD_MAX_PIXELS", "20000"))     # (env: A/B of the cross-over, tools/)
+# Small-grid decisions (batch x h x w pixels), one constant each so that moving ONE cross-over for an A/B does not silently change the others.
+# SMALL_GRID_MAX_PIXELS (batch 1-4 at 60 x 80) is where they all sit today:
+SMALL_GRID_MAX_PIXELS = 20000
+THIN_HEAD_MAX_PIXELS = int(os.environ.get("BFLOW_THIN_HEAD_MAX_PIXELS", str(SMALL_GRID_MAX_PIXELS)))   # thin Bezier head vs the MFMA halo kernel (env: tools A/B)
+ONE_QUEUE_MAX_PIXELS = SMALL_GRID_MAX_PIXELS     # the motion encoder's two branches as pair launches on one queue (else a side stream)
+MASK_TILE96_MAX_PIXELS = SMALL_GRID_MAX_PIXELS   # 96-channel tiles for the mask head's 1x1 (one round of 228 workgroups at batch 1)
 MERGE_BEZIER_BLOCK = os.environ.get("BFLOW_NO_MERGED_BEZIER") is None     # A/B switch (tools/): see SplitWorkspace
 MASK_TILE = int(os.environ["BFLOW_MASK_TILE"]) if "BFLOW_MASK_TILE" in os.environ else None   # tools A/B: channel tile of the mask head's 1x1 (None: pick_tile)
 
@@ -73,14 +78,6 @@ class BasicMotionEncoder(nn.Module):
         return out
 
 
-class FusedLookup:
-    """`corr` argument of `step_split` when the look-up can run fused with convc1 (CorrBlockParallelMultiTarget.conv1x1_fusable):
-    the pyramid, the Bezier parameters the look-up evaluates (read at launch time: they are updated in place) and the time coefficients."""
-
-    def __init__(self, corr_block, bezier: torch.Tensor, coef):
-        self.corr_block, self.bezier, self.coef = corr_block, bezier, coef
-
-
 class SplitLookup:
     """`corr` argument of `step_split` for the ordinary look-up (CorrBlockParallelMultiTarget.lookup_bezier_split into `out`): a callable the
     step invokes where the look-up belongs.  With im2col = (SplitTensor, kh, kw, padding) the same launch also writes the filter windows of the
@@ -109,7 +106,7 @@ class SplitWorkspace:
         # of a block and leave the rest alone: the thin head kernel (batch <= THIN_HEAD_MAX_PIXELS pixels) and a degree with 2*deg % 4 == 0.
         # Otherwise: [motion conv (md - 2deg, zero padded to md) | Bezier block (2*deg, zero padded to 32)].
         bz = blk.bezier_planes
-        self.merged = MERGE_BEZIER_BLOCK and bz % 4 == 0 and batch * h * w <= THIN_HEAD_MAX_PIXELS and (md - bz) // 32 == (md - 1) // 32
+        self.merged = MERGE_BEZIER_BLOCK and bz % 4 == 0 and batch * h * w <= min(THIN_HEAD_MAX_PIXELS, SMALL_GRID_MAX_PIXELS) and (md - bz) // 32 == (md - 1) // 32
         self.bez_channel = md - bz if self.merged else md                        # first Bezier channel of M
         self.H = S.SplitTensor.empty(batch, h, w, hd, device)                    # hidden state
         self.RH = S.SplitTensor.empty(batch, h, w, hd, device)                   # r * h
@@ -117,7 +114,6 @@ class SplitWorkspace:
         self.M = S.SplitTensor.empty(batch, h, w, md if self.merged else md + 32, device, zero=True)
         self.INP = None                                                          # relu(context) split, set by set_context
         self.corbez = S.SplitTensor.empty(batch, h, w, 256, device)
-        self.C1 = None                                                           # relu(convc1(look-up)) of the fused look-up launch
         self.COL = None                                                          # 7x7 windows of the Bezier parameters (one-queue path)
         self.inp_terms = None
         self.overlap = True                                                      # independent branches on a side stream
@@ -222,7 +218,7 @@ class BasicUpdateBlock(nn.Module):
 
     def step_split(self, ws: SplitWorkspace, corr, bezier: torch.Tensor, need_mask: bool, mask_blocked: bool = False):
         """One iteration of update.py:116-126 on the split-fp16 engine.  corr: (B, P*81, h, w) fp32 (look-up output), the same as a blocked SplitTensor, a
-        callable producing either (then the look-up itself overlaps with the Bezier branch), or a FusedLookup (look-up + convc1 in one launch), bezier: (B, 2*deg, h, w) fp32 updated IN PLACE.
+        callable producing either (then the look-up itself overlaps with the Bezier branch), bezier: (B, 2*deg, h, w) fp32 updated IN PLACE.
         Returns the mask logits incl. bias (B, 576, h, w) fp32 -- mask_blocked: as the last convolution writes them, blocked fp32
         (B, 18, h*w, 32), for hip.cvx_upsample_blocked -- or None."""
         enc = self.encoder
@@ -231,7 +227,7 @@ class BasicUpdateBlock(nn.Module):
         # The LONGER one is issued on the side stream: the graph keeps the captured stream's nodes on one hardware queue, and a
         # cross-queue join costs ~10 us unless the other side finished long before (measured both ways).
         kh, kw = enc.convf1.kernel_size
-        if ws.overlap and ONE_QUEUE and callable(corr) and getattr(corr, "im2col_rider", False) and ws.H.shape[0] * ws.H.H * ws.H.W <= THIN_HEAD_MAX_PIXELS:
+        if ws.overlap and ONE_QUEUE and callable(corr) and getattr(corr, "im2col_rider", False) and ws.H.shape[0] * ws.H.H * ws.H.W <= ONE_QUEUE_MAX_PIXELS:
             # Small grids (batch 1 at DSEC size): the two branches as PAIR launches on ONE queue -- look-up | im2col, convc1 | convf1,
             # convc2 | convf2 -- instead of two queues: every cross-queue edge of the captured graph cost the chain 5-7 us
             # (profiles/r04_iteration_launches.txt), about what the overlap saved.
@@ -249,17 +245,10 @@ class BasicUpdateBlock(nn.Module):
                      out_split=ws.corbez, channel_offset=192))
             return self._step_tail(ws, bezier, need_mask, mask_blocked)
         with hip.Branch(ws.overlap and ITER_BRANCH) as corr_branch:
-            if isinstance(corr, FusedLookup):
-                # look-up + convc1 + ReLU as ONE launch (bflow_corr_lookup_conv1x1): the correlation features stay in the CU
-                if ws.C1 is None:
-                    ws.C1 = S.SplitTensor.empty(ws.H.shape[0], ws.H.H, ws.H.W, enc.convc1.out_channels, ws.H.planes.device)
-                c1 = corr.corr_block.lookup_bezier_conv1x1(corr.bezier, corr.coef, self._pk("convc1", lambda a=enc.convc1.weight: a),
-                                                           enc.convc1.bias, S.ACT_RELU, ws.C1)
-            else:
-                cs = corr() if callable(corr) else corr
-                if not isinstance(cs, S.SplitTensor):
-                    cs = S.from_nchw(cs)
-                c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
+            cs = corr() if callable(corr) else corr
+            if not isinstance(cs, S.SplitTensor):
+                cs = S.from_nchw(cs)
+            c1, _ = S.conv(cs, self._pk("convc1", lambda a=enc.convc1.weight: a), shift=enc.convc1.bias, act=S.ACT_RELU)
             S.conv(c1, self._pk("convc2", lambda a=enc.convc2.weight: a), padding=1, shift=enc.convc2.bias, act=S.ACT_RELU,
                    out_split=ws.corbez, channel_offset=0)
         col = S.im2col_small(bezier, kh, kw, enc.convf1.padding)
@@ -289,7 +278,7 @@ class BasicUpdateBlock(nn.Module):
                 m1, _ = S.conv(ws.H, self._pk("mask0", lambda a=self.mask[0].weight: a), padding=1, shift=self.mask[0].bias, act=S.ACT_RELU)
                 m2, m2f = S.conv(m1, self._pk("mask2", lambda a=self.mask[2].weight: a), shift=self.mask[2].bias, want_split=not mask_blocked,
                                  want_f32=mask_blocked,
-                                 tile=MASK_TILE if MASK_TILE is not None else (96 if m1.shape[0] * m1.H * m1.W <= THIN_HEAD_MAX_PIXELS else None))
+                                 tile=MASK_TILE if MASK_TILE is not None else (96 if m1.shape[0] * m1.H * m1.W <= MASK_TILE96_MAX_PIXELS else None))
                 # (batch 1: 96-channel tiles = 228 workgroups, one round, 229 KB of operands each, instead of 342 of 64 channels:
                 #  3.643-3.647 vs 3.648-3.668 ms per frame over three alternating pairs)
                 mask = m2f if mask_blocked else m2.to_nchw()     # blocked: the up-sampling kernel reads the convolution's own layout
@@ -297,11 +286,12 @@ class BasicUpdateBlock(nn.Module):
         d1, _ = S.conv(ws.H, self._pk("head1", lambda a=bh.conv1.weight: a), padding=1, shift=bh.conv1.bias, act=S.ACT_RELU)
         # bezier += delta (bezier.py:137-139) and the new Bezier channel block of M are produced by the epilogue
         if d1.shape[0] * d1.H * d1.W <= THIN_HEAD_MAX_PIXELS:
+            # (the merged layout of M needs a producer that writes a few channels of a block: SplitWorkspace.merged implies this branch)
             # a 2*deg-channel output on a grid of 40 patches: the thin vector-ALU kernel, not a 32-wide MFMA tile on 40 workgroups
             S.conv_thin_acc(d1, self.__dict__.setdefault("_head2_w", S.ThinConvWeight()).get(bh.conv2.weight), bh.conv2.bias, bezier,
                             out_split=ws.M, channel_offset=ws.bez_channel)
         else:
-            assert not ws.merged
+            assert not ws.merged, "SplitWorkspace.merged needs the thin head (THIN_HEAD_MAX_PIXELS below the workspace's pixel count?)"
             S.conv(d1, self._pk("head2", lambda a=bh.conv2.weight: a), padding=1, shift=bh.conv2.bias, acc_nchw=bezier, out_split=ws.M,
                    channel_offset=self.motion_dim)
         mask_branch.join()

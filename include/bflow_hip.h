@@ -396,20 +396,6 @@ int bflow_corr_lookup_bezier_split_tiled(const bflow_plane_t* planes, int P, con
                                          bflow_stream_t stream);
 int bflow_corr_pool2x2_tiled(const float* in, float* out, long long planes, int h, int w, bflow_stream_t stream);
 
-/* K7 + convc1 in ONE launch (raft.py:180-184 + corr.py:307-351 + update.py:88 `cor = relu(convc1(corr))`): the tiled look-up above with the
- * 1x1 convolution that consumes its features fused behind it -- the (B, P*81, h1, w1) correlation features never leave the CU.  A workgroup
- * owns <= 28 query pixels x all planes x all output channels (wave w: channels 32 w .. 32 w + 31, weight fragments in registers); the features are bit-identical to bflow_corr_lookup_bezier_split_tiled, the
- * convolution is the split-fp16 product of bflow_conv_split (fp32-class) with its own summation order.
- *   planes / params / coef / T / deg / B / h1 / w1 : as bflow_corr_lookup_bezier_split_tiled (fp32 tiled planes)
- *   w_hi, w_lo : bflow_conv_pack_weights of the (Cout, P*81, 1, 1) filter with cin_pad = 32 * k_blocks, k_blocks = ceil(P*81 / 32), P <= 8
- *                (two gather passes of four planes), Cout <= 256, cout_pad % 32 == 0;  bias (Cout) or NULL;  act: 0 none, 1 ReLU, 2 tanh
- *   out_hi, out_lo : blocked split output (B, out_channel_blocks, out_rows_per_image, 32), written at block `out_block_offset`
- * Shapes outside these limits return BFLOW_E_LIMIT: run the two kernels separately.                                                        */
-int bflow_corr_lookup_conv1x1(const bflow_plane_t* planes, int P, const float* params, const float* coef, int T, int deg,
-                              const void* w_hi, const void* w_lo, int Cout, int cout_pad, int k_blocks, const float* bias, int act,
-                              void* out_hi, void* out_lo, int out_channel_blocks, int out_block_offset, int out_rows_per_image,
-                              int B, int h1, int w1, bflow_stream_t stream);
-
 /* fp16 correlation (BASELINE configs[4]: "fp16 MFMA correlation ... HBM-bound 4D volume stress").  The same three kernels on an fp16
  * volume: the build takes the PLAIN fp16 features (the hi planes of the split operands), runs ONE fp16 MFMA pass with fp32 accumulation
  * and stores fp16 tiled planes (half the bytes, a third of the matrix-core work; accuracy 2^-11 per operand and stored value instead of

@@ -307,44 +307,6 @@ def test_conv_pair_equals_two_launches(case, monkeypatch):
     assert torch.equal(sa.planes, ra.planes) and torch.equal(sb.planes, rb.planes)
 
 
-@pytest.mark.parametrize("deg,B,h,w,levels,cout", [(2, 1, 60, 80, [1, 1, 1, 4], 256), (2, 2, 18, 22, [1, 2, 4], 256), (10, 1, 15, 20, [1, 1, 3], 96),
-                                                   (2, 3, 9, 11, [3], 64), (3, 1, 20, 33, [4], 256), (2, 1, 12, 16, [2, 2, 4], 128), (2, 1, 8, 8, [1], 32), (2, 2, 9, 11, [1, 2, 3], 160), (2, 1, 16, 9, [2], 256)])
-def test_lookup_conv1x1_fused_vs_separate_and_fp64(deg, B, h, w, levels, cout, monkeypatch):
-    """bflow_corr_lookup_conv1x1 (look-up + convc1 + ReLU in one launch; opt-in, BFLOW_LOOKUP_CONV=1) against
-    (a) the same two operations as separate launches (tile look-up -> bflow_conv_split 1x1): same features, the split product in a
-    different summation order, and (b) an fp64 convolution of the separately looked-up features: fp32-class (a few fp32 ulps of the
-    accumulated magnitude).  Plane counts 1 .. 8 (one and two gather passes), tile sizes with partial last workgroups, far-outside
-    coordinates (all-zero windows), output-channel counts that leave waves idle, batch > 1."""
-    from bflow_amd import corr as corr_mod, split as S
-    monkeypatch.setattr(corr_mod, "FUSE_LOOKUP_CONV", True)      # opt-in path (off by default: not faster inside the iteration, see corr.py)
-    T, D = len(levels), 64
-    rs = np.random.RandomState(21)
-    f1, f2 = cu(rs.standard_normal((B, D, h, w)).astype(np.float32)), cu(rs.standard_normal((T, B, D, h, w)).astype(np.float32))
-    params = (rs.standard_normal((B, 2 * deg, h, w)) * 2).astype(np.float32)
-    params[:, :, 0, :3] *= 60.0
-    params[:, :, 1, :] = np.round(params[:, :, 1, :])
-    coef = hip.bezier_coeffs([(i + 1) / T for i in range(T)], deg)
-    blk = CorrBlockParallelMultiTarget(corr_computation_events=CorrComputation(f1, f2, levels), layout="tiled")
-    C = blk.num_planes * 81
-    assert blk.conv1x1_fusable(cout)
-    weight = cu((rs.standard_normal((cout, C, 1, 1)) / np.sqrt(C)).astype(np.float32))
-    bias = cu(rs.standard_normal(cout).astype(np.float32))
-    packed = S.PackedConvWeight().get(weight)
-    feat = blk.lookup_bezier_split(cu(params), coef, blk.new_output_split())
-    sep, _ = S.conv(feat, packed, shift=bias, act=S.ACT_RELU)
-    out = S.SplitTensor.empty(B, h, w, cout + 32, DEV, zero=True)             # written at channel block 1 of a wider buffer
-    blk.lookup_bezier_conv1x1(cu(params), coef, packed, bias, S.ACT_RELU, out, channel_offset=32)
-    got = out.float_nhwc()[..., 32:32 + cout]
-    assert float(out.float_nhwc()[..., :32].abs().max()) == 0.0             # the neighbouring block is left alone
-    x = feat.float_nhwc().double()                                           # (B, h, w, C): the split features ARE the operands of both paths
-    ref = torch.relu(x @ weight.double().reshape(cout, C).t() + bias.double())
-    mag = (x.abs() @ weight.double().reshape(cout, C).abs().t() + bias.double().abs()).clamp_min(1e-3)
-    err_fused = ((got.double() - ref).abs() / mag).max().item()
-    err_sep = ((sep.float_nhwc().double() - ref).abs() / mag).max().item()
-    assert err_fused < 4e-7 and err_sep < 4e-7, (err_fused, err_sep)        # ~3 fp32 ulps of the accumulated magnitude (output split: 2^-22)
-    assert (got - sep.float_nhwc()).abs().max().item() < 2e-6 * float(ref.abs().max())
-
-
 # ------------------------------------------------------------------------------------------------- fp16 correlation (BASELINE configs[4])
 @pytest.mark.parametrize("B,D,h,w,levels,shared", [(1, 256, 60, 80, [1, 1, 1, 4], True), (2, 128, 15, 20, [2, 3], True), (2, 256, 17, 24, [1, 2], False)])
 def test_corr_f16_volume_pyramid_and_lookup(B, D, h, w, levels, shared):
@@ -852,24 +814,6 @@ def test_e2e_forward_vs_reference_golden(golden_dir, name, graph):
     assert (up.get_params()[:, :, ::4, ::4].cpu() - torch.from_numpy(d["bezier_up_sub"])).abs().max().item() < 2e-2
 
 
-def test_e2e_fused_lookup_conv_equals_separate_launches(golden_dir, monkeypatch):
-    """The opt-in fused look-up + convc1 launch inside the whole forward (captured graph): flow within 1e-5 px of the default path (same
-    features, one convolution in a different summation order) and inside the golden bar."""
-    from bflow_amd import corr as corr_mod
-    d = g(golden_dir, "e2e_E_LU4_BD2")
-    cfg, m, sd = _model(str(d["config"]))
-    vox, imgs = _e2e_inputs(d, cfg)
-    flows = []
-    for fused in (False, True):
-        monkeypatch.setattr(corr_mod, "FUSE_LOOKUP_CONV", fused)
-        low, up = m(voxel_grid=vox, images=imgs, iters=int(d["iters"]), test_mode=True)
-        flows.append(up.get_flow_from_reference(1.0).contiguous())
-    assert float(epe_masked(flows[1], cu(d["flow_t1"]))) < EPE_TOL
-    diff = float((flows[0] - flows[1]).norm(dim=1).max())
-    print(f"fused vs separate look-up + convc1: max flow difference {diff:.2e} px")
-    assert diff < 1e-4
-
-
 def test_e2e_train_mode_list_and_flow_init():
     cfg, m, sd = _model("E_LU4_BD2")
     vox = torch.from_numpy(synthetic.voxel_grid(1, 9, 128, 160, seed=8))
@@ -1165,44 +1109,6 @@ def test_no_silent_library_paths(monkeypatch):
     assert torch.isfinite(y).all() and y.shape == (1, 256, 8, 12)
     low, up = m(voxel_grid=vox, iters=2, test_mode=True)       # the inference path itself is untouched
     assert torch.isfinite(up.get_params()).all()
-
-
-@pytest.mark.parametrize("cin,cout,nin", [(64, 96, False), (96, 96, True), (96, 160, False)])
-def test_conv_halo_half_tile_equals_full_tile(cin, cout, nin, monkeypatch):
-    """Layers whose last 64-channel tile is half empty (Cout % 64 in (0, 32]: the encoder's 96-channel stage): the workgroups of that tile skip the
-    fragment reads and MFMAs of the empty half (conv_halo_kernel<..., HT>; opt-in, BFLOW_CONV_HALF_TILE=1: measured neutral).  Same bits as
-    the default kernel, which multiplies the padding, for the plain fp32 + statistics output and for the normalise-on-load input."""
-    from bflow_amd import split as S
-    rs = np.random.RandomState(12)
-    B, H, W = 2, 64, 208                                     # 8 x 13 patches x 2 images x 2 tiles >= 200: the 64-channel-tile grid
-    w = cu((rs.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32))
-    pk = S.PackedConvWeight().get(w)
-    x = cu(rs.standard_normal((B, cin, H, W)).astype(np.float32))
-
-    def run():
-        st = torch.zeros((8, B, cout, 2), dtype=torch.float64, device=DEV)
-        if nin:
-            raw = S.from_nchw(x).float_nhwc().permute(0, 3, 1, 2).contiguous()                # any fp32 "previous convolution output"
-            st_in = torch.zeros((8, B, cin, 2), dtype=torch.float64, device=DEV)
-            blocked = torch.empty((B, cin // 32, H * W, 32), device=DEV)
-            blocked.copy_(raw.view(B, cin // 32, 32, H * W).permute(0, 1, 3, 2))
-            st_in[0, :, :, 0] = raw.double().sum(dim=(2, 3))
-            st_in[0, :, :, 1] = (raw.double() ** 2).sum(dim=(2, 3))
-            out = S.conv_norm_in(blocked, (B, H, W, cin), st_in, pk, stats=st)
-        else:
-            _, out = S.conv(S.from_nchw(x), pk, padding=1, want_split=False, want_f32=True, stats=st)
-        return out.clone(), st.sum(0)
-    monkeypatch.setenv("BFLOW_CONV_HALF_TILE", "1")
-    got, st_a = run()
-    monkeypatch.delenv("BFLOW_CONV_HALF_TILE")
-    want, st_b = run()
-    assert torch.equal(got, want)
-    np.testing.assert_allclose(st_a.cpu().numpy(), st_b.cpu().numpy(), rtol=1e-12, atol=1e-9)
-    if not nin:
-        ref = torch.nn.functional.conv2d(x.cpu().double(), w.cpu().double(), None, padding=1)
-        mag = torch.nn.functional.conv2d(x.cpu().double().abs(), w.cpu().double().abs(), None, padding=1) + 1.0
-        g = S.blocked_f32_to_nhwc(got, H, W, cout).permute(0, 3, 1, 2).cpu().double()
-        assert float(((g - ref).abs() / mag).max()) < 5e-7
 
 
 @pytest.mark.parametrize("cin,cout,k,pad,H,W,B,force", [
