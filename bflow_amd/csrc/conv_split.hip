@@ -2134,9 +2134,10 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
         // 114 -> 96 us / 900 -> 749 us (-16 %), 96 -> 96 72 -> 67 / 533 -> 468 us -- the kernel runs any block count >= 2 (tested), the dispatch
         // takes it where it wins: x_raw always, else two input blocks.  BFLOW_CONV_STREAM=all (tests, A/B) takes it wherever it can run, =0 never.
         static const int stream_mode = [] { const char* e = getenv("BFLOW_CONV_STREAM"); return !e ? 1 : !strcmp(e, "0") ? 0 : !strcmp(e, "all") ? 2 : 1; }();
+        static const long long stream_min_items = [] { const char* e = getenv("BFLOW_CONV_STREAM_MIN_ITEMS"); return e ? atoll(e) : 1024LL; }();   // tools A/B
         const long long items = (long long)patches * d->B * a.n_tiles;
         if (shape == 1 && nt == 2 && direct && (!a.xraw || a.CB <= 4) && !a.x2h && a.act != 2 && stream_mode && !force && a.CB >= 2 && (a.CB == 2 || a.xraw || stream_mode == 2) &&
-            items >= 1024 && items < (1LL << 30)) {
+            items >= stream_min_items && items < (1LL << 30)) {
             // ranges of `per` patches x one channel tile; <= 512 of them (two workgroups per CU), a multiple of 8 x n_tiles (whole XCDs of
             // whole patch ranges; a few trailing workgroups may own no patch)
             const long long bp = (long long)patches * d->B;
