@@ -18,7 +18,7 @@ import torch
 from bflow_amd import hip, split as S
 from bflow_amd.corr import CorrBlockParallelMultiTarget, CorrComputation
 
-CONV_NAME = "conv_halo_kernel<2,3,3> (encoder layer1 3x3 64->64, 5x240x320)"
+CONV_NAME = "conv_halo_stream_kernel<false> (encoder layer1 3x3 64->64, 5x240x320; rounds 1-4: conv_halo_kernel<2,3,3>)"
 HALO8_NAME = ("conv_halo8_pair_kernel<3,3> (motion encoder convc2 | convf2 as ONE launch: 3x3 256->192 and 3x3 128->64, + bias + ReLU, 1x60x80 -- the 8-wave "
               "small-grid 3x3 kernel on its largest launch; the small-grid 3x3 / 1x5 / 5x1 family has the largest total time of the frame)")
 HALO8_REGEX = "conv_halo8_pair_kernel"
