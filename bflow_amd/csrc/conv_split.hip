@@ -2141,17 +2141,24 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
             // ranges of `per` patches x one channel tile; <= 512 of them (two workgroups per CU), a multiple of 8 x n_tiles (whole XCDs of
             // whole patch ranges; a few trailing workgroups may own no patch)
             const long long bp = (long long)patches * d->B;
-            const int per = (int)bflow::ceil_div(bp * a.n_tiles, 512);
-            int g = (int)bflow::ceil_div(bp, per) * a.n_tiles;
-            g = bflow::ceil_div(g, 8 * a.n_tiles) * 8 * a.n_tiles;
+            // <= 512 workgroups (two per CU) = 256 / n_tiles pairs of ranges per channel tile; a pair = an older and a younger workgroup (see the
+            // kernel: blockIdx < gridDim / 2 is dispatched first), which share pair_sum consecutive items share_old : 1 - share_old.
+            // BFLOW_CONV_STREAM_SHARE (percent, tools A/B; 50 = the equal ranges of the first version)
+            static const int share_pct = [] { const char* e = getenv("BFLOW_CONV_STREAM_SHARE"); const int v = e ? atoi(e) : 0; return v >= 50 && v <= 80 ? v : 57; }();
+            const int g = 512;
+            const int pairs = g / a.n_tiles / 2;
+            const int pair_sum = (int)bflow::ceil_div(bp, pairs);
+            int per_old = (pair_sum * share_pct + 50) / 100;
+            if (per_old >= pair_sum && pair_sum > 1) per_old = pair_sum - 1;
+            const int per_young = pair_sum - per_old;
             const int lds = 2 * 2 * 12 * 1024 + 4 * 2 * 4096;
             const int tiles_x = bflow::ceil_div(d->W, 16);
             if (a.xraw) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL(conv_halo_stream_kernel<true>, dim3(g), dim3(CT), lds, s, a, per, patches, tiles_x, (int)bp, d->B);
+                hipLaunchKernelGGL(conv_halo_stream_kernel<true>, dim3(g), dim3(CT), lds, s, a, per_old, per_young, patches, tiles_x, (int)bp, d->B);
             } else {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL(conv_halo_stream_kernel<false>, dim3(g), dim3(CT), lds, s, a, per, patches, tiles_x, (int)bp, d->B);
+                hipLaunchKernelGGL(conv_halo_stream_kernel<false>, dim3(g), dim3(CT), lds, s, a, per_old, per_young, patches, tiles_x, (int)bp, d->B);
             }
             return bflow::launch_status("conv_split(stream)");
         }

@@ -25,16 +25,27 @@
 // the unrolled code (and its register pressure) does not grow with it.  64-channel output tiles (NT = 2).
 //
 // CSTREAM_ABL (tools/enc_stream_ablate.sh only; timing builds with WRONG results): 1 no stores, 2 no in-loop LDS-DMA, 4 no fragment reads,
-// 5 no barrier / vmcnt wait.
+// 5 no barrier / vmcnt wait, 6 a third of the fragment reads less (the weight fragments of the second k-half), 7 half the weight pieces (no
+// counted waits) -- 6 and 7 price a 64 x 64 wave tile / a weight tile per CU before anybody writes them.
 #ifndef CSTREAM_ABL
 #define CSTREAM_ABL 0
+#endif
+// CSTREAM_PIN (tools A/B): 1 = scheduling barriers hold the fragment reads where the source puts them (set 1 of a tap at the top of its step,
+// set 0 of the next tap between the two halves of the matrix work) instead of where the scheduler sinks them (right in front of their use)
+#ifndef CSTREAM_PIN
+#define CSTREAM_PIN 0
+#endif
+// CSTREAM_PRIO (tools A/B): 1 = s_setprio 1 around the matrix instructions of a half step (the wave that has its fragments issues ahead of its
+// SIMD mate's loads and address arithmetic)
+#ifndef CSTREAM_PRIO
+#define CSTREAM_PRIO 0
 #endif
 // NIN (as conv_halo_kernel<..., NIN>): the input is the previous convolution's PRE-NORMALISATION fp32 output + its InstanceNorm statistics
 // (ConvArgs.xraw / xstats); a thread loads 4 channels of a halo row as a float4, applies relu((x - mean) * rstd) with the coefficients the
 // normalisation kernel would use, splits and writes the halo buffer by ds_write -- the LDS image the LDS-DMA path produces.  The six loads
 // of a channel block go in three thirds (taps 1, 3, 5 of the block before; written at taps 3, 5, 7): eight registers, not twenty-four.
 template <bool NIN>
-__global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int per, int n_patches, int tiles_x, int total, int n_images) {
+__global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int per_old, int per_young, int n_patches, int tiles_x, int total, int n_images) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 2, KH = 3, KW = 3, NW = 4;
     constexpr int TH = 2 * NW, TW = 16;
@@ -56,6 +67,9 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
     const int CB = a.CB;
+#ifdef H8_STAMPS   // tools/conv_stamps.sh build: workgroup w -> [4 w]: shader clock / 100 MHz wall clock at its start and end
+    if (a.stamps && tid == 0) { a.stamps[blockIdx.x * 4 + 0] = __builtin_readcyclecounter(); a.stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
     // ---- per-lane constants of the LDS-DMA pieces (independent of the item)
     const int urow = lane >> 2;
@@ -70,6 +84,27 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
     const int wsw = (l31 >> 2) & 3;
     const long long oplane = (long long)a.P_out * 32;  // floats of one channel block of one output image
     const float act_floor = a.act == 1 ? 0.f : -__builtin_inff();      // act 0 / 1 (tanh epilogues stay on conv_halo_kernel: see the dispatch)
+    // Interior patches (the whole halo inside the image: 84 % of the patches at 240 x 320): the source offset of a halo piece is a per-lane
+    // CONSTANT (halo row, column -> hrel) + a per-patch SCALAR that rides in the instruction's scalar offset, so a piece costs no vector
+    // instruction at all; only the patches on the image border (and the out-of-range pieces behind a range's last item) form their
+    // offsets lane by lane with the four bounds checks (`halo_offset` / `nin_load`'s slow path: ~25 instructions per piece).
+    unsigned hrel[NIN ? NHL : AP];
+    if constexpr (NIN) {
+#pragma unroll
+        for (int i = 0; i < NHL; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            const int hy = row / HWD, hx = row - hy * HWD;
+            hrel[i] = row < HR ? (unsigned)(((hy * a.W + hx) * 32 + (tid & 7) * 4) * 4) : 0x80000000u;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const int row = ((wave >> 1) + (NW / 2) * i) * 16 + urow;
+            const int hy = row / HWD, hx = row - hy * HWD;
+            hrel[i] = row < HR ? (unsigned)(((hy * a.W + hx) * 32 + uchunk) * 2) : 0x80000000u;
+        }
+    }
+    auto interior = [&](int y0, int x0) -> bool { return y0 >= 1 && x0 >= 1 && y0 + TH < a.H && x0 + TW < a.W; };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // workgroup -> range.  A range = `per` consecutive patches of the (image, patch) list x ONE channel tile; the ranges are numbered with
@@ -77,11 +112,20 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
     // i.e. both channel tiles of the same patches -- walked at the same time by neighbouring workgroups, so that the halo they share is
     // fetched into that XCD's L2 once (as conv_halo_kernel's "all channel tiles of a patch on one XCD, back to back") -- and a band of
     // ~19 patch rows of an image at the layer-1 size, whose vertically adjacent patches share halo rows
-    const int nwg = gridDim.x;
-    const int chunk = (nwg & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3);
-    const int n0 = (chunk % a.n_tiles) * (32 * NT);
-    int q = (chunk / a.n_tiles) * per;
-    const int q_end = q + per < total ? q + per : total;
+    //
+    // Uneven ranges (round 5, profiles/r05_enc_stream_clock.txt): the two workgroups of a CU do not run at the same speed -- the one that was
+    // dispatched first (blockIdx < gridDim / 2: the dispatcher fills one slot of every CU before it doubles up) needs 16.2 k cycles per item, its
+    // younger mate 21.2 k (the SIMD's issue arbitration prefers the older wave), at the same clock; with equal ranges the older half of the grid
+    // finishes at 0.76 of the launch and the rest of it runs one workgroup per CU.  The older workgroup of a pair therefore takes per_old, the
+    // younger per_young < per_old consecutive items.  The grid is a multiple of 16 n_tiles: an XCD (blockIdx % 8) owns gridDim / 8 n_tiles ranges
+    // = the older ones first, then the younger ones, all consecutive.
+    const int nx = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    const int chunk = xcd * nx + j;
+    const int n0 = (j % a.n_tiles) * (32 * NT);
+    const int rx2 = (nx / a.n_tiles) >> 1, k = j / a.n_tiles;          // pairs of ranges per XCD; this workgroup's range inside the XCD's band
+    const bool older = k < rx2;
+    int q = xcd * rx2 * (per_old + per_young) + (older ? k * per_old : rx2 * per_old + (k - rx2) * per_young);
+    const int q_end = min(q + (older ? per_old : per_young), total);
     while (q < q_end) {
         // ---- one segment: patches q .. seg_end - 1 of ONE image
         const int b = q / n_patches;
@@ -133,13 +177,22 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
             constexpr int hf = decltype(hfc)::value;
             const int ty = m / tiles_x;
             const int y0 = ty * TH, x0 = (m - ty * tiles_x) * TW;
+            if (exists && interior(y0, x0)) {
+                const int sbase = cbi * a.P_in * 128 + ((y0 - 1) * a.W + (x0 - 1)) * 128;
+                nval = (1u << NHH) - 1;                 // (rows >= HR are never written: nin_write checks the row)
+#pragma unroll
+                for (int i = 0; i < NHH; ++i)
+                    nv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_raw, hrel[hf * NHH + i], sbase, 0));
+                return;
+            }
             nval = 0;
 #pragma unroll
             for (int i = 0; i < NHH; ++i) {
-                const int row = (tid >> 3) + 32 * (hf * NHH + i);
+                int row = (tid >> 3) + 32 * (hf * NHH + i);
+                asm volatile("" : "+v"(row));
                 const int hy = row / HWD, hx = row - hy * HWD;
                 const int py = y0 - 1 + hy, px = x0 - 1 + hx;
-                const bool ok = exists && row < HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
+                const bool ok = exists & (row < HR) & ((unsigned)py < (unsigned)a.H) & ((unsigned)px < (unsigned)a.W);
                 nval |= ok ? (1u << i) : 0u;
                 nv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_raw, ok ? (unsigned)(((py * a.W + px) * 32 + ng * 4) * 4) : 0x80000000u,
                                                                                       cbi * a.P_in * 128, 0));
@@ -171,10 +224,11 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
         // LDS-DMA source offsets of the halo of patch m (all out of range when there is no such item: the pieces are issued all the same,
         // the counts stay); formed where the pieces are issued -- twelve registers that would otherwise live through the whole k-loop
         auto halo_offset = [&](int i, int y0, int x0, bool exists) -> unsigned {
-            const int row = ((wave >> 1) + (NW / 2) * i) * 16 + urow;
+            int row = ((wave >> 1) + (NW / 2) * i) * 16 + urow;
+            asm volatile("" : "+v"(row));               // border patches only: re-formed here, not carried through the k-loop in 12 registers
             const int hy = row / HWD, hx = row - hy * HWD;
             const int py = y0 - 1 + hy, px = x0 - 1 + hx;
-            const bool ok = exists && row < HR && py >= 0 && py < a.H && px >= 0 && px < a.W;
+            const bool ok = exists & (row < HR) & ((unsigned)py < (unsigned)a.H) & ((unsigned)px < (unsigned)a.W);
             return ok ? (unsigned)(((py * a.W + px) * 32 + uchunk) * 2) : 0x80000000u;
         };
         // drain side: byte offsets (inside one channel block of the output image) of the two pixel rows of this lane's slab half, for
@@ -211,14 +265,22 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
     {                                                                                                                    \
         const int ty_ = (M) / tiles_x;                                                                                   \
         const int y0_ = ty_ * TH, x0_ = ((M) - ty_ * tiles_x) * TW;                                                      \
-        _Pragma("unroll") for (int i = 0; i < AP; ++i)                                                                   \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (lptr_t)(a_dst + (BUF) * A_BUF + i * (NW / 2) * 1024), 16,     \
-                                                     halo_offset(i, y0_, x0_, (EXISTS)), (CBI) * plane_b, 0, 0);         \
+        if constexpr (!NIN) {                                                                                            \
+            if ((EXISTS) && interior(y0_, x0_)) {                                                                        \
+                const int sb_ = (CBI) * plane_b + ((y0_ - 1) * a.W + (x0_ - 1)) * 64;                                    \
+                _Pragma("unroll") for (int i = 0; i < AP; ++i)                                                           \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (lptr_t)(a_dst + (BUF) * A_BUF + i * (NW / 2) * 1024), 16, hrel[i], sb_, 0, 0); \
+            } else {                                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < AP; ++i)                                                           \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_a, (lptr_t)(a_dst + (BUF) * A_BUF + i * (NW / 2) * 1024), 16, \
+                                                             halo_offset(i, y0_, x0_, (EXISTS)), (CBI) * plane_b, 0, 0); \
+            }                                                                                                            \
+        }                                                                                                                \
     }
 #define STREAM_ISSUE_B(CBI, TAP, SLOT)                                                                                   \
     {                                                                                                                    \
         const int so_ = ((TAP) * CB + (CBI)) * wtile_b;                                                                  \
-        _Pragma("unroll") for (int j = 0; j < NBP; ++j)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < (CSTREAM_ABL == 7 ? NBP / 2 : NBP); ++j)   /* 7: half the weight pieces (a tile per CU) */ \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (SLOT) * B_SLOT + ((wave * NBP + j) % (2 * NT)) * 1024), 16, \
                                                      wvo[j], so_, 0, 0);                                                 \
     }
@@ -236,10 +298,14 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
         } else {                                                                                                         \
             XH = *reinterpret_cast<const half8*>((ABUF) + ao_);                                                          \
             XL = *reinterpret_cast<const half8*>((ABUF) + A_PLANE + ao_);                                                \
-            _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                             \
-                const int wo_ = (n * 32 + l31) * 64 + co_;                                                               \
-                WH[n] = *reinterpret_cast<const half8*>((WSLOT) + wo_);                                                  \
-                WL[n] = *reinterpret_cast<const half8*>((WSLOT) + B_PLANE + wo_);                                        \
+            if (CSTREAM_ABL == 6 && (KS) == 1) {  /* a third of the reads less: what a 64 x 64 wave tile would read per MFMA */    \
+                asm volatile("" : "+v"(WH[0]), "+v"(WL[0]), "+v"(WH[1]), "+v"(WL[1]));                                    \
+            } else {                                                                                                     \
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                         \
+                    const int wo_ = (n * 32 + l31) * 64 + co_;                                                           \
+                    WH[n] = *reinterpret_cast<const half8*>((WSLOT) + wo_);                                              \
+                    WL[n] = *reinterpret_cast<const half8*>((WSLOT) + B_PLANE + wo_);                                    \
+                }                                                                                                        \
             }                                                                                                            \
         }                                                                                                                \
     }
@@ -282,7 +348,7 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
                 constexpr int tm2 = (t + NTAPS - 2) % NTAPS, tm1 = (t + NTAPS - 1) % NTAPS;
                 constexpr int n2 = (KIND < 2 && t >= 2 && tm2 < DTAPS) ? ((tm2 + 1 < DTAPS ? ((tm2 + 1) * 16 + DTAPS - 1) / DTAPS : 16) - (tm2 * 16 + DTAPS - 1) / DTAPS) : 0;
                 constexpr int n1 = (KIND < 2 && t >= 1 && tm1 < DTAPS) ? ((tm1 + 1 < DTAPS ? ((tm1 + 1) * 16 + DTAPS - 1) / DTAPS : 16) - (tm1 * 16 + DTAPS - 1) / DTAPS) : 0;
-                if (CSTREAM_ABL != 5 && CSTREAM_ABL != 1 && CSTREAM_ABL != 2) {
+                if (CSTREAM_ABL != 5 && CSTREAM_ABL != 1 && CSTREAM_ABL != 2 && CSTREAM_ABL != 7) {
                     // (NIN: the raw loads of taps 1, 3 and 5 stand where the halo pieces of tap 1 stand)
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + n2 + n1 + (NIN ? ((t == 2 || t == 4 || t == 6) ? NHH : 0) : (t == 2 ? AP : 0))) : "memory");
                 }
@@ -321,24 +387,31 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
                 // second half of THIS tap -> set 1, first half's matrix work (set 0, read half a step ago), the drain of the previous item,
                 // first half of the NEXT tap -> set 0 (its tile landed before this step's barrier), second half's matrix work
                 STREAM_READ(xh1, xl1, wh1, wl1, abuf, wcur, t, 1)
+                if (CSTREAM_PIN) __builtin_amdgcn_sched_barrier(0);
+                if (CSTREAM_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh0, wh0[n], first ? zero16 : hh[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh0, wl0[n], first ? zero16 : xx[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl0, wh0[n], xx[n], 0, 0, 0);
+                if (CSTREAM_PRIO) __builtin_amdgcn_s_setprio(0);
+                if (CSTREAM_PIN) __builtin_amdgcn_sched_barrier(0);
                 static_for<r_lo, r_hi>([&](auto rc) __attribute__((always_inline)) { drain_store(std::integral_constant<int, (KIND < 2 ? KIND : 0)>{}, rc); });
                 if (t + 1 < NTAPS) {
                     STREAM_READ(xh0, xl0, wh0, wl0, abuf, wnext, (t + 1) % NTAPS, 0)
                 } else {
                     STREAM_READ(xh0, xl0, wh0, wl0, lds + (hbuf ^ 1) * A_BUF, wnext, 0, 0)
                 }
+                if (CSTREAM_PIN) __builtin_amdgcn_sched_barrier(0);
+                if (CSTREAM_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh1, wh1[n], hh[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh1, wl1[n], xx[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl1, wh1[n], xx[n], 0, 0, 0);
+                if (CSTREAM_PRIO) { __builtin_amdgcn_s_setprio(0); if (CSTREAM_PIN) __builtin_amdgcn_sched_barrier(0); }
             });
             hbuf ^= 1;
         };
@@ -399,5 +472,8 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
             __syncthreads();                                        // `red` is LDS the next segment's prologue refills
         }
     }
+#ifdef H8_STAMPS
+    if (a.stamps && tid == 0) { a.stamps[blockIdx.x * 4 + 2] = __builtin_readcyclecounter(); a.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 #endif
 }
