@@ -97,7 +97,12 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     float* s_cy = s_cx + npair;
     int* s_ox = reinterpret_cast<int*>(s_cy + npair);                              // [npair] patch origins (x: aligned down to a unit)
     int* s_oy = s_ox + npair;
-    int* s_at = s_oy + npair;                                // [npair][18]: patch-relative west index of the 9 columns, north index of the 9 rows
+    // [npair] gather record, 16 B: the pair's plane (64-bit address) | tile rows << 16 | tiles per row | origin y << 16 | origin x (16 bits,
+    // signed: the centre is clamped to the plane +- 64) -- everything the gather needs per pair in ONE ds_read_b128, formed ONCE by the pair's thread of phase A (the gather's 48 units per pair looked the plane table up, clamped the
+    // pixel and multiplied 64-bit plane offsets unit by unit: 85 instructions per unit, the largest share of a kernel that is
+    // instruction-bound at batch 8 -- 75 workgroups per CU: profiles/r05_k7_instruction_diet.txt)
+    int* s_rec = s_oy + npair;                               // (16-B aligned: 16 MAX_PLANES + 16 npair bytes precede it)
+    int* s_at = s_rec + 4 * npair;                           // [npair][18]: patch-relative west index of the 9 columns, north index of the 9 rows
     float* s_wt = reinterpret_cast<float*>(s_at + npair * 18);   // [npair][18][2]: (west, east) / (north, south) weights, ZERO where the corner
                                                                  // lies outside the plane (= grid_sample's zero padding) or outside the patch
     float* stage = s_wt + npair * 36;                        // [TP][cstride]: the tile's features in channel order
@@ -152,6 +157,14 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
         s_cy[tid] = cy;
         s_ox[tid] = ox & ~(EPU - 1);                  // floor to a unit boundary (two's complement: also for negative origins)
         s_oy[tid] = (int)floorf(ccy) - (R + 1);
+        const int th = (pl_h + TILE_H - 1) >> 2, tw = (pl_w + TILE_W - 1) >> 3;
+        const long long plane = (long long)b * N + min(n, N - 1);                        // pixels past the end re-read the last one (never stored)
+        const char* pb = reinterpret_cast<const char*>(args.planes[p].base) + plane * (th * tw * 32) * (long long)sizeof(VT);
+        const unsigned long long pbu = (unsigned long long)pb;
+        s_rec[4 * tid + 0] = (int)(unsigned)pbu;
+        s_rec[4 * tid + 1] = (int)(unsigned)(pbu >> 32);
+        s_rec[4 * tid + 2] = (th << 16) | tw;
+        s_rec[4 * tid + 3] = (s_oy[tid] << 16) | (s_ox[tid] & 0xffff);
     }
     __syncthreads();
 
@@ -163,16 +176,21 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
             const int u = min(u0 + lane, units - 1);
             const int pair = u / UPP, ru = u - pair * UPP;
             const int r = ru / UPR, k = ru - r * UPR;
-            const int p = pair / TP, i = pair - p * TP;
-            const int th = (s_h[p] + TILE_H - 1) >> 2, tw = (s_w[p] + TILE_W - 1) >> 3;
+            // (inline assembly: the compiler puts a visible LDS read that redefines the address registers of the LDS-DMA in flight behind
+            //  vmcnt(0) -- the hardware has read them at issue --, which would make every iteration wait for the previous one's gather)
+            typedef int i32x4_ __attribute__((ext_vector_type(4)));
+            i32x4_ rq;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rq) : "v"((unsigned)(size_t)(s_rec + 4 * pair)));
+            const int rec_x = rq[0], rec_y = rq[1], rec_z = rq[2], rec_w = rq[3];
+            const int oy = rec_w >> 16, ox = (int)(short)(rec_w & 0xffff);
+            const int th = rec_z >> 16, tw = rec_z & 0xffff;
             // LDS position (pair, r, k) holds source unit k ^ swz(r, pair): spreads the interpolation's reads over the banks (a patch row is
             // 64 B and a patch 768 B, so without it rows alternate between two bank groups and all pairs share them)
             const int ks = (UPR == 4 && swz_on) ? (k ^ (((r >> 1) ^ pair) & 3)) : k;
-            const int gy = s_oy[pair] + r, gx = s_ox[pair] + ks * EPU;
-            const bool in = gy >= 0 && gy < th * TILE_H && gx >= 0 && gx < tw * TILE_W;   // inside the tile grid (pads included)
-            const long long plane = (long long)b * N + min(n0 + i, N - 1);               // pixels past the end re-read the last one (never stored)
-            const long long off = plane * (th * tw * 32) + (in ? tiled_index(gy, gx, tw) : 0);
-            const char* src = s_base[p] + off * (long long)sizeof(VT);
+            const int gy = oy + r, gx = ox + ks * EPU;
+            const bool in = (unsigned)gy < (unsigned)(th * TILE_H) && (unsigned)gx < (unsigned)(tw * TILE_W);   // inside the tile grid (pads included)
+            const int idx = in ? tiled_index(gy, gx, tw) : 0;     // units outside the grid re-read the slab's first unit (they only meet zero weights)
+            const char* src = reinterpret_cast<const char*>(((unsigned long long)(unsigned)rec_y << 32) | (unsigned)rec_x) + (long long)idx * (int)sizeof(VT);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(reinterpret_cast<char*>(patch) + u0 * 16), 16, 0, 0);
         }
     }
@@ -195,8 +213,8 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
         s_wt[2 * it + 1] = (inpatch && g0 + 1 >= 0 && g0 + 1 < size) ? w1_ : 0.f;
     }
     // pad channels of the last channel block are written as zeros
-    for (int it = tid; it < TP * (cstride - P * NCH); it += THREADS) {
-        const int i = it / (cstride - P * NCH), c = it - i * (cstride - P * NCH);
+    if (tid < TP * (cstride - P * NCH)) {            // (< 32 TP <= THREADS items)
+        const int i = tid / (cstride - P * NCH), c = tid - i * (cstride - P * NCH);
         stage[i * cstride + P * NCH + c] = 0.f;
     }
     __syncthreads();   // (the compiler drains the DMA with vmcnt(0) in front of it)
@@ -315,7 +333,7 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
     static const int abl = [] { const char* e = getenv("BFLOW_LOOKUP_ABL"); return e ? atoi(e) : 0; }();
     const int tp = (tp_env == 2 || tp_env == 4 || tp_env == 8) ? tp_env : 2;
     const int cstride = ((P * NCH + 31) >> 5) * 32;
-    const int lds = 16 * BFLOW_MAX_PLANES + P * tp * (4 + 18 + 36) * 4 + P * tp * PATCH * 16 * (f16_planes ? 3 : 4) + tp * cstride * 4 + 1024;
+    const int lds = 16 * BFLOW_MAX_PLANES + P * tp * (4 + 4 + 18 + 36) * 4 + P * tp * PATCH * 16 * (f16_planes ? 3 : 4) + tp * cstride * 4 + 1024;
     Im2colArgs m = {};
     int rider_blocks = 0;
     if (rider) {
