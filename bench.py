@@ -40,6 +40,12 @@ H, W, ITERS, CFG = 480, 640, 12, "E_LU4_BD2"
 GLOBAL_BATCH, MICRO_BATCH = 64, 8          # BASELINE configs[3]
 PEAK_SPLIT_TFLOPS = round(2500.0 / 3, 1)   # fp16 dense MFMA peak (~2.5 PFLOP/s) / 3 MFMA passes per fp32-class product
 PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# Shader clock a PURE stream of the split format's matrix instructions (6 x v_mfma_f32_32x32x16_f16 per 32-channel block, random data, nothing
+# else) sustains on this part: 1.39-1.58 GHz (tools/micro/fp8_cross, profiles/r05_mfma_clock_fp8_cross.txt) -- the chip clocks to its power
+# budget, so the 2.4-GHz peak is not reachable by ANY kernel that keeps the matrix pipes busy.  The encoder's persistent convolution runs at
+# 1.31-1.38 GHz (batch 40) / 1.6-1.7 GHz (batch 5) with the matrix pipes 0.75 busy in cycles (profiles/r05_enc_stream_clock.txt).
+MFMA_STREAM_SUSTAINED_GHZ = 1.5
+PEAK_CLOCK_GHZ = 2.4
 K5_SUSTAINED_GHZ = 1.7                     # shader clock of K5 under load (cycle stamps / wall clock per workgroup: profiles/r0x_k5_stamps_split8.txt, 1.66-1.8)
 PMC_FILE = "r05_pmc.json"                  # rocprofv3 --pmc evidence of this round (tools/collect_profiles.sh)
 
@@ -337,7 +343,13 @@ def main():
                      "frac": round(tf / PEAK_SPLIT_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4), "flop_per_launch": k["flops"],
                      "algorithmic_bytes_per_launch": k["bytes"],
                      "note": "algorithmic (fp32-equivalent) FLOPs; the split scheme executes 3 fp16 MFMAs per product, so "
-                             "peak = 2500 TFLOP/s fp16 dense / 3"}
+                             "peak = 2500 TFLOP/s fp16 dense / 3",
+                     # second reading of the same number: against what the matrix pipes deliver at the clock the chip SUSTAINS under a pure
+                     # matrix stream (power-limited); `frac` above stays against the 2.4-GHz peak
+                     "power_model": {"mfma_stream_clock_ghz": MFMA_STREAM_SUSTAINED_GHZ,
+                                     "peak_at_that_clock": round(PEAK_SPLIT_TFLOPS * MFMA_STREAM_SUSTAINED_GHZ / PEAK_CLOCK_GHZ, 1),
+                                     "frac_of_that": round(tf / (PEAK_SPLIT_TFLOPS * MFMA_STREAM_SUSTAINED_GHZ / PEAK_CLOCK_GHZ), 4),
+                                     "source": "profiles/r05_mfma_clock_fp8_cross.txt (1.39-1.58 GHz), profiles/r05_enc_stream_clock.txt"}}
             else:
                 gbs = k["bytes"] / (ms * 1e-3) / 1e9
                 r = {"kernel": k["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -447,7 +459,8 @@ def main():
                           "k1_int_xy_frac": g("voxel_kernels", "k1_int_xy", "frac"), "k2_frac": g("voxel_kernels", "k2_norm", "frac"),
                           "frac": fr, "lookup_frac_of_line_cap": g("roofline_lookup", "frac_of_line_granular_cap"),
                           "lookup_c4_frac_of_line_cap": g("roofline_lookup_c4_shard", "frac_of_line_granular_cap"),
-                          "k5_model_cap": g("roofline_corr_build", "model_cap", "frac"), "cpu_frames_s": g("cpu_baseline", "value"),
+                          "k5_model_cap": g("roofline_corr_build", "model_cap", "frac"),
+                          "roofline_frac_at_sustained_mfma_clock": g("roofline", "power_model", "frac_of_that"), "cpu_frames_s": g("cpu_baseline", "value"),
                           "gpu_stage_ms": {k: v for k, v in (out.get("gpu_stage_ms") or {}).items() if isinstance(v, (int, float))},
                           "epe_ranks_gathered": out.get("epe_ranks_gathered"), "rccl": out.get("rccl_version")}
         print(json.dumps(out), flush=True)

@@ -102,6 +102,13 @@ class BasicEncoder(nn.Module):
         """Eval-mode BatchNorm folded with the conv bias: y = conv * scale + shift.  Cached per (norm, bias) until a source
         tensor changes (load_state_dict, .to(device)), so the steady-state forward launches nothing for it."""
         cache = self.__dict__.setdefault("_affine_cache", {})
+        if not isinstance(norm, nn.BatchNorm2d):      # norm_fn = 'none' (extractor.py:33-37,69-70: an empty nn.Sequential): y = conv + bias
+            key = (conv_bias.data_ptr(), conv_bias._version)
+            hit = cache.get(id(conv_bias))
+            if hit is None or hit[0] != key:
+                hit = (key, torch.ones_like(conv_bias, dtype=torch.float32), conv_bias.detach().float().contiguous())
+                cache[id(conv_bias)] = hit
+            return hit[1], hit[2]
         srcs = [norm.weight, norm.bias, norm.running_mean, norm.running_var] + ([conv_bias] if conv_bias is not None else [])
         key = tuple((t.data_ptr(), t._version) for t in srcs)
         hit = cache.get(id(norm))
@@ -115,6 +122,31 @@ class BasicEncoder(nn.Module):
             cache[id(norm)] = hit
         return hit[1], hit[2]
 
+    @staticmethod
+    def _group_stats(st: torch.Tensor, norm: nn.GroupNorm, hw: int) -> torch.Tensor:
+        """GroupNorm (extractor.py:13-19,63-64: groups of 8 channels, per-channel affine) through the InstanceNorm machinery.  The conv
+        epilogues deliver per-(image, channel) sums and sums of squares (fp64, `st`: (R, n, C, 2)); a group's statistics are the sums over
+        its channels, and the normalisation of channel c of image b is the affine map x * mul + add with mul = rstd_g * gamma_c,
+        add = beta_c - mean_g * mul.  The normalisation kernel derives (mul, add) from a statistics table as 1 / sqrt(var + eps) and
+        -mean * mul, so the table handed to it is REWRITTEN to the (mean', var') that produce exactly these coefficients with eps = 0:
+        mean' = -add / mul, var' = 1 / mul^2.  A few tiny fp64 torch kernels per normalised convolution: this norm_fn is supported for the
+        constructor surface of the reference (no shipped experiment uses it), not tuned.  gamma must be positive (checked once per weight
+        version in `check_engine_support`)."""
+        s = st.sum(0)                                        # (n, C, 2)
+        n, C, _ = s.shape
+        G = norm.num_groups
+        cpg = C // G
+        sg = s.view(n, G, cpg, 2).sum(2)                     # (n, G, 2)
+        cnt = float(hw * cpg)
+        mean_g = sg[..., 0] / cnt
+        var_g = (sg[..., 1] / cnt - mean_g * mean_g).clamp_min(0.0)
+        rstd_g = torch.rsqrt(var_g + norm.eps)
+        mul = rstd_g.repeat_interleave(cpg, dim=1) * norm.weight.double()
+        add = norm.bias.double() - mean_g.repeat_interleave(cpg, dim=1) * mul
+        mean_p = -add / mul
+        var_p = 1.0 / (mul * mul)
+        return torch.stack((mean_p * hw, (var_p + mean_p * mean_p) * hw), dim=-1).unsqueeze(0).contiguous()   # (1, n, C, 2)
+
     def forward_split(self, x, out_rows: Optional[int] = None, trunk_only: bool = False, after_layer=None):
         """The same network on the split-fp16 MFMA engine (csrc/conv_split.hip): channels-last split activations, implicit-GEMM
         convolutions with bias / folded BatchNorm / ReLU / InstanceNorm statistics fused into their epilogues, and one
@@ -122,7 +154,14 @@ class BasicEncoder(nn.Module):
         pixel rows of the result with zeros (K5 wants a multiple of 128).  after_layer = (i, fn): fn() is called once the launches of
         layer i are enqueued (the caller forks work there that should start behind them, e.g. the context encoder)."""
         kind = self.norm_fn
-        assert kind in ("instance", "batch"), kind
+        assert kind in ("instance", "batch", "group", "none"), kind
+        group = kind == "group"
+        if group:
+            kind = "instance"          # the statistics path; every table is rewritten by `_group_stats` behind its convolution, nothing is fused on load
+        elif kind == "none":
+            kind = "batch"             # the affine path with the identity (scale 1, shift = conv bias)
+        neps = 0.0 if group else 1e-5  # eps of the normalisation kernel (GroupNorm's own eps sits inside the rewritten table)
+        fuse_in = FUSE_NORM_IN and not group
         n = x.shape[0]
         dev = x.device
         # InstanceNorm statistics of all 16 normalised convolutions: ONE zero-filled arena per forward.  Every table has STATS_R
@@ -130,6 +169,7 @@ class BasicEncoder(nn.Module):
         # fp64 atomics to the same 128 addresses per image serialise otherwise (+20 % on these launches, measured).
         R = STATS_R
         arena = torch.zeros((16 * R * n * 128 * 2,), dtype=torch.float64, device=dev) if kind == "instance" else None
+        gs = (lambda st, norm, hw: self._group_stats(st, norm, hw)) if group else (lambda st, norm, hw: st)
         used = [0]
 
         def new_stats(c):
@@ -148,14 +188,16 @@ class BasicEncoder(nn.Module):
         raw0 = None                # (f0, st0): the stem's pre-normalisation output when relu(norm1(conv1)) is never materialised
         if kind == "instance":     # the conv bias cancels under InstanceNorm; statistics come out of the epilogue
             st0 = new_stats(c0)
-            _, f0 = S.conv_stem(xin, pk0, stats=st0, want_split=False, want_f32=True)
-            if FUSE_NORM_IN and FUSE_NORM_IN_STEM and c0 <= 128 and c0 % 32 == 0 and self.layer1[0].conv1.stride[0] == 1:
+            # (the conv bias cancels under InstanceNorm and is never added; under GroupNorm it does not: channels of a group differ in it)
+            _, f0 = S.conv_stem(xin, pk0, stats=st0, want_split=False, want_f32=True, shift=self.conv1.bias if group else None)
+            st0 = gs(st0, self.norm1, h0 * w0)
+            if fuse_in and FUSE_NORM_IN_STEM and c0 <= 128 and c0 % 32 == 0 and self.layer1[0].conv1.stride[0] == 1:
                 # extractor.py:113 `x = relu(norm1(conv1(x)))` has two consumers: layer1.0.conv1 normalises it on load (x_raw), and the
                 # block's residual `x + y` (extractor.py:55) takes it as relu(norm_b(b)) inside the block-end kernel: one launch and one
                 # read + write of the half-resolution map less
                 raw0, cur = (f0, st0), None
             else:
-                cur, _ = S.norm_act(f0, (n, h0, w0, c0), stats_a=st0, act_a=S.ACT_RELU)
+                cur, _ = S.norm_act(f0, (n, h0, w0, c0), stats_a=st0, act_a=S.ACT_RELU, eps=neps)
         else:                      # folded BatchNorm + ReLU in the epilogue: the stem is ONE launch
             sc, sh = self._bn_affine(self.norm1, self.conv1.bias)
             cur, _ = S.conv_stem(xin, pk0, scale=sc, shift=sh, act=S.ACT_RELU)
@@ -167,8 +209,9 @@ class BasicEncoder(nn.Module):
             pk = self._packed(name, conv)
             if kind == "instance":
                 st = new_stats(conv.out_channels)
-                _, f = S.conv(src, pk, stride=stride, padding=pad, want_split=False, want_f32=True, stats=st)
-                return f, st
+                _, f = S.conv(src, pk, stride=stride, padding=pad, want_split=False, want_f32=True, stats=st, shift=conv.bias if group else None)
+                ho_, wo_ = out_hw(src, conv, stride)
+                return f, gs(st, norm, ho_ * wo_)
             sc, sh = self._bn_affine(norm, conv.bias)
             _, f = S.conv(src, pk, stride=stride, padding=pad, scale=sc, shift=sh, act=S.ACT_RELU if relu else S.ACT_NONE,
                           want_split=False, want_f32=True)
@@ -183,7 +226,7 @@ class BasicEncoder(nn.Module):
             ho_wo = out_hw(src, conv, stride)
             if kind == "instance":
                 f, st = conv_norm(name, conv, norm, src, stride, True)
-                out, _ = S.norm_act(f, (n, ho_wo[0], ho_wo[1], conv.out_channels), stats_a=st, act_a=S.ACT_RELU)
+                out, _ = S.norm_act(f, (n, ho_wo[0], ho_wo[1], conv.out_channels), stats_a=st, act_a=S.ACT_RELU, eps=neps)
                 return out
             sc, sh = self._bn_affine(norm, conv.bias)
             out, _ = S.conv(src, pk, stride=stride, padding=conv.padding, scale=sc, shift=sh, act=S.ACT_RELU)
@@ -194,7 +237,7 @@ class BasicEncoder(nn.Module):
             for bi, blk in enumerate(layer):
                 stride = blk.conv1.stride[0]
                 pre = f"layer{li}.{bi}"
-                if kind == "instance" and FUSE_NORM_IN and blk.conv1.out_channels <= 128 and blk.conv1.out_channels % 32 == 0:
+                if kind == "instance" and fuse_in and blk.conv1.out_channels <= 128 and blk.conv1.out_channels % 32 == 0:
                     # relu(norm1(conv1(x))) is never materialised: conv2 normalises conv1's fp32 output while it stages its halo
                     # (bflow_conv_desc_t.x_raw): the same arithmetic, one read + write of the activation and one launch less
                     if raw0 is not None and li == 1 and bi == 0:
@@ -230,15 +273,15 @@ class BasicEncoder(nn.Module):
                     shape = (n, a1.H, a1.W, blk.conv2.out_channels)
                 if blk.downsample is None and raw0 is not None and li == 1 and bi == 0:
                     # relu(x + relu(norm2(conv2))) with x = relu(norm1(stem)) taken from the stem's raw output
-                    cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU, b=raw0[0], stats_b=raw0[1], act_b=S.ACT_RELU, act_out=S.ACT_RELU)
+                    cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU, b=raw0[0], stats_b=raw0[1], act_b=S.ACT_RELU, act_out=S.ACT_RELU, eps=neps)
                 elif blk.downsample is None:
                     # relu(x + relu(norm2(conv2)))          (extractor.py:50-55)
                     cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU if kind == "instance" else S.ACT_NONE, res=cur,
-                                        act_out=S.ACT_RELU)
+                                        act_out=S.ACT_RELU, eps=neps)
                 else:
                     d, std = conv_norm(pre + ".downsample.0", blk.downsample[0], blk.norm3, cur, stride, False)
                     cur, _ = S.norm_act(c2, shape, stats_a=st2, act_a=S.ACT_RELU if kind == "instance" else S.ACT_NONE, b=d, stats_b=std,
-                                        act_out=S.ACT_RELU)
+                                        act_out=S.ACT_RELU, eps=neps)
             if after_layer is not None and after_layer[0] == li:
                 after_layer[1]()
         if trunk_only:      # the caller applies the 1x1 projection itself (e.g. split into tanh / relu halves, raft.py:145-147)

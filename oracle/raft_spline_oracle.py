@@ -40,10 +40,12 @@ def _encoder_shapes(prefix: str, c_in: int, c_out: int, norm: str, out: Dict[str
         out[f"{prefix}.{name}.bias"] = (co,)
 
     def bn(name, c):
-        if norm != "batch":
-            return  # InstanceNorm2d has no parameters (affine=False), extractor.py:27-31
+        if norm not in ("batch", "group"):
+            return  # InstanceNorm2d has no parameters (affine=False), extractor.py:27-31; 'none' is an empty nn.Sequential (:33-37)
         out[f"{prefix}.{name}.weight"] = (c,)
         out[f"{prefix}.{name}.bias"] = (c,)
+        if norm == "group":
+            return  # nn.GroupNorm: affine parameters only (extractor.py:15-19)
         out[f"{prefix}.{name}.running_mean"] = (c,)
         out[f"{prefix}.{name}.running_var"] = (c,)
         out[f"{prefix}.{name}.num_batches_tracked"] = ()
@@ -173,6 +175,8 @@ def _norm(sd: StateDict, name: str, x: Tensor, kind: str, training: bool = False
         #                     (momentum 0.1) -- freeze_bn (raft.py:75-78) is defined but never called by the reference's training
         return F.batch_norm(x, sd[f"{name}.running_mean"], sd[f"{name}.running_var"],
                             sd[f"{name}.weight"], sd[f"{name}.bias"], training=training, momentum=0.1, eps=1e-5)
+    if kind == "group":     # extractor.py:13-19 (num_groups = planes // 8) and :63-64 (8 groups of the stem's 64 channels): C // 8 both times
+        return F.group_norm(x, x.shape[1] // 8, sd[f"{name}.weight"], sd[f"{name}.bias"], eps=1e-5)
     if kind == "none":
         return x
     raise NotImplementedError(kind)

@@ -814,6 +814,28 @@ def test_e2e_forward_vs_reference_golden(golden_dir, name, graph):
     assert (up.get_params()[:, :, ::4, ::4].cpu() - torch.from_numpy(d["bezier_up_sub"])).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("fnorm,cnorm", [("group", "none"), ("none", "group"), ("group", "batch")])
+def test_e2e_other_encoder_norms_vs_oracle(fnorm, cnorm):
+    """The rest of the reference's encoder constructor surface on the HIP engine (extractor.py:13-37,63-70): norm_fn 'group' (GroupNorm through
+    the InstanceNorm kernels on rewritten statistics, BasicEncoder._group_stats) and 'none' (the affine epilogue with the identity).  The
+    oracle's restatement of both is pinned against the live reference in tests/test_oracle_vs_reference.py."""
+    import copy
+    cfg = copy.deepcopy(configs.model_config("E_LU4_BD2"))
+    cfg["feature"]["norm"], cfg["context"]["norm"] = fnorm, cnorm
+    m = bflow_amd.RAFTSpline(cfg).eval()
+    sd = O.make_state_dict(cfg, seed=4, gain=0.35)      # (an encoder without normalisation overflows on the gains tuned for normalised ones)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    vox = torch.from_numpy(synthetic.voxel_grid(2, 9, 128, 160, seed=9))
+    low, up = m(voxel_grid=vox.to(DEV), iters=3, test_mode=True)
+    with torch.inference_mode():
+        olo, oup = O.forward(sd, cfg, vox, None, iters=3, test_mode=True)
+    assert bool(torch.isfinite(oup).all()) and float(oup.abs().max()) > 1e-3
+    e = float(O.epe_masked(up.get_flow_from_reference(1.0).cpu(), O.bezier_flow(oup, 1.0)))
+    print(f"fnet {fnorm} / cnet {cnorm}: EPE vs oracle {e:.2e} px (|flow| max {float(O.bezier_flow(oup, 1.0).abs().max()):.2f})")
+    assert e < EPE_TOL
+
+
 def test_e2e_train_mode_list_and_flow_init():
     cfg, m, sd = _model("E_LU4_BD2")
     vox = torch.from_numpy(synthetic.voxel_grid(1, 9, 128, 160, seed=8))

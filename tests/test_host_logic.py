@@ -80,15 +80,22 @@ def test_unsupported_configurations_raise_instead_of_falling_back():
     from bflow_amd import configs, hip
     base = configs.model_config("E_LU4_BD2")
     cases = []
-    c = copy.deepcopy(base); c["feature"]["norm"] = "group"; cases.append((c, "norm_fn"))
+    c = copy.deepcopy(base); c["feature"]["norm"] = "layer"; cases.append((c, None))     # not a norm_fn of the reference either (extractor.py:13-37)
     c = copy.deepcopy(base); c["feature"]["dim"] = 96; cases.append((c, "output dim 96"))
     c = copy.deepcopy(base); c["bezier_degree"] = 20; cases.append((c, "bezier_degree"))
     c = copy.deepcopy(base); c["motion"]["dim"] = 100; cases.append((c, "multiples of 32"))
     for cfg, needle in cases:
+        if needle is None:
+            with _pt.raises(NotImplementedError):
+                bflow_amd.RAFTSpline(cfg)
+            continue
         m = bflow_amd.RAFTSpline(cfg)
         with _pt.raises(hip.BflowHipError) as ei:
             m.check_engine_support()
         assert needle in str(ei.value), (needle, str(ei.value))
+    for fn, cn in (("group", "none"), ("none", "group")):       # round 5: the whole norm_fn surface of the reference passes
+        c = copy.deepcopy(base); c["feature"]["norm"], c["context"]["norm"] = fn, cn
+        bflow_amd.RAFTSpline(c).check_engine_support()
     bflow_amd.RAFTSpline(base).check_engine_support()     # every shipped configuration passes
     for name in configs.EXPERIMENTS:
         bflow_amd.RAFTSpline(configs.model_config(name)).check_engine_support()

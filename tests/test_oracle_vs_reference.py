@@ -48,6 +48,29 @@ def test_forward_and_state_dict(ref, cname, B, H, W, iters):
         assert torch.equal(up.get_flow_from_reference(t), O.bezier_flow(oup, t))
 
 
+@pytest.mark.parametrize("fnorm,cnorm", [("group", "none"), ("none", "group")])
+def test_other_encoder_norms_match_reference(ref, fnorm, cnorm):
+    """The rest of the reference's encoder constructor surface (extractor.py:13-37,63-70): norm_fn 'group' and 'none' -- state-dict keys /
+    shapes and the forward, bit for bit."""
+    import copy
+    cfg = copy.deepcopy(O.model_config("E_LU4_BD2"))
+    cfg["feature"]["norm"], cfg["context"]["norm"] = fnorm, cnorm
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref.RAFTSpline(cfg).eval()
+    ref_sd = model.state_dict()
+    shapes = O.param_shapes(cfg)
+    assert list(ref_sd.keys()) == list(shapes.keys())
+    assert all(tuple(ref_sd[k].shape) == shapes[k] for k in shapes)
+    sd = O.make_state_dict(cfg, seed=4, gain=0.35)     # (an encoder without normalisation overflows on the gains tuned for normalised ones)
+    model.load_state_dict(sd)
+    vox = torch.from_numpy(synthetic.voxel_grid(1, 9, 128, 160, seed=9))
+    with torch.inference_mode():
+        lo, up = model(voxel_grid=vox, iters=2, test_mode=True)
+        olo, oup = O.forward(sd, cfg, vox, None, iters=2, test_mode=True)
+    assert bool(torch.isfinite(oup).all()) and float(oup.abs().max()) > 1e-3
+    assert torch.equal(lo.get_params(), olo) and torch.equal(up.get_params(), oup)
+
+
 def test_flow_init_warm_start(ref):
     cfg = O.model_config("E_LU4_BD2")
     with contextlib.redirect_stdout(io.StringIO()):
