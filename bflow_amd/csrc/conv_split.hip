@@ -2137,7 +2137,7 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
         static const long long stream_min_items = [] { const char* e = getenv("BFLOW_CONV_STREAM_MIN_ITEMS"); return e ? atoll(e) : 1024LL; }();   // tools A/B
         const long long items = (long long)patches * d->B * a.n_tiles;
         if (shape == 1 && nt == 2 && direct && (!a.xraw || a.CB <= 4) && !a.x2h && a.act != 2 && stream_mode && !force && a.CB >= 2 && (a.CB == 2 || a.xraw || stream_mode == 2) &&
-            items >= stream_min_items && items < (1LL << 30)) {
+            items >= stream_min_items && items < (1LL << 30) && a.n_tiles <= 32) {
             // ranges of `per` patches x one channel tile; <= 512 of them (two workgroups per CU), a multiple of 8 x n_tiles (whole XCDs of
             // whole patch ranges; a few trailing workgroups may own no patch)
             const long long bp = (long long)patches * d->B;
@@ -2145,7 +2145,7 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
             // kernel: blockIdx < gridDim / 2 is dispatched first), which share pair_sum consecutive items share_old : 1 - share_old.
             // BFLOW_CONV_STREAM_SHARE (percent, tools A/B; 50 = the equal ranges of the first version)
             static const int share_pct = [] { const char* e = getenv("BFLOW_CONV_STREAM_SHARE"); const int v = e ? atoi(e) : 0; return v >= 50 && v <= 80 ? v : 57; }();
-            const int g = 512;
+            const int g = 512 / (16 * a.n_tiles) * (16 * a.n_tiles);   // whole pairs of ranges per XCD for every channel tile (n_tiles = 3: 480)
             const int pairs = g / a.n_tiles / 2;
             const int pair_sum = (int)bflow::ceil_div(bp, pairs);
             int per_old = (pair_sum * share_pct + 50) / 100;

@@ -1005,6 +1005,7 @@ def test_conv_fp32_stats_and_direct_kernels_vs_fp64(cin, cout, k, stride, pad, H
     (96, 96, 120, 160, 5, False),     # encoder layer 2 at its own size: three input channel blocks (the third runs the no-drain body)
     (128, 128, 60, 80, 16, True),     # four input channel blocks, a ragged last patch row (60 = 7.5 x 8)
     (160, 64, 72, 112, 24, False),    # five
+    (64, 192, 64, 96, 12, True),      # three channel tiles: the grid is 480 workgroups (whole older / younger pairs of ranges per XCD and tile)
 ])
 def test_conv_stream_kernel_vs_fp64_and_halo_kernel(cin, cout, H, W, B, relu, monkeypatch):
     """conv_halo_stream_kernel (round 5: persistent workgroups, the store drain of item i between the MFMAs of item i + 1, statistics kept
