@@ -2143,8 +2143,11 @@ static int conv_split_impl(const bflow_conv_desc_t* d, bflow_stream_t stream, Pa
             const long long bp = (long long)patches * d->B;
             // <= 512 workgroups (two per CU) = 256 / n_tiles pairs of ranges per channel tile; a pair = an older and a younger workgroup (see the
             // kernel: blockIdx < gridDim / 2 is dispatched first), which share pair_sum consecutive items share_old : 1 - share_old.
-            // BFLOW_CONV_STREAM_SHARE (percent, tools A/B; 50 = the equal ranges of the first version)
-            static const int share_pct = [] { const char* e = getenv("BFLOW_CONV_STREAM_SHARE"); const int v = e ? atoi(e) : 0; return v >= 50 && v <= 80 ? v : 57; }();
+            // BFLOW_CONV_STREAM_SHARE (percent for the older one; tools A/B).  Default 50 = equal ranges: 57 : 43 shortens the launch ALONE by 2-3 %
+            // (profiles/r05_enc_stream_clock.txt) but not the frame (303.8 vs 301.2 frames/s over three alternating pairs, c4_strong equal:
+            // profiles/r05_stream_share_frame_ab.txt) -- next to the context encoder's launches the early-finishing older workgroups are the CUs
+            // (and the LDS) those launches get
+            static const int share_pct = [] { const char* e = getenv("BFLOW_CONV_STREAM_SHARE"); const int v = e ? atoi(e) : 0; return v >= 50 && v <= 80 ? v : 50; }();
             const int g = 512 / (16 * a.n_tiles) * (16 * a.n_tiles);   // whole pairs of ranges per XCD for every channel tile (n_tiles = 3: 480)
             const int pairs = g / a.n_tiles / 2;
             const int pair_sum = (int)bflow::ceil_div(bp, pairs);

@@ -116,8 +116,8 @@ __global__ __launch_bounds__(CT, 2) void conv_halo_stream_kernel(ConvArgs a, int
     // Uneven ranges (round 5, profiles/r05_enc_stream_clock.txt): the two workgroups of a CU do not run at the same speed -- the one that was
     // dispatched first (blockIdx < gridDim / 2: the dispatcher fills one slot of every CU before it doubles up) needs 16.2 k cycles per item, its
     // younger mate 21.2 k (the SIMD's issue arbitration prefers the older wave), at the same clock; with equal ranges the older half of the grid
-    // finishes at 0.76 of the launch and the rest of it runs one workgroup per CU.  The older workgroup of a pair therefore takes per_old, the
-    // younger per_young < per_old consecutive items.  The grid is a multiple of 16 n_tiles: an XCD (blockIdx % 8) owns gridDim / 8 n_tiles ranges
+    // finishes at 0.76 of the launch and the rest of it runs one workgroup per CU.  The older workgroup of a pair can therefore take per_old, the
+    // younger per_young <= per_old consecutive items (the dispatch's BFLOW_CONV_STREAM_SHARE; equal by default: see there).  The grid is a multiple of 16 n_tiles: an XCD (blockIdx % 8) owns gridDim / 8 n_tiles ranges
     // = the older ones first, then the younger ones, all consecutive.
     const int nx = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
     const int chunk = xcd * nx + j;
