@@ -246,29 +246,38 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     __syncthreads();
 
     // ---- phase D: output in memory order.  item = (channel block, pixel, 8-channel chunk), chunk fastest: 16 B of hi + 16 B of lo ----------
+    // (round 5, instruction diet: the staged values are read as two 16-B vectors -- stage rows are 128-B aligned --, and the stores go through
+    //  one buffer descriptor per plane and image with a 32-bit offset: the per-item 64-bit row arithmetic was a tenth of this phase)
     const int items = (cstride >> 5) * TP * 4;
+    const long long img = (long long)b * CBk * Prow * 32;                         // elements of the images before this one
+    const __amdgpu_buffer_rsrc_t r_oh = __builtin_amdgcn_make_buffer_rsrc((void*)(oh + img), 0, CBk * Prow * 64, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_ol = __builtin_amdgcn_make_buffer_rsrc((void*)(ol + img), 0, CBk * Prow * 64, 0x00020000);
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    typedef int i32x4v_ __attribute__((ext_vector_type(4)));
     for (int it = tid; it < items && !(abl & 4); it += THREADS) {
         const int chunk = it & 3, i = (it >> 2) % TP, cb = it / (4 * TP);
         const int n = n0 + i;
         if (n >= N) continue;
-        const float* sp = stage + i * cstride + cb * 32 + chunk * 8;
+        const f32x4_* sp = reinterpret_cast<const f32x4_*>(stage + i * cstride + cb * 32 + chunk * 8);
+        const f32x4_ v0 = sp[0], v1 = sp[1];
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         half8 h8, l8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             _Float16 hh, ll;
-            bflow::split1(sp[j], hh, ll);
+            bflow::split1(v[j], hh, ll);
             h8[j] = hh;
             l8[j] = ll;
         }
-        const long long o = (((long long)b * CBk + cb) * Prow + n) * 32 + chunk * 8;
+        const unsigned o = (unsigned)(((cb * Prow + n) * 32 + chunk * 8) * 2);    // bytes inside the image's plane (< 2^31: checked by the launcher)
         // non-temporal: the consumer (convc1) is the next kernel and starts with a cold L2 anyway; the 13.5 MB of features then leave during
         // the kernel instead of in the write-back at its end (round 4: 12.8 -> 11.8 us at C2; LOOKUP_PLAIN_STORES for A/B)
 #ifdef LOOKUP_PLAIN_STORES
-        *reinterpret_cast<half8*>(oh + o) = h8;
-        *reinterpret_cast<half8*>(ol + o) = l8;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4v_, h8), r_oh, o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4v_, l8), r_ol, o, 0, 0);
 #else
-        __builtin_nontemporal_store(h8, reinterpret_cast<half8*>(oh + o));
-        __builtin_nontemporal_store(l8, reinterpret_cast<half8*>(ol + o));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4v_, h8), r_oh, o, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4v_, l8), r_ol, o, 0, 2);
 #endif
     }
 }
@@ -311,6 +320,7 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
     BFLOW_REQUIRE(params && coef && out_hi && out_lo && B > 0 && h1 > 0 && w1 > 0, BFLOW_E_ARG, "corr_lookup_bezier_split: bad arguments");
     BFLOW_REQUIRE(B <= 65535, BFLOW_E_LIMIT, "corr_lookup_bezier_split: batch %d", B);
     BFLOW_REQUIRE(channel_blocks * 32 >= P * NCH && rows_per_image >= h1 * w1, BFLOW_E_ARG, "corr_lookup_bezier_split: output too small");
+    BFLOW_REQUIRE((long long)channel_blocks * rows_per_image * 64 < (1LL << 31), BFLOW_E_LIMIT, "corr_lookup_bezier_split: one image's feature plane exceeds 2 GiB");
     TileArgs a;
     a.P = P;
     a.T = T;
