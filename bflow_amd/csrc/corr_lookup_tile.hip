@@ -19,7 +19,7 @@
 //     and zero padding is applied through the WEIGHTS (a corner outside the plane gets weight 0; every stored value is finite);
 //   * the 18 taps of a pair (west / north index + two corner weights each; they sit behind the reference's normalise / un-normalise
 //     round trip, a true fp32 division) are computed once while the gather is in flight;
-//   * phase C: thread = (pair, window row) produces 9 samples into a channel-ordered staging tile; phase D: thread = (channel block,
+//   * phase C: thread = (pair, window column) produces 9 samples into a channel-ordered staging tile; phase D: thread = (channel block,
 //     pixel, 8-channel chunk) converts to the split format and stores 16 B of hi + 16 B of lo in the conv engine's blocked layout
 //     (B, CB, rows, 32): 512 B contiguous per channel block and workgroup.
 //   * the volume element type is a template parameter: fp32 planes, or fp16 planes (bflow_corr_build_f16: BASELINE configs[4]).
@@ -62,7 +62,9 @@ __device__ __forceinline__ int tiled_index(int y, int x, int tw) {
     return (((y >> 2) * tw + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
 }
 
-template <typename VT, int TP, int THREADS>
+// COLS: phase C as (pair, window column) threads -- fewer instructions, the form for grids of many rounds (instruction-bound: batch >= 4 at
+// 60 x 80) -- instead of (pair, window row) threads, the form of the latency-bound single-round grids (batch 1: 11.1 vs 11.6 us at C2).
+template <typename VT, int TP, int THREADS, bool COLS = false>
 __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args, const float* __restrict__ params, _Float16* __restrict__ oh,
                                                                  _Float16* __restrict__ ol, int CBk, int Prow, int h1, int w1, int abl,
                                                                  bflow::Im2colArgs rider, int rider_blocks) {
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     // pixel and multiplied 64-bit plane offsets unit by unit: 85 instructions per unit, the largest share of a kernel that is
     // instruction-bound at batch 8 -- 75 workgroups per CU: profiles/r05_k7_instruction_diet.txt)
     int* s_rec = s_oy + npair;                               // (16-B aligned: 16 MAX_PLANES + 16 npair bytes precede it)
-    int* s_at = s_rec + 4 * npair;                           // [npair][18]: patch-relative west index of the 9 columns, north index of the 9 rows
+    int* s_uni = s_rec + 4 * npair;                          // [npair] 1: the 9 window rows are the patch rows 1 .. 10 in order (see phase C)
+    int* s_at = s_uni + npair;                               // [npair][18]: patch-relative west index of the 9 columns, north index of the 9 rows
     float* s_wt = reinterpret_cast<float*>(s_at + npair * 18);   // [npair][18][2]: (west, east) / (north, south) weights, ZERO where the corner
                                                                  // lies outside the plane (= grid_sample's zero padding) or outside the patch
     float* stage = s_wt + npair * 36;                        // [TP][cstride]: the tile's features in channel order
@@ -165,6 +168,12 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
         s_rec[4 * tid + 1] = (int)(unsigned)(pbu >> 32);
         s_rec[4 * tid + 2] = (th << 16) | tw;
         s_rec[4 * tid + 3] = (s_oy[tid] << 16) | (s_ox[tid] & 0xffff);
+        // Window row ky samples y = cy + ky - 4: north corner floor(cy) + ky - 4 = patch row 1 + ky -- unless the centre was clamped (far
+        // outside: every weight is zero) or cy sits within the round trip's error of an integer, where `roundtrip` may move single rows
+        // across it.  Those pairs take phase C's general form; EDGE >> the round trip's error (a few ulps of the coordinate).
+        const float fry = cy - floorf(cy);
+        const float edge = fmaxf(1.0f / 1024.0f, (float)pl_h * 1.0e-6f);
+        s_uni[tid] = (cy == ccy && fry > edge && fry < 1.0f - edge) ? 1 : 0;
     }
     __syncthreads();
 
@@ -220,28 +229,78 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     __syncthreads();   // (the compiler drains the DMA with vmcnt(0) in front of it)
 
     // ---- phase C: interpolation.  unit = (pair, window row): 9 samples -> stage[pixel][plane*81 + row*9 ..] -------------------------
+    if constexpr (!COLS) {
+        for (int it = tid; it < npair * WIN && !(abl & 2); it += THREADS) {
+            const int pair = it / WIN, ky = it - pair * WIN;
+            const int p = pair / TP, i = pair - p * TP;
+            const int* at = s_at + pair * 18;
+            const float* wt = s_wt + pair * 36;
+            const float wn = wt[2 * (WIN + ky)], ws = wt[2 * (WIN + ky) + 1];
+            const int ay = at[WIN + ky];
+            const VT* row0 = patch + pair * PELEMS + ay * PCOLS;
+            const VT* row1 = row0 + PCOLS;
+            const int z0 = (UPR == 4 && swz_on) ? ((((ay >> 1) ^ pair) & 3) << 2) : 0, z1 = (UPR == 4 && swz_on) ? (((((ay + 1) >> 1) ^ pair) & 3) << 2) : 0;
+            float* dst = stage + i * cstride + p * NCH + ky * WIN;
+#pragma unroll
+            for (int kx = 0; kx < WIN; ++kx) {
+                const float ww = wt[2 * kx], we = wt[2 * kx + 1];
+                const int c0 = at[kx], c1 = c0 + 1;
+                // utils.py:19 / grid_sample: nw*I_nw + ne*I_ne + sw*I_sw + se*I_se, weights as products of the axis weights
+                float v = (float)row0[c0 ^ z0] * (ww * wn);
+                v += (float)row0[c1 ^ z0] * (we * wn);
+                v += (float)row1[c0 ^ z1] * (ww * ws);
+                v += (float)row1[c1 ^ z1] * (we * ws);
+                dst[kx] = v;
+            }
+        }
+    } else {
+    // (round 5, instruction diet, COLS: thread = (pair, window COLUMN).  In the regular case -- s_uni -- the 9 window rows of a pair are the patch
+    //  rows 1 .. 10 in order, so a column thread reads its two patch columns of those ten rows ONCE (20 reads and address computations instead
+    //  of 36) and every sample is the same expression, in the same order, on the same operands as in the general form below.)
     for (int it = tid; it < npair * WIN && !(abl & 2); it += THREADS) {
-        const int pair = it / WIN, ky = it - pair * WIN;
+        const int pair = it / WIN, kx = it - pair * WIN;
         const int p = pair / TP, i = pair - p * TP;
         const int* at = s_at + pair * 18;
         const float* wt = s_wt + pair * 36;
-        const float wn = wt[2 * (WIN + ky)], ws = wt[2 * (WIN + ky) + 1];
-        const int ay = at[WIN + ky];
-        const VT* row0 = patch + pair * PELEMS + ay * PCOLS;
-        const VT* row1 = row0 + PCOLS;
-        const int z0 = (UPR == 4 && swz_on) ? ((((ay >> 1) ^ pair) & 3) << 2) : 0, z1 = (UPR == 4 && swz_on) ? (((((ay + 1) >> 1) ^ pair) & 3) << 2) : 0;
-        float* dst = stage + i * cstride + p * NCH + ky * WIN;
+        const float ww = wt[2 * kx], we = wt[2 * kx + 1];
+        const int c0 = at[kx], c1 = c0 + 1;
+        const VT* pb = patch + pair * PELEMS;
+        float* dst = stage + i * cstride + p * NCH + kx;
+        auto zof = [&](int row) -> int { return (UPR == 4 && swz_on) ? ((((row >> 1) ^ pair) & 3) << 2) : 0; };
+        if (s_uni[pair] && at[WIN] == 1) {
+            float a[WIN + 1], bq[WIN + 1];
 #pragma unroll
-        for (int kx = 0; kx < WIN; ++kx) {
-            const float ww = wt[2 * kx], we = wt[2 * kx + 1];
-            const int c0 = at[kx], c1 = c0 + 1;
-            // utils.py:19 / grid_sample: nw*I_nw + ne*I_ne + sw*I_sw + se*I_se, weights as products of the axis weights
-            float v = (float)row0[c0 ^ z0] * (ww * wn);
-            v += (float)row0[c1 ^ z0] * (we * wn);
-            v += (float)row1[c0 ^ z1] * (ww * ws);
-            v += (float)row1[c1 ^ z1] * (we * ws);
-            dst[kx] = v;
+            for (int r = 0; r <= WIN; ++r) {
+                const int z = zof(1 + r);
+                a[r] = (float)pb[(1 + r) * PCOLS + (c0 ^ z)];
+                bq[r] = (float)pb[(1 + r) * PCOLS + (c1 ^ z)];
+            }
+#pragma unroll
+            for (int ky = 0; ky < WIN; ++ky) {
+                const float wn = wt[2 * (WIN + ky)], ws = wt[2 * (WIN + ky) + 1];
+                // utils.py:19 / grid_sample: nw*I_nw + ne*I_ne + sw*I_sw + se*I_se, weights as products of the axis weights
+                float v = a[ky] * (ww * wn);
+                v += bq[ky] * (we * wn);
+                v += a[ky + 1] * (ww * ws);
+                v += bq[ky + 1] * (we * ws);
+                dst[ky * WIN] = v;
+            }
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < WIN; ++ky) {
+                const float wn = wt[2 * (WIN + ky)], ws = wt[2 * (WIN + ky) + 1];
+                const int ay = at[WIN + ky];
+                const VT* row0 = pb + ay * PCOLS;
+                const VT* row1 = row0 + PCOLS;
+                const int z0 = zof(ay), z1 = zof(ay + 1);
+                float v = (float)row0[c0 ^ z0] * (ww * wn);
+                v += (float)row0[c1 ^ z0] * (we * wn);
+                v += (float)row1[c0 ^ z1] * (ww * ws);
+                v += (float)row1[c1 ^ z1] * (we * ws);
+                dst[ky * WIN] = v;
+            }
         }
+    }
     }
     __syncthreads();
 
@@ -343,7 +402,7 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
     static const int abl = [] { const char* e = getenv("BFLOW_LOOKUP_ABL"); return e ? atoi(e) : 0; }();
     const int tp = (tp_env == 2 || tp_env == 4 || tp_env == 8) ? tp_env : 2;
     const int cstride = ((P * NCH + 31) >> 5) * 32;
-    const int lds = 16 * BFLOW_MAX_PLANES + P * tp * (4 + 4 + 18 + 36) * 4 + P * tp * PATCH * 16 * (f16_planes ? 3 : 4) + tp * cstride * 4 + 1024;
+    const int lds = 16 * BFLOW_MAX_PLANES + P * tp * (4 + 4 + 1 + 18 + 36) * 4 + P * tp * PATCH * 16 * (f16_planes ? 3 : 4) + tp * cstride * 4 + 1024;
     Im2colArgs m = {};
     int rider_blocks = 0;
     if (rider) {
@@ -357,7 +416,12 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, params, (_Float16*)out_hi, (_Float16*)out_lo, channel_blocks, rows_per_image, h1, w1, abl,
                            m, rider_blocks);
     };
-    if (f16_planes) {
+    static const int cols_env = [] { const char* e = getenv("BFLOW_LOOKUP_COLS"); return e ? atoi(e) : -1; }();   // tools A/B: 0 / 1 force a form
+    const bool cols = cols_env >= 0 ? cols_env != 0 : (long long)B * h1 * w1 >= 16000;
+    if (cols && tp == 2) {
+        if (f16_planes) go(corr_lookup_tile_kernel<_Float16, 2, 256, true>);
+        else go(corr_lookup_tile_kernel<float, 2, 256, true>);
+    } else if (f16_planes) {
         if (tp == 2) go(corr_lookup_tile_kernel<_Float16, 2, 256>);
         else if (tp == 4) go(corr_lookup_tile_kernel<_Float16, 4, 256>);
         else go(corr_lookup_tile_kernel<_Float16, 8, 256>);
