@@ -66,6 +66,8 @@ the same value.
 | `r05_enc_stream_clock.txt` | `tools/enc_stream_clock.py` on `-DH8_STAMPS` builds (`tools/build_flag_variant.sh st_<x> "-DH8_STAMPS [-DCSTREAM_ABL=n]" conv_split.hip`) | **the persistent kernel is power-limited**: cycles AND clock per workgroup (`s_memtime` / `s_memrealtime`) — 0.75 of the matrix pipes busy in cycles at 1.31–1.38 GHz; fragment reads cost clock, LDS-DMA and stores cost cycles; older vs younger workgroup of a CU; one workgroup per CU; uneven ranges; the predictive ablations 6 / 7 (what a 64×64 wave tile / one weight tile per CU are worth) |
 | `r05_enc_stream_pin_prio.txt`, `r05_enc_stream_fastpath.txt` | `tools/enc_stream_probe.py` on `-DCSTREAM_PIN=1` / `-DCSTREAM_PRIO=1` builds; before / after the interior-patch halo offsets | scheduling barriers, `s_setprio` and 35 % fewer instructions on the halo step: all neutral — issue slots are not the limit |
 | `r05_k7_instruction_diet.txt`, `r05_k7_trimmed_gather.txt` | `tools/k7_probe.py` alternating with the previous library; `tools/micro/gather_lines` | K7 is instruction-bound at batch 8: per-pair gather records −4 % at every shape; a pure gather of the kernel's shape runs at 6.1–6.9 TB/s; fetching 26 % fewer lines is neutral |
+| `r05_flag_edge.txt` | `tools/experiments/r05_edge_probe.py` on the tree + `tools/experiments/r05_flag_edge.patch` | the flag-synchronised edge (q convolution → next z\|r convolution as ONE launch with per-patch flags): parity-checked, 41.5 µs (65.6 with agent-scope fences) against 32.8 µs for the product's two launches — not kept |
+| `r05_stream_share_frame_ab.txt` | `tools/ab_bench.sh "BFLOW_CONV_STREAM_SHARE=50" "BFLOW_CONV_STREAM_SHARE=57" 3` | older : younger range lengths of the persistent encoder kernel in the FRAME: no gain (the launch alone: −2…−3 %) — default 50 : 50 |
 | `r05_mfma_clock_fp8_cross.txt`, `r05_store_patterns.txt`, `r05_k5_stamps_split8.txt`, `r05_k5_stamps_split.txt`, `r05_k5_modes.txt`, `r05_corr_precision_e2e.txt` | as in round 4 (`README_r04.md`) | K5 is unchanged this round: re-collected on this round's box (the sustained clock `bench.py` uses for `roofline_corr_build.model_cap` comes from the stamps) |
 | `r05_train_probe.txt` | `BFLOW_TRAIN_PROBE_GRAPH=1 python tools/train_probe.py 10` | training path (SURVEY §8 f-4), unchanged, re-measured for regressions: {train} |
 
