@@ -147,12 +147,14 @@ class BasicEncoder(nn.Module):
         var_p = 1.0 / (mul * mul)
         return torch.stack((mean_p * hw, (var_p + mean_p * mean_p) * hw), dim=-1).unsqueeze(0).contiguous()   # (1, n, C, 2)
 
-    def forward_split(self, x, out_rows: Optional[int] = None, trunk_only: bool = False, after_layer=None):
+    def forward_split(self, x, out_rows: Optional[int] = None, trunk_only: bool = False, after_layer=None, out: Optional["S.SplitTensor"] = None,
+                      out_ready=None):
         """The same network on the split-fp16 MFMA engine (csrc/conv_split.hip): channels-last split activations, implicit-GEMM
         convolutions with bias / folded BatchNorm / ReLU / InstanceNorm statistics fused into their epilogues, and one
         normalise+activate+residual kernel between convolutions; the 7x7 stem reads the fp32 NCHW input directly (im2col in LDS).  x: (n, c_in, H, W) fp32 -> SplitTensor (n, H/8, W/8, out_dim); `out_rows` pads the
         pixel rows of the result with zeros (K5 wants a multiple of 128).  after_layer = (i, fn): fn() is called once the launches of
-        layer i are enqueued (the caller forks work there that should start behind them, e.g. the context encoder)."""
+        layer i are enqueued (the caller forks work there that should start behind them, e.g. the context encoder).  out / out_ready: see the
+        last convolution."""
         kind = self.norm_fn
         assert kind in ("instance", "batch", "group", "none"), kind
         group = kind == "group"
@@ -288,7 +290,14 @@ class BasicEncoder(nn.Module):
             return cur
         pk = self._packed("conv2", self.conv2)
         bias = self.conv2.bias
-        out, _ = S.conv(cur, pk, shift=bias, out_rows=out_rows)
+        if out is not None:
+            # a caller-owned output whose pad rows were zeroed elsewhere (`out_ready`: the event behind that fill) -- on the frame's context
+            # branch, instead of a 7.5-us strided fill on the feature encoder's chain right in front of its last convolution
+            if out_ready is not None:
+                torch.cuda.current_stream().wait_event(out_ready)
+            out, _ = S.conv(cur, pk, shift=bias, out_split=out, out_rows=out.rows)
+        else:
+            out, _ = S.conv(cur, pk, shift=bias, out_rows=out_rows)
         return out
 
     def forward(self, x: Union[torch.Tensor, Sequence[torch.Tensor]], project: bool = True):

@@ -263,7 +263,11 @@ class RAFTSpline(nn.Module):
             nb, _, Hh, Ww = x.shape
             h8, w8 = Hh // 8, Ww // 8
             D = net.conv2.out_channels
-            planes = net.forward_split(x, out_rows=hip.padded_rows(h8 * w8), after_layer=after_layer).planes
+            pre = feat_out.pop(id(net), None)        # (output tensor with zeroed pad rows, event): allocated on the context branch
+            if pre is not None and after_layer is None:
+                planes = net.forward_split(x, out=pre[0], out_ready=pre[1]).planes
+            else:
+                planes = net.forward_split(x, out_rows=hip.padded_rows(h8 * w8), after_layer=after_layer).planes
             return CorrComputation.from_packed(planes[:, :n_ref], planes[:, n_ref:], n_ref, D, h8, w8, levels)
 
         # ---- inputs of the three encoders (raft.py:118-141)
@@ -299,11 +303,22 @@ class RAFTSpline(nn.Module):
         # smaller stages and K5 only, conserves the total (the work is the same and the chip is busy either way) -- measured, no gain
         ub = self.update_block
         state = {}
+        feat_out = {}
 
         def run_cnet():
             if tm: tm.start("cnet")
             with hip.Branch(tm is None) as br:
                 if pr: pr("cnet.begin")
+                # the feature encoders' outputs (K5's operand format: pad rows zero) are allocated HERE: their strided pad-row fill leaves the
+                # feature encoder's chain (7.5 us right in front of its last convolution) for the start of the context branch
+                if br.enabled and os.environ.get("BFLOW_NO_FEAT_PREALLOC") is None:      # (A/B switch, tools/)
+                    for net_, nimg in ((self.fnet_ev, (1 + len(self.ev_corr_target_indices)) * B if self.fnet_ev is not None else 0),
+                                       (self.fnet_img, 2 * B)):
+                        if net_ is not None:
+                            t_ = S.SplitTensor.empty(nimg, h, w, net_.conv2.out_channels, device, rows=hip.padded_rows(h * w), zero_tail=True)
+                            ev_ = torch.cuda.Event()
+                            ev_.record()
+                            feat_out[id(net_)] = (t_, ev_)
                 ws_ = ub.new_split_workspace(B, h, w, device)
                 state["bezier0"] = torch.zeros((B, 2 * self.bezier_degree, h, w), dtype=torch.float32, device=device)   # raft.py:150
                 ws_.overlap = tm is None and hip.BRANCHING
