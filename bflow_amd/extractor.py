@@ -148,7 +148,7 @@ class BasicEncoder(nn.Module):
         return torch.stack((mean_p * hw, (var_p + mean_p * mean_p) * hw), dim=-1).unsqueeze(0).contiguous()   # (1, n, C, 2)
 
     def forward_split(self, x, out_rows: Optional[int] = None, trunk_only: bool = False, after_layer=None, out: Optional["S.SplitTensor"] = None,
-                      out_ready=None):
+                      out_ready=None, out_gain: Optional[float] = None):
         """The same network on the split-fp16 MFMA engine (csrc/conv_split.hip): channels-last split activations, implicit-GEMM
         convolutions with bias / folded BatchNorm / ReLU / InstanceNorm statistics fused into their epilogues, and one
         normalise+activate+residual kernel between convolutions; the 7x7 stem reads the fp32 NCHW input directly (im2col in LDS).  x: (n, c_in, H, W) fp32 -> SplitTensor (n, H/8, W/8, out_dim); `out_rows` pads the
@@ -295,7 +295,11 @@ class BasicEncoder(nn.Module):
             # branch, instead of a 7.5-us strided fill on the feature encoder's chain right in front of its last convolution
             if out_ready is not None:
                 torch.cuda.current_stream().wait_event(out_ready)
-            out, _ = S.conv(cur, pk, shift=bias, out_split=out, out_rows=out.rows)
+            if out_gain is not None:      # the projection times a constant (see RAFTSpline._encode: feature dims the correlation kernel pads)
+                gain = torch.full((self.conv2.out_channels,), out_gain, dtype=torch.float32, device=bias.device)
+                out, _ = S.conv(cur, pk, scale=gain, shift=bias.detach().float() * out_gain, out_split=out, out_rows=out.rows)
+            else:
+                out, _ = S.conv(cur, pk, shift=bias, out_split=out, out_rows=out.rows)
         else:
             out, _ = S.conv(cur, pk, shift=bias, out_rows=out_rows)
         return out

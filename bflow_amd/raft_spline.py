@@ -139,7 +139,8 @@ class RAFTSpline(nn.Module):
         if self.corr_precision is not None:
             return _corr.check_precision(self.corr_precision)
         enc = self.fnet_ev if self.fnet_ev is not None else self.fnet_img
-        return _corr.default_precision(enc.conv2.out_channels, tiled=True)      # the ONE resolver (BFLOW_CORR_PRECISION, else split8 / split)
+        D = enc.conv2.out_channels
+        return _corr.default_precision(64 if D <= 64 else 128 if D <= 128 else 256, tiled=True)   # the ONE resolver (BFLOW_CORR_PRECISION, else split8 / split) on the PADDED dim
 
     # ---------------------------------------------------------------------------------------- reference API
     def freeze_bn(self):
@@ -232,8 +233,8 @@ class RAFTSpline(nn.Module):
                         bad.append(f"{name}: a GroupNorm weight <= 0 (the engine's GroupNorm path needs positive scales)")
                     else:
                         net.__dict__["_gamma_checked"] = key
-            if name != "cnet" and net.conv2.out_channels not in (64, 128, 256):
-                bad.append(f"{name} output dim {net.conv2.out_channels} (the correlation kernels take 64, 128 or 256 feature channels)")
+            if name != "cnet" and net.conv2.out_channels > 256:
+                bad.append(f"{name} output dim {net.conv2.out_channels} (the correlation kernels contract at most 256 feature channels; smaller dims are zero-padded to 64 / 128 / 256)")
         if self.fnet_ev is not None and len(self.ev_corr_target_indices) + 1 > 8:
             bad.append(f"{len(self.ev_corr_target_indices)} event targets (the stem reads at most 8 channel windows in place)")
         if bad:
@@ -263,6 +264,16 @@ class RAFTSpline(nn.Module):
             nb, _, Hh, Ww = x.shape
             h8, w8 = Hh // 8, Ww // 8
             D = net.conv2.out_channels
+            Dp = 64 if D <= 64 else 128 if D <= 128 else 256
+            if Dp != D:
+                # K5's streaming kernel contracts 64, 128 or 256 channels: other feature dims are ZERO-PADDED to the next of them (whole
+                # channel blocks of zeros add nothing to a dot product).  The kernel then divides by sqrt(Dp) where corr.py:270 divides by
+                # sqrt(D): both feature maps leave the encoder's projection multiplied by (Dp / D)^(1/4), so that the product carries the
+                # missing sqrt(Dp / D) (an fp32 rounding of each feature apart -- not bit-faithful to the reference's order, inside the parity bar)
+                feat_out.pop(id(net), None)
+                buf = S.SplitTensor.empty(nb, h8, w8, Dp, x.device, rows=hip.padded_rows(h8 * w8), zero=True)
+                planes = net.forward_split(x, out=buf, out_gain=float((Dp / D) ** 0.25), after_layer=after_layer).planes
+                return CorrComputation.from_packed(planes[:, :n_ref], planes[:, n_ref:], n_ref, Dp, h8, w8, levels)
             pre = feat_out.pop(id(net), None)        # (output tensor with zeroed pad rows, event): allocated on the context branch
             if pre is not None and after_layer is None:
                 planes = net.forward_split(x, out=pre[0], out_ready=pre[1]).planes

@@ -814,6 +814,26 @@ def test_e2e_forward_vs_reference_golden(golden_dir, name, graph):
     assert (up.get_params()[:, :, ::4, ::4].cpu() - torch.from_numpy(d["bezier_up_sub"])).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("fdim", [96, 192, 32])
+def test_e2e_other_feature_dims_vs_oracle(fdim):
+    """Feature dims the correlation kernel does not contract natively (model key feature.dim, raft.py:52): zero-padded to 64 / 128 / 256 with the
+    1 / sqrt(D) of corr.py:270 carried by the encoder's projection ((Dp / D)^(1/4) on both feature maps)."""
+    import copy
+    cfg = copy.deepcopy(configs.model_config("E_LU4_BD2"))
+    cfg["feature"]["dim"] = fdim
+    m = bflow_amd.RAFTSpline(cfg).eval()
+    sd = O.make_state_dict(cfg, seed=5)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    vox = torch.from_numpy(synthetic.voxel_grid(2, 9, 128, 160, seed=11))
+    low, up = m(voxel_grid=vox.to(DEV), iters=3, test_mode=True)
+    with torch.inference_mode():
+        olo, oup = O.forward(sd, cfg, vox, None, iters=3, test_mode=True)
+    e = float(O.epe_masked(up.get_flow_from_reference(1.0).cpu(), O.bezier_flow(oup, 1.0)))
+    print(f"feature dim {fdim}: EPE vs oracle {e:.2e} px (|flow| max {float(O.bezier_flow(oup, 1.0).abs().max()):.2f})")
+    assert bool(torch.isfinite(oup).all()) and float(oup.abs().max()) > 1e-3 and e < EPE_TOL
+
+
 @pytest.mark.parametrize("fnorm,cnorm", [("group", "none"), ("none", "group"), ("group", "batch")])
 def test_e2e_other_encoder_norms_vs_oracle(fnorm, cnorm):
     """The rest of the reference's encoder constructor surface on the HIP engine (extractor.py:13-37,63-70): norm_fn 'group' (GroupNorm through

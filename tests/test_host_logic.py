@@ -81,7 +81,7 @@ def test_unsupported_configurations_raise_instead_of_falling_back():
     base = configs.model_config("E_LU4_BD2")
     cases = []
     c = copy.deepcopy(base); c["feature"]["norm"] = "layer"; cases.append((c, None))     # not a norm_fn of the reference either (extractor.py:13-37)
-    c = copy.deepcopy(base); c["feature"]["dim"] = 96; cases.append((c, "output dim 96"))
+    c = copy.deepcopy(base); c["feature"]["dim"] = 320; cases.append((c, "output dim 320"))   # (<= 256 is zero-padded to 64 / 128 / 256: round 5)
     c = copy.deepcopy(base); c["bezier_degree"] = 20; cases.append((c, "bezier_degree"))
     c = copy.deepcopy(base); c["motion"]["dim"] = 100; cases.append((c, "multiples of 32"))
     for cfg, needle in cases:
@@ -95,6 +95,9 @@ def test_unsupported_configurations_raise_instead_of_falling_back():
         assert needle in str(ei.value), (needle, str(ei.value))
     for fn, cn in (("group", "none"), ("none", "group")):       # round 5: the whole norm_fn surface of the reference passes
         c = copy.deepcopy(base); c["feature"]["norm"], c["context"]["norm"] = fn, cn
+        bflow_amd.RAFTSpline(c).check_engine_support()
+    for fd in (32, 96, 192):                                      # and feature dims below 256
+        c = copy.deepcopy(base); c["feature"]["dim"] = fd
         bflow_amd.RAFTSpline(c).check_engine_support()
     bflow_amd.RAFTSpline(base).check_engine_support()     # every shipped configuration passes
     for name in configs.EXPERIMENTS:
