@@ -179,15 +179,19 @@ def main():
     sd = deterministic_state_dict(model, seed=0)
     model.load_state_dict(sd)
     model.to(dev)
-    if not args.no_graph:
-        model.enable_hipgraph()
+    # NO opt-in here: `value` is measured on what the drop-in seam delivers by itself -- the call val.py makes (eval(), inference_mode,
+    # test_mode=True; modules/raft_spline.py:57-58 under val.py:75) replays a captured hipGraph and returns private copies of its outputs
+    # (bflow_amd/raft_spline.py `_use_graph`).  `value_eager` below is the same call with BFLOW_HIPGRAPH=0 semantics.
+    if args.no_graph:
+        model.enable_hipgraph(False)
 
     # ---- workload A: C2, batch 1 per GPU (weak scaling); sample index = rank
     vox1_np = synthetic.voxel_grid(1, 9, H, W, seed=1234, first_sample=rank)
     vox1 = torch.from_numpy(vox1_np).to(dev)
 
     def step_c2():
-        return model(voxel_grid=vox1, iters=ITERS, test_mode=True)
+        with torch.inference_mode():
+            return model(voxel_grid=vox1, iters=ITERS, test_mode=True)
 
     # ---- workload B: C4, global batch 64 -> contiguous shard of this rank, micro-batches of 8 (one captured graph, replayed per micro-batch)
     assert GLOBAL_BATCH % (world * MICRO_BATCH) == 0 or world * MICRO_BATCH > GLOBAL_BATCH, "global batch 64 must split into micro-batches of 8"
@@ -214,8 +218,9 @@ def main():
             for k in range(0, n_micro, 2):
                 out = pair([vox8[k], vox8[k + 1]])
             return out
-        for v in vox8:
-            out = model(voxel_grid=v, iters=ITERS, test_mode=True)
+        with torch.inference_mode():
+            for v in vox8:
+                out = model(voxel_grid=v, iters=ITERS, test_mode=True)
         return out
 
     def measure(step, frames_per_step_per_rank, steps, warmup):
@@ -257,6 +262,7 @@ def main():
             "arithmetic": "fp32 values carried as split fp16 pairs (hi + lo*2^-11) on the fp16 matrix cores, fp32 accumulation; correlation cross terms (hi*lo + lo*hi) on the fp8 matrix rate; parity 2e-5 px EPE vs the fp32 CPU reference; `value_split` = the same frame with the correlation on three fp16 passes (fp32 class everywhere)",
             "data": "synthetic",
             "config": {"workload": wl_c2, "global_batch": world, "frames_per_rank_per_step": 1, "iters": ITERS, "hipgraph": not args.no_graph,
+                       "hipgraph_mode": "off (--no-graph)" if args.no_graph else "auto: the model's default for eval + inference_mode + test_mode=True forwards, no opt-in call (what val.py gets)",
                        "same_workload_at_every_n_gpus": True,
                        "input_handover": "every step copies its resident frame (device to device, 11 MB) into the captured graph's static input buffer, inside "
                                          "the timed region (measured: no difference to a zero-copy hand-over, 277-279 frames/s either way)"},
@@ -273,7 +279,8 @@ def main():
     # ---- extras outside the timed region: ms/GRU-iter (N=1), rooflines of the hand-written kernels (rank 0), CPU baseline (N=1)
     if world == 1 and not args.no_extras:
         def step6():
-            return model(voxel_grid=vox1, iters=ITERS // 2, test_mode=True)
+            with torch.inference_mode():
+                return model(voxel_grid=vox1, iters=ITERS // 2, test_mode=True)
         for _ in range(3):
             step6()
         n_it = max(args.steps // 2, 5)
@@ -305,6 +312,18 @@ def main():
             out["value_split"] = dict(r_split, unit="frames/s", corr_precision="split",
                                       note="whole frame, correlation on three fp16 MFMA passes: fp32-class arithmetic everywhere (1.3e-5 px vs the fp32 oracle)")
             step_c2()        # back on the default graph
+            # the same call with graph replay switched off (BFLOW_HIPGRAPH=0 / enable_hipgraph(False)): ~230 launches enqueued by the host
+            model.enable_hipgraph(False)
+            r_eager = measure(step_c2, 1, max(args.steps // 2, 5), 2)
+            model.enable_hipgraph(None)
+            out["value_eager"] = dict(r_eager, unit="frames/s", note="the same forward as eager launches (graph replay off): what the seam delivered "
+                                      "before replay became its default; host-enqueue-bound")
+            # and with the graph's static output buffers handed out as they are (enable_hipgraph(): aliasing documented in INTEGRATION.md)
+            model.enable_hipgraph()
+            r_static = measure(step_c2, 1, max(args.steps // 2, 5), 2)
+            model.enable_hipgraph(None)
+            out["value_static_outputs"] = dict(r_static, unit="frames/s", note="explicit enable_hipgraph(): no private copies of the two outputs")
+            step_c2()
         # frame-level matrix roofline: algorithmic FLOPs as executed (context share of the gate convolutions hoisted, mask head once) over
         # the frame / the marginal iteration, against the split format's peak (fp16 dense / 3)
         from tools.roofline_kernels import frame_flops
@@ -452,6 +471,7 @@ def main():
         fr = {k: out[k].get("frac") for k in out if k.startswith("roofline") and isinstance(out[k], dict)}
         out["summary"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "ms_per_gru_iter": out.get("ms_per_gru_iter"),
                           "ms_fixed_part": out.get("ms_fixed_part"), "value_split": g("value_split", "value"),
+                          "value_eager": g("value_eager", "value"), "value_static_outputs": g("value_static_outputs", "value"),
                           "c4_strong": g("c4_strong", "value"), "c2_two_in_flight": g("c2_two_in_flight", "value"),
                           "c4_rank_shape_at_n8": g("c4_rank_shape_at_n8", "value"), "c3_batch8": g("c3_batch8", "value"), "c5": g("c5", "value"),
                           "pipeline_from_events": g("pipeline_from_events", "value"),

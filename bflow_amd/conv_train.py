@@ -55,7 +55,7 @@ class _PackCache:
         self._epoch = {"fwd": 0, "bwd": 0}
 
     def get(self, which: str, weight: torch.Tensor, srcs):
-        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in srcs)
+        key = tuple((t.data_ptr(), hip.tensor_version(t), str(t.device)) for t in srcs)
         if self._key[which] != key or (CAPTURE_EPOCH and self._epoch[which] != CAPTURE_EPOCH):
             with torch.no_grad():
                 w = weight.detach().float().contiguous()

@@ -313,6 +313,20 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     const __amdgpu_buffer_rsrc_t r_ol = __builtin_amdgcn_make_buffer_rsrc((void*)(ol + img), 0, CBk * Prow * 64, 0x00020000);
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
     typedef int i32x4v_ __attribute__((ext_vector_type(4)));
+#ifndef K7_SPLIT1
+    // (round 6, instruction diet: the split of the output phase.  bflow::split1 per value is 11 vector instructions -- clamp, NaN select,
+    //  convert, convert back, subnormal select, subtract, scale, convert, pack: 88 of the ~110 of an item, and this phase is a quarter of a
+    //  kernel that is bound by VALU issue at batch 8.  Here the special cases are the HARDWARE's, set once per wave in the MODE register:
+    //    FP16_OVFL = 1   a finite value beyond +-65504 converts to +-65504 instead of inf (saturation; split1's clamp),
+    //    FP_DENORM (f16) = flush results, keep sources: a conversion whose result would be an fp16 subnormal gives 0 -- split1's
+    //                    "hi = 0 below 2^-14" (the matrix cores flush subnormal fp16 INPUTS anyway, also those of the lo plane),
+    //  and two values share v_cvt_pk_f16_f32 / v_pk_add_f32 / v_pk_mul_f32: 6 instructions per PAIR.  Normal values get the bits split1
+    //  gives them; NaN stays NaN; +-inf (which split1 saturates) becomes hi = inf, lo = NaN -- a volume with infinities has no meaning.)
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);     // hwreg(HW_REG_MODE, 23, 1): FP16_OVFL
+    __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 1);      // hwreg(HW_REG_MODE, 6, 2): f16 / f64 denormals: sources kept, results flushed
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+#endif
     for (int it = tid; it < items && !(abl & 4); it += THREADS) {
         const int chunk = it & 3, i = (it >> 2) % TP, cb = it / (4 * TP);
         const int n = n0 + i;
@@ -321,6 +335,7 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
         const f32x4_ v0 = sp[0], v1 = sp[1];
         const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         half8 h8, l8;
+#ifdef K7_SPLIT1
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             _Float16 hh, ll;
@@ -328,6 +343,19 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
             h8[j] = hh;
             l8[j] = ll;
         }
+#else
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2_ x = {v[j], v[j + 1]};
+            const f16x2_ hh = __builtin_convertvector(x, f16x2_);
+            const f32x2_ r = (x - __builtin_convertvector(hh, f32x2_)) * bflow::SPLIT_LO_SCALE;      // (exact: hh is x rounded to 11 bits)
+            const f16x2_ ll = __builtin_convertvector(r, f16x2_);
+            h8[j] = hh[0];
+            h8[j + 1] = hh[1];
+            l8[j] = ll[0];
+            l8[j + 1] = ll[1];
+        }
+#endif
         const unsigned o = (unsigned)(((cb * Prow + n) * 32 + chunk * 8) * 2);    // bytes inside the image's plane (< 2^31: checked by the launcher)
         // non-temporal: the consumer (convc1) is the next kernel and starts with a cold L2 anyway; the 13.5 MB of features then leave during
         // the kernel instead of in the write-back at its end (round 4: 12.8 -> 11.8 us at C2; LOOKUP_PLAIN_STORES for A/B)

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import hip
 from . import split as S
 from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backward run on the HIP conv engine
 from .norm_train import norm_act  # [relu](norm(x)): hand-written forward / backward in GPU training mode
@@ -103,14 +104,14 @@ class BasicEncoder(nn.Module):
         tensor changes (load_state_dict, .to(device)), so the steady-state forward launches nothing for it."""
         cache = self.__dict__.setdefault("_affine_cache", {})
         if not isinstance(norm, nn.BatchNorm2d):      # norm_fn = 'none' (extractor.py:33-37,69-70: an empty nn.Sequential): y = conv + bias
-            key = (conv_bias.data_ptr(), conv_bias._version)
+            key = (conv_bias.data_ptr(), hip.tensor_version(conv_bias))
             hit = cache.get(id(conv_bias))
             if hit is None or hit[0] != key:
                 hit = (key, torch.ones_like(conv_bias, dtype=torch.float32), conv_bias.detach().float().contiguous())
                 cache[id(conv_bias)] = hit
             return hit[1], hit[2]
         srcs = [norm.weight, norm.bias, norm.running_mean, norm.running_var] + ([conv_bias] if conv_bias is not None else [])
-        key = tuple((t.data_ptr(), t._version) for t in srcs)
+        key = tuple((t.data_ptr(), hip.tensor_version(t)) for t in srcs)
         hit = cache.get(id(norm))
         if hit is None or hit[0] != key:
             with torch.no_grad():

@@ -11,14 +11,25 @@ valid because they only depend on the signature (shapes, config) and on buffers 
 from __future__ import annotations
 
 import gc
+from operator import attrgetter
 from typing import Dict, Optional, Tuple
 
 import torch
 from . import corr as _corr      # the kernel-selection switches are part of a captured graph's identity
 
 
+_VERSION = attrgetter("_version")
+
+
 class _Captured:
     def __init__(self, model, voxel_grid, images, iters, flow_init, test_mode):
+        # The graph and its static buffers outlive this call and are written in place by later replays (`static_voxel.copy_`): they must be
+        # ordinary tensors even when the FIRST forward runs under torch.inference_mode() (val.py:75) -- an inference tensor cannot be
+        # updated in place outside inference mode, i.e. by a later replay under plain no_grad.
+        with torch.inference_mode(False), torch.no_grad():
+            self._capture(model, voxel_grid, images, iters, flow_init, test_mode)
+
+    def _capture(self, model, voxel_grid, images, iters, flow_init, test_mode):
         self.static_voxel = None if voxel_grid is None else voxel_grid.clone()
         self.static_images = None if images is None else [x.clone() for x in images]
         self.static_init = None if flow_init is None else flow_init.clone()
@@ -67,6 +78,42 @@ class _Captured:
         return self.low, self.ups
 
 
+class WeightsWatch:
+    """Tells a graph cache whether the model's weights are still the ones frozen into its graphs -- in O(1) per call."""
+
+    def __init__(self, model):
+        self.model = model
+        self._tensors = None          # parameters + buffers, listed once per weight generation (the module-tree walk costs ~0.3 ms)
+        self._gen = None              # model._weights_gen this list / signature was taken at
+        self._full = None             # (data_ptr, _version) of every tensor: the exact identity of the frozen weights
+        self._vsum = None             # sum of the in-place version counters (monotone: any in-place edit changes it)
+
+    def _walk(self) -> bool:
+        """The full signature: storage + in-place version of every parameter and buffer.  The engine's packed weights (and folded
+        BatchNorm terms) are frozen into a captured graph; whatever changes them must invalidate it.  True = changed."""
+        m = self.model
+        every = list(m.parameters()) + list(m.buffers())
+        # (tensors created under torch.inference_mode() carry no version counter: they cannot be edited in place outside it either)
+        self._tensors = [t for t in every if not t.is_inference()]
+        full = tuple((t.data_ptr(), -1 if t.is_inference() else t._version) for t in every)
+        changed = full != self._full
+        self._full = full
+        self._vsum = sum(map(_VERSION, self._tensors))
+        self._gen = getattr(m, "_weights_gen", None)
+        return changed
+
+    def changed(self) -> bool:
+        """Per call: ONE integer comparison -- `model._weights_gen`, bumped by RAFTSpline.load_state_dict / _apply (.to(), .cuda(), .half())
+        / train() -- and, as the net under in-place edits that no hook sees (`p.data.mul_()`, an optimiser stepped in eval mode), the sum of
+        the version counters over the CACHED tensor list (C-level map, no module-tree walk: ~14 us for 169 tensors against ~300 us for
+        the walk).  The full (data_ptr, version) walk runs only when one of the two differs."""
+        if self._tensors is None or getattr(self.model, "_weights_gen", None) != self._gen:
+            return self._walk()
+        if sum(map(_VERSION, self._tensors)) != self._vsum:
+            return self._walk()
+        return False
+
+
 class GraphCache:
     """One captured graph per (shapes, dtypes, iters, test_mode, has flow_init).  Outputs are the graph's static buffers:
     they are overwritten by the next replay of the same signature (clone them to keep them)."""
@@ -76,13 +123,9 @@ class GraphCache:
     def __init__(self, model):
         self.model = model
         self._graphs: Dict[Tuple, _Captured] = {}
-        self._weights_key = None
-
-    def _weights_signature(self):
-        """Storage + in-place version of every parameter and buffer.  The engine's packed weights (and folded BatchNorm terms) are
-        frozen into a captured graph; load_state_dict / optimizer steps / .to() after the capture must invalidate it."""
-        m = self.model
-        return tuple((t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
+        self._weights = WeightsWatch(model)
+        self.replays = 0              # graph replays served (tests, bench: "was this forward a replay?")
+        self.captures = 0
 
     @staticmethod
     def _sig(t: Optional[torch.Tensor]):
@@ -91,16 +134,16 @@ class GraphCache:
     def run(self, voxel_grid, images, iters: int, flow_init, test_mode: bool):
         key = (self._sig(voxel_grid), None if images is None else tuple(self._sig(x) for x in images), int(iters),
                self._sig(flow_init), bool(test_mode), self.model.resolved_corr_precision(), _corr.FUSE_POOL1)
-        wkey = self._weights_signature()
-        if wkey != self._weights_key:
+        if self._weights.changed():
             self.clear()                         # destroyed here, outside any capture
-            self._weights_key = wkey
         cap = self._graphs.pop(key, None)
         if cap is None:
             while len(self._graphs) >= self.MAX_GRAPHS:
                 torch.cuda.synchronize()                        # (a graph is only destroyed when its last replay has finished, see clear())
                 self._graphs.pop(next(iter(self._graphs)))      # least recently used first (dict order = recency, see below)
             cap = _Captured(self.model, voxel_grid, images, iters, flow_init, test_mode)
+            self.captures += 1
+        self.replays += 1
         self._graphs[key] = cap                  # (re-)insert at the end: most recently used
         return cap.replay(voxel_grid, images, flow_init)
 

@@ -34,6 +34,13 @@ EXPORTS = (
 )
 
 
+def tensor_version(t) -> int:
+    """In-place version counter of a tensor for cache keys.  Tensors created under torch.inference_mode() -- what val.py:75 runs the forward
+    in: every temporary derived from a weight there is one -- carry no counter (`_version` raises); they cannot be edited in place outside
+    inference mode either, so a constant is a valid key component for them."""
+    return -1 if t.is_inference() else t._version
+
+
 class BflowHipError(RuntimeError):
     pass
 

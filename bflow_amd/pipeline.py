@@ -42,16 +42,20 @@ class ConcurrentRunner:
         self.model, self.iters, self.streams = model, iters, streams
         self._graph = None
         self._sig = None
+        from .graph import WeightsWatch
+        self._weights = WeightsWatch(model)
 
     def _capture(self, voxels: Sequence[torch.Tensor]):
         m, dev = self.model, voxels[0].device
         assert not m.training, "inference only"
-        self._static = [v.clone() for v in voxels]
+        with torch.inference_mode(False):
+            self._static = [v.clone() for v in voxels]
         self._side = [torch.cuda.Stream(device=dev) for _ in range(self.streams - 1)]
         was = hip.BRANCHING
         hip.BRANCHING = False                 # flat: every stream forks from the capture stream, none from a forked one
         try:
-            with torch.no_grad():
+            # (inference_mode(False): the static inputs are written in place by every later call, whatever mode that call runs in -- graph.py)
+            with torch.inference_mode(False), torch.no_grad():
                 for v in self._static:        # warm-up outside the capture (lazy packing, allocator growth)
                     m._forward_impl(v, None, self.iters, None, True)
                 torch.cuda.synchronize(dev)
@@ -82,10 +86,10 @@ class ConcurrentRunner:
         assert len(voxels) == self.streams
         if not all(v.is_cuda for v in voxels):
             raise hip.BflowHipError("ConcurrentRunner runs on MI355X only: move the inputs to the GPU")
-        sig = (tuple(tuple(v.shape) for v in voxels), voxels[0].dtype, voxels[0].device.index,
-               tuple((t.data_ptr(), t._version) for t in list(self.model.parameters()) + list(self.model.buffers())))
+        sig = (tuple(tuple(v.shape) for v in voxels), voxels[0].dtype, voxels[0].device.index)
+        stale = self._weights.changed()       # (graph.py: one integer + a 14-us version sum per call, the full walk only on a mismatch)
         with torch.cuda.device(voxels[0].device), torch.no_grad():
-            if self._graph is None or sig != self._sig:
+            if self._graph is None or stale or sig != self._sig:
                 self.close()                  # an older graph is destroyed here, outside any capture and after its last replay has finished
                 self._capture(voxels)
                 self._sig = sig

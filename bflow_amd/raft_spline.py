@@ -15,8 +15,10 @@ checkpoints load through `load_state_dict`.  What differs is how the hot path is
                         two branches are pair launches (bflow_conv_split_pair)
     last iteration      mask head + bflow_cvx_upsample_blocked (the mask in the convolution's own layout)    (K13)
 
-The whole forward is free of host synchronisation, so `enable_hipgraph()` captures it once per input signature into
-a hipGraph (bflow_amd/graph.py) and replays it; eager execution stays available for debugging and stage timing.
+The whole forward is free of host synchronisation, so it is captured once per input signature into a hipGraph
+(bflow_amd/graph.py) and replayed: BY DEFAULT for the call val.py makes (eval(), inference_mode, test_mode=True; opt out with
+BFLOW_HIPGRAPH=0 or enable_hipgraph(False)), for every inference forward after `enable_hipgraph()`; eager execution stays
+available for debugging and stage timing.
 Inputs must live on the GPU: there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only).
 """
 from __future__ import annotations
@@ -129,7 +131,13 @@ class RAFTSpline(nn.Module):
         # An OPTIONAL model key `correlation.precision` (absent from the reference's YAML files, so they mean what they always meant)
         # presets it: configs.BASELINE_CONFIGS[4] ("fp16 MFMA correlation") selects "f16/w" this way.
         self.corr_precision: Optional[str] = corr_params.get("precision") if hasattr(corr_params, "get") else None
+        # hipGraph replay of the inference forward.  "auto" (the default: what a caller gets who never heard of this package -- val.py ->
+        # modules/raft_spline.py:57-58): eval() + grad disabled (val.py:75 inference_mode) + test_mode=True forwards replay a captured graph
+        # and return PRIVATE copies of the outputs; "on" (enable_hipgraph()): every inference forward replays and returns the graph's
+        # static buffers; "off" (enable_hipgraph(False) or BFLOW_HIPGRAPH=0): eager launches.
+        self._graph_mode = "auto"
         self._graphs = None
+        self._weights_gen = 0          # bumped by whatever replaces / rewrites parameters wholesale (graph.WeightsWatch reads it)
         self.stage_timer: Optional[StageTimer] = None
         self._probe = None            # tools only: callable(name) invoked at stage boundaries inside the captured forward
 
@@ -162,13 +170,56 @@ class RAFTSpline(nn.Module):
         return grids, input_[:, -self.nbins_context:, ...]
 
     # ---------------------------------------------------------------------------------------- execution control
-    def enable_hipgraph(self, enabled: bool = True):
-        """Replay the forward from a captured hipGraph (one graph per input signature).
-        ALIASING: under replay the returned BezierCurves wrap the graph's static output buffers; the next forward with the same
-        signature overwrites them.  Clone (`curves.detach(clone=True)`) whatever must outlive the next call -- Validator does."""
+    def enable_hipgraph(self, enabled: Optional[bool] = True):
+        """Replay EVERY inference forward from a captured hipGraph (one graph per input signature), or none (`enabled=False`);
+        `enabled=None` returns to the default "auto" mode.
+        Without this call the model is in "auto" mode: forwards in eval() with grad disabled and test_mode=True -- the call
+        modules/raft_spline.py:57-58 makes under val.py:75 -- replay by themselves and return private copies of their outputs.
+        ALIASING (this explicit mode only): the returned BezierCurves wrap the graph's static output buffers; the next forward with the
+        same signature overwrites them.  Clone (`curves.detach(clone=True)`) whatever must outlive the next call -- Validator does."""
         from .graph import GraphCache
-        self._graphs = GraphCache(self) if enabled else None
+        if enabled is None:
+            self._graph_mode = "auto"
+            return self
+        self._graph_mode = "on" if enabled else "off"
+        if not enabled:
+            self._graphs = None
+        elif self._graphs is None:
+            self._graphs = GraphCache(self)
         return self
+
+    def graph_replays(self) -> int:
+        """Number of forwards served by a hipGraph replay so far (0 = every forward ran eager)."""
+        return 0 if self._graphs is None else self._graphs.replays
+
+    def _use_graph(self, test_mode: bool) -> bool:
+        if self.stage_timer is not None:                     # stage timing brackets eager launches with hipEvents
+            return False
+        if self._graph_mode == "on":
+            return True
+        if self._graph_mode == "off" or not test_mode or torch.is_grad_enabled():
+            return False
+        if os.environ.get("BFLOW_HIPGRAPH", "1").lower() in ("0", "off", "false", "no"):
+            return False
+        if self._graphs is None:
+            from .graph import GraphCache
+            self._graphs = GraphCache(self)
+        return True
+
+    # whatever rewrites the weights wholesale tells the graph caches in O(1) (graph.WeightsWatch); in-place edits of single tensors are
+    # caught by its version-counter sum
+    def _apply(self, fn, *args, **kwargs):
+        self._weights_gen += 1
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._weights_gen += 1
+        return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode: bool = True):
+        if mode:
+            self._weights_gen += 1                           # a training step rewrites every parameter
+        return super().train(mode)
 
     def enable_stage_timing(self, enabled: bool = True):
         """hipEvent stage timers with the reference's hook names (raft.py:116-186, utils/timers.py); eager mode only."""
@@ -203,10 +254,15 @@ class RAFTSpline(nn.Module):
                 low, ups = forward_train(self, voxel_grid, images, iters, None if flow_init is None else flow_init.get_params())
             return (BezierCurves(low), ups[-1]) if test_mode else ups
         # kernels are launched on the CURRENT device's stream: make the inputs' device current for the duration of the call
+        use_graph = self._use_graph(test_mode)      # (asks whether the CALLER disabled grad: before this method's own no_grad)
         with torch.cuda.device(ref.device), torch.no_grad():
             init = None if flow_init is None else flow_init.get_params()
-            if self._graphs is not None and self.stage_timer is None:
+            if use_graph:
                 low, ups = self._graphs.run(voxel_grid, images, iters, init, test_mode)
+                if self._graph_mode == "auto":
+                    # the drop-in seam hands out tensors the caller owns: nothing aliases the graph's static buffers (two small
+                    # device-to-device copies, 77 KB + 4.9 MB at DSEC size, enqueued behind the replay)
+                    low, ups = low.clone(), [ups[-1].clone()]
             else:
                 low, ups = self._forward_impl(voxel_grid, images, iters, init, test_mode)
         if test_mode:
@@ -227,7 +283,7 @@ class RAFTSpline(nn.Module):
                 # GroupNorm runs through the InstanceNorm kernels on rewritten statistics (BasicEncoder._group_stats), which needs gamma > 0;
                 # checked once per weight version (a device -> host read: never inside a captured forward)
                 gammas = [m.weight for m in net.modules() if isinstance(m, torch.nn.GroupNorm)]
-                key = tuple((g.data_ptr(), g._version) for g in gammas)
+                key = tuple((g.data_ptr(), hip.tensor_version(g)) for g in gammas)
                 if net.__dict__.get("_gamma_checked") != key:
                     if any(bool((g <= 0).any()) for g in gammas):
                         bad.append(f"{name}: a GroupNorm weight <= 0 (the engine's GroupNorm path needs positive scales)")

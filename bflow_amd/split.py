@@ -112,7 +112,7 @@ class PackedConvWeight:
             cout, cin = cin, cout
         cin_pad = (cin + 31) // 32 * 32 if cin_pad is None else cin_pad
         cout_pad = (cout + 127) // 128 * 128   # any channel tile (64/96/128) may read up to 128 rows from its first row
-        key = (weight.data_ptr(), weight._version, cin_pad, str(weight.device), adjoint)
+        key = (weight.data_ptr(), hip.tensor_version(weight), cin_pad, str(weight.device), adjoint)
         if self._key != key:
             w = weight.detach().float().contiguous()
             planes = torch.empty((2, kh * kw * (cin_pad // 32), cout_pad, 32), dtype=torch.float16, device=w.device)
@@ -136,7 +136,7 @@ class ThinConvWeight:
         self.mfma = None
 
     def get(self, weight: torch.Tensor):
-        key = (weight.data_ptr(), weight._version, str(weight.device))
+        key = (weight.data_ptr(), hip.tensor_version(weight), str(weight.device))
         if self._key != key:
             cout, cin, kh, kw = weight.shape
             with torch.no_grad():
@@ -204,7 +204,7 @@ class PackedStemWeight:
     def get(self, weight: torch.Tensor):
         cout, cin, kh, kw = weight.shape
         assert kh == kw == 7
-        key = (weight.data_ptr(), weight._version, str(weight.device))
+        key = (weight.data_ptr(), hip.tensor_version(weight), str(weight.device))
         if self._key != key:
             chunk = min(cin, 8)
             kpc = (chunk * kh * kw + 31) // 32 * 32

@@ -153,7 +153,7 @@ class BasicUpdateBlock(nn.Module):
             cache[name] = [S.PackedConvWeight(), None, None]
         entry = cache[name]
         srcs = weight_fn.__defaults__            # the source parameters the derived weight is built from
-        key = tuple((t.data_ptr(), t._version) for t in srcs)
+        key = tuple((t.data_ptr(), hip.tensor_version(t)) for t in srcs)
         if entry[1] != key:
             with torch.no_grad():
                 entry[2] = weight_fn().contiguous()
@@ -207,7 +207,7 @@ class BasicUpdateBlock(nn.Module):
         for sfx in ("1", "2"):
             _, _, zr_inp, q_inp, zr_bias, q_bias, pad = self._gate_weights(sfx)
             bz = self.__dict__.setdefault("_bias_cache", {})
-            bkey = tuple((t.data_ptr(), t._version, str(t.device)) for t in zr_bias.__defaults__)   # .to() / param swaps keep _version
+            bkey = tuple((t.data_ptr(), hip.tensor_version(t), str(t.device)) for t in zr_bias.__defaults__)   # .to() / param swaps keep _version
             if ("zr" + sfx) not in bz or bz["zr" + sfx][0] != bkey:
                 with torch.no_grad():
                     bz["zr" + sfx] = (bkey, zr_bias().contiguous())

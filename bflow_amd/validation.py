@@ -104,8 +104,8 @@ class Validator:
 
     def forward(self, voxel_grid, images, iters, test_mode: bool):
         out = self.net(voxel_grid=voxel_grid, images=images, iters=iters, test_mode=test_mode)
-        if getattr(self.net, "_graphs", None) is not None:
-            # under hipGraph replay the curves wrap the graph's static output buffers, which the NEXT replay overwrites; the reference
+        if getattr(self.net, "_graph_mode", None) == "on":
+            # under explicit hipGraph replay (enable_hipgraph(); the default "auto" mode returns private copies itself) the curves wrap the graph's static output buffers, which the NEXT replay overwrites; the reference
             # hands out detached copies (@to_cpu, modules/raft_spline.py:190), so what a validation step returns must survive later steps
             out = tuple(c.detach(clone=True) for c in out) if isinstance(out, tuple) else [c.detach(clone=True) for c in out]
         return out

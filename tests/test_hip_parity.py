@@ -908,6 +908,73 @@ def test_e2e_baseline_configs_full_size_vs_oracle(cname, B, H, W, iters, check):
         assert e < EPE_TOL
 
 
+def test_dropin_seam_replays_a_hipgraph_by_default():
+    """The path val.py takes, with NO opt-in: `from models.raft_spline.raft import RAFTSpline` through <repo>/dropin
+    (modules/raft_spline.py:9), `RAFTSpline(config['model'])` (:24), eval + inference_mode (val.py:75) and
+    `net(voxel_grid=, images=, iters=, test_mode=True)` (:57-58).  Those forwards must be hipGraph replays, must equal the eager
+    forward, and must hand out tensors the caller owns (a later forward does not overwrite an earlier result).  Separate process: other
+    tests import the real reference under the same module names."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+sys.path[:0] = [{dropin!r}, {root!r}]
+os.environ.pop("BFLOW_HIPGRAPH", None)
+import torch
+from models.raft_spline.raft import RAFTSpline, BezierCurves
+import bflow_amd
+from bflow_amd import configs, synthetic
+from bflow_amd.weights import deterministic_state_dict
+assert RAFTSpline is bflow_amd.RAFTSpline
+cfg = configs.model_config("E_LU4_BD2")
+net = RAFTSpline(cfg)
+net.load_state_dict(deterministic_state_dict(net, 0))
+net = net.to("cuda").eval()
+va = torch.from_numpy(synthetic.voxel_grid(1, 9, 128, 160, seed=3)).cuda()
+vb = torch.from_numpy(synthetic.voxel_grid(1, 9, 128, 160, seed=4)).cuda()
+with torch.inference_mode():
+    low_a, up_a = net(voxel_grid=va, images=None, iters=4, test_mode=True)
+    assert net.graph_replays() == 1 and net._graphs.captures == 1
+    fa = up_a.get_flow_from_reference(1.0)                  # tau = 1: a VIEW of the returned parameters (bezier.py:195-197)
+    keep = fa.clone()
+    low_b, up_b = net(voxel_grid=vb, images=None, iters=4, test_mode=True)
+    assert net.graph_replays() == 2 and net._graphs.captures == 1      # second frame: replay of the same graph, no capture
+    fb = up_b.get_flow_from_reference(1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(fa, keep), "a later forward overwrote an earlier result"
+    assert float((fa - fb).abs().max()) > 1e-3
+with torch.no_grad():                                       # the graph captured under inference_mode serves a later no_grad call too
+    _, up_n = net(voxel_grid=va, images=None, iters=4, test_mode=True)
+    assert net.graph_replays() == 3 and net._graphs.captures == 1
+    assert torch.equal(up_n.get_flow_from_reference(1.0), keep)
+with torch.inference_mode():
+    net.enable_hipgraph(False)                              # the eager forward of the same frames
+    _, eup_a = net(voxel_grid=va, images=None, iters=4, test_mode=True)
+    _, eup_b = net(voxel_grid=vb, images=None, iters=4, test_mode=True)
+    assert net.graph_replays() == 0
+    for g_, e_ in ((fa, eup_a), (fb, eup_b)):
+        d = g_ - e_.get_flow_from_reference(1.0)
+        epe = float(torch.sqrt((d * d).sum(1)).mean())
+        assert epe < 1e-6, epe                              # px; same kernels, same order: replay vs eager
+    net.enable_hipgraph(None)
+    net.load_state_dict(deterministic_state_dict(net, 5))   # new weights: the graph must not outlive them
+    _, up_c = net(voxel_grid=va, images=None, iters=4, test_mode=True)
+    assert net._graphs.captures == 1 and net.graph_replays() == 1      # fresh cache object after enable_hipgraph(False): one capture
+    assert float((up_c.get_flow_from_reference(1.0) - keep).abs().max()) > 1e-3
+# grad enabled (not what val.py does): eager, as documented
+_ = net(voxel_grid=va, images=None, iters=2, test_mode=True)
+assert net.graph_replays() == 1
+os.environ["BFLOW_HIPGRAPH"] = "0"
+with torch.inference_mode():
+    _ = net(voxel_grid=va, images=None, iters=4, test_mode=True)
+assert net.graph_replays() == 1
+print("SEAM-OK")
+""".format(dropin=os.path.join(root, "dropin"), root=root)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0 and "SEAM-OK" in out.stdout, out.stdout[-4000:]
+
+
 def test_graph_recaptured_after_weight_update_and_lru():
     """Packed weights are frozen into a captured graph: load_state_dict after the first forward must invalidate it (same output as
     a fresh model), and the cache keeps at most MAX_GRAPHS signatures."""
