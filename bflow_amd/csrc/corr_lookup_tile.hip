@@ -41,6 +41,7 @@ struct TilePlane {
     int h, w;
     float inv_scale;
     int target;
+    float rcp_hm1, rcp_wm1;     // 1 / (h - 1), 1 / (w - 1), correctly rounded (host division): see exact_div
 };
 
 struct TileArgs {
@@ -51,19 +52,68 @@ struct TileArgs {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float roundtrip(float x, int size) {   // see corr_lookup.hip: utils.py:13-14 + grid_sample's un-normalisation
-    const float sm1 = (float)(size - 1);
-    const float g = 2.0f * x / sm1 - 1.0f;
-    return (g + 1.0f) * (sm1 / 2.0f);
+// a / b as IEEE division gives it, from r = RN(1 / b): the refinement the compiler's own division expands to (v_div_scale / v_rcp / two
+// Newton steps on the quotient / v_div_fmas / v_div_fixup: ~13 vector instructions) without the reciprocal's own refinement -- r is a
+// per-plane constant, correctly rounded on the host -- and without the scaling / fix-up of operands near the ends of the exponent range
+// (coordinates and plane sizes are far from them).  Checked against `a / b` on the host for every fp32 mantissa of a and every
+// b = 1 .. 140, random mantissas up to b = 4096: no difference (tools/micro/exact_div_check.c).  b == 0 (a plane one element wide) has
+// r = inf: a * inf is what IEEE a / 0 is (+-inf, NaN for a == 0).
+__device__ __forceinline__ float exact_div(float a, float b, float r) {
+    const float q0 = a * r;
+    const float q1 = fmaf(fmaf(-b, q0, a), r, q0);
+    const float q = fmaf(fmaf(-b, q1, a), r, q1);
+    return b == 0.0f ? q0 : q;
+}
+
+__device__ __forceinline__ float roundtrip(float x, float sm1, float rcp) {   // see corr_lookup.hip: utils.py:13-14 + grid_sample's un-normalisation
+    const float g = exact_div(2.0f * x, sm1, rcp) - 1.0f;
+    return (g + 1.0f) * (sm1 * 0.5f);
 }
 
 // element offset of (y, x) inside a tiled plane with `tw` tiles per tile row
+// (24-bit multiply: v_mul_lo_u32 issues at a quarter of the rate; callers pass non-negative coordinates inside the tile grid)
 __device__ __forceinline__ int tiled_index(int y, int x, int tw) {
-    return (((y >> 2) * tw + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
+    return ((int)(__umul24(y >> 2, tw) + (x >> 3)) << 5) + ((y & 3) << 3) + (x & 7);
+}
+
+// small-index arithmetic of the phases on the full-rate 24-bit multiplier; i / 9 for i < 16 k
+__device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24(a, b); }
+__device__ __forceinline__ int div9(int i) { return (int)(__umul24(i, 7282) >> 16); }
+
+// LDS carve-up of the look-up kernel (byte offsets), shared by the kernel and its launcher.  `stage` and `patch` start on 128-B boundaries:
+// phase D reads `stage` as 16-B vectors and `patch` is the destination of 16-B LDS-DMA units.
+struct LookupLds {
+    int hw, cxy, rec, at, wt, uni, stage, patch, total;
+};
+__host__ __device__ inline LookupLds lookup_lds(int P, int TP, int unit_bytes_per_pair) {
+    const int np = P * TP, cstride = ((P * NCH + 31) >> 5) * 32;
+    LookupLds L;
+    L.hw = 0;                                  // [4][MAX_PLANES]: h, w (int), 1/(h-1), 1/(w-1) (float)
+    L.cxy = 16 * BFLOW_MAX_PLANES;             // [2][np] sampling centres
+    L.rec = L.cxy + 8 * np;                    // [np] gather record, 32 B (np is even: 16-B aligned)
+    L.at = L.rec + 32 * np;                    // [np][18] patch-relative west index of the 9 columns, north index of the 9 rows
+    L.wt = L.at + 72 * np;                     // [np][18][2] (west, east) / (north, south) weights
+    L.uni = L.wt + 144 * np;                   // [np] 1: the 9 window rows are the patch rows 1 .. 10 in order
+    L.stage = (L.uni + 4 * np + 127) & ~127;   // [TP][cstride] the tile's features in channel order
+    L.patch = L.stage + TP * cstride * 4;      // [np][12][PCOLS]
+    L.total = L.patch + np * unit_bytes_per_pair;
+    return L;
 }
 
 // COLS: phase C as (pair, window column) threads -- fewer instructions, the form for grids of many rounds (instruction-bound: batch >= 4 at
-// 60 x 80) -- instead of (pair, window row) threads, the form of the latency-bound single-round grids (batch 1: 11.1 vs 11.6 us at C2).
+// 60 x 80) -- instead of (pair, window row) threads, the form of the latency-bound single-round grids.
+//
+// Round 6: the kernel is bound by VALU ISSUE at batch 8 (75 workgroups per CU x ~1 500 vector instructions per workgroup x 4 cycles per
+// wave64 instruction = the launch; the dispatcher rotates a workgroup's first wave over the SIMDs, tools/micro/simd_map, so it is the
+// TOTAL that counts, not the per-wave split).  Four cuts of that total (profiles/r06_k7_valu_diet.txt):
+//   * gather: ONE wave instruction per pair (48 / 36 active lanes, LDS slots 768 / 576 B apart), so a lane's (row, unit) is loop-invariant
+//     and the pair's record -- plane address, origin, tile-grid limits, unpacked by the pair's thread of phase A -- is wave-uniform:
+//     14 vector instructions per pair instead of 38 per 64 units;
+//   * tap tables: one thread per (pair, tap) does both axes; the round trip's division is `exact_div` (5 instead of ~13 instructions);
+//   * interpolation (COLS, regular pairs): horizontal pass over the ten patch rows, then the vertical pass -- 2 x (mul + fma) per sample on
+//     packed fp32 instructions instead of four weight products and four multiply-adds (the weights' products are never formed; the
+//     rounding differs from the reference's nw*I_nw + ne*I_ne + sw*I_sw + se*I_se by the order of four fp32 operations);
+//   * output: the split as hardware conversions under FP16_OVFL + flushed fp16 results, two values per instruction (see phase D).
 template <typename VT, int TP, int THREADS, bool COLS = false>
 __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args, const float* __restrict__ params, _Float16* __restrict__ oh,
                                                                  _Float16* __restrict__ ol, int CBk, int Prow, int h1, int w1, int abl,
@@ -73,7 +123,7 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     constexpr int PCOLS = UPR * EPU;                   // 16 / 24
     constexpr int UPP = PATCH * UPR;                   // units per pair: 48 / 36
     constexpr int PELEMS = PATCH * PCOLS;              // patch elements per pair: 192 / 288
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // the only shared object; carved below (sizes follow P)
+    extern __shared__ __attribute__((aligned(128))) char smem[];   // the only shared object; carved by lookup_lds (sizes follow P)
     const int tid = threadIdx.x;
     const int N = h1 * w1;
     const int P = args.P;
@@ -91,35 +141,34 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     const int npair = P * TP;                 // pair = plane * TP + pixel of the tile
     const bool swz_on = !(abl & 16);
     const int cstride = ((P * NCH + 31) >> 5) * 32;   // staged channels per pixel (whole channel blocks)
+    const LookupLds L = lookup_lds(P, TP, UPP * 16);
     // plane table (indexed per lane: a runtime index into the kernel-argument struct would spill the struct to scratch)
-    const char** s_base = reinterpret_cast<const char**>(smem);                   // [MAX_PLANES]
-    int* s_h = reinterpret_cast<int*>(smem + 8 * BFLOW_MAX_PLANES);                // [MAX_PLANES]
-    int* s_w = s_h + BFLOW_MAX_PLANES;                                             // [MAX_PLANES]
-    float* s_cx = reinterpret_cast<float*>(s_w + BFLOW_MAX_PLANES);                // [npair] sampling centres
+    int* s_h = reinterpret_cast<int*>(smem + L.hw);                                // [MAX_PLANES]
+    int* s_w = s_h + BFLOW_MAX_PLANES;
+    float* s_rh = reinterpret_cast<float*>(s_w + BFLOW_MAX_PLANES);               // 1 / (h - 1), 1 / (w - 1)
+    float* s_rw = s_rh + BFLOW_MAX_PLANES;
+    float* s_cx = reinterpret_cast<float*>(smem + L.cxy);                          // [npair] sampling centres
     float* s_cy = s_cx + npair;
-    int* s_ox = reinterpret_cast<int*>(s_cy + npair);                              // [npair] patch origins (x: aligned down to a unit)
-    int* s_oy = s_ox + npair;
-    // [npair] gather record, 16 B: the pair's plane (64-bit address) | tile rows << 16 | tiles per row | origin y << 16 | origin x (16 bits,
-    // signed: the centre is clamped to the plane +- 64) -- everything the gather needs per pair in ONE ds_read_b128, formed ONCE by the pair's thread of phase A (the gather's 48 units per pair looked the plane table up, clamped the
-    // pixel and multiplied 64-bit plane offsets unit by unit: 85 instructions per unit, the largest share of a kernel that is
-    // instruction-bound at batch 8 -- 75 workgroups per CU: profiles/r05_k7_instruction_diet.txt)
-    int* s_rec = s_oy + npair;                               // (16-B aligned: 16 MAX_PLANES + 16 npair bytes precede it)
-    int* s_uni = s_rec + 4 * npair;                          // [npair] 1: the 9 window rows are the patch rows 1 .. 10 in order (see phase C)
-    int* s_at = s_uni + npair;                               // [npair][18]: patch-relative west index of the 9 columns, north index of the 9 rows
-    float* s_wt = reinterpret_cast<float*>(s_at + npair * 18);   // [npair][18][2]: (west, east) / (north, south) weights, ZERO where the corner
-                                                                 // lies outside the plane (= grid_sample's zero padding) or outside the patch
-    float* stage = s_wt + npair * 36;                        // [TP][cstride]: the tile's features in channel order
-    VT* patch = reinterpret_cast<VT*>(stage + TP * cstride);  // [npair][12][PCOLS] (+ 1 KB: the last DMA instruction's idle lanes land there)
+    // [npair] gather record, 32 B: plane address (64 bits) | origin y | origin x (aligned down to a unit) | tile-grid rows | tile-grid
+    // columns (elements) | tiles per tile row | -- everything the gather needs per pair, unpacked ONCE by the pair's thread of phase A
+    int* s_rec = reinterpret_cast<int*>(smem + L.rec);
+    int* s_at = reinterpret_cast<int*>(smem + L.at);
+    float* s_wt = reinterpret_cast<float*>(smem + L.wt);       // ZERO where the corner lies outside the plane (= grid_sample's zero padding) or the patch
+    int* s_uni = reinterpret_cast<int*>(smem + L.uni);
+    float* stage = reinterpret_cast<float*>(smem + L.stage);
+    VT* patch = reinterpret_cast<VT*>(smem + L.patch);
 
     // ---- phase A: thread = (plane, pixel) pair: Bezier evaluation -> sampling centre and patch origin ---------------------------
     // Every global load of a pair's thread is issued up front: the pair's plane record and time
     // coefficients sit in kernel-argument memory indexed per lane, i.e. they are global loads like the parameters, and as
     // "record -> coefficient row -> parameters" they were a chain of three dependent round trips at the head of a latency-bound kernel
     // (the phase was 3.7 of its 13.2 us at DSEC size).
-    if (tid < P) {
-        s_base[tid] = reinterpret_cast<const char*>(args.planes[tid].base);
-        s_h[tid] = args.planes[tid].h;
-        s_w[tid] = args.planes[tid].w;
+    if (tid >= THREADS - BFLOW_MAX_PLANES && tid - (THREADS - BFLOW_MAX_PLANES) < P) {      // (last wave: the first one has the pairs)
+        const int p = tid - (THREADS - BFLOW_MAX_PLANES);
+        s_h[p] = args.planes[p].h;
+        s_w[p] = args.planes[p].w;
+        s_rh[p] = args.planes[p].rcp_hm1;
+        s_rw[p] = args.planes[p].rcp_wm1;
     }
     if (tid < npair) {
         const int p = tid / TP, i = tid - p * TP;
@@ -155,19 +204,18 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
         // patch origin from the (clamped) centre; far-away centres see an all-zero neighbourhood, as zero padding demands
         const float ccx = fminf(fmaxf(cx, -64.f), (float)pl_w + 64.f);
         const float ccy = fminf(fmaxf(cy, -64.f), (float)pl_h + 64.f);
-        const int ox = (int)floorf(ccx) - (R + 1);
+        const int ox = ((int)floorf(ccx) - (R + 1)) & ~(EPU - 1);   // floor to a unit boundary (two's complement: also for negative origins)
+        const int oy = (int)floorf(ccy) - (R + 1);
         s_cx[tid] = cx;
         s_cy[tid] = cy;
-        s_ox[tid] = ox & ~(EPU - 1);                  // floor to a unit boundary (two's complement: also for negative origins)
-        s_oy[tid] = (int)floorf(ccy) - (R + 1);
         const int th = (pl_h + TILE_H - 1) >> 2, tw = (pl_w + TILE_W - 1) >> 3;
         const long long plane = (long long)b * N + min(n, N - 1);                        // pixels past the end re-read the last one (never stored)
         const char* pb = reinterpret_cast<const char*>(args.planes[p].base) + plane * (th * tw * 32) * (long long)sizeof(VT);
         const unsigned long long pbu = (unsigned long long)pb;
-        s_rec[4 * tid + 0] = (int)(unsigned)pbu;
-        s_rec[4 * tid + 1] = (int)(unsigned)(pbu >> 32);
-        s_rec[4 * tid + 2] = (th << 16) | tw;
-        s_rec[4 * tid + 3] = (s_oy[tid] << 16) | (s_ox[tid] & 0xffff);
+        typedef int i32x4_ __attribute__((ext_vector_type(4)));
+        i32x4_* rec = reinterpret_cast<i32x4_*>(s_rec + 8 * tid);
+        rec[0] = i32x4_{(int)(unsigned)pbu, (int)(unsigned)(pbu >> 32), oy, ox};
+        rec[1] = i32x4_{th * TILE_H, tw * TILE_W, tw, 0};
         // Window row ky samples y = cy + ky - 4: north corner floor(cy) + ky - 4 = patch row 1 + ky -- unless the centre was clamped (far
         // outside: every weight is zero) or cy sits within the round trip's error of an integer, where `roundtrip` may move single rows
         // across it.  Those pairs take phase C's general form; EDGE >> the round trip's error (a few ulps of the coordinate).
@@ -177,49 +225,51 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     }
     __syncthreads();
 
-    // ---- phase B: gather by LDS-DMA: unit u = (pair, row, unit of the row), 64 consecutive units per wave instruction ---------------
+    // ---- phase B: gather by LDS-DMA: ONE wave instruction per pair; lane = (patch row, unit of the row), UPP active lanes ----------------
     {
-        const int units = npair * UPP;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        for (int u0 = wave * 64; u0 < units && !(abl & 1); u0 += THREADS) {
-            const int u = min(u0 + lane, units - 1);
-            const int pair = u / UPP, ru = u - pair * UPP;
-            const int r = ru / UPR, k = ru - r * UPR;
-            // (inline assembly: the compiler puts a visible LDS read that redefines the address registers of the LDS-DMA in flight behind
-            //  vmcnt(0) -- the hardware has read them at issue --, which would make every iteration wait for the previous one's gather)
+        const int r = lane / UPR, k = lane - r * UPR;
+        // LDS position (pair, r, k) holds source unit k ^ swz(r, pair): spreads the interpolation's reads over the banks (a patch row is
+        // 64 B and a patch 768 B, so without it rows alternate between two bank groups and all pairs share them)
+        const int kr = (UPR == 4 && swz_on) ? (k ^ ((r >> 1) & 3)) : k;
+        for (int pair = wave; pair < npair && !(abl & 1); pair += THREADS / 64) {
+            // (inline assembly: the compiler puts a visible LDS read behind vmcnt(0) while an LDS-DMA is in flight -- the DMA writes LDS --,
+            //  which would make every iteration wait for the previous one's gather; the records are not what the DMA writes)
             typedef int i32x4_ __attribute__((ext_vector_type(4)));
-            i32x4_ rq;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rq) : "v"((unsigned)(size_t)(s_rec + 4 * pair)));
-            const int rec_x = rq[0], rec_y = rq[1], rec_z = rq[2], rec_w = rq[3];
-            const int oy = rec_w >> 16, ox = (int)(short)(rec_w & 0xffff);
-            const int th = rec_z >> 16, tw = rec_z & 0xffff;
-            // LDS position (pair, r, k) holds source unit k ^ swz(r, pair): spreads the interpolation's reads over the banks (a patch row is
-            // 64 B and a patch 768 B, so without it rows alternate between two bank groups and all pairs share them)
-            const int ks = (UPR == 4 && swz_on) ? (k ^ (((r >> 1) ^ pair) & 3)) : k;
-            const int gy = oy + r, gx = ox + ks * EPU;
-            const bool in = (unsigned)gy < (unsigned)(th * TILE_H) && (unsigned)gx < (unsigned)(tw * TILE_W);   // inside the tile grid (pads included)
-            const int idx = in ? tiled_index(gy, gx, tw) : 0;     // units outside the grid re-read the slab's first unit (they only meet zero weights)
-            const char* src = reinterpret_cast<const char*>(((unsigned long long)(unsigned)rec_y << 32) | (unsigned)rec_x) + (long long)idx * (int)sizeof(VT);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(reinterpret_cast<char*>(patch) + u0 * 16), 16, 0, 0);
+            i32x4_ ra, rb;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(ra), "=&v"(rb)
+                         : "v"((unsigned)(size_t)(s_rec + 8 * pair)));
+            const int ks = (UPR == 4 && swz_on) ? (kr ^ (pair & 3)) : kr;
+            const int gy = ra[2] + r, gx = ra[3] + ks * EPU;
+            const bool in = (unsigned)gy < (unsigned)rb[0] && (unsigned)gx < (unsigned)rb[1];   // inside the tile grid (pads included)
+            const int idx = in ? tiled_index(gy, gx, rb[2]) : 0;     // units outside the grid re-read the slab's first unit (they only meet zero weights)
+            const char* src = reinterpret_cast<const char*>(((unsigned long long)(unsigned)ra[1] << 32) | (unsigned)ra[0]) + (long long)idx * (int)sizeof(VT);
+            if (lane < UPP)
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(reinterpret_cast<char*>(patch) + pair * (UPP * 16)), 16, 0, 0);
         }
     }
-    // tap tables while the gather is in flight: item = (pair, axis, tap)
-    for (int it = tid; it < npair * 18 && !(abl & 8); it += THREADS) {
-        const int pair = it / 18, a = it - pair * 18;
+    // tap tables while the gather is in flight: item = (pair, tap), both axes
+    for (int it = tid; it < npair * WIN && !(abl & 8); it += THREADS) {
+        const int pair = div9(it), d = it - mul24(pair, WIN);
         const int p = pair / TP;
-        const bool isy = a >= WIN;
-        const int d = isy ? a - WIN : a;
-        const int size = isy ? s_h[p] : s_w[p];
-        float ic = roundtrip((isy ? s_cy[pair] : s_cx[pair]) + (float)(d - R), size);
-        ic = fminf(fmaxf(ic, -1.0e4f), 1.0e4f);
-        const float f0 = floorf(ic);
-        const float w1_ = ic - f0, w0_ = 1.f - w1_;     // far (east / south) and near (west / north) corner weights
-        const int g0 = (int)f0;                         // plane coordinate of the near corner
-        const int ai = g0 - (isy ? s_oy[pair] : s_ox[pair]);
-        const bool inpatch = ai >= 0 && ai + 1 < (isy ? PATCH : PCOLS);
-        s_at[it] = inpatch ? ai : 0;
-        s_wt[2 * it] = (inpatch && g0 >= 0 && g0 < size) ? w0_ : 0.f;
-        s_wt[2 * it + 1] = (inpatch && g0 + 1 >= 0 && g0 + 1 < size) ? w1_ : 0.f;
+        const float off = (float)(d - R);
+#pragma unroll
+        for (int isy = 0; isy < 2; ++isy) {
+            const int size = isy ? s_h[p] : s_w[p];
+            float ic = roundtrip((isy ? s_cy[pair] : s_cx[pair]) + off, (float)(size - 1), isy ? s_rh[p] : s_rw[p]);
+            ic = fminf(fmaxf(ic, -1.0e4f), 1.0e4f);
+            const float f0 = floorf(ic);
+            const float w1_ = ic - f0, w0_ = 1.f - w1_;     // far (east / south) and near (west / north) corner weights
+            const int g0 = (int)f0;                         // plane coordinate of the near corner
+            const int ai = g0 - s_rec[8 * pair + (isy ? 2 : 3)];
+            const bool inpatch = (unsigned)ai < (unsigned)((isy ? PATCH : PCOLS) - 1);
+            const int o = mul24(pair, 18) + isy * WIN + d;
+            s_at[o] = inpatch ? ai : 0;
+            typedef float f32x2w_ __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f32x2w_*>(s_wt + 2 * o) = f32x2w_{(inpatch && (unsigned)g0 < (unsigned)size) ? w0_ : 0.f,
+                                                               (inpatch && (unsigned)(g0 + 1) < (unsigned)size) ? w1_ : 0.f};
+        }
     }
     // pad channels of the last channel block are written as zeros
     if (tid < TP * (cstride - P * NCH)) {            // (< 32 TP <= THREADS items)
@@ -231,59 +281,52 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     // ---- phase C: interpolation.  unit = (pair, window row): 9 samples -> stage[pixel][plane*81 + row*9 ..] -------------------------
     if constexpr (!COLS) {
         for (int it = tid; it < npair * WIN && !(abl & 2); it += THREADS) {
-            const int pair = it / WIN, ky = it - pair * WIN;
+            const int pair = div9(it), ky = it - mul24(pair, WIN);
             const int p = pair / TP, i = pair - p * TP;
-            const int* at = s_at + pair * 18;
-            const float* wt = s_wt + pair * 36;
+            const int* at = s_at + mul24(pair, 18);
+            const float* wt = s_wt + mul24(pair, 36);
             const float wn = wt[2 * (WIN + ky)], ws = wt[2 * (WIN + ky) + 1];
             const int ay = at[WIN + ky];
-            const VT* row0 = patch + pair * PELEMS + ay * PCOLS;
+            const VT* row0 = patch + mul24(pair, PELEMS) + ay * PCOLS;
             const VT* row1 = row0 + PCOLS;
             const int z0 = (UPR == 4 && swz_on) ? ((((ay >> 1) ^ pair) & 3) << 2) : 0, z1 = (UPR == 4 && swz_on) ? (((((ay + 1) >> 1) ^ pair) & 3) << 2) : 0;
-            float* dst = stage + i * cstride + p * NCH + ky * WIN;
+            float* dst = stage + mul24(i, cstride) + mul24(p, NCH) + ky * WIN;
 #pragma unroll
             for (int kx = 0; kx < WIN; ++kx) {
                 const float ww = wt[2 * kx], we = wt[2 * kx + 1];
                 const int c0 = at[kx], c1 = c0 + 1;
-                // utils.py:19 / grid_sample: nw*I_nw + ne*I_ne + sw*I_sw + se*I_se, weights as products of the axis weights
-                float v = (float)row0[c0 ^ z0] * (ww * wn);
-                v += (float)row0[c1 ^ z0] * (we * wn);
-                v += (float)row1[c0 ^ z1] * (ww * ws);
-                v += (float)row1[c1 ^ z1] * (we * ws);
-                dst[kx] = v;
+                // utils.py:19 / grid_sample: nw*I_nw + ne*I_ne + sw*I_sw + se*I_se with the weights the products of the axis weights --
+                // evaluated as horizontal pass, then vertical pass (the SAME expression in every form of this phase: a sample does not
+                // depend on the batch size that selects the form)
+                const float hn = fmaf((float)row0[c1 ^ z0], we, (float)row0[c0 ^ z0] * ww);
+                const float hs = fmaf((float)row1[c1 ^ z1], we, (float)row1[c0 ^ z1] * ww);
+                dst[kx] = fmaf(hs, ws, hn * wn);
             }
         }
     } else {
-    // (round 5, instruction diet, COLS: thread = (pair, window COLUMN).  In the regular case -- s_uni -- the 9 window rows of a pair are the patch
-    //  rows 1 .. 10 in order, so a column thread reads its two patch columns of those ten rows ONCE (20 reads and address computations instead
-    //  of 36) and every sample is the same expression, in the same order, on the same operands as in the general form below.)
+    // (COLS: thread = (pair, window COLUMN).  In the regular case -- s_uni -- the 9 window rows of a pair are the patch rows 1 .. 10 in order,
+    //  so a column thread reads its two patch columns of those ten rows ONCE, interpolates them horizontally (ten values) and then vertically.)
     for (int it = tid; it < npair * WIN && !(abl & 2); it += THREADS) {
-        const int pair = it / WIN, kx = it - pair * WIN;
+        const int pair = div9(it), kx = it - mul24(pair, WIN);
         const int p = pair / TP, i = pair - p * TP;
-        const int* at = s_at + pair * 18;
-        const float* wt = s_wt + pair * 36;
+        const int* at = s_at + mul24(pair, 18);
+        const float* wt = s_wt + mul24(pair, 36);
         const float ww = wt[2 * kx], we = wt[2 * kx + 1];
         const int c0 = at[kx], c1 = c0 + 1;
-        const VT* pb = patch + pair * PELEMS;
-        float* dst = stage + i * cstride + p * NCH + kx;
+        const VT* pb = patch + mul24(pair, PELEMS);
+        float* dst = stage + mul24(i, cstride) + mul24(p, NCH) + kx;
         auto zof = [&](int row) -> int { return (UPR == 4 && swz_on) ? ((((row >> 1) ^ pair) & 3) << 2) : 0; };
         if (s_uni[pair] && at[WIN] == 1) {
-            float a[WIN + 1], bq[WIN + 1];
+            float hr[WIN + 1];
 #pragma unroll
             for (int r = 0; r <= WIN; ++r) {
                 const int z = zof(1 + r);
-                a[r] = (float)pb[(1 + r) * PCOLS + (c0 ^ z)];
-                bq[r] = (float)pb[(1 + r) * PCOLS + (c1 ^ z)];
+                hr[r] = fmaf((float)pb[(1 + r) * PCOLS + (c1 ^ z)], we, (float)pb[(1 + r) * PCOLS + (c0 ^ z)] * ww);
             }
 #pragma unroll
             for (int ky = 0; ky < WIN; ++ky) {
                 const float wn = wt[2 * (WIN + ky)], ws = wt[2 * (WIN + ky) + 1];
-                // utils.py:19 / grid_sample: nw*I_nw + ne*I_ne + sw*I_sw + se*I_se, weights as products of the axis weights
-                float v = a[ky] * (ww * wn);
-                v += bq[ky] * (we * wn);
-                v += a[ky + 1] * (ww * ws);
-                v += bq[ky + 1] * (we * ws);
-                dst[ky * WIN] = v;
+                dst[ky * WIN] = fmaf(hr[ky + 1], ws, hr[ky] * wn);
             }
         } else {
 #pragma unroll
@@ -293,11 +336,10 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
                 const VT* row0 = pb + ay * PCOLS;
                 const VT* row1 = row0 + PCOLS;
                 const int z0 = zof(ay), z1 = zof(ay + 1);
-                float v = (float)row0[c0 ^ z0] * (ww * wn);
-                v += (float)row0[c1 ^ z0] * (we * wn);
-                v += (float)row1[c0 ^ z1] * (ww * ws);
-                v += (float)row1[c1 ^ z1] * (we * ws);
-                dst[ky * WIN] = v;
+                // (the same two-pass expression as above: a pair's samples do not depend on which form its neighbours in the wave take)
+                const float hn = fmaf((float)row0[c1 ^ z0], we, (float)row0[c0 ^ z0] * ww);
+                const float hs = fmaf((float)row1[c1 ^ z1], we, (float)row1[c0 ^ z1] * ww);
+                dst[ky * WIN] = fmaf(hs, ws, hn * wn);
             }
         }
     }
@@ -305,8 +347,8 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     __syncthreads();
 
     // ---- phase D: output in memory order.  item = (channel block, pixel, 8-channel chunk), chunk fastest: 16 B of hi + 16 B of lo ----------
-    // (round 5, instruction diet: the staged values are read as two 16-B vectors -- stage rows are 128-B aligned --, and the stores go through
-    //  one buffer descriptor per plane and image with a 32-bit offset: the per-item 64-bit row arithmetic was a tenth of this phase)
+    // (round 5, instruction diet: the staged values are read as two 16-B vectors -- `stage` is 128-B aligned (lookup_lds) --, and the stores go
+    //  through one buffer descriptor per plane and image with a 32-bit offset: the per-item 64-bit row arithmetic was a tenth of this phase)
     const int items = (cstride >> 5) * TP * 4;
     const long long img = (long long)b * CBk * Prow * 32;                         // elements of the images before this one
     const __amdgpu_buffer_rsrc_t r_oh = __builtin_amdgcn_make_buffer_rsrc((void*)(oh + img), 0, CBk * Prow * 64, 0x00020000);
@@ -331,7 +373,7 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
         const int chunk = it & 3, i = (it >> 2) % TP, cb = it / (4 * TP);
         const int n = n0 + i;
         if (n >= N) continue;
-        const f32x4_* sp = reinterpret_cast<const f32x4_*>(stage + i * cstride + cb * 32 + chunk * 8);
+        const f32x4_* sp = reinterpret_cast<const f32x4_*>(stage + mul24(i, cstride) + cb * 32 + chunk * 8);
         const f32x4_ v0 = sp[0], v1 = sp[1];
         const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         half8 h8, l8;
@@ -356,7 +398,7 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
             l8[j + 1] = ll[1];
         }
 #endif
-        const unsigned o = (unsigned)(((cb * Prow + n) * 32 + chunk * 8) * 2);    // bytes inside the image's plane (< 2^31: checked by the launcher)
+        const unsigned o = (unsigned)(((mul24(cb, Prow) + n) * 32 + chunk * 8) * 2);    // bytes inside the image's plane (< 2^31: checked by the launcher)
         // non-temporal: the consumer (convc1) is the next kernel and starts with a cold L2 anyway; the 13.5 MB of features then leave during
         // the kernel instead of in the write-back at its end (round 4: 12.8 -> 11.8 us at C2; LOOKUP_PLAIN_STORES for A/B)
 #ifdef LOOKUP_PLAIN_STORES
@@ -421,6 +463,8 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
         a.planes[p].w = planes[p].w;
         a.planes[p].inv_scale = 1.0f / (float)(1 << planes[p].level);
         a.planes[p].target = planes[p].target;
+        a.planes[p].rcp_hm1 = 1.0f / (float)(planes[p].h - 1);      // correctly rounded (IEEE host division); inf for a one-row plane
+        a.planes[p].rcp_wm1 = 1.0f / (float)(planes[p].w - 1);
     }
     for (int p = 0; p < P; ++p)
         for (int i = 0; i < deg; ++i) a.pcoef[p * BFLOW_MAX_DEGREE + i] = coef[planes[p].target * deg + i];
@@ -429,8 +473,7 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
     static const int tp_env = [] { const char* e = getenv("BFLOW_LOOKUP_TP"); return e ? atoi(e) : 0; }();
     static const int abl = [] { const char* e = getenv("BFLOW_LOOKUP_ABL"); return e ? atoi(e) : 0; }();
     const int tp = (tp_env == 2 || tp_env == 4 || tp_env == 8) ? tp_env : 2;
-    const int cstride = ((P * NCH + 31) >> 5) * 32;
-    const int lds = 16 * BFLOW_MAX_PLANES + P * tp * (4 + 4 + 1 + 18 + 36) * 4 + P * tp * PATCH * 16 * (f16_planes ? 3 : 4) + tp * cstride * 4 + 1024;
+    const int lds = lookup_lds(P, tp, PATCH * 16 * (f16_planes ? 3 : 4)).total;
     Im2colArgs m = {};
     int rider_blocks = 0;
     if (rider) {
