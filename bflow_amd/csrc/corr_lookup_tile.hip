@@ -90,8 +90,8 @@ __host__ __device__ inline LookupLds lookup_lds(int P, int TP, int unit_bytes_pe
     LookupLds L;
     L.hw = 0;                                  // [4][MAX_PLANES]: h, w (int), 1/(h-1), 1/(w-1) (float)
     L.cxy = 16 * BFLOW_MAX_PLANES;             // [2][np] sampling centres
-    L.rec = L.cxy + 8 * np;                    // [np] gather record, 32 B (np is even: 16-B aligned)
-    L.at = L.rec + 32 * np;                    // [np][18] patch-relative west index of the 9 columns, north index of the 9 rows
+    L.rec = L.cxy + 8 * np;                    // [np] gather record, 48 B (np is even: 16-B aligned)
+    L.at = L.rec + 48 * np;                    // [np][18] patch-relative west index of the 9 columns, north index of the 9 rows
     L.wt = L.at + 72 * np;                     // [np][18][2] (west, east) / (north, south) weights
     L.uni = L.wt + 144 * np;                   // [np] 1: the 9 window rows are the patch rows 1 .. 10 in order
     L.stage = (L.uni + 4 * np + 127) & ~127;   // [TP][cstride] the tile's features in channel order
@@ -149,8 +149,9 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
     float* s_rw = s_rh + BFLOW_MAX_PLANES;
     float* s_cx = reinterpret_cast<float*>(smem + L.cxy);                          // [npair] sampling centres
     float* s_cy = s_cx + npair;
-    // [npair] gather record, 32 B: plane address (64 bits) | origin y | origin x (aligned down to a unit) | tile-grid rows | tile-grid
-    // columns (elements) | tiles per tile row | -- everything the gather needs per pair, unpacked ONCE by the pair's thread of phase A
+    // [npair] gather record, 48 B: plane address (64 bits) | origin y | origin x (aligned down to a unit) | tile-grid rows | tile-grid
+    // columns (elements) | tiles per tile row | - | first patch row to fetch | rows - 1 | first unit of a row | units - 1 -- everything the
+    // gather needs per pair, unpacked ONCE by the pair's thread of phase A
     int* s_rec = reinterpret_cast<int*>(smem + L.rec);
     int* s_at = reinterpret_cast<int*>(smem + L.at);
     float* s_wt = reinterpret_cast<float*>(smem + L.wt);       // ZERO where the corner lies outside the plane (= grid_sample's zero padding) or the patch
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
         const char* pb = reinterpret_cast<const char*>(args.planes[p].base) + plane * (th * tw * 32) * (long long)sizeof(VT);
         const unsigned long long pbu = (unsigned long long)pb;
         typedef int i32x4_ __attribute__((ext_vector_type(4)));
-        i32x4_* rec = reinterpret_cast<i32x4_*>(s_rec + 8 * tid);
+        i32x4_* rec = reinterpret_cast<i32x4_*>(s_rec + 12 * tid);
         rec[0] = i32x4_{(int)(unsigned)pbu, (int)(unsigned)(pbu >> 32), oy, ox};
         rec[1] = i32x4_{th * TILE_H, tw * TILE_W, tw, 0};
         // Window row ky samples y = cy + ky - 4: north corner floor(cy) + ky - 4 = patch row 1 + ky -- unless the centre was clamped (far
@@ -221,7 +222,18 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
         // across it.  Those pairs take phase C's general form; EDGE >> the round trip's error (a few ulps of the coordinate).
         const float fry = cy - floorf(cy);
         const float edge = fmaxf(1.0f / 1024.0f, (float)pl_h * 1.0e-6f);
-        s_uni[tid] = (cy == ccy && fry > edge && fry < 1.0f - edge) ? 1 : 0;
+        const bool uni_y = cy == ccy && fry > edge && fry < 1.0f - edge;
+        s_uni[tid] = uni_y ? 1 : 0;
+        // The taps of a REGULAR pair touch the patch rows 1 .. 10 and the plane columns floor(cx) - 4 .. floor(cx) + 5 only: rows 0 / 11 and
+        // the outer units exist for the round trip's integer flips.  What no tap can touch is not fetched (the kernel moves HBM lines at
+        // the rate a pure gather of its shape reaches once its instruction count is cut: profiles/r06_k7_valu_diet.txt); the LDS positions
+        // keep stale data that no regular pair reads.  Pairs near an integer or clamped fetch the full patch.
+        const float frx = cx - floorf(cx);
+        const float edgx = fmaxf(1.0f / 1024.0f, (float)pl_w * 1.0e-6f);
+        const bool uni_x = cx == ccx && frx > edgx && frx < 1.0f - edgx && !(abl & 32);
+        const int offx = ((int)floorf(ccx) - (R + 1)) & (EPU - 1);          // first tap column - 1, relative to the aligned origin
+        const int klo = uni_x ? (offx + 1) / EPU : 0, khi = uni_x ? (offx + 2 * R + 2) / EPU : UPR - 1;
+        rec[2] = (uni_y && !(abl & 32)) ? i32x4_{1, 2 * R + 1, klo, khi - klo} : i32x4_{0, PATCH - 1, klo, khi - klo};
     }
     __syncthreads();
 
@@ -236,16 +248,16 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
             // (inline assembly: the compiler puts a visible LDS read behind vmcnt(0) while an LDS-DMA is in flight -- the DMA writes LDS --,
             //  which would make every iteration wait for the previous one's gather; the records are not what the DMA writes)
             typedef int i32x4_ __attribute__((ext_vector_type(4)));
-            i32x4_ ra, rb;
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(ra), "=&v"(rb)
-                         : "v"((unsigned)(size_t)(s_rec + 8 * pair)));
+            i32x4_ ra, rb, rc;
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(ra), "=&v"(rb), "=&v"(rc)
+                         : "v"((unsigned)(size_t)(s_rec + 12 * pair)));
             const int ks = (UPR == 4 && swz_on) ? (kr ^ (pair & 3)) : kr;
             const int gy = ra[2] + r, gx = ra[3] + ks * EPU;
             const bool in = (unsigned)gy < (unsigned)rb[0] && (unsigned)gx < (unsigned)rb[1];   // inside the tile grid (pads included)
             const int idx = in ? tiled_index(gy, gx, rb[2]) : 0;     // units outside the grid re-read the slab's first unit (they only meet zero weights)
             const char* src = reinterpret_cast<const char*>(((unsigned long long)(unsigned)ra[1] << 32) | (unsigned)ra[0]) + (long long)idx * (int)sizeof(VT);
-            if (lane < UPP)
+            if (lane < UPP && (unsigned)(r - rc[0]) <= (unsigned)rc[1] && (unsigned)(ks - rc[2]) <= (unsigned)rc[3])
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(reinterpret_cast<char*>(patch) + pair * (UPP * 16)), 16, 0, 0);
         }
     }
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(THREADS) void corr_lookup_tile_kernel(TileArgs args
             const float f0 = floorf(ic);
             const float w1_ = ic - f0, w0_ = 1.f - w1_;     // far (east / south) and near (west / north) corner weights
             const int g0 = (int)f0;                         // plane coordinate of the near corner
-            const int ai = g0 - s_rec[8 * pair + (isy ? 2 : 3)];
+            const int ai = g0 - s_rec[12 * pair + (isy ? 2 : 3)];
             const bool inpatch = (unsigned)ai < (unsigned)((isy ? PATCH : PCOLS) - 1);
             const int o = mul24(pair, 18) + isy * WIN + d;
             s_at[o] = inpatch ? ai : 0;
@@ -488,10 +500,19 @@ int lookup_tile_launch(const bflow_plane_t* planes, int P, const float* params, 
                            m, rider_blocks);
     };
     static const int cols_env = [] { const char* e = getenv("BFLOW_LOOKUP_COLS"); return e ? atoi(e) : -1; }();   // tools A/B: 0 / 1 force a form
-    const bool cols = cols_env >= 0 ? cols_env != 0 : (long long)B * h1 * w1 >= 16000;
-    if (cols && tp == 2) {
-        if (f16_planes) go(corr_lookup_tile_kernel<_Float16, 2, 256, true>);
-        else go(corr_lookup_tile_kernel<float, 2, 256, true>);
+    // (round 6: with the two-pass interpolation the column form is the faster one at every BASELINE shape -- C2 10.4 vs 10.5 us, C4 shard
+    //  56.7 vs 59.3, C5 60.9 vs 63.7 us, profiles/r06_k7_tp_cols.txt -- and one form for every batch size keeps a sample's bits independent of it)
+    const bool cols = cols_env >= 0 ? cols_env != 0 : true;
+    if (cols) {
+        if (f16_planes) {
+            if (tp == 2) go(corr_lookup_tile_kernel<_Float16, 2, 256, true>);
+            else if (tp == 4) go(corr_lookup_tile_kernel<_Float16, 4, 256, true>);
+            else go(corr_lookup_tile_kernel<_Float16, 8, 256, true>);
+        } else {
+            if (tp == 2) go(corr_lookup_tile_kernel<float, 2, 256, true>);
+            else if (tp == 4) go(corr_lookup_tile_kernel<float, 4, 256, true>);
+            else go(corr_lookup_tile_kernel<float, 8, 256, true>);
+        }
     } else if (f16_planes) {
         if (tp == 2) go(corr_lookup_tile_kernel<_Float16, 2, 256>);
         else if (tp == 4) go(corr_lookup_tile_kernel<_Float16, 4, 256>);
