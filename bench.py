@@ -151,19 +151,25 @@ def main():
         return float(t.item())
 
     def kernel_event_ms(launch, n):
-        """Average duration (ms) of one launch: `n` launches captured into one hipGraph, hipEvents recorded on the launch stream (torch's
+        """(average duration in ms of one launch, average SHADER clock in GHz during the launches): `n` launches captured into one hipGraph
+        between two bflow_shader_clock_stamp launches (s_memtime / s_memrealtime of XCD 0), hipEvents recorded on the launch stream (torch's
         current stream) around its replay.  (An event pair around every single eager launch also times the HOST's enqueue latency -- 5-8 us
-        of Python per launch, box dependent -- which is 40 % of the 13-us look-up and moved its fraction between 0.14 and 0.17.)"""
+        of Python per launch, box dependent -- which is 40 % of the 13-us look-up and moved its fraction between 0.14 and 0.17.)  The
+        clock is what tells a slow box from a regression: the part clocks to its power budget, 1.3-2.1 GHz under load."""
+        from bflow_amd import hip as _hip
         for _ in range(3):
             launch()
         torch.cuda.synchronize()
+        pairs = torch.zeros((2, 2), dtype=torch.int64, device=dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
+            _hip.shader_clock_stamp(pairs, 0)
             for _ in range(n):
                 launch()
+            _hip.shader_clock_stamp(pairs, 1)
         g.replay()
         torch.cuda.synchronize()
-        times = []
+        times, clocks = [], []
         for _ in range(3):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -171,8 +177,27 @@ def main():
             b.record()
             torch.cuda.synchronize()
             times.append(a.elapsed_time(b) / n)
+            clocks.append(_hip.shader_clock_ghz(pairs))
         del g
-        return float(np.mean(times))
+        return float(np.mean(times)), float(np.mean(clocks))
+
+    def clocked(fn, steps):
+        """time_steps(fn, steps) with the average shader clock of the timed region (two stamps on the launch stream around it)."""
+        from bflow_amd import hip as _hip
+        pairs = torch.zeros((2, 2), dtype=torch.int64, device=dev)
+        barrier()
+        torch.cuda.synchronize()
+        _hip.shader_clock_stamp(pairs, 0)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        _hip.shader_clock_stamp(pairs, 1)
+        torch.cuda.synchronize()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item()), round(_hip.shader_clock_ghz(pairs), 3)
 
     cfg = configs.model_config(CFG)
     model = bflow_amd.RAFTSpline(cfg).eval()
@@ -226,8 +251,9 @@ def main():
     def measure(step, frames_per_step_per_rank, steps, warmup):
         for _ in range(max(warmup, 1)):
             step()
-        el = time_steps(step, steps)
-        return {"value": round(world * frames_per_step_per_rank * steps / el, 3), "ms_per_step": round(el / steps * 1e3, 4), "steps": steps}
+        el, ghz = clocked(step, steps)
+        return {"value": round(world * frames_per_step_per_rank * steps / el, 3), "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+                "clock_ghz": ghz}
 
     # `value` = C2 weak at EVERY N (one workload for the whole 1/2/4/8 series); C4 strong is measured next to it
     res_c2 = measure(step_c2, 1, args.steps, args.warmup)
@@ -257,7 +283,7 @@ def main():
         out = {
             "metric": "frames/sec (whole node), raft-spline DSEC 640x480 12-iter",
             "value": res_c2["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": res_c2["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": res_c2["ms_per_step"], "clock_ghz": res_c2.get("clock_ghz"), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (split-fp16 pairs)",
             "arithmetic": "fp32 values carried as split fp16 pairs (hi + lo*2^-11) on the fp16 matrix cores, fp32 accumulation; correlation cross terms (hi*lo + lo*hi) on the fp8 matrix rate; parity 2e-5 px EPE vs the fp32 CPU reference; `value_split` = the same frame with the correlation on three fp16 passes (fp32 class everywhere)",
             "data": "synthetic",
@@ -352,10 +378,25 @@ def main():
         pmc = pmc_doc.get("kernels", {}) if pmc_ok else {}
         out["kernel_source_hash"] = src_hash
 
+        # the clock a PURE stream of the split format's matrix instructions sustains on THIS box, measured now (tools/micro/fp8_cross, built by
+        # __graft_entry__.build(); the constant is the round-5 reading and only stands in when the binary is missing)
+        mfma_clock = {"ghz": MFMA_STREAM_SUSTAINED_GHZ, "source": "constant: profiles/r05_mfma_clock_fp8_cross.txt (1.39-1.58 GHz); tools/micro/fp8_cross not built"}
+        fx = os.path.join(ROOT, "tools", "micro", "fp8_cross")
+        if os.path.isfile(fx) and os.access(fx, os.X_OK):
+            try:
+                txt = subprocess.run([fx], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120).stdout
+                cl = sorted(float(l.split("shader clock")[1].split("GHz")[0]) for l in txt.splitlines() if l.startswith("6 x fp16 MFMA per block") and "shader clock" in l)
+                if cl:
+                    mfma_clock = {"ghz": cl[len(cl) // 2], "all": cl, "source": "measured in this run: tools/micro/fp8_cross rate_kernel<0> (6 x v_mfma_f32_32x32x16_f16 "
+                                  "per 32-channel block on every SIMD, random data; s_memtime / s_memrealtime per workgroup), median of 3"}
+            except Exception as e:       # a tools binary: its failure must not take the bench line down
+                mfma_clock["error"] = repr(e)[:200]
+        out["mfma_stream_clock"] = mfma_clock
+
         def price(k):
             for _ in range(3):
                 k["launch"]()
-            ms = kernel_event_ms(k["launch"], max(args.steps, 10))
+            ms, ghz = kernel_event_ms(k["launch"], max(args.steps, 10))
             if k["bound"] == "mfma":
                 tf = k["flops"] / (ms * 1e-3) / 1e12
                 r = {"kernel": k["name"], "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s",
@@ -365,10 +406,10 @@ def main():
                              "peak = 2500 TFLOP/s fp16 dense / 3",
                      # second reading of the same number: against what the matrix pipes deliver at the clock the chip SUSTAINS under a pure
                      # matrix stream (power-limited); `frac` above stays against the 2.4-GHz peak
-                     "power_model": {"mfma_stream_clock_ghz": MFMA_STREAM_SUSTAINED_GHZ,
-                                     "peak_at_that_clock": round(PEAK_SPLIT_TFLOPS * MFMA_STREAM_SUSTAINED_GHZ / PEAK_CLOCK_GHZ, 1),
-                                     "frac_of_that": round(tf / (PEAK_SPLIT_TFLOPS * MFMA_STREAM_SUSTAINED_GHZ / PEAK_CLOCK_GHZ), 4),
-                                     "source": "profiles/r05_mfma_clock_fp8_cross.txt (1.39-1.58 GHz), profiles/r05_enc_stream_clock.txt"}}
+                     "power_model": {"mfma_stream_clock_ghz": mfma_clock["ghz"],
+                                     "peak_at_that_clock": round(PEAK_SPLIT_TFLOPS * mfma_clock["ghz"] / PEAK_CLOCK_GHZ, 1),
+                                     "frac_of_that": round(tf / (PEAK_SPLIT_TFLOPS * mfma_clock["ghz"] / PEAK_CLOCK_GHZ), 4),
+                                     "source": mfma_clock["source"]}}
             else:
                 gbs = k["bytes"] / (ms * 1e-3) / 1e9
                 r = {"kernel": k["name"], "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -385,6 +426,9 @@ def main():
                     r["frac_of_line_granular_cap"] = round(k["line_bytes"] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
                     r["line_note"] = ("line_bytes = the 128-B lines (4 x 8-element tiles) a 10 x 10 tap window touches on tiled fp32 planes + the 81 values written: the "
                                       "floor of ANY gather on a materialised volume; frac_of_line_granular_cap = line_bytes / time / 8 TB/s")
+            r["clock_ghz"] = round(ghz, 3)      # average shader clock DURING these launches (bflow_shader_clock_stamp): measured, in-run
+            if k["bound"] == "mfma":
+                r["frac_at_measured_clock"] = round(r["achieved"] / (PEAK_SPLIT_TFLOPS * ghz / PEAK_CLOCK_GHZ), 4)
             if k.get("note"):
                 r["note"] = (r.get("note", "") + "; " if r.get("note") else "") + k["note"]
             # HBM traffic per launch cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the SAME launches
@@ -414,7 +458,7 @@ def main():
         # C2 volume (368.6 MB; torch's zero_() is that call) -- and, when the tools binary is there, K5's own store shape
         # (tools/micro/store_patterns: 256 persistent 8-wave workgroups, 32 rows x 1 KB per item, 4 B per lane, nt)
         volz = torch.empty((4, 4800, 4800), device=dev)
-        ms_set = kernel_event_ms(lambda: volz.zero_(), 10)
+        ms_set, _ = kernel_event_ms(lambda: volz.zero_(), 10)
         ceil = {"hipMemsetAsync_gbs": round(volz.numel() * 4 / (ms_set * 1e-3) / 1e9, 1)}
         del volz
         sp = os.path.join(ROOT, "tools", "micro", "store_patterns")
@@ -439,12 +483,14 @@ def main():
                 # v_mfma_f32_32x32x16_f16 per SIMD, 16 k-steps x `units` per 32x32x256 block, 1024 SIMDs) NEXT TO the store stream at the
                 # measured ceiling of a pure store stream of K5's own shape; perfectly overlapped = the slower of the two
                 blocks = r["flop_per_launch"] / (2.0 * 32 * 32 * 256)
-                t_mfma = blocks * 16 * units * 32 / 1024 / (K5_SUSTAINED_GHZ * 1e9)
+                k5_ghz = r.get("clock_ghz") or K5_SUSTAINED_GHZ          # the clock measured during THESE launches
+                t_mfma = blocks * 16 * units * 32 / 1024 / (k5_ghz * 1e9)
                 k5_store = ceil.get("k5_shape_4B_nt_gbs", ceil["hipMemsetAsync_gbs"])
                 t_store = r["algorithmic_bytes_per_launch"] / (k5_store * 1e9)
                 r["model_cap"] = {"frac": round(r["algorithmic_bytes_per_launch"] / max(t_mfma, t_store) / 1e9 / PEAK_HBM_GBS, 4),
                                   "frac_if_additive": round(r["algorithmic_bytes_per_launch"] / (t_mfma + t_store) / 1e9 / PEAK_HBM_GBS, 4),
-                                  "t_mfma_us": round(t_mfma * 1e6, 1), "t_store_us": round(t_store * 1e6, 1), "sustained_clock_ghz": K5_SUSTAINED_GHZ,
+                                  "t_mfma_us": round(t_mfma * 1e6, 1), "t_store_us": round(t_store * 1e6, 1), "sustained_clock_ghz": round(k5_ghz, 3),
+                                  "clock_source": "measured in this run (bflow_shader_clock_stamp around the timed launches)",
                                   "store_stream_gbs": k5_store,
                                   "note": "cap of this arithmetic = max(matrix pipes at the sustained clock, store stream of K5's shape); "
                                           "frac is measured against 8 TB/s, which no arithmetic with matrix work can reach here"}
@@ -469,7 +515,8 @@ def main():
                 d = d[k]
             return d
         fr = {k: out[k].get("frac") for k in out if k.startswith("roofline") and isinstance(out[k], dict)}
-        out["summary"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "ms_per_gru_iter": out.get("ms_per_gru_iter"),
+        ck = {k: out[k].get("clock_ghz") for k in out if k.startswith("roofline") and isinstance(out[k], dict) and out[k].get("clock_ghz") is not None}
+        out["summary"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "clock_ghz": out.get("clock_ghz"), "clock_ghz_per_roofline": ck, "ms_per_gru_iter": out.get("ms_per_gru_iter"),
                           "ms_fixed_part": out.get("ms_fixed_part"), "value_split": g("value_split", "value"),
                           "value_eager": g("value_eager", "value"), "value_static_outputs": g("value_static_outputs", "value"),
                           "c4_strong": g("c4_strong", "value"), "c2_two_in_flight": g("c2_two_in_flight", "value"),

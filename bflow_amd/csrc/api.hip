@@ -30,12 +30,30 @@ extern "C" const char* bflow_last_error_string(void) { return bflow::g_err; }
 
 namespace {
 __global__ void clock_stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+// 16 one-wave workgroups (dispatched round-robin over the XCDs): the ones that land on XCD 0 write its two counters
+__global__ void shader_clock_stamp_kernel(unsigned long long* pair) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if ((xcc & 0xf) == 0 && threadIdx.x == 0) {
+        unsigned long long cyc, rt;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(cyc), "=s"(rt));
+        pair[0] = cyc;
+        pair[1] = rt;
+    }
+}
 }  // namespace
 
 extern "C" int bflow_clock_stamp(unsigned long long* slot, bflow_stream_t stream) {
     BFLOW_REQUIRE(slot, BFLOW_E_ARG, "clock_stamp: null slot");
     hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
     return bflow::launch_status("clock_stamp");
+}
+
+extern "C" int bflow_shader_clock_stamp(unsigned long long* pair, bflow_stream_t stream) {
+    BFLOW_REQUIRE(pair, BFLOW_E_ARG, "shader_clock_stamp: null slot");
+    hipLaunchKernelGGL(shader_clock_stamp_kernel, dim3(16), dim3(64), 0, (hipStream_t)stream, pair);
+    return bflow::launch_status("shader_clock_stamp");
 }
 
 // models/raft_spline/bezier.py:141-180: binom(deg, i) * (1-t)^(deg-i) * t^i in float64, then cast to fp32.

@@ -47,7 +47,8 @@ struct ConvArgs {
     unsigned long long* stamps;   // H8_STAMPS builds only (tools/conv_stamps.sh)
 };
 
-// InstanceNorm / affine coefficients of one channel: y = x * mul + add (shared by the normalisation kernel and the NIN halo kernel)
+// InstanceNorm / affine coefficients of one channel: y = x * mul + add (shared by the normalisation kernel and the NIN halo kernel).
+// `stats` holds per-(image, channel) (sum, sum of squares) in fp64 -- or, with eps < 0, the coefficients (mul, add) themselves.
 __device__ __forceinline__ void norm_coeffs(const double* stats, const float* scale, const float* shift, int b, int c, int C, int HW,
                                             float eps, float& mul, float& add, int reps, long long rep_stride) {
     if (c >= C) { mul = 0.f; add = 0.f; return; }   // padded channels of the last block stay zero
@@ -56,6 +57,11 @@ __device__ __forceinline__ void norm_coeffs(const double* stats, const float* sc
         for (int r = 0; r < reps; ++r) {
             s1 += stats[r * rep_stride + ((long long)b * C + c) * 2];
             s2 += stats[r * rep_stride + ((long long)b * C + c) * 2 + 1];
+        }
+        if (eps < 0.f) {   // DIRECT table (eps = -1): the entries ARE (mul, add) -- GroupNorm's per-(image, channel) affine map, any sign of gamma
+            mul = (float)s1;
+            add = (float)s2;
+            return;
         }
         const double mean = s1 / HW;
         double var = s2 / HW - mean * mean;

@@ -128,11 +128,10 @@ class BasicEncoder(nn.Module):
         """GroupNorm (extractor.py:13-19,63-64: groups of 8 channels, per-channel affine) through the InstanceNorm machinery.  The conv
         epilogues deliver per-(image, channel) sums and sums of squares (fp64, `st`: (R, n, C, 2)); a group's statistics are the sums over
         its channels, and the normalisation of channel c of image b is the affine map x * mul + add with mul = rstd_g * gamma_c,
-        add = beta_c - mean_g * mul.  The normalisation kernel derives (mul, add) from a statistics table as 1 / sqrt(var + eps) and
-        -mean * mul, so the table handed to it is REWRITTEN to the (mean', var') that produce exactly these coefficients with eps = 0:
-        mean' = -add / mul, var' = 1 / mul^2.  A few tiny fp64 torch kernels per normalised convolution: this norm_fn is supported for the
-        constructor surface of the reference (no shipped experiment uses it), not tuned.  gamma must be positive (checked once per weight
-        version in `check_engine_support`)."""
+        add = beta_c - mean_g * mul.  The table handed to the normalisation kernel holds (mul, add) THEMSELVES (its direct mode, eps = -1:
+        csrc/conv_engine.h norm_coeffs), so gamma may have any sign or be zero (round 5 rewrote the table to a (mean', var') pair and
+        needed gamma > 0).  A few tiny fp64 torch kernels per normalised convolution: this norm_fn is supported for the constructor
+        surface of the reference (no shipped experiment uses it), not tuned."""
         s = st.sum(0)                                        # (n, C, 2)
         n, C, _ = s.shape
         G = norm.num_groups
@@ -144,9 +143,7 @@ class BasicEncoder(nn.Module):
         rstd_g = torch.rsqrt(var_g + norm.eps)
         mul = rstd_g.repeat_interleave(cpg, dim=1) * norm.weight.double()
         add = norm.bias.double() - mean_g.repeat_interleave(cpg, dim=1) * mul
-        mean_p = -add / mul
-        var_p = 1.0 / (mul * mul)
-        return torch.stack((mean_p * hw, (var_p + mean_p * mean_p) * hw), dim=-1).unsqueeze(0).contiguous()   # (1, n, C, 2)
+        return torch.stack((mul, add), dim=-1).unsqueeze(0).contiguous()   # (1, n, C, 2): direct coefficients
 
     def forward_split(self, x, out_rows: Optional[int] = None, trunk_only: bool = False, after_layer=None, out: Optional["S.SplitTensor"] = None,
                       out_ready=None, out_gain: Optional[float] = None):
@@ -163,7 +160,7 @@ class BasicEncoder(nn.Module):
             kind = "instance"          # the statistics path; every table is rewritten by `_group_stats` behind its convolution, nothing is fused on load
         elif kind == "none":
             kind = "batch"             # the affine path with the identity (scale 1, shift = conv bias)
-        neps = 0.0 if group else 1e-5  # eps of the normalisation kernel (GroupNorm's own eps sits inside the rewritten table)
+        neps = -1.0 if group else 1e-5  # eps of the normalisation kernel; -1 = the table holds (mul, add) directly (GroupNorm's own eps is inside them)
         fuse_in = FUSE_NORM_IN and not group
         n = x.shape[0]
         dev = x.device

@@ -20,6 +20,10 @@ import torch
 # BFLOW_HIP_LIB points at an alternative build of the SAME ABI (A/B timing of two kernel versions inside one gpurun call)
 _LIB_PATH = os.environ.get("BFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libbflow_hip.so")
 
+ABI_VERSION = 2        # include/bflow_hip.h BFLOW_ABI_VERSION this binding was written against (checked on load)
+# tools only (A/B timing against a library built from an OLDER revision whose entry points for the timed kernels kept their meaning):
+# BFLOW_HIP_ABI_ANY=1 skips the version check and binds the entry points the variant has
+_ABI_ANY = bool(os.environ.get("BFLOW_HIP_LIB")) and os.environ.get("BFLOW_HIP_ABI_ANY") == "1"
 MAX_PLANES, MAX_TARGETS, MAX_DEGREE, LOOKUP_RADIUS = 16, 8, 16, 4
 ACT_NONE, ACT_RELU = 0, 1
 
@@ -27,7 +31,7 @@ EXPORTS = (
     "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_build_tiled", "bflow_split_to_x8", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_conv_thin_mfma_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_rows_to_split", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_norm_train_finalize", "bflow_norm_train_apply", "bflow_norm_train_bwd_stats", "bflow_norm_train_bwd_finalize", "bflow_norm_train_bwd_apply", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
-    "bflow_clock_stamp", "bflow_voxel_workspace_bytes", "bflow_voxel_grid_f32xy", "bflow_voxel_grid_i16xy", "bflow_voxel_grid_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
+    "bflow_clock_stamp", "bflow_shader_clock_stamp", "bflow_voxel_workspace_bytes", "bflow_voxel_grid_f32xy", "bflow_voxel_grid_i16xy", "bflow_voxel_grid_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
     "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_grid_rectified", "bflow_maxabs_diff",
     "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
     "bflow_l1_masked_grad", "bflow_conv_split_pair", "bflow_corr_lookup_im2col", "bflow_cvx_upsample_blocked",
@@ -112,6 +116,9 @@ def lib() -> ctypes.CDLL:
     L.bflow_version.argtypes = []
     L.bflow_last_error_string.restype = ctypes.c_char_p
     L.bflow_last_error_string.argtypes = []
+    if L.bflow_version() != ABI_VERSION and not _ABI_ANY:      # a stale build (or a BFLOW_HIP_LIB variant of another round): entry points changed meaning
+        raise BflowHipError(f"{_LIB_PATH} reports ABI version {L.bflow_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                            "(python -m bflow_amd.build)")
     sig = {
         "bflow_corr_build_f32": [vp, vp, vp, i, i, i, i, ll, vp],
         "bflow_split_pack": [vp, vp, vp, i, i, i, i, vp],
@@ -163,6 +170,7 @@ def lib() -> ctypes.CDLL:
         "bflow_cvx_upsample": [vp, vp, vp, f, vp, i, i, i, i, vp],
         "bflow_cvx_upsample_blocked": [vp, vp, f, vp, i, i, i, i, i, vp],
         "bflow_clock_stamp": [vp, vp],
+        "bflow_shader_clock_stamp": [vp, vp],
         "bflow_voxel_workspace_bytes": [ll, i, i, i, i],
         "bflow_voxel_grid_f32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp, ll, vp],
         "bflow_voxel_grid_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp, ll, vp],
@@ -182,6 +190,8 @@ def lib() -> ctypes.CDLL:
         "bflow_l1_masked_grad": [vp, vp, vp, i, i, ll, vp, vp, f, vp, vp],
     }
     for name, args in sig.items():
+        if _ABI_ANY and not hasattr(L, name):
+            continue
         fn = getattr(L, name)
         fn.restype = ll if name == "bflow_voxel_workspace_bytes" else i
         fn.argtypes = args
@@ -462,6 +472,19 @@ def cvx_upsample(data: torch.Tensor, mask: torch.Tensor, mask_bias: Optional[tor
     _check(lib().bflow_cvx_upsample(_dev(data, name="data"), _dev(mask, name="mask"), _opt(mask_bias, "mask_bias"), float(mask_scale),
                                     _dev(out), B, C, h, w, _stream()), "bflow_cvx_upsample")
     return out
+
+
+def shader_clock_stamp(pairs: torch.Tensor, index: int):
+    """Writes (s_memtime, s_memrealtime) of XCD 0 into pairs[index] (int64 (n, 2)) on the current stream (capture-safe)."""
+    assert pairs.dtype == torch.int64 and pairs.dim() == 2 and pairs.shape[1] == 2 and 0 <= index < pairs.shape[0]
+    _check(lib().bflow_shader_clock_stamp(_dev(pairs, torch.int64, "pairs") + 16 * index, _stream()), "bflow_shader_clock_stamp")
+
+
+def shader_clock_ghz(pairs: torch.Tensor, first: int = 0, last: int = 1) -> float:
+    """Average shader clock (GHz) between two stamps: cycles / 100-MHz ticks x 0.1."""
+    p = pairs.cpu()
+    dc, dt = int(p[last, 0] - p[first, 0]), int(p[last, 1] - p[first, 1])
+    return dc / dt * 0.1 if dt > 0 else float("nan")
 
 
 def clock_stamp(slots: torch.Tensor, index: int):

@@ -279,16 +279,6 @@ class RAFTSpline(nn.Module):
                 continue
             if net.norm_fn not in ("instance", "batch", "group", "none"):
                 bad.append(f"{name}.norm_fn = {net.norm_fn!r}")
-            if net.norm_fn == "group":
-                # GroupNorm runs through the InstanceNorm kernels on rewritten statistics (BasicEncoder._group_stats), which needs gamma > 0;
-                # checked once per weight version (a device -> host read: never inside a captured forward)
-                gammas = [m.weight for m in net.modules() if isinstance(m, torch.nn.GroupNorm)]
-                key = tuple((g.data_ptr(), hip.tensor_version(g)) for g in gammas)
-                if net.__dict__.get("_gamma_checked") != key:
-                    if any(bool((g <= 0).any()) for g in gammas):
-                        bad.append(f"{name}: a GroupNorm weight <= 0 (the engine's GroupNorm path needs positive scales)")
-                    else:
-                        net.__dict__["_gamma_checked"] = key
             if name != "cnet" and net.conv2.out_channels > 256:
                 bad.append(f"{name} output dim {net.conv2.out_channels} (the correlation kernels contract at most 256 feature channels; smaller dims are zero-padded to 64 / 128 / 256)")
         if self.fnet_ev is not None and len(self.ev_corr_target_indices) + 1 > 8:

@@ -30,7 +30,8 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only this ABI is exported */
 
-#define BFLOW_ABI_VERSION 1
+#define BFLOW_ABI_VERSION 2   /* 2 (round 6): bflow_voxel_scatter_* became bflow_voxel_grid_* (whole-grid overwrite, workspace argument) and
+                               bflow_corr_lookup_conv1x1 was removed in round 5 without a bump; bflow_shader_clock_stamp added.  bflow_amd/hip.py checks it on load */
 
 #define BFLOW_E_ARG      (-1)   /* bad size / null pointer / unsupported configuration */
 #define BFLOW_E_LIMIT    (-2)   /* exceeds a compile-time limit (BFLOW_MAX_*) */
@@ -48,6 +49,12 @@ const char* bflow_last_error_string(void);
  * one-thread launch that writes the device's 100 MHz wall clock into *slot.  Capture-safe, so the stage boundaries of a hipGraph
  * replay can be read back without a tracer (bflow_amd/timers.py StampTimer; bench.py `gpu_stage_ms`).                           */
 int         bflow_clock_stamp(unsigned long long* slot, bflow_stream_t stream);
+/* Second measurement hook: the SHADER clock under load.  One small launch whose workgroup on XCD 0 writes pair[0] = s_memtime (shader-clock
+ * cycles) and pair[1] = s_memrealtime (100 MHz) -- both counters of the same XCD in every stamp.  Two stamps around a stretch of launches on
+ * one stream (or inside one hipGraph) give the average shader clock of that stretch: (d pair[0] / d pair[1]) x 100 MHz.  The part clocks to
+ * its power budget (1.3-2.1 GHz under matrix-core load), so a roofline fraction is only comparable between boxes with this number next to it
+ * (bench.py `clock_ghz`).                                                                                                                  */
+int         bflow_shader_clock_stamp(unsigned long long* pair, bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K5  all-pairs correlation volume ("feature_dot_product").

@@ -30,7 +30,7 @@ def cu(a):
 
 
 def test_library_loaded_from_tree():
-    assert hip.lib().bflow_version() == 1
+    assert hip.lib().bflow_version() == hip.ABI_VERSION == 2
     assert os.path.samefile(os.path.dirname(hip.library_path()), os.path.join(os.path.dirname(bflow_amd.__file__), "lib"))
 
 
@@ -834,8 +834,9 @@ def test_e2e_other_feature_dims_vs_oracle(fdim):
     assert bool(torch.isfinite(oup).all()) and float(oup.abs().max()) > 1e-3 and e < EPE_TOL
 
 
-@pytest.mark.parametrize("fnorm,cnorm", [("group", "none"), ("none", "group"), ("group", "batch")])
-def test_e2e_other_encoder_norms_vs_oracle(fnorm, cnorm):
+@pytest.mark.parametrize("fnorm,cnorm,signed_gamma", [("group", "none", False), ("none", "group", False), ("group", "batch", False),
+                                                      ("group", "group", True)])
+def test_e2e_other_encoder_norms_vs_oracle(fnorm, cnorm, signed_gamma):
     """The rest of the reference's encoder constructor surface on the HIP engine (extractor.py:13-37,63-70): norm_fn 'group' (GroupNorm through
     the InstanceNorm kernels on rewritten statistics, BasicEncoder._group_stats) and 'none' (the affine epilogue with the identity).  The
     oracle's restatement of both is pinned against the live reference in tests/test_oracle_vs_reference.py."""
@@ -844,6 +845,19 @@ def test_e2e_other_encoder_norms_vs_oracle(fnorm, cnorm):
     cfg["feature"]["norm"], cfg["context"]["norm"] = fnorm, cnorm
     m = bflow_amd.RAFTSpline(cfg).eval()
     sd = O.make_state_dict(cfg, seed=4, gain=0.35)      # (an encoder without normalisation overflows on the gains tuned for normalised ones)
+    if signed_gamma:
+        # trained GroupNorm scales can have either sign or be zero: the engine takes (mul, add) tables, not 1/sqrt(var) ones (round 6)
+        rs = np.random.RandomState(5)
+        flipped = 0
+        for k, v in sd.items():
+            if v.ndim == 1 and k.endswith(".weight") and "norm" in k:
+                sign = torch.from_numpy(np.where(rs.rand(v.numel()) < 0.4, -1.0, 1.0).astype(np.float32))
+                sign[rs.randint(v.numel())] = 0.0
+                sd[k] = v * sign
+                flipped += 1
+                if k.endswith(".norm3.weight"):           # extractor.py:38-40: downsample[1] IS norm3 (one module, two state-dict keys)
+                    sd[k.replace(".norm3.", ".downsample.1.")] = sd[k]
+        assert flipped >= 10
     m.load_state_dict(sd)
     m.to(DEV)
     vox = torch.from_numpy(synthetic.voxel_grid(2, 9, 128, 160, seed=9))

@@ -7,6 +7,6 @@ for i in $(seq 1 $N); do
   for tag in A B; do
     if [ $tag = A ]; then L="$A"; else L="$B"; fi
     echo "== $tag $L"
-    BFLOW_HIP_LIB="$L" python tools/k7_probe.py --shapes $SH 2>/dev/null | grep -E "tiled  |tiled-f16|max"
+    BFLOW_HIP_ABI_ANY=1 BFLOW_HIP_LIB="$L" python tools/k7_probe.py --shapes $SH 2>/dev/null | grep -E "tiled  |tiled-f16|max"
   done
 done

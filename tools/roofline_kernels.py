@@ -23,7 +23,7 @@ HALO8_NAME = ("conv_halo8_pair_kernel<3,3> (motion encoder convc2 | convf2 as ON
               "small-grid 3x3 kernel on its largest launch; the small-grid 3x3 / 1x5 / 5x1 family has the largest total time of the frame)")
 HALO8_REGEX = "conv_halo8_pair_kernel"
 K5_SPLIT_NAME = "corr_stream_kernel<8, true, 0, false> (bflow_corr_build_tiled: 3-pass split arithmetic = fp32 class, fp32 tiled volume, D = 256)"
-LOOKUP_C4_NAME = "corr_lookup_tile_kernel<float, 2, 256> (C4 per-GPU shard: batch 8)"
+LOOKUP_C4_NAME = "corr_lookup_tile_kernel<float, 2, 256, true> (C4 per-GPU shard: batch 8)"
 K5_C5_NAME = "corr_stream_kernel (BASELINE configs[4]: 1024x1024, 5 event targets + 1 image target, f16/w = fp16 operands, one MFMA pass, fp32 tiled volume)"
 
 
@@ -72,7 +72,7 @@ def frame_flops(model, B, H, W, iters):
     frame = sum(v for k, v in parts.items() if k != "update_iteration") + iters * it
     return frame, it, parts
 K5_NAME = "corr_stream_kernel<8, true, 2, false> (bflow_corr_build_tiled: split8 arithmetic, fp32 tiled volume, D = 256 -- the product launch)"
-LOOKUP_NAME = "corr_lookup_tile_kernel<float, 2, 256> (fused bezier, tiled planes, split out; + the im2col rider of bflow_corr_lookup_im2col)"
+LOOKUP_NAME = "corr_lookup_tile_kernel<float, 2, 256, true> (fused bezier, tiled planes, split out; + the im2col rider of bflow_corr_lookup_im2col)"
 
 
 def build(model, vox, cfg, low_params=None):
