@@ -152,7 +152,7 @@ def main():
 
     def kernel_event_ms(launch, n):
         """(average duration in ms of one launch, average SHADER clock in GHz during the launches): `n` launches captured into one hipGraph
-        between two bflow_shader_clock_stamp launches (s_memtime / s_memrealtime of XCD 0), hipEvents recorded on the launch stream (torch's
+        between two bflow_shader_clock_stamp launches (s_memtime / s_memrealtime per CU), hipEvents recorded on the launch stream (torch's
         current stream) around its replay.  (An event pair around every single eager launch also times the HOST's enqueue latency -- 5-8 us
         of Python per launch, box dependent -- which is 40 % of the 13-us look-up and moved its fraction between 0.14 and 0.17.)  The
         clock is what tells a slow box from a regression: the part clocks to its power budget, 1.3-2.1 GHz under load."""
@@ -160,7 +160,7 @@ def main():
         for _ in range(3):
             launch()
         torch.cuda.synchronize()
-        pairs = torch.zeros((2, 2), dtype=torch.int64, device=dev)
+        pairs = _hip.shader_clock_tables(2, dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             _hip.shader_clock_stamp(pairs, 0)
@@ -184,7 +184,7 @@ def main():
     def clocked(fn, steps):
         """time_steps(fn, steps) with the average shader clock of the timed region (two stamps on the launch stream around it)."""
         from bflow_amd import hip as _hip
-        pairs = torch.zeros((2, 2), dtype=torch.int64, device=dev)
+        pairs = _hip.shader_clock_tables(2, dev)
         barrier()
         torch.cuda.synchronize()
         _hip.shader_clock_stamp(pairs, 0)
@@ -671,12 +671,12 @@ def voxel_kernels(dev):
                             "bit_identical_run_to_run": bool(torch.equal(a, grid)), "workspace_mb": round(ws.numel() / 1e6, 1),
                             "kernel": "voxel_count / scan / place / gather (tile-binned, LDS fixed-point accumulation, no global atomics)"}
     g = torch.randn(9, Hh, Ww, device=dev) * (torch.rand(9, Hh, Ww, device=dev) < 0.3)
-    wsn = torch.empty(4, dtype=torch.float64, device=dev)
+    wsn = hip.voxel_norm_workspace(dev)
     q = g.clone()
     ms = graph_ms(lambda: hip.voxel_norm(q, wsn))
     by = 4 * g.numel() * 4
     out["k2_norm"] = {"ms": round(ms, 4), "algorithmic_gb_s": round(by / ms / 1e6, 1), "frac": round(by / ms / 1e6 / PEAK_HBM_GBS, 4), "bound": "hbm",
-                      "grid": [9, Hh, Ww], "note": "three reading passes + one writing pass over the 11-MB grid"}
+                      "grid": [9, Hh, Ww], "note": "algorithmic bytes as in rounds 1-5 (4 passes over the 11-MB grid); round 6 executes 2 reads + 1 write in two launches"}
     return out
 
 
@@ -698,12 +698,21 @@ def pipeline_from_events(model, cfg, dev, steps=10):
     stream = EventStream(**ev, device=dev)
     asm = TwoStepAssembler(bins, H, W, rect, device=dev)
 
+    from bflow_amd.pipeline import EventFramePipeline
+    pipe = EventFramePipeline(model, asm, ITERS)
+
     def frame():
-        vox = asm.assemble(stream, ts, 1, check=False)
-        return model(voxel_grid=vox[None], iters=ITERS, test_mode=True)
+        with torch.inference_mode():       # (the call val.py makes: the forward is a graph replay; the assembly of the NEXT frame runs next to it)
+            return pipe(stream, ts, 1)
+
+    def frame_serial():
+        with torch.inference_mode():
+            vox = asm.assemble(stream, ts, 1, check=False)
+            return model(voxel_grid=vox[None], iters=ITERS, test_mode=True)
 
     def assemble_only():
-        return asm.assemble(stream, ts, 1, check=False)
+        with torch.inference_mode():
+            return asm.assemble(stream, ts, 1, check=False)
 
     def timed(fn, k):
         for _ in range(3):
@@ -715,10 +724,14 @@ def pipeline_from_events(model, cfg, dev, steps=10):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / k
 
-    t_frame, t_asm = timed(frame, steps), timed(assemble_only, steps)
+    t_frame, t_ser, t_asm = timed(frame, steps), timed(frame_serial, steps), timed(assemble_only, steps)
     return {"value": round(1.0 / t_frame, 2), "unit": "frames/s", "ms_per_frame": round(t_frame * 1e3, 4), "ms_assembly": round(t_asm * 1e3, 4),
+            "one_stream": {"value": round(1.0 / t_ser, 2), "ms_per_frame": round(t_ser * 1e3, 4),
+                           "note": "assembly and forward of a frame one after the other on one stream (round 5's number)"},
             "events_per_window": int(n * 100_000 / 260_000), "steps": steps,
-            "workload": "raw events -> 2 x K1 (rectified, 5 bins) -> merge -> K2 -> C2 forward (12 iters); wall clock incl. the host's eager enqueue of the assembly"}
+            "workload": "a stream of frames: raw events -> 2 x K1 (rectified, 5 bins) -> merge + K2 (one launch pair) -> C2 forward (12 iters); the assembly of "
+                        "frame k + 1 runs on its own stream next to the GRU loop of frame k (bflow_amd/pipeline.py EventFramePipeline); wall clock incl. "
+                        "the host's eager enqueue of the assembly"}
 
 
 def other_baseline_configs(dev, steps):

@@ -31,15 +31,19 @@ extern "C" const char* bflow_last_error_string(void) { return bflow::g_err; }
 namespace {
 __global__ void clock_stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
 
-// 16 one-wave workgroups (dispatched round-robin over the XCDs): the ones that land on XCD 0 write its two counters
-__global__ void shader_clock_stamp_kernel(unsigned long long* pair) {
-    unsigned xcc;
+// s_memtime is a counter PER CU (tools/micro/memtime_domains: offsets of 10^6..10^12 cycles between the CUs of one XCD, < 120 cycles inside
+// a CU), so two stamps are only comparable CU by CU: 2048 one-wave workgroups cover the chip, each writes its CU's two counters into the
+// CU's row of a (1024, 2) table, row = (XCD * 8 + shader engine) * 16 + CU (later writers of a CU overwrite earlier ones: same instant).
+__global__ void shader_clock_stamp_kernel(unsigned long long* table) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    if ((xcc & 0xf) == 0 && threadIdx.x == 0) {
+    if (threadIdx.x == 0) {
         unsigned long long cyc, rt;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(cyc), "=s"(rt));
-        pair[0] = cyc;
-        pair[1] = rt;
+        const unsigned row = (((xcc & 7) * 8 + ((hw >> 13) & 7)) * 16 + ((hw >> 8) & 15)) & (BFLOW_CLOCK_TABLE_ROWS - 1);
+        table[row * 2] = cyc;
+        table[row * 2 + 1] = rt;
     }
 }
 }  // namespace
@@ -50,9 +54,9 @@ extern "C" int bflow_clock_stamp(unsigned long long* slot, bflow_stream_t stream
     return bflow::launch_status("clock_stamp");
 }
 
-extern "C" int bflow_shader_clock_stamp(unsigned long long* pair, bflow_stream_t stream) {
-    BFLOW_REQUIRE(pair, BFLOW_E_ARG, "shader_clock_stamp: null slot");
-    hipLaunchKernelGGL(shader_clock_stamp_kernel, dim3(16), dim3(64), 0, (hipStream_t)stream, pair);
+extern "C" int bflow_shader_clock_stamp(unsigned long long* table, bflow_stream_t stream) {
+    BFLOW_REQUIRE(table, BFLOW_E_ARG, "shader_clock_stamp: null table");
+    hipLaunchKernelGGL(shader_clock_stamp_kernel, dim3(2048), dim3(64), 0, (hipStream_t)stream, table);
     return bflow::launch_status("shader_clock_stamp");
 }
 

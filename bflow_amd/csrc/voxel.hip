@@ -403,43 +403,104 @@ __device__ __forceinline__ void block_accumulate(double v0, double v1, double* d
     }
 }
 
-// ws[0] = sum, ws[1] = count, ws[2] = sum of squared deviations
-__global__ __launch_bounds__(256) void norm_pass1(const float* __restrict__ g, long long n, double* ws) {
-    double s = 0.0, c = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float v = g[i];
-        if (v != 0.f) {
-            s += (double)v;
-            c += 1.0;
-        }
+// ---- K2 (round 6): TWO launches, three passes over memory (was: a memset + three kernels, four passes, two rounds of fp64 atomics).
+//   norm_stats_kernel   one read: per-block partial (sum, sum of squares, count) of the non-zero entries in fp64 -> ws[block][3]
+//                       (plain stores: the workspace needs no zero fill and no atomics)
+//   norm_apply_kernel   every block folds the <= NORM_BLOCKS partials (L2-resident, 24 KB), derives mean / std as torch does -- fp32 mean of
+//                       the masked values, unbiased std of the deviations from THAT mean: sum (v - m)^2 = S2 - 2 m S1 + n m^2, exact algebra
+//                       in fp64 -- and writes (v - mean) / std over the non-zero entries.
+// The input is the concatenation of up to two segments [a | b] (the merge of TwoStepSubSequence.__getitem__, twostep.py:77-85: previous
+// grid | current grid without its first bin), the output one contiguous array (which may be `a` itself: in place).
+constexpr int NORM_BLOCKS = 1024;
+
+__device__ __forceinline__ void norm_acc(float v, double& s1, double& s2, double& c) {
+    if (v != 0.f) {
+        const double d = (double)v;
+        s1 += d;
+        s2 = fma(d, d, s2);
+        c += 1.0;
     }
-    block_accumulate(s, c, ws + 0, ws + 1);
 }
 
-__global__ __launch_bounds__(256) void norm_pass2(const float* __restrict__ g, long long n, double* ws) {
-    const double cnt = ws[1];
-    const float mean = cnt > 0.0 ? (float)(ws[0] / cnt) : 0.f;   // torch: fp32 mean of the masked values
-    double s = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float v = g[i];
-        if (v != 0.f) {
-            const double d = (double)v - (double)mean;
-            s += d * d;
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ a, long long na, const float* __restrict__ b, long long nb,
+                                                         double* __restrict__ ws) {
+    double s1 = 0.0, s2 = 0.0, c = 0.0;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long long)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        const float* g = seg ? b : a;
+        const long long n = seg ? nb : na;
+        if (n <= 0) continue;
+        const long long head = (long long)((16 - ((uintptr_t)g & 15)) & 15) / 4;       // scalars in front of the first 16-B boundary
+        const long long h = head < n ? head : n;
+        const long long nv = (n - h) / 4;
+        const float4* g4 = reinterpret_cast<const float4*>(g + h);
+        for (long long i = tid; i < nv; i += nthr) {
+            const float4 v = g4[i];
+            norm_acc(v.x, s1, s2, c);
+            norm_acc(v.y, s1, s2, c);
+            norm_acc(v.z, s1, s2, c);
+            norm_acc(v.w, s1, s2, c);
         }
+        for (long long i = tid; i < h; i += nthr) norm_acc(g[i], s1, s2, c);
+        for (long long i = h + nv * 4 + tid; i < n; i += nthr) norm_acc(g[i], s1, s2, c);
     }
-    block_accumulate(s, 0.0, ws + 2, nullptr);
+    __shared__ double sh[3][4];
+    s1 = bflow::wave_sum(s1);
+    s2 = bflow::wave_sum(s2);
+    c = bflow::wave_sum(c);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][wv] = s1;
+        sh[1][wv] = s2;
+        sh[2][wv] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) ws[(long long)blockIdx.x * 3 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
 }
 
-__global__ __launch_bounds__(256) void norm_pass3(float* __restrict__ g, long long n, const double* ws) {
-    const double cnt = ws[1];
-    if (cnt <= 0.0) return;                                        // representations.py:11: nothing to do
-    const float mean = (float)(ws[0] / cnt);
-    // unbiased std (torch.Tensor.std default, representations.py:13); a single element gives NaN in torch and
-    // `std > 0` is then False -> mean-only branch
-    const float stdv = cnt > 1.0 ? (float)sqrt(ws[2] / (cnt - 1.0)) : 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float v = g[i];
-        if (v != 0.f) g[i] = stdv > 0.f ? (v - mean) / stdv : v - mean;
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ a, long long na, const float* __restrict__ b, long long nb,
+                                                         float* __restrict__ out, const double* __restrict__ ws, int nparts) {
+    // every block folds the partials in the SAME order: all blocks apply the same (mean, std), bit for bit
+    __shared__ double sh[3][4];
+    double p[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        p[0] += ws[i * 3];
+        p[1] += ws[i * 3 + 1];
+        p[2] += ws[i * 3 + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = bflow::wave_sum(p[k]);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[0][wv] = p[0];
+        sh[1][wv] = p[1];
+        sh[2][wv] = p[2];
+    }
+    __syncthreads();
+    const double S1 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), S2 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]),
+                 cnt = (sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3]);
+    const bool any = cnt > 0.0;                                    // representations.py:11: nothing to do (the merge copy still happens)
+    const float mean = any ? (float)(S1 / cnt) : 0.f;              // torch: fp32 mean of the masked values
+    // unbiased std (torch.Tensor.std default, representations.py:13) of the deviations from the fp32 mean; a single element gives NaN in
+    // torch and `std > 0` is then False -> mean-only branch
+    const double m = (double)mean;
+    const double ssd = fmax(S2 - 2.0 * m * S1 + cnt * m * m, 0.0);
+    const float stdv = cnt > 1.0 ? (float)sqrt(ssd / (cnt - 1.0)) : 0.f;
+    const long long n = na + nb;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long long)gridDim.x * blockDim.x;
+    auto f = [&](float v) -> float { return (v != 0.f && any) ? (stdv > 0.f ? (v - mean) / stdv : v - mean) : v; };
+    // 16-B vectors where source segment, segment boundary and destination allow it (torch tensors and whole bins do); scalars otherwise
+    const bool vec = (((uintptr_t)a | (uintptr_t)out | (uintptr_t)(b ? b : a)) & 15) == 0 && (na & 3) == 0 && (nb & 3) == 0;
+    if (vec) {
+        const long long nva = na / 4, nv = n / 4;
+        for (long long i = tid; i < nv; i += nthr) {
+            float4 v = i < nva ? reinterpret_cast<const float4*>(a)[i] : reinterpret_cast<const float4*>(b)[i - nva];
+            v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+            reinterpret_cast<float4*>(out)[i] = v;
+        }
+    } else {
+        for (long long i = tid; i < n; i += nthr) out[i] = f(i < na ? a[i] : b[i - na]);
     }
 }
 
@@ -549,19 +610,24 @@ extern "C" int bflow_voxel_grid_i32xy(const int* x, const int* y, const signed c
     return vox_run<SRC_I32>(VoxSrc{x, y, pol, t, nullptr, n}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_i32xy");
 }
 
-extern "C" int bflow_voxel_norm(float* grid, long long n, double* ws, bflow_stream_t stream) {
-    BFLOW_REQUIRE(grid && ws && n > 0, BFLOW_E_ARG, "voxel_norm: bad arguments");
+static int norm_run(const float* a, long long na, const float* b, long long nb, float* out, double* ws, bflow_stream_t stream, const char* what) {
+    BFLOW_REQUIRE(a && out && ws && na > 0 && nb >= 0 && (nb == 0 || b), BFLOW_E_ARG, "%s: bad arguments", what);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ws, 0, 4 * sizeof(double), s);
-    if (e != hipSuccess) {
-        bflow::set_error("voxel_norm: memset: %s", hipGetErrorString(e));
-        return (int)e;
-    }
-    const int g = bflow::stream_grid(n, 256), gr = bflow::reduce_grid(n, 256);
-    hipLaunchKernelGGL(norm_pass1, dim3(gr), dim3(256), 0, s, grid, n, ws);
-    hipLaunchKernelGGL(norm_pass2, dim3(gr), dim3(256), 0, s, grid, n, ws);
-    hipLaunchKernelGGL(norm_pass3, dim3(g), dim3(256), 0, s, grid, n, ws);
-    return bflow::launch_status("voxel_norm");
+    const long long n = na + nb;
+    int nblk = (int)((n / 4 + 255) / 256);
+    nblk = nblk < 1 ? 1 : nblk > NORM_BLOCKS ? NORM_BLOCKS : nblk;
+    hipLaunchKernelGGL(norm_stats_kernel, dim3(nblk), dim3(256), 0, s, a, na, b, nb, ws);
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(nblk), dim3(256), 0, s, a, na, b, nb, out, ws, nblk);
+    return bflow::launch_status(what);
+}
+
+extern "C" int bflow_voxel_norm(float* grid, long long n, double* ws, bflow_stream_t stream) {
+    return norm_run(grid, n, nullptr, 0, grid, ws, stream, "voxel_norm");
+}
+
+extern "C" int bflow_voxel_merge_norm(const float* a, long long na, const float* b, long long nb, float* out, double* ws, bflow_stream_t stream) {
+    BFLOW_REQUIRE(out != b || nb == 0, BFLOW_E_ARG, "voxel_merge_norm: the output may alias the FIRST segment only");
+    return norm_run(a, na, b, nb, out, ws, stream, "voxel_merge_norm");
 }
 
 extern "C" int bflow_voxel_grid_rectified(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,

@@ -135,9 +135,11 @@ class TwoStepAssembler:
         return torch.from_numpy(cached).to(self.device)
 
     # twostep.py:44-92 ------------------------------------------------------------------------------------------------
-    def assemble(self, events, forward_flow_timestamps, index: int, check: bool = True, flow_file_index: Optional[int] = None) -> torch.Tensor:
+    def assemble(self, events, forward_flow_timestamps, index: int, check: bool = True, flow_file_index: Optional[int] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`flow_file_index` (the index in the flow file's name, twostep.py:41) selects the cache files: it for the current window,
-        it - 2 for the previous one (100-ms steps, twostep.py:63-64)."""
+        it - 2 for the previous one (100-ms steps, twostep.py:63-64).  `out`: a caller-owned (2 * bins - 1, H, W) buffer for the merged grid
+        (a frame stream double-buffers it, bflow_amd/pipeline.py EventFramePipeline)."""
         (cf, ct), (pf, pt) = twostep_windows(forward_flow_timestamps, index)
         self._bad.zero_()     # the counter is per sample: one bad sample must not fail (or hide in) the following ones
         ev_cur = self.get_voxel_grid(events, cf, ct, flow_file_index)
@@ -149,9 +151,15 @@ class TwoStepAssembler:
             if check:
                 d = float(hip.maxabs_diff(ev_prev[-1], ev_cur[0]))
                 assert d < 0.5, f"{d}"                                                      # twostep.py:83
-            out = torch.empty((2 * self.num_bins - 1, self.height, self.width), dtype=torch.float32, device=self.device)
+            if out is None:
+                out = torch.empty((2 * self.num_bins - 1, self.height, self.width), dtype=torch.float32, device=self.device)
+            assert tuple(out.shape) == (2 * self.num_bins - 1, self.height, self.width) and out.is_contiguous()
+            if self.normalize:
+                # torch.cat((ev_repr_0, ev_repr_1[1:])) and norm_voxel_grid of the result (twostep.py:77-85) as ONE statistics pass over the
+                # two per-window grids + one pass that writes the merged, normalised grid (bflow_voxel_merge_norm; round 5: two copies + K2)
+                return hip.voxel_merge_norm(ev_prev, ev_cur[1:], out)
             out[:self.num_bins].copy_(ev_prev)                                              # torch.cat((ev_repr_0, ev_repr_1[1:]))
             out[self.num_bins:].copy_(ev_cur[1:])
-            return norm_voxel_grid(out) if self.normalize else out
+            return out
         grids = [norm_voxel_grid(g) for g in (ev_prev, ev_cur)] if self.normalize else [ev_prev, ev_cur]
         return torch.stack(grids)

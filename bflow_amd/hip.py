@@ -31,7 +31,7 @@ EXPORTS = (
     "bflow_version", "bflow_last_error_string", "bflow_corr_build_f32", "bflow_split_pack", "bflow_corr_build_split", "bflow_corr_build_split_tiled", "bflow_corr_build_tiled", "bflow_split_to_x8", "bflow_corr_pool2x2_tiled", "bflow_corr_lookup_bezier_split_tiled", "bflow_corr_build_f16_tiled", "bflow_corr_pool2x2_tiled_f16", "bflow_corr_lookup_bezier_split_tiled_f16", "bflow_conv_pack_weights", "bflow_conv_pack_weights_adjoint", "bflow_conv_split", "bflow_conv_thin_acc", "bflow_conv_thin_mfma_acc", "bflow_wgrad_pack", "bflow_blocked_f32_to_nchw", "bflow_pow2_scale", "bflow_rows_to_split", "bflow_grad_stats", "bflow_wgrad_reduce", "bflow_conv_wgrad_halo", "bflow_conv_wgrad_finish", "bflow_norm_train_finalize", "bflow_norm_train_apply", "bflow_norm_train_bwd_stats", "bflow_norm_train_bwd_finalize", "bflow_norm_train_bwd_apply", "bflow_gru_zr_fwd", "bflow_gru_zr_bwd", "bflow_gru_blend_fwd", "bflow_gru_blend_bwd", "bflow_conv_stem", "bflow_plane_stats", "bflow_norm_act_split", "bflow_split_to_nchw", "bflow_bezier_update", "bflow_im2col_small", "bflow_corr_pool2x2", "bflow_corr_lookup",
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
-    "bflow_clock_stamp", "bflow_shader_clock_stamp", "bflow_voxel_workspace_bytes", "bflow_voxel_grid_f32xy", "bflow_voxel_grid_i16xy", "bflow_voxel_grid_i32xy", "bflow_voxel_norm", "bflow_epe_accumulate",
+    "bflow_clock_stamp", "bflow_shader_clock_stamp", "bflow_voxel_workspace_bytes", "bflow_voxel_grid_f32xy", "bflow_voxel_grid_i16xy", "bflow_voxel_grid_i32xy", "bflow_voxel_norm", "bflow_voxel_merge_norm", "bflow_epe_accumulate",
     "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_grid_rectified", "bflow_maxabs_diff",
     "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
     "bflow_l1_masked_grad", "bflow_conv_split_pair", "bflow_corr_lookup_im2col", "bflow_cvx_upsample_blocked",
@@ -176,6 +176,7 @@ def lib() -> ctypes.CDLL:
         "bflow_voxel_grid_i16xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp, ll, vp],
         "bflow_voxel_grid_i32xy": [vp, vp, vp, vp, ll, ll, ll, vp, i, i, i, vp, ll, vp],
         "bflow_voxel_norm": [vp, ll, vp, vp],
+        "bflow_voxel_merge_norm": [vp, ll, vp, ll, vp, vp, vp],
         "bflow_voxel_grid_rectified": [vp, vp, vp, vp, ll, vp, ll, ll, vp, i, i, i, vp, vp, ll, vp],
         "bflow_maxabs_diff": [vp, vp, ll, vp, vp],
         "bflow_epe_accumulate": [vp, vp, vp, i, i, ll, vp, vp],
@@ -474,17 +475,30 @@ def cvx_upsample(data: torch.Tensor, mask: torch.Tensor, mask_bias: Optional[tor
     return out
 
 
-def shader_clock_stamp(pairs: torch.Tensor, index: int):
-    """Writes (s_memtime, s_memrealtime) of XCD 0 into pairs[index] (int64 (n, 2)) on the current stream (capture-safe)."""
-    assert pairs.dtype == torch.int64 and pairs.dim() == 2 and pairs.shape[1] == 2 and 0 <= index < pairs.shape[0]
-    _check(lib().bflow_shader_clock_stamp(_dev(pairs, torch.int64, "pairs") + 16 * index, _stream()), "bflow_shader_clock_stamp")
+CLOCK_TABLE_ROWS = 1024      # include/bflow_hip.h BFLOW_CLOCK_TABLE_ROWS
 
 
-def shader_clock_ghz(pairs: torch.Tensor, first: int = 0, last: int = 1) -> float:
-    """Average shader clock (GHz) between two stamps: cycles / 100-MHz ticks x 0.1."""
-    p = pairs.cpu()
-    dc, dt = int(p[last, 0] - p[first, 0]), int(p[last, 1] - p[first, 1])
-    return dc / dt * 0.1 if dt > 0 else float("nan")
+def shader_clock_tables(n: int, device) -> torch.Tensor:
+    """Zeroed (n, CLOCK_TABLE_ROWS, 2) int64: one table per stamp."""
+    return torch.zeros((n, CLOCK_TABLE_ROWS, 2), dtype=torch.int64, device=device)
+
+
+def shader_clock_stamp(tables: torch.Tensor, index: int):
+    """Writes (s_memtime, s_memrealtime) of every CU into tables[index] on the current stream (capture-safe)."""
+    assert tables.dtype == torch.int64 and tables.dim() == 3 and tuple(tables.shape[1:]) == (CLOCK_TABLE_ROWS, 2) and 0 <= index < tables.shape[0]
+    _check(lib().bflow_shader_clock_stamp(_dev(tables, torch.int64, "tables") + 16 * CLOCK_TABLE_ROWS * index, _stream()), "bflow_shader_clock_stamp")
+
+
+def shader_clock_ghz(tables: torch.Tensor, first: int = 0, last: int = 1) -> float:
+    """Average shader clock (GHz) between two stamps: per CU cycles / 100-MHz ticks x 0.1, median over the CUs both stamps reached
+    (s_memtime is a per-CU counter: only differences on the same CU mean anything)."""
+    t = tables.cpu()
+    a, b = t[first], t[last]
+    ok = (a[:, 1] != 0) & (b[:, 1] != 0) & (b[:, 1] > a[:, 1])
+    if not bool(ok.any()):
+        return float("nan")
+    ghz = (b[ok, 0] - a[ok, 0]).double() / (b[ok, 1] - a[ok, 1]).double() * 0.1
+    return float(ghz.median())
 
 
 def clock_stamp(slots: torch.Tensor, index: int):
@@ -494,11 +508,26 @@ def clock_stamp(slots: torch.Tensor, index: int):
 
 
 # ------------------------------------------------------------------------------------------------ K1 / K2
+_VOXEL_WS = {}      # (device index, stream) -> grow-only byte buffer
+
+
 def _voxel_workspace(n: int, C: int, H: int, W: int, float_xy: bool, device) -> torch.Tensor:
+    """K1's workspace (counts, bases and one 16-B record per (event, bin): up to 8 records per float-xy event with more than 8 bins --
+    ~256 MB for a 2 M-event, 15-bin window).  ONE grow-only buffer per (device, stream) instead of an allocation per call: launches
+    of one stream are ordered, so consecutive calls may share it (a buffer that had to grow is replaced; the old one stays alive until its
+    last launch has run, as any torch allocation does)."""
     nbytes = int(lib().bflow_voxel_workspace_bytes(n, C, H, W, int(float_xy)))
     if nbytes < 0:
         raise BflowHipError("voxel grid: " + lib().bflow_last_error_string().decode("utf-8", "replace"))
-    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+    buf = _VOXEL_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if len(_VOXEL_WS) > 8:       # streams come and go: keep the table small
+            _VOXEL_WS.clear()
+        buf = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=device)
+        _VOXEL_WS[key] = buf
+    return buf
 
 
 def voxel_grid(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.Tensor, t0_center: int, t1_center: int,
@@ -546,11 +575,29 @@ def maxabs_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+VOXEL_NORM_WS_DOUBLES = 3072      # include/bflow_hip.h BFLOW_VOXEL_NORM_WS_DOUBLES
+
+
+def voxel_norm_workspace(device) -> torch.Tensor:
+    return torch.empty(VOXEL_NORM_WS_DOUBLES, dtype=torch.float64, device=device)
+
+
 def voxel_norm(grid: torch.Tensor, workspace: Optional[torch.Tensor] = None):
-    if workspace is None:
-        workspace = torch.empty(4, dtype=torch.float64, device=grid.device)
+    if workspace is None or workspace.numel() < VOXEL_NORM_WS_DOUBLES:
+        workspace = voxel_norm_workspace(grid.device)
     _check(lib().bflow_voxel_norm(_dev(grid, name="grid"), grid.numel(), _dev(workspace, torch.float64, "workspace"), _stream()),
            "bflow_voxel_norm")
+
+
+def voxel_merge_norm(a: torch.Tensor, b: Optional[torch.Tensor], out: torch.Tensor, workspace: Optional[torch.Tensor] = None):
+    """out = norm_voxel_grid(cat(a.flatten(), b.flatten())) (representations.py:9-18 on the merged grid of twostep.py:77-85); out may be a."""
+    if workspace is None or workspace.numel() < VOXEL_NORM_WS_DOUBLES:
+        workspace = voxel_norm_workspace(out.device)
+    nb = 0 if b is None else b.numel()
+    assert out.numel() == a.numel() + nb and out.is_contiguous()
+    _check(lib().bflow_voxel_merge_norm(_dev(a, name="a"), a.numel(), None if b is None else _dev(b, name="b"), nb, _dev(out, name="out"),
+                                        _dev(workspace, torch.float64, "workspace"), _stream()), "bflow_voxel_merge_norm")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ K15

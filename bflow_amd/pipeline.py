@@ -111,3 +111,40 @@ class ConcurrentRunner:
             self.close()
         except Exception:
             pass
+
+
+class EventFramePipeline:
+    """Raw events -> flow for a STREAM of frames: the voxel-grid assembly of frame k + 1 (2 x K1 + merge + K2, bflow_amd/dsec.py; ~0.2 ms of
+    HBM-bound launches) runs on its own stream next to the GRU loop of frame k (a chain of small launches that leaves most CUs idle), the
+    forward of frame k + 1 waits for it through an event.  Two grid buffers alternate; the forward is whatever `model(...)` does (a graph
+    replay under eval + inference_mode).  Results are the model's own return values.
+
+    SURVEY 8(f-1) / twostep.py:44-100 feeding raft.py:101-200; measured by bench.py `pipeline_from_events`."""
+
+    def __init__(self, model, assembler, iters: int = 12):
+        self.model, self.asm, self.iters = model, assembler, iters
+        dev = assembler.device
+        self.side = torch.cuda.Stream(device=dev)
+        shape = (2 * assembler.num_bins - 1, assembler.height, assembler.width)
+        self.bufs = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.free = [None, None]          # event behind the last forward that read the buffer
+        self.k = 0
+
+    def __call__(self, events, forward_flow_timestamps, index: int, check: bool = False):
+        slot = self.k & 1
+        self.k += 1
+        main = torch.cuda.current_stream()
+        if self.k == 1:
+            self.side.wait_stream(main)        # (first call: whatever produced the event arrays has been enqueued on `main`)
+        with torch.cuda.stream(self.side):
+            if self.free[slot] is not None:
+                self.side.wait_event(self.free[slot])
+            grid = self.asm.assemble(events, forward_flow_timestamps, index, check=check, out=self.bufs[slot])
+            self.ready[slot].record(self.side)
+        main.wait_event(self.ready[slot])
+        out = self.model(voxel_grid=grid[None], iters=self.iters, test_mode=True)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.free[slot] = ev
+        return out

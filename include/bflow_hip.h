@@ -49,12 +49,14 @@ const char* bflow_last_error_string(void);
  * one-thread launch that writes the device's 100 MHz wall clock into *slot.  Capture-safe, so the stage boundaries of a hipGraph
  * replay can be read back without a tracer (bflow_amd/timers.py StampTimer; bench.py `gpu_stage_ms`).                           */
 int         bflow_clock_stamp(unsigned long long* slot, bflow_stream_t stream);
-/* Second measurement hook: the SHADER clock under load.  One small launch whose workgroup on XCD 0 writes pair[0] = s_memtime (shader-clock
- * cycles) and pair[1] = s_memrealtime (100 MHz) -- both counters of the same XCD in every stamp.  Two stamps around a stretch of launches on
- * one stream (or inside one hipGraph) give the average shader clock of that stretch: (d pair[0] / d pair[1]) x 100 MHz.  The part clocks to
- * its power budget (1.3-2.1 GHz under matrix-core load), so a roofline fraction is only comparable between boxes with this number next to it
- * (bench.py `clock_ghz`).                                                                                                                  */
-int         bflow_shader_clock_stamp(unsigned long long* pair, bflow_stream_t stream);
+/* Second measurement hook: the SHADER clock under load.  One small launch (2048 one-wave workgroups) that writes, for every CU it reaches,
+ * table[row][0] = s_memtime (shader-clock cycles, a counter PER CU) and table[row][1] = s_memrealtime (100 MHz), row = (XCD * 8 + shader
+ * engine) * 16 + CU; `table` is BFLOW_CLOCK_TABLE_ROWS x 2 uint64, zeroed by the caller once.  Two stamps (two tables) around a stretch of
+ * launches on one stream (or inside one hipGraph) give the average shader clock of that stretch, CU by CU: (d cycles / d ticks) x 100 MHz
+ * over the rows both stamps filled.  The part clocks to its power budget (1.3-2.2 GHz under load), so a roofline fraction is only comparable
+ * between boxes with this number next to it (bench.py `clock_ghz`).                                                                        */
+#define BFLOW_CLOCK_TABLE_ROWS 1024
+int         bflow_shader_clock_stamp(unsigned long long* table, bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K5  all-pairs correlation volume ("feature_dot_product").
@@ -490,8 +492,14 @@ int bflow_voxel_grid_i32xy(const int* x, const int* y, const signed char* pol, c
                            float* grid, int C, int H, int W, void* workspace, long long workspace_bytes, bflow_stream_t stream);
 
 /* K2  in-place normalisation over the NON-ZERO entries: (v - mean) / std (unbiased), or v - mean if std == 0.
- * Replaces norm_voxel_grid, representations.py:9-18.  workspace: device, >= 4 doubles, any contents.    */
+ * Replaces norm_voxel_grid, representations.py:9-18.  workspace: device, >= BFLOW_VOXEL_NORM_WS_DOUBLES doubles, any contents (round 6:
+ * two launches -- per-block partial sums by plain stores, then fold + apply -- instead of a memset and three kernels).
+ * bflow_voxel_merge_norm: the same over the concatenation [a | b] written to `out` (which may be `a`): the merge of the two per-window
+ * grids of TwoStepSubSequence.__getitem__ (twostep.py:77-85: previous grid | current grid without its first bin) and its normalisation
+ * in one read of each grid.                                                                                                            */
+#define BFLOW_VOXEL_NORM_WS_DOUBLES 3072
 int bflow_voxel_norm(float* grid, long long n, double* workspace, bflow_stream_t stream);
+int bflow_voxel_merge_norm(const float* a, long long na, const float* b, long long nb, float* out, double* workspace, bflow_stream_t stream);
 
 /* DSEC sample assembly: BaseSubSequence._rectify_events + _events_to_voxel_grid (data/dsec/subsequence/base.py:121-143)
  * inside K1's binning passes.  x, y: raw sensor coordinates (uint16, as stored in events.h5), pol: 0/1, t: int64 us;

@@ -34,6 +34,22 @@ def test_library_loaded_from_tree():
     assert os.path.samefile(os.path.dirname(hip.library_path()), os.path.join(os.path.dirname(bflow_amd.__file__), "lib"))
 
 
+def test_shader_clock_stamp_reads_a_plausible_clock():
+    """bflow_shader_clock_stamp (the in-run clock bench.py prints next to every roofline fraction): two stamps around a stretch of launches
+    give a shader clock inside the part's range, from counters of the SAME CUs (s_memtime is per CU: tools/micro/memtime_domains)."""
+    tabs = hip.shader_clock_tables(2, DEV)
+    x = torch.randn(4096, 4096, device=DEV)
+    hip.shader_clock_stamp(tabs, 0)
+    for _ in range(20):
+        x = x * 1.0001 + 0.5
+    hip.shader_clock_stamp(tabs, 1)
+    torch.cuda.synchronize()
+    filled = int(((tabs[0, :, 1] != 0) & (tabs[1, :, 1] != 0)).sum())
+    ghz = hip.shader_clock_ghz(tabs)
+    print(f"shader clock over 20 element-wise launches: {ghz:.3f} GHz from {filled} CUs")
+    assert filled >= 64 and 0.3 < ghz < 2.6
+
+
 # ------------------------------------------------------------------------------------------------- K5 / K6 / K7
 def test_corr_build_pool_lookup_1toN_golden(golden_dir):
     d = g(golden_dir, "corr_1toN")
@@ -532,6 +548,59 @@ def test_voxel_norm_edge_cases(golden_dir):
     empty = VoxelGrid(5, 24, 32).convert(*(torch.zeros(0, dtype=dt, device=DEV) for dt in (torch.float32, torch.float32, torch.int8, torch.int64)),
                                          0, 100)
     assert empty.shape == (5, 24, 32) and float(empty.abs().sum()) == 0
+
+
+def test_voxel_merge_norm_equals_cat_then_norm_and_the_oracle():
+    """bflow_voxel_merge_norm (round 6: twostep.py:77-85's cat + norm_voxel_grid as one statistics pass + one writing pass) against the oracle's
+    norm_voxel_grid of the concatenation, and against the library's own in-place K2 of the same data; odd sizes take the scalar path."""
+    from bflow_amd import hip as H_
+    rs = np.random.RandomState(9)
+    for shape in ((5, 48, 64), (5, 33, 47), (3, 7, 5)):
+        prev = (rs.standard_normal(shape) * (rs.rand(*shape) < 0.3)).astype(np.float32)
+        cur = (rs.standard_normal(shape) * 3 * (rs.rand(*shape) < 0.3)).astype(np.float32)
+        merged = np.concatenate([prev, cur[1:]], 0)
+        ref = O.norm_voxel_grid(torch.from_numpy(merged.copy())).numpy()
+        out = torch.empty(merged.shape, device=DEV)
+        H_.voxel_merge_norm(cu(prev), cu(cur)[1:], out)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)          # fp64 sums vs torch's fp32 mean / std
+        np.testing.assert_array_equal(out.cpu().numpy() == 0, merged == 0)                # zeros stay zeros
+        inplace = norm_voxel_grid(cu(merged))
+        assert torch.equal(inplace, out), shape                                             # same statistics, same arithmetic: bit for bit
+    zero = torch.zeros(4, 6, 8, device=DEV)
+    assert float(H_.voxel_merge_norm(zero, zero[1:], torch.empty(7, 6, 8, device=DEV)).abs().sum()) == 0
+    one = torch.zeros(2, 3, 4, device=DEV)
+    one[0, 1, 1] = 2.5                                                                      # a single non-zero entry: std is NaN in torch -> v - mean = 0
+    np.testing.assert_array_equal(norm_voxel_grid(one.clone()).cpu().numpy(), O.norm_voxel_grid(one.cpu().clone()).numpy())
+
+
+def test_event_frame_pipeline_equals_the_serial_chain():
+    """EventFramePipeline (assembly of frame k + 1 on its own stream next to the forward of frame k, two alternating grid buffers) gives every
+    frame of a stream the flow the one-stream chain gives it."""
+    from bflow_amd.dsec import EventStream, TwoStepAssembler
+    from bflow_amd.pipeline import EventFramePipeline
+    cfg, sd, m = _small_model("E_LU4_BD2")
+    H, W, bins = 176, 208, cfg["num_bins"]["correlation"]
+    rs = np.random.RandomState(3)
+    n = 200_000
+    ev = dict(x=rs.randint(0, W, n).astype(np.uint16), y=rs.randint(0, H, n).astype(np.uint16), p=rs.randint(0, 2, n).astype(np.uint8),
+              t=np.sort(rs.randint(1_000_000, 1_460_000, n)).astype(np.int64))
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    rect = np.stack([xx + 0.3 * np.sin(yy / 9.0), yy + 0.3 * np.cos(xx / 11.0)], -1).astype(np.float32)
+    ts = np.array([[1_030_000 + 100_000 * k, 1_130_000 + 100_000 * k] for k in range(4)], dtype=np.int64)
+    stream, asm = EventStream(**ev), TwoStepAssembler(bins, H, W, rect)
+    iters = 3
+    with torch.inference_mode():
+        serial = []
+        for idx in (1, 2, 3, 1, 2):
+            vox = asm.assemble(stream, ts, idx, check=False)
+            serial.append(m(voxel_grid=vox[None], iters=iters, test_mode=True)[1].get_flow_from_reference(1.0).clone())
+        pipe = EventFramePipeline(m, asm, iters)
+        piped = [pipe(stream, ts, idx)[1].get_flow_from_reference(1.0) for idx in (1, 2, 3, 1, 2)]
+        torch.cuda.synchronize()
+    assert m.graph_replays() >= 10
+    for a, b in zip(serial, piped):
+        assert torch.equal(a, b)
+    assert float((serial[0] - serial[1]).abs().max()) > 1e-3
 
 
 def test_voxel_grid_dsec_size_vs_oracle():

@@ -28,7 +28,7 @@ for n_ev in (500_000, 2_000_000):
     xi, yi = x.round().to(torch.int16), y.round().to(torch.int16)
     timed(lambda: hip.voxel_grid(xi, yi, p, t, 0, 100_000, grid), f"K1 voxel_scatter i16xy, {n_ev/1e6:.1f} M events", n_ev * (13 + 2 * 8))
 grid = torch.from_numpy((rs.standard_normal((C, H, W)) * (rs.uniform(size=(C, H, W)) < 0.3)).astype(np.float32)).to(dev)
-ws = torch.empty(4, dtype=torch.float64, device=dev)
+ws = hip.voxel_norm_workspace(dev)
 timed(lambda: hip.voxel_norm(grid, ws), "K2 voxel_norm 9x480x640", 4.0 * grid.numel() * 4, note="(3 reads + 1 write)")
 N = 4800
 src = torch.randn((N, 60, 80), device=dev); dst = torch.empty((N, 30, 40), device=dev)
