@@ -47,7 +47,7 @@ PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s (
 MFMA_STREAM_SUSTAINED_GHZ = 1.5
 PEAK_CLOCK_GHZ = 2.4
 K5_SUSTAINED_GHZ = 1.7                     # shader clock of K5 under load (cycle stamps / wall clock per workgroup: profiles/r0x_k5_stamps_split8.txt, 1.66-1.8)
-PMC_FILE = "r05_pmc.json"                  # rocprofv3 --pmc evidence of this round (tools/collect_profiles.sh)
+PMC_FILE = "r06_pmc.json"                  # rocprofv3 --pmc evidence of this round (tools/collect_profiles.sh)
 
 
 def kernel_source_hash() -> str:
@@ -366,7 +366,7 @@ def main():
     if rank == 0 and not args.no_extras and not args.frame_only:
         # rooflines of the hand-written kernels (tools/roofline_kernels.py), each timed with hipEvents on the launch stream on the operands
         # of the C2 workload (the timed region above is graph replays, inside which events cannot be recorded)
-        from tools.roofline_kernels import build as roofline_kernels, build_big
+        from tools.roofline_kernels import build as roofline_kernels, build_big, build_c4_convs
         vox8 = None
         torch.cuda.empty_cache()
         src_hash = kernel_source_hash()
@@ -435,6 +435,9 @@ def main():
             # (tools/collect_profiles.sh -> profiles/<PMC_FILE>), and only when that file was collected on kernels built from these sources
             if k["name"] in pmc:
                 r["traffic"] = pmc[k["name"]]["traffic"]
+                mu = (pmc[k["name"]].get("mfma") or {}).get("mfma_utilisation")
+                if mu is not None:      # matrix-pipe busy cycles per cycle with waves of this kernel, normalised by a pure MFMA stream (same file)
+                    r["mfma_utilisation"] = round(mu, 4)
                 r["traffic_source"] = f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; same kernel sources)"
             elif pmc_doc and not pmc_ok:
                 r["traffic_source"] = f"none: profiles/{PMC_FILE} was collected on different kernel sources (re-run tools/collect_profiles.sh)"
@@ -452,6 +455,10 @@ def main():
                     "note": "bflow_corr_lookup_im2col: the 7x7 windows of the Bezier parameters for convf1 written by the first workgroups of the look-up launch"}
         torch.cuda.empty_cache()
         for k in build_big(model, cfg, dev):
+            price(k)
+        torch.cuda.empty_cache()
+        # the convolution kernels that lead the FULL trace, at the shape that sets whole-node throughput (C4 per-GPU shard, batch 8)
+        for k in build_c4_convs(model, dev):
             price(k)
         torch.cuda.empty_cache()
         # K5 is bound by its STORE stream: the ceiling of a pure store stream, measured in this process on this box -- hipMemsetAsync of the
@@ -496,6 +503,11 @@ def main():
                                           "frac is measured against 8 TB/s, which no arithmetic with matrix work can reach here"}
         if world == 1:
             out["gpu_stage_ms"] = gpu_stage_ms(cfg, sd, vox1, dev)
+            v8 = torch.from_numpy(synthetic.voxel_grid(MICRO_BATCH, 9, H, W, seed=1234)).to(dev)
+            out["gpu_stage_ms_c4"] = gpu_stage_ms(cfg, sd, v8, dev)      # ONE micro-batch of 8 (C4's per-GPU batch at N = 8), one forward in flight
+            out["gpu_stage_ms_c4"]["workload"] = "one forward at batch 8 (BASELINE configs[3]'s per-GPU batch), same in-graph stamps"
+            del v8
+            torch.cuda.empty_cache()
             out["voxel_kernels"] = voxel_kernels(dev)
             out["pipeline_from_events"] = pipeline_from_events(model, cfg, dev)
             torch.cuda.empty_cache()
@@ -529,6 +541,7 @@ def main():
                           "k5_model_cap": g("roofline_corr_build", "model_cap", "frac"),
                           "roofline_frac_at_sustained_mfma_clock": g("roofline", "power_model", "frac_of_that"), "cpu_frames_s": g("cpu_baseline", "value"),
                           "gpu_stage_ms": {k: v for k, v in (out.get("gpu_stage_ms") or {}).items() if isinstance(v, (int, float))},
+                          "gpu_stage_ms_c4": {k: v for k, v in (out.get("gpu_stage_ms_c4") or {}).items() if isinstance(v, (int, float))},
                           "epe_ranks_gathered": out.get("epe_ranks_gathered"), "rccl": out.get("rccl_version")}
         print(json.dumps(out), flush=True)
     if world > 1:

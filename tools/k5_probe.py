@@ -144,6 +144,34 @@ def main():
         for x in range(8):
             m = live & (np.arange(256) % 8 == x)
             print(f"  xcd {x}: end us median {np.median(en[m]):.1f} max {en[m].max():.1f}, cycles median {np.median(cyc[m]):.0f}")
+        # ---- cycle budget of the launch (round 6): every workgroup's stamps are prologue | step | step | ... | end
+        floor = {"split8": 2 * 1024 * 2, "split": 2 * 1536 * 2, "f16/w": 2 * 512 * 2}[args.stamp_mode]     # matrix-pipe cycles per step and SIMD: 2 chunks x 2 waves per SIMD
+        pro, stp, nst, tail = [], [], [], []
+        for wg in range(256):
+            r = s[wg]
+            its = [int(x) for x in r[:61] if x]
+            if len(its) < 3 or not live[wg]:
+                continue
+            d = np.diff(its)
+            pro.append(d[0]); stp.extend(d[1:].tolist()); nst.append(len(d) - 1); tail.append(int(r[61]) - its[-1])
+        pro, stp, nst, tail = np.array(pro), np.array(stp), np.array(nst), np.array(tail)
+        ghz = float(np.median(cyc[live] / (en[live] - st[live]))) / 1e3
+        smed = float(np.median(stp))
+        slow = float((stp > 1.2 * smed).mean())
+        print(f"BUDGET {args.stamp_shape} {args.stamp_mode}: clock {ghz:.3f} GHz; prologue median {np.median(pro):.0f} cycles ({np.median(pro)/ghz/1e3:.1f} us); "
+              f"step (2 chunks) median {smed:.0f} cycles = {floor/smed:.2f} of them matrix-pipe busy (floor {floor}); {100*slow:.1f} % of the steps take > 1.2 x the median "
+              f"(panel hand-over: mean extra {float((stp[stp > 1.2*smed] - smed).mean()) if slow > 0 else 0:.0f} cycles); steps per workgroup min/median/max "
+              f"{nst.min()}/{int(np.median(nst))}/{nst.max()}; tail (last step stamp -> end: last stores) median {np.median(tail):.0f} cycles")
+        worst = int(np.argmax(np.where(live, en, 0)))
+        r = s[worst]; its = [int(x) for x in r[:61] if x]; d = np.diff(its)
+        parts = {"start skew": st[worst] * ghz * 1e3, "prologue": float(d[0]), "steps x median": float((len(d) - 1) * smed),
+                 "steps above the median (hand-overs)": float(d[1:].sum() - (len(d) - 1) * smed), "tail": float(int(r[61]) - its[-1])}
+        tot = sum(parts.values())
+        print(f"BUDGET critical workgroup {worst} (ends last, {en[worst]:.1f} us): " + "; ".join(f"{k} {v:.0f} cyc = {v/ghz/1e3:.1f} us" for k, v in parts.items()) +
+              f"; sum {tot/ghz/1e3:.1f} us of {en[worst]:.1f} us")
+        mean_steps = float(nst.mean())
+        print(f"BUDGET balance: mean steps per workgroup {mean_steps:.2f} vs max {nst.max()}: a perfectly balanced panel assignment would end at "
+              f"{(np.median(pro) + mean_steps * smed + np.median(tail))/ghz/1e3:.1f} us (stamps of wave 0 only; the launch itself adds dispatch + the write-back at its end)")
     print("PROBE", "OK" if ok else "FAILED")
     return 0 if ok else 1
 

@@ -109,7 +109,7 @@ def build(model, vox, cfg, low_params=None):
                         bytes=4.0 * B * h8_ * w8_ * (256 + 192 + 128 + 64) + 4.0 * 9 * (192 * 256 + 64 * 128),
                         note="batch 1: 240 + 80 workgroups on 256 CUs, a link of a chain of dependent launches -- bound by the operand fill of a CU and launch "
                              "latency, not by the matrix cores"))
-        out.insert(0, dict(key="roofline", name=CONV_NAME, regex="conv_halo_kernel<", bound="mfma",
+        out.insert(0, dict(key="roofline", name=CONV_NAME, regex="conv_halo_stream_kernel<false>", bound="mfma",
                         launch=lambda: S.conv(cur, pk, stride=1, padding=1, want_split=False, out_f32=o32, stats=st),
                         flops=2.0 * n5 * h0 * w0 * 64 * 64 * 9,
                         # split input (4 B/elem) + fp32 output (4 B/elem) + packed weights
@@ -178,6 +178,50 @@ def lookup_line_bytes(cblk, B):
         cols = min(sum(-(-(o + 10) // 8) for o in range(8)) / 8.0, -(-pw // 8))
         tot += rows * cols * 128.0 + 81 * 4.0
     return B * N * tot
+
+
+C4_CONV3_NAME = "conv_halo_kernel<2, 3, 3, false, false> (C4 per-GPU shard, batch 8: motion encoder convc2, 3x3 256->192 + bias + ReLU on 8x60x80)"
+C4_STREAM_NIN_NAME = "conv_halo_stream_kernel<true> (C4 per-GPU shard, batch 8: feature encoder layer1 conv2, 3x3 64->64 normalise-on-load on 40x240x320, fp32 out + statistics)"
+C4_GRU_NAME = "conv_halo_kernel<2, 1, 5, false, false> (C4 per-GPU shard, batch 8: SepConvGRU z|r, 1x5 [h | M] 288->256 on 8x60x80; plain epilogue here, the product launch carries the gate epilogue)"
+
+
+def build_c4_convs(model, dev):
+    """The three convolution kernels that lead the FULL kernel trace (profiles/r0x_rocprofv3_kernel_stats.csv: the default bench command, where
+    the batch-8 workloads set whole-node throughput), each on its largest launch of the C4 per-GPU shard (batch 8).  Random operands of the
+    product's shapes; durations do not depend on the values."""
+    out = []
+    g = torch.Generator(device="cpu").manual_seed(7)
+    B, h8, w8 = 8, 60, 80
+    ub = model.update_block
+    with torch.no_grad():
+        # (1) the large-grid per-item halo kernel, split output: convc2 of the motion encoder (update.py:90), 256 -> 192, bias + ReLU
+        c1 = S.from_nchw(torch.relu(torch.randn((B, 256, h8, w8), generator=g)).to(dev))
+        pk2 = S.PackedConvWeight().get(ub.encoder.convc2.weight)
+        o2 = S.SplitTensor.empty(B, h8, w8, 192, dev)
+        out.append(dict(key="roofline_conv3x3_c4", name=C4_CONV3_NAME, regex="conv_halo_kernel<2, 3, 3, false, false>", bound="mfma",
+                        launch=lambda: S.conv(c1, pk2, padding=1, shift=ub.encoder.convc2.bias, act=S.ACT_RELU, out_split=o2),
+                        flops=conv_flops(ub.encoder.convc2, h8, w8, B), bytes=4.0 * B * h8 * w8 * (256 + 192) + 4.0 * 9 * 192 * 256, keep=(c1, o2)))
+        # (2) the persistent stream kernel, normalise-on-load: layer1.0.conv2 of the feature encoder on the shard's 5 x 8 = 40 half-resolution maps
+        n, H2, W2 = 5 * B, 240, 320
+        raw = torch.randn((n, 2, H2 * W2, 32), generator=g).to(dev)
+        xs = torch.zeros((8, n, 64, 2), dtype=torch.float64, device=dev)
+        xs[0, :, :, 0] = 0.0
+        xs[0, :, :, 1] = float(H2 * W2)          # mean 0, variance 1 per (image, channel)
+        pkc = S.PackedConvWeight().get(model.fnet_ev.layer1[0].conv2.weight)
+        st = torch.zeros((8, n, 64, 2), dtype=torch.float64, device=dev)
+        o32 = torch.empty((n, 2, H2 * W2, 32), dtype=torch.float32, device=dev)
+        out.append(dict(key="roofline_conv_stream_nin_c4", name=C4_STREAM_NIN_NAME, regex="conv_halo_stream_kernel<true>", bound="mfma",
+                        launch=lambda: S.conv_norm_in(raw, (n, H2, W2, 64), xs, pkc, stats=st, out_f32=o32),
+                        flops=2.0 * n * H2 * W2 * 64 * 64 * 9, bytes=4.0 * n * H2 * W2 * 64 * 2 + 4.0 * 64 * 64 * 9, keep=(raw, o32, xs, st)))
+        # (3) the 1x5 gate convolution of the separable GRU at batch 8: [h | M] = 128 + 160 channels -> z | r (256)
+        hm = S.from_nchw(torch.randn((B, 288, h8, w8), generator=g).to(dev))
+        wz = (torch.randn((256, 288, 1, 5), generator=g) / (288 * 5) ** 0.5).to(dev)
+        pkg = S.PackedConvWeight().get(wz)
+        og = S.SplitTensor.empty(B, h8, w8, 256, dev)
+        out.append(dict(key="roofline_gru_conv_c4", name=C4_GRU_NAME, regex="conv_halo_kernel<2, 1, 5, false, false>", bound="mfma",
+                        launch=lambda: S.conv(hm, pkg, padding=(0, 2), out_split=og),
+                        flops=2.0 * B * h8 * w8 * 256 * 288 * 5, bytes=4.0 * B * h8 * w8 * (288 + 256) + 4.0 * 5 * 256 * 288, keep=(hm, og, wz)))
+    return out
 
 
 def build_big(model, cfg, dev):
