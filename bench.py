@@ -711,11 +711,22 @@ def pipeline_from_events(model, cfg, dev, steps=10):
     stream = EventStream(**ev, device=dev)
     asm = TwoStepAssembler(bins, H, W, rect, device=dev)
 
-    from bflow_amd.pipeline import EventFramePipeline
+    from bflow_amd.pipeline import EventFrameGraph, EventFramePipeline
     pipe = EventFramePipeline(model, asm, ITERS)
+    n_win = max(asm.window_descriptor(stream, int(a), int(b))[1] for a, b in ts)
+    graph_pipe = EventFrameGraph(model, asm, stream, ITERS, max_events=n_win + n_win // 8)
+    graph_over = EventFrameGraph(model, asm, stream, ITERS, max_events=n_win + n_win // 8, overlap=True)
+
+    def frame_graph():
+        with torch.inference_mode():       # ONE replay per frame: its assembly (device-side windows), then its forward
+            return graph_pipe(ts, 1)
+
+    def frame_graph_overlap():
+        with torch.inference_mode():       # ONE replay per frame: the forward of the previous submission | the assembly of this one
+            return graph_over.submit(ts, 1)
 
     def frame():
-        with torch.inference_mode():       # (the call val.py makes: the forward is a graph replay; the assembly of the NEXT frame runs next to it)
+        with torch.inference_mode():       # (the call val.py makes: the forward is a graph replay; the assembly of the NEXT frame is eager, on a second stream)
             return pipe(stream, ts, 1)
 
     def frame_serial():
@@ -737,14 +748,25 @@ def pipeline_from_events(model, cfg, dev, steps=10):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / k
 
+    t_graph = timed(frame_graph, steps)
+    graph_pipe.close()
+    t_over = timed(frame_graph_overlap, steps)
+    graph_over.flush()
+    graph_over.close()
     t_frame, t_ser, t_asm = timed(frame, steps), timed(frame_serial, steps), timed(assemble_only, steps)
-    return {"value": round(1.0 / t_frame, 2), "unit": "frames/s", "ms_per_frame": round(t_frame * 1e3, 4), "ms_assembly": round(t_asm * 1e3, 4),
+    return {"value": round(1.0 / t_graph, 2), "unit": "frames/s", "ms_per_frame": round(t_graph * 1e3, 4), "ms_assembly": round(t_asm * 1e3, 4),
+            "graph_branch": {"value": round(1.0 / t_over, 2), "ms_per_frame": round(t_over * 1e3, 4),
+                             "note": "EventFrameGraph(overlap=True): the assembly of frame k + 1 as a branch of frame k's graph, next to its GRU loop -- K1's "
+                                     "chip-filling launches take the wave slots the loop's dependent launches wait for"},
+            "two_streams_eager": {"value": round(1.0 / t_frame, 2), "ms_per_frame": round(t_frame * 1e3, 4),
+                                  "note": "round 6 first form (EventFramePipeline): the assembly as eager launches on a second stream -- eager launches do not run "
+                                          "next to a graph replay on this runtime"},
             "one_stream": {"value": round(1.0 / t_ser, 2), "ms_per_frame": round(t_ser * 1e3, 4),
                            "note": "assembly and forward of a frame one after the other on one stream (round 5's number)"},
-            "events_per_window": int(n * 100_000 / 260_000), "steps": steps,
-            "workload": "a stream of frames: raw events -> 2 x K1 (rectified, 5 bins) -> merge + K2 (one launch pair) -> C2 forward (12 iters); the assembly of "
-                        "frame k + 1 runs on its own stream next to the GRU loop of frame k (bflow_amd/pipeline.py EventFramePipeline); wall clock incl. "
-                        "the host's eager enqueue of the assembly"}
+            "events_per_window": int(n_win), "planned_max_events_per_window": int(graph_pipe.max_events), "steps": steps,
+            "workload": "a stream of frames of one resident recording: raw events -> 2 x K1 (rectified, 5 bins, windows read from a device descriptor) -> merge + "
+                        "K2 (one launch pair) -> C2 forward (12 iters); ONE hipGraph replay per frame = its assembly, then its forward (bflow_amd/pipeline.py "
+                        "EventFrameGraph; outputs bit-identical to eager assemble-then-forward); wall clock incl. the host's window search and descriptor copy"}
 
 
 def other_baseline_configs(dev, steps):

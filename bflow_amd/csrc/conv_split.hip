@@ -1402,7 +1402,7 @@ struct StemArgs {
 };
 
 #ifndef STEM_ABL
-#define STEM_ABL 0      // tools/stem_ablate.sh: 1 no epilogue, 2 no tile build, 4 no patch load, 8 no MFMA
+#define STEM_ABL 0      // tools/stem_ablate.sh: 1 no epilogue, 2 no tile build / patch split, 4 no patch load, 8 no MFMA, 16 no weight DMA (rows kernel)
 #endif
 template <int KS, int STRIDE, bool TR = false>   // TR: transposed accumulators + direct fp32 epilogue, as in conv_halo_kernel
 __global__ __launch_bounds__(CT, 2) void conv_stem_kernel(ConvArgs a, StemArgs sa) {
@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
     const rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc((void*)((wave >> 1) ? a.wl : a.wh), 0, nkb * wtile_b, 0x00020000);
     char* const w_dst = lds + O_W + ((wave >> 1) ? NT * 2048 : 0);
 #define STEMR_ISSUE_W(KB, BUF)                                                                                           \
-    {                                                                                                                    \
+    if (!(STEM_ABL & 16)) {                                                                                              \
         const int so_ = ((KB) < nkb ? (KB) : nkb - 1) * wtile_b;                                                         \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                    \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lptr_t)(w_dst + (BUF) * W_TILE + ((wave * 2 + j) & 3) * 1024), 16, wvo[j], so_, 0, 0); \
@@ -1697,7 +1697,7 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const unsigned off = (ok && c < nch) ? (unsigned)(((c * sa.H + gy) * sa.W + gx) * 4) : 0x80000000u;
-                    pv[j][c] = c < CH ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_x, off, 0, 0)) : 0.f;
+                    pv[j][c] = (STEM_ABL & 4) ? 1.f : c < CH ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_x, off, 0, 0)) : 0.f;
                 }
             }
             } else {
@@ -1740,7 +1740,7 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
 #pragma unroll
             for (int j = 0; j < NPX; ++j) {
                 const int p = tid + j * CT;
-                if (p < PR * PC) {
+                if (p < PR * PC && !((STEM_ABL & 2) && pv[j][0] != 12345.f)) {
                     const int pr = p / PC, pc = p - pr * PC;
                     const int o = pr * pitch + pc * CH;
 #pragma unroll
@@ -1777,7 +1777,9 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
                         const int wo = (n * 32 + l31) * 64 + co;
                         const half8 wh = *reinterpret_cast<const half8*>(wt + wo);
                         const half8 wl = *reinterpret_cast<const half8*>(wt + NT * 2048 + wo);
-                        if constexpr (TR) {
+                        if constexpr ((STEM_ABL & 8) != 0) {
+                            if (xh[0] == (_Float16)123.f && wh[0] == (_Float16)77.f && wl[1] == xl[1]) hh[n][0] += 1.f;
+                        } else if constexpr (TR) {
                             hh[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, hh[n], 0, 0, 0);
                             xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, xx[n], 0, 0, 0);
                             xx[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, xx[n], 0, 0, 0);
@@ -1796,7 +1798,14 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
     __syncthreads();
 
     const int Wo = a.Wo, Ho = a.Ho, yw = y0 + wave * 2;
-    if constexpr (TR) {
+    if constexpr ((STEM_ABL & 1) != 0) {
+        float acc_ = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_ += hh[n][r] + xx[n][r];
+        if (acc_ == 1.2345f) a.out_f32[tid] = acc_;
+    } else if constexpr (TR) {
         const int kh_ = lane >> 5, c4 = (lane & 31) * 4;
         conv_epilogue_direct<NT>(a, hh, xx, b, [=](int r) {
             const int y = yw + (r >> 3), x = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh_;

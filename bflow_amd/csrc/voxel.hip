@@ -42,6 +42,11 @@ struct VoxSrc {
     const long long* t;
     const float* rect;
     long long n;
+    // Device-resident window (bflow_voxel_grid_rectified_window; null otherwise): {first event, event count, t0_center, t1_center} read by
+    // the kernels at run time, so that ONE captured launch sequence serves every window of a recording.  x / y / pol / t then address the
+    // whole recording of n_total events and `n` is the capacity the launch and its workspace were planned for.
+    const long long* win;
+    long long n_total;
 };
 
 struct VoxRec {        // 16 bytes
@@ -217,9 +222,31 @@ __device__ __forceinline__ void vox_chunk(long long n, int nb, int b, long long&
     if (lo > n) lo = n;
 }
 
+// The window descriptor -> the by-value copies of the launch's geometry / source (uniform: every lane reads the same four values).
+// Clamped to the recording and to the planned capacity: no descriptor can make a kernel read outside the arrays or write outside the workspace.
+template <int SRC>
+__device__ __forceinline__ void vox_apply_window(VoxGeo& g, VoxSrc& s) {
+    if (!s.win) return;
+    long long first = s.win[0], cnt = s.win[1];
+    const long long t0c = s.win[2], t1c = s.win[3];
+    first = first < 0 ? 0 : (first > s.n_total ? s.n_total : first);
+    cnt = cnt < 0 ? 0 : cnt;
+    cnt = cnt > s.n_total - first ? s.n_total - first : cnt;
+    cnt = cnt > s.n ? s.n : cnt;
+    constexpr int xy_bytes = (SRC == SRC_F32 || SRC == SRC_I32) ? 4 : 2;
+    s.x = reinterpret_cast<const char*>(s.x) + first * xy_bytes;
+    s.y = reinterpret_cast<const char*>(s.y) + first * xy_bytes;
+    s.pol = reinterpret_cast<const char*>(s.pol) + first;
+    s.t += first;
+    s.n = cnt;
+    g.t0c = t0c;
+    g.denom = (float)(t1c - t0c);            // what the host forms for a plain call (vox_run)
+}
+
 template <int SRC>
 __global__ __launch_bounds__(VOX_BIN_THREADS) void voxel_count_kernel(VoxGeo g, VoxSrc s, int* __restrict__ counts, int* __restrict__ bad) {
     extern __shared__ int hist[];
+    vox_apply_window<SRC>(g, s);
     for (int i = threadIdx.x; i < g.nbins; i += VOX_BIN_THREADS) hist[i] = 0;
     __syncthreads();
     const int chunk = vox_chunk_of_block(gridDim.x, blockIdx.x);
@@ -271,6 +298,7 @@ __global__ __launch_bounds__(VOX_BIN_THREADS) void voxel_place_kernel(VoxGeo g, 
                                                                       int* __restrict__ bin_base, VoxRec* __restrict__ recs) {
     extern __shared__ int cursor[];
     __shared__ int wave_tot[VOX_BIN_THREADS / 64];
+    vox_apply_window<SRC>(g, s);
     const int chunk = vox_chunk_of_block(gridDim.x, blockIdx.x);
     // exclusive scan of the bin totals: thread i owns the run [i * per, (i + 1) * per)
     const int per = (g.nbins + VOX_BIN_THREADS - 1) / VOX_BIN_THREADS;     // <= 8
@@ -558,7 +586,7 @@ int vox_run(const VoxSrc& s, long long t0c, long long t1c, float* grid, int C, i
     VoxPlan p;
     if (int rc = vox_plan(s.n, C, H, W, FLOAT_XY, p, what)) return rc;
     BFLOW_REQUIRE(grid, BFLOW_E_ARG, "%s: bad grid", what);
-    BFLOW_REQUIRE(t1c > t0c, BFLOW_E_ARG, "%s: t1_center must be > t0_center", what);
+    BFLOW_REQUIRE(s.win || t1c > t0c, BFLOW_E_ARG, "%s: t1_center must be > t0_center", what);
     BFLOW_REQUIRE(s.n == 0 || (s.x && s.y && s.pol && s.t), BFLOW_E_ARG, "%s: bad event arrays", what);
     BFLOW_REQUIRE(ws && ((uintptr_t)ws & 15) == 0 && ws_bytes >= (long long)p.bytes, BFLOW_E_ARG,
                   "%s: workspace of %lld bytes needed (bflow_voxel_workspace_bytes), 16-byte aligned", what, (long long)p.bytes);
@@ -595,19 +623,19 @@ extern "C" long long bflow_voxel_workspace_bytes(long long n_events, int C, int 
 extern "C" int bflow_voxel_grid_f32xy(const float* x, const float* y, const signed char* pol, const long long* t, long long n,
                                       long long t0c, long long t1c, float* grid, int C, int H, int W, void* ws, long long ws_bytes,
                                       bflow_stream_t stream) {
-    return vox_run<SRC_F32>(VoxSrc{x, y, pol, t, nullptr, n}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_f32xy");
+    return vox_run<SRC_F32>(VoxSrc{x, y, pol, t, nullptr, n, nullptr, 0}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_f32xy");
 }
 
 extern "C" int bflow_voxel_grid_i16xy(const short* x, const short* y, const signed char* pol, const long long* t, long long n,
                                       long long t0c, long long t1c, float* grid, int C, int H, int W, void* ws, long long ws_bytes,
                                       bflow_stream_t stream) {
-    return vox_run<SRC_I16>(VoxSrc{x, y, pol, t, nullptr, n}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_i16xy");
+    return vox_run<SRC_I16>(VoxSrc{x, y, pol, t, nullptr, n, nullptr, 0}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_i16xy");
 }
 
 extern "C" int bflow_voxel_grid_i32xy(const int* x, const int* y, const signed char* pol, const long long* t, long long n,
                                       long long t0c, long long t1c, float* grid, int C, int H, int W, void* ws, long long ws_bytes,
                                       bflow_stream_t stream) {
-    return vox_run<SRC_I32>(VoxSrc{x, y, pol, t, nullptr, n}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_i32xy");
+    return vox_run<SRC_I32>(VoxSrc{x, y, pol, t, nullptr, n, nullptr, 0}, t0c, t1c, grid, C, H, W, ws, ws_bytes, nullptr, stream, "voxel_grid_i32xy");
 }
 
 static int norm_run(const float* a, long long na, const float* b, long long nb, float* out, double* ws, bflow_stream_t stream, const char* what) {
@@ -634,8 +662,19 @@ extern "C" int bflow_voxel_grid_rectified(const unsigned short* x, const unsigne
                                           long long n, const float* rectify_map, long long t0c, long long t1c, float* grid, int C, int H,
                                           int W, int* bad_count, void* ws, long long ws_bytes, bflow_stream_t stream) {
     BFLOW_REQUIRE(rectify_map && ((uintptr_t)rectify_map & 7) == 0, BFLOW_E_ARG, "voxel_grid_rectified: the map must be 8-byte aligned");
-    return vox_run<SRC_RECT>(VoxSrc{x, y, pol, t, rectify_map, n}, t0c, t1c, grid, C, H, W, ws, ws_bytes, bad_count, stream,
+    return vox_run<SRC_RECT>(VoxSrc{x, y, pol, t, rectify_map, n, nullptr, 0}, t0c, t1c, grid, C, H, W, ws, ws_bytes, bad_count, stream,
                              "voxel_grid_rectified");
+}
+
+extern "C" int bflow_voxel_grid_rectified_window(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,
+                                                 long long n_total, long long max_events, const long long* window, const float* rectify_map,
+                                                 float* grid, int C, int H, int W, int* bad_count, void* ws, long long ws_bytes,
+                                                 bflow_stream_t stream) {
+    BFLOW_REQUIRE(rectify_map && ((uintptr_t)rectify_map & 7) == 0, BFLOW_E_ARG, "voxel_grid_rectified_window: the map must be 8-byte aligned");
+    BFLOW_REQUIRE(window && ((uintptr_t)window & 7) == 0, BFLOW_E_ARG, "voxel_grid_rectified_window: the window descriptor is 4 device int64");
+    BFLOW_REQUIRE(n_total > 0 && max_events > 0, BFLOW_E_ARG, "voxel_grid_rectified_window: empty recording / capacity");
+    return vox_run<SRC_RECT>(VoxSrc{x, y, pol, t, rectify_map, max_events, window, n_total}, 0, 1, grid, C, H, W, ws, ws_bytes, bad_count, stream,
+                             "voxel_grid_rectified_window");
 }
 
 extern "C" int bflow_maxabs_diff(const float* a, const float* b, long long n, float* out, bflow_stream_t stream) {

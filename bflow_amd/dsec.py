@@ -99,7 +99,9 @@ class TwoStepAssembler:
                 assert self.voxel_grid_dir.is_dir()
 
     # base.py:160-204 -------------------------------------------------------------------------------------------------
-    def construct_voxel_grid(self, events, ts_from: int, ts_to: int) -> torch.Tensor:
+    def time_window(self, events, ts_from: int, ts_to: int):
+        """(t_start, t_end, t0_center, t1_center) of the window [ts_from, ts_to]: the extended window of version 1, clamped to the recording,
+        with the reference's sanity asserts (base.py:165-191).  Version 0's centres are the first / last event's times (None here)."""
         if self.version == 1:
             t_start, t_end = self.voxel_grid.get_extended_time_window(ts_from, ts_to)
             assert (ts_from - t_start) < 50000, f"ts_from: {ts_from}, t_start: {t_start}"
@@ -112,6 +114,18 @@ class TwoStepAssembler:
         assert t_end < final_us + 50000, "Do not request more than 50 ms past the maximum time. Otherwise, something might be wrong."
         t_start, t_end = max(t_start, start_us), min(t_end, final_us)
         assert t_start < t_end
+        return t_start, t_end, t0c, t1c
+
+    def window_descriptor(self, events: "EventStream", ts_from: int, ts_to: int) -> Tuple[int, int, int, int]:
+        """{first event, event count, t0_center, t1_center} of the window: what bflow_voxel_grid_rectified_window reads from device memory
+        (extended voxel grids only: version 0 takes its centres from the events themselves)."""
+        assert self.version == 1, "device-side windows need extended_voxel_grid (the centres are the window's own timestamps)"
+        t_start, t_end, t0c, t1c = self.time_window(events, ts_from, ts_to)
+        i0, i1 = event_window_indices(events.t_host, t_start, t_end)
+        return i0, i1 - i0, t0c, t1c
+
+    def construct_voxel_grid(self, events, ts_from: int, ts_to: int) -> torch.Tensor:
+        t_start, t_end, t0c, t1c = self.time_window(events, ts_from, ts_to)
         x, y, p, t = events.window(t_start, t_end)
         if t0c is None:                                                                     # version 0: centres = first / last event
             t0c, t1c = int(t[0]), int(t[-1])

@@ -32,7 +32,7 @@ EXPORTS = (
     "bflow_corr_lookup_bezier", "bflow_corr_lookup_bezier_split", "bflow_bezier_coeffs", "bflow_bezier_eval", 
     "bflow_cvx_upsample",
     "bflow_clock_stamp", "bflow_shader_clock_stamp", "bflow_voxel_workspace_bytes", "bflow_voxel_grid_f32xy", "bflow_voxel_grid_i16xy", "bflow_voxel_grid_i32xy", "bflow_voxel_norm", "bflow_voxel_merge_norm", "bflow_epe_accumulate",
-    "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_grid_rectified", "bflow_maxabs_diff",
+    "bflow_flow_metrics_accumulate", "bflow_traj_len", "bflow_pad_replicate", "bflow_voxel_grid_rectified", "bflow_voxel_grid_rectified_window", "bflow_maxabs_diff",
     "bflow_corr_lookup_bwd", "bflow_corr_lookup_bezier_bwd", "bflow_corr_pool2x2_bwd", "bflow_cvx_upsample_bwd", "bflow_l1_masked_accumulate",
     "bflow_l1_masked_grad", "bflow_conv_split_pair", "bflow_corr_lookup_im2col", "bflow_cvx_upsample_blocked",
 )
@@ -178,6 +178,7 @@ def lib() -> ctypes.CDLL:
         "bflow_voxel_norm": [vp, ll, vp, vp],
         "bflow_voxel_merge_norm": [vp, ll, vp, ll, vp, vp, vp],
         "bflow_voxel_grid_rectified": [vp, vp, vp, vp, ll, vp, ll, ll, vp, i, i, i, vp, vp, ll, vp],
+        "bflow_voxel_grid_rectified_window": [vp, vp, vp, vp, ll, ll, vp, vp, vp, i, i, i, vp, vp, ll, vp],
         "bflow_maxabs_diff": [vp, vp, ll, vp, vp],
         "bflow_epe_accumulate": [vp, vp, vp, i, i, ll, vp, vp],
         "bflow_flow_metrics_accumulate": [vp, vp, vp, i, i, ll, f, f, f, vp, vp],
@@ -530,6 +531,14 @@ def _voxel_workspace(n: int, C: int, H: int, W: int, float_xy: bool, device) -> 
     return buf
 
 
+def voxel_workspace(n: int, C: int, H: int, W: int, float_xy: bool, device) -> torch.Tensor:
+    """A caller-owned K1 workspace for windows of at most `n` events (captured launch sequences keep theirs for the graph's lifetime)."""
+    nbytes = int(lib().bflow_voxel_workspace_bytes(n, C, H, W, int(float_xy)))
+    if nbytes < 0:
+        raise BflowHipError("voxel grid: " + lib().bflow_last_error_string().decode("utf-8", "replace"))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
 def voxel_grid(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.Tensor, t0_center: int, t1_center: int,
                grid: torch.Tensor, workspace: Optional[torch.Tensor] = None):
     """K1: `grid` (C, H, W) is written whole (it need not be zeroed)."""
@@ -565,6 +574,20 @@ def voxel_grid_rectified(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t:
                                             None if bad_count is None else _dev(bad_count, torch.int32, "bad_count"),
                                             _dev(workspace, torch.uint8, "workspace"), workspace.numel(), _stream()),
            "bflow_voxel_grid_rectified")
+
+
+def voxel_grid_rectified_window(x: torch.Tensor, y: torch.Tensor, pol: torch.Tensor, t: torch.Tensor, window: torch.Tensor, max_events: int,
+                                rectify_map: torch.Tensor, grid: torch.Tensor, workspace: torch.Tensor, bad_count: Optional[torch.Tensor] = None):
+    """bflow_voxel_grid_rectified with the window {first, count, t0_center, t1_center} read from the device tensor `window` (4 int64) at run
+    time: hipGraph-capturable, one capture for every frame of a recording.  `workspace`: hip.voxel_workspace(max_events, ...) owned by the caller."""
+    C, H, W = grid.shape
+    assert tuple(rectify_map.shape) == (H, W, 2) and window.dtype == torch.int64 and window.numel() == 4 and window.is_contiguous()
+    _check(lib().bflow_voxel_grid_rectified_window(_dev(x, torch.uint16, "x"), _dev(y, torch.uint16, "y"), _dev(pol, torch.uint8, "pol"),
+                                                   _dev(t, torch.int64, "time"), x.numel(), int(max_events), _dev(window, torch.int64, "window"),
+                                                   _dev(rectify_map, name="rectify_map"), _dev(grid, name="grid"), C, H, W,
+                                                   None if bad_count is None else _dev(bad_count, torch.int32, "bad_count"),
+                                                   _dev(workspace, torch.uint8, "workspace"), workspace.numel(), _stream()),
+           "bflow_voxel_grid_rectified_window")
 
 
 def maxabs_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -148,3 +148,162 @@ class EventFramePipeline:
         ev.record(main)
         self.free[slot] = ev
         return out
+
+
+class EventFrameGraph:
+    """Raw events -> flow for the frames of ONE resident recording, one hipGraph replay per frame.  K1 takes its window {first event, count,
+    centres} from a device descriptor the host rewrites before every replay (bflow_voxel_grid_rectified_window); its launches and workspace
+    are planned for `max_events` per window.  Two forms (profiles/r06_pipeline_graph.txt):
+
+    * serial (default): replay = 2 x K1 + merge + K2 of frame k, then frame k's forward.  No eager launch, no host gap between the
+      assembly's ten launches, no frame of latency:      out = g(forward_flow_timestamps, index)
+    * `overlap=True`: the assembly of frame k + 1 as a BRANCH of the graph that runs frame k's forward, on the forward's own side stream
+      behind the context encoder (idle during the batch-1 GRU loop; the graph keeps two parallel chains -- more are not safe on this
+      runtime: ConcurrentRunner); two graphs alternate (forward on grid[p], assembly into grid[1 - p]):
+            out = g.submit(forward_flow_timestamps, index)     # curves of the PREVIOUS submission (None at first);  last = g.flush()
+      Built, bit-identical, and SLOWER than the serial form (258 vs 274 frames/s for eager assembly + replay on one box): K1's launches are
+      sized to fill the chip (512 workgroups of 16 waves = every wave slot), so next to them each of the GRU loop's ~120 dependent
+      launches waits for slots -- the loop stretches by more than the assembly takes alone.  Kept for the measurement.
+      (`EventFramePipeline` above, eager assembly on a second stream, gains nothing either: eager launches do not run next to a replay.)
+
+    Bit-identical to `model(voxel_grid=assembler.assemble(...)[None])`: K1's fixed-point accumulation does not depend on the chunking, the
+    forward is the same launches (tests/test_hip_parity.py::test_event_frame_graph_matches_eager).  The reference's per-sample asserts
+    (coordinates inside the map, agreement of the shared slice: base.py:141, twostep.py:83) are host reads and are not part of a replay;
+    `bad_events()` returns the out-of-map counter of the last assembly.
+
+    SURVEY 8(f-1) / twostep.py:44-100 feeding raft.py:101-200; measured by bench.py `pipeline_from_events`."""
+
+    def __init__(self, model, assembler, events, iters: int = 12, max_events: Optional[int] = None, overlap: bool = False):
+        assert assembler.merge_grids and assembler.normalize and assembler.version == 1 and assembler.voxel_grid_dir is None, \
+            "EventFrameGraph: merged, normalised, extended voxel grids built from the events (the DSEC two-step default)"
+        self.model, self.asm, self.events, self.iters, self.overlap = model, assembler, events, iters, bool(overlap)
+        dev = torch.device(assembler.device)
+        self.device = dev
+        C, H, W = assembler.num_bins, assembler.height, assembler.width
+        self.max_events = int(max_events if max_events is not None else min(events.t_host.size, 1 << 22))
+        with torch.inference_mode(False):      # static buffers: rewritten in place by every later call, whatever mode that call runs in (graph.py)
+            self.ws = hip.voxel_workspace(self.max_events, C, H, W, True, dev)
+            self.norm_ws = hip.voxel_norm_workspace(dev)
+            self.win = torch.zeros((2, 4), dtype=torch.int64, device=dev)          # [current, previous] window of the frame being assembled
+            self._pin = [torch.zeros((2, 4), dtype=torch.int64).pin_memory() for _ in range(4)]
+            self.parts = [torch.empty((C, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.grid = [torch.empty((2 * C - 1, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        self._pin_ev = [None] * 4
+        self._graphs = [None, None]
+        self._outs = [None, None]
+        self._p = 0                 # grid[_p] holds the frame whose forward runs next
+        self._pending = False
+        self._n = 0
+        from .graph import WeightsWatch
+        self._weights = WeightsWatch(model)
+
+    # -- the assembly as capturable launches: windows from self.win, everything else static
+    def _assemble(self, out: torch.Tensor):
+        a, ev = self.asm, self.events
+        a._bad.zero_()
+        for j, part in ((0, self.parts[0]), (1, self.parts[1])):
+            hip.voxel_grid_rectified_window(ev.x, ev.y, ev.p, ev.t, self.win[j], self.max_events, a.rectify_events_map, part, self.ws, a._bad)
+        hip.voxel_merge_norm(self.parts[1], self.parts[0][1:], out, workspace=self.norm_ws)      # cat((previous, current[1:])), twostep.py:77-85
+
+    def _write_windows(self, forward_flow_timestamps, index: int):
+        from .dsec import twostep_windows
+        (cf, ct), (pf, pt) = twostep_windows(forward_flow_timestamps, index)
+        rows = [self.asm.window_descriptor(self.events, cf, ct), self.asm.window_descriptor(self.events, pf, pt)]
+        for r in rows:
+            assert r[1] <= self.max_events, f"window of {r[1]} events: EventFrameGraph was planned for {self.max_events} (max_events)"
+        slot = self._n & 3
+        self._n += 1
+        if self._pin_ev[slot] is not None:
+            self._pin_ev[slot].synchronize()           # the copy out of this staging buffer (four submissions ago) has run
+        self._pin[slot].copy_(torch.tensor(rows, dtype=torch.int64))
+        with torch.inference_mode(False):
+            self.win.copy_(self._pin[slot], non_blocking=True)
+        e = torch.cuda.Event()
+        e.record()
+        self._pin_ev[slot] = e
+
+    def _capture(self, p: int):
+        m = self.model
+        assert not m.training, "inference only"
+        with torch.inference_mode(False), torch.no_grad():
+            m._forward_impl(self.grid[p][None], None, self.iters, None, True)          # warm-up outside the capture (lazy packing, allocator growth)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            gc.collect()
+            gc_on = gc.isenabled()
+            gc.disable()                  # (graph.py: a collection inside a capture can abort the process)
+            try:
+                with torch.cuda.graph(g):
+                    if self.overlap:
+                        fr = m._encode(self.grid[p][None], None, None)
+                        with hip.Branch(True) as br:      # the forward's own side stream: idle from here to the last iteration's mask head
+                            self._assemble(self.grid[1 - p])
+                        low, ups = m._iterate(fr, self.iters, True)
+                        br.join()
+                    else:
+                        self._assemble(self.grid[p])
+                        low, ups = m._forward_impl(self.grid[p][None], None, self.iters, None, True)
+            finally:
+                if gc_on:
+                    gc.enable()
+        self._graphs[p], self._outs[p] = g, (low, ups[-1])
+
+    def __call__(self, forward_flow_timestamps, index: int):
+        """Serial form (`overlap=False`, the default): ONE replay = assembly of frame `index` + its forward; returns its curves."""
+        assert not self.overlap, "overlap=True: use submit() / flush()"
+        with torch.cuda.device(self.device), torch.no_grad():
+            if self._weights.changed():
+                self.close()
+            self._write_windows(forward_flow_timestamps, index)
+            if self._graphs[0] is None:
+                with torch.inference_mode(False):
+                    self._assemble(self.grid[0])       # a real grid under the capture's warm-up forward
+                self._capture(0)
+            self._graphs[0].replay()
+            low, up = self._outs[0]
+            return BezierCurves(low.clone()), BezierCurves(up.clone())
+
+    def submit(self, forward_flow_timestamps, index: int):
+        """Overlapped form (`overlap=True`): queues frame `index` (its two windows are assembled next to the GRU loop of the previously
+        submitted frame) and returns that previous frame's (low-resolution curves, full-resolution curves), or None for the first submission."""
+        assert self.overlap, "overlap=False: call the object"
+        with torch.cuda.device(self.device), torch.no_grad():
+            if self._weights.changed():
+                self.close()
+            self._write_windows(forward_flow_timestamps, index)
+            if not self._pending:
+                with torch.inference_mode(False):
+                    self._assemble(self.grid[self._p])
+                self._pending = True
+                return None
+            p = self._p
+            if self._graphs[p] is None:
+                # the windows just written belong to the NEXT frame; the capture's warm-up forward reads grid[p] only
+                self._capture(p)
+            self._graphs[p].replay()
+            low, up = self._outs[p]
+            self._p = 1 - p
+            return BezierCurves(low.clone()), BezierCurves(up.clone())
+
+    def flush(self):
+        """The curves of the last submitted frame (a plain forward on its grid: nothing is left to assemble)."""
+        if not self._pending:
+            return None
+        self._pending = False
+        with torch.cuda.device(self.device):
+            return self.model(voxel_grid=self.grid[self._p][None], iters=self.iters, test_mode=True)
+
+    def bad_events(self) -> int:
+        """Events of the last assembled frame whose raw coordinates lie outside the rectification map (one device -> host read)."""
+        return int(self.asm._bad)
+
+    def close(self):
+        if any(g is not None for g in self._graphs):
+            torch.cuda.synchronize(self.device)        # (ConcurrentRunner.close: a graph is destroyed only after its last replay has finished)
+        self._graphs, self._outs = [None, None], [None, None]
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -511,6 +511,20 @@ int bflow_voxel_merge_norm(const float* a, long long na, const float* b, long lo
 int bflow_voxel_grid_rectified(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,
                                long long n, const float* rectify_map, long long t0_center, long long t1_center, float* grid,
                                int C, int H, int W, int* bad_count, void* workspace, long long workspace_bytes, bflow_stream_t stream);
+/* The same four launches with the WINDOW taken from device memory at run time, so that one captured hipGraph serves every frame of a
+ * recording (bflow_amd/pipeline.py EventFrameGraph: the assembly of frame k + 1 as a branch of the graph that runs frame k's forward).
+ *   x, y, pol, t : the whole time-sorted recording (n_total events, resident);
+ *   window       : device, 4 int64, 8-byte aligned: {first event, event count, t0_center, t1_center} -- what
+ *                  BaseSubSequence._get_events / construct_voxel_grid derive on the host (data/dsec/subsequence/base.py:160-204:
+ *                  np.searchsorted of the extended time window, centres = ts_from / ts_to), written by the caller before each replay;
+ *   max_events   : the capacity the launches and the workspace (bflow_voxel_workspace_bytes(max_events, C, H, W, 1)) are planned for.
+ * The kernels clamp the window to [0, n_total) and to max_events (the host side asserts count <= max_events: a clamped window would
+ * silently drop events).  Results are bit-identical to bflow_voxel_grid_rectified on the same window (fixed-point accumulation does not
+ * depend on the chunking).                                                                                                          */
+int bflow_voxel_grid_rectified_window(const unsigned short* x, const unsigned short* y, const unsigned char* pol, const long long* t,
+                                      long long n_total, long long max_events, const long long* window, const float* rectify_map,
+                                      float* grid, int C, int H, int W, int* bad_count, void* workspace, long long workspace_bytes,
+                                      bflow_stream_t stream);
 int bflow_maxabs_diff(const float* a, const float* b, long long n, float* out, bflow_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------

@@ -1940,6 +1940,54 @@ def test_conv_engine_random_shapes_vs_fp64():
             assert float(o_split.planes[:, :, -1, :, cout % 32:].abs().max()) == 0.0
 
 
+def test_event_frame_graph_matches_eager():
+    """bflow_amd.pipeline.EventFrameGraph: the assembly of frame k + 1 (2 x K1 with DEVICE-side windows + merge + K2) as a branch of the
+    hipGraph that runs frame k's forward.  Every frame's curves equal `model(voxel_grid=assembler.assemble(...))` bit for bit (K1's
+    fixed-point sums do not depend on the chunking planned for max_events; the forward is the same launches), over frames with different
+    windows / event counts, and a window larger than the planned capacity is refused on the host."""
+    from bflow_amd.dsec import EventStream, TwoStepAssembler
+    from bflow_amd.pipeline import EventFrameGraph
+    cfg, sd, m = _small_model("E_LU4_BD2")
+    H, W, bins = 176, 208, cfg["num_bins"]["correlation"]
+    rs = np.random.RandomState(31)
+    n = 400_000
+    # a rate that varies over the recording: the windows of the frames below hold different event counts
+    tt = np.sort(np.concatenate([rs.randint(1_000_000, 1_300_000, n // 2), rs.randint(1_150_000, 1_500_000, n - n // 2)])).astype(np.int64)
+    ev = dict(x=rs.randint(0, W, n).astype(np.uint16), y=rs.randint(0, H, n).astype(np.uint16), p=rs.randint(0, 2, n).astype(np.uint8), t=tt)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    rect = np.stack([xx + 0.3 * np.sin(yy / 9.0), yy + 0.3 * np.cos(xx / 11.0)], -1).astype(np.float32)
+    ts = np.array([[1_030_000 + 100_000 * k, 1_130_000 + 100_000 * k] for k in range(4)], dtype=np.int64)
+    stream = EventStream(**ev)
+    asm = TwoStepAssembler(bins, H, W, rect)
+    iters = cfg["num_iter"]["test"]
+    frames = [1, 2, 3, 2, 1, 3]
+    counts = {k: asm.window_descriptor(stream, int(ts[k][0]), int(ts[k][1]))[1] for k in (0, 1, 2, 3)}
+    assert len(set(counts.values())) > 1
+    g = EventFrameGraph(m, asm, stream, iters=iters, max_events=max(counts.values()) + 1000, overlap=True)
+    gs = EventFrameGraph(m, asm, stream, iters=iters, max_events=max(counts.values()) + 1000)
+    got = []
+    with torch.inference_mode():
+        for k in frames:
+            r = g.submit(ts, k)
+            if r is not None:
+                got.append(r)
+        got.append(g.flush())
+        assert g.bad_events() == 0
+        assert len(got) == len(frames)
+        for k, (low, up) in zip(frames, got):          # the serial form (one replay = this frame's assembly + forward)
+            low1, up1 = gs(ts, k)
+            assert torch.equal(low.get_params(), low1.get_params()) and torch.equal(up.get_params(), up1.get_params()), f"serial form, frame {k}"
+        m.enable_hipgraph(False)            # the reference chain: eager assembly (host-side windows), eager forward
+        for k, (low, up) in zip(frames, got):
+            vox = asm.assemble(stream, ts, k)
+            low0, up0 = m(voxel_grid=vox[None], iters=iters, test_mode=True)
+            assert torch.equal(low.get_params(), low0.get_params()) and torch.equal(up.get_params(), up0.get_params()), f"frame {k}"
+        m.enable_hipgraph(None)
+    small = EventFrameGraph(m, asm, stream, iters=iters, max_events=min(counts.values()) // 2)
+    with pytest.raises(AssertionError, match="max_events"):
+        small(ts, 1)
+
+
 def test_pipeline_raw_events_to_metrics():
     """The three stages either side of the network chained on the GPU: raw DSEC-style events -> two-step voxel assembly (f-1) ->
     RAFTSpline forward -> validation metrics (f-3); compared with the same chain on the CPU oracle."""
