@@ -1818,6 +1818,8 @@ __global__ __launch_bounds__(CT, 2) void conv_stem_rows_kernel(ConvArgs a, StemA
 #endif
 }
 
+#include "conv_stem_persist.h"
+
 // ---------------------------------------------------------------------------------------------------------------------
 // weights (Cout, Cin, KH, KW) fp32 -> split (KH*KW*CB, Cout_pad, 32), zero padded (k-tile-major)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2365,11 +2367,12 @@ extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream
         }
     }
     sa.layout = d->layout;
-    BFLOW_REQUIRE(d->layout == 0 || d->layout == 1, BFLOW_E_ARG, "conv_stem: layout must be 0 (im2col tiles) or 1 (row windows)");
+    BFLOW_REQUIRE(d->layout >= 0 && d->layout <= 3, BFLOW_E_ARG, "conv_stem: layout must be 0 (im2col tiles), 1 (row windows), 2 / 3 (row windows, persistent / per-patch form forced)");
+    const bool rows_layout = d->layout >= 1;
     sa.general = 0; sa.c1 = d->Cin; sa.x2 = nullptr; sa.dt0 = sa.dt1 = sa.norm0 = sa.norm1 = 0;
     for (int i = 0; i < 8; ++i) sa.xw[i] = d->x;
     if (d->window_bases || d->x2 || d->x_dtype || d->x_image_norm) {
-        BFLOW_REQUIRE(d->layout == 1, BFLOW_E_ARG, "conv_stem: multi-source / uint8 / normalised input needs the row-window kernel (layout 1)");
+        BFLOW_REQUIRE(rows_layout, BFLOW_E_ARG, "conv_stem: multi-source / uint8 / normalised input needs the row-window kernel (layout 1)");
         BFLOW_REQUIRE((d->x_dtype == 0 || d->x_dtype == 1) && (d->x2_dtype == 0 || d->x2_dtype == 1), BFLOW_E_ARG, "conv_stem: element types are 0 (fp32) or 1 (uint8)");
         BFLOW_REQUIRE(!d->x2 || (d->x2_channels > 0 && d->x2_channels < d->Cin), BFLOW_E_ARG, "conv_stem: x2_channels must be in (0, Cin)");
         BFLOW_REQUIRE(!d->window_bases || d->n_windows > 0, BFLOW_E_ARG, "conv_stem: window_bases needs n_windows");
@@ -2388,7 +2391,7 @@ extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream
         sa.x2 = d->x2; sa.dt0 = d->x_dtype; sa.dt1 = d->x2_dtype; sa.norm0 = d->x_image_norm; sa.norm1 = d->x2_image_norm;
     }
     const int ksteps_row = (d->ksize * sa.chunk + 15) / 16;                       // layout 1: 16-deep steps per filter row
-    const int kb_expected = ((d->Cin + sa.chunk - 1) / sa.chunk) * (d->layout == 1 ? (d->ksize * ksteps_row + 1) / 2 : sa.kblocks_per_chunk);
+    const int kb_expected = ((d->Cin + sa.chunk - 1) / sa.chunk) * (rows_layout ? (d->ksize * ksteps_row + 1) / 2 : sa.kblocks_per_chunk);
     BFLOW_REQUIRE(d->k_blocks == kb_expected, BFLOW_E_ARG,
                   "conv_stem: the packed weights hold %d k-blocks, expected %d (chunks of %d channels, layout %d)", d->k_blocks, kb_expected, sa.chunk, d->layout);
     ConvArgs a = {};
@@ -2405,10 +2408,41 @@ extern "C" int bflow_conv_stem(const bflow_stem_desc_t* d, bflow_stream_t stream
     dim3 grid((patches + 7) / 8 * 8 * a.n_tiles, 1, d->B);
     const int lds = 2 * (2 * CBM * 64) + 2 * (2 * 2 * 2048) + 8 * 21 * 37 * 4 + sa.kblocks_per_chunk * 32 * 4;
     static const bool no_direct = getenv("BFLOW_CONV_NO_DIRECT") != nullptr;      // A/B timing (tools/)
-    if (d->layout == 1) {
+    if (rows_layout) {
         const int pitch = (37 * sa.chunk + 1) & ~1, plane_h = 21 * pitch + 64;
         const int body = ((2 * plane_h * 2 + 15) & ~15) + 2 * (2 * 2 * 2048);
         const bool tr = !no_direct && a.out_f32 && !a.oh;
+        // the persistent form (conv_stem_persist.h): plain 5-channel fp32 input (the event encoders of every DSEC / MultiFlow configuration with
+        // five correlation bins), fp32 + statistics output, one channel tile; from 4 slabs per wave on (below that the 2048 waves of the
+        // launch are not filled evenly).  Measured: profiles/r06_stem_persist.txt.  BFLOW_STEM_PERSIST=0: never (A/B).
+        {
+            static const bool persist_on = [] { const char* e = getenv("BFLOW_STEM_PERSIST"); return !(e && !strcmp(e, "0")); }();
+            const int rows2 = bflow::ceil_div(Ho, 2), tiles_x = bflow::ceil_div(Wo, 16);
+            const long long n_slabs = (long long)d->B * rows2 * tiles_x;
+            const bool can = tr && !sa.general && d->Cin == 5 && a.n_tiles == 1 && n_slabs < (1LL << 30);
+            BFLOW_REQUIRE(d->layout != 2 || can, BFLOW_E_LIMIT, "conv_stem: layout 2 (persistent form) needs a plain 5-channel fp32 input, fp32 output and <= 64 output channels");
+            if (can && (d->layout == 2 || (d->layout == 1 && persist_on && n_slabs >= 8192))) {
+                constexpr int CH = 5, CUS = 256;
+                constexpr int p_pitch = (37 * CH + 1 - 32 + 63) / 64 * 64 + 32, p_plane = 9 * p_pitch + 64, p_slab = (2 * p_plane * 2 + 15) & ~15;   // (as in the kernel)
+                constexpr int p_nkb = (7 * ((7 * CH + 15) >> 4) + 1) >> 1;
+                // 8 waves per CU, every fragment read from LDS in the k-loop.  BFLOW_STEM_PERSIST_FORM=4 (tools A/B): 4 waves (one per SIMD), the hi-plane
+                // weight fragments of all 21 k-steps in registers (168 of 414) -- built, bit-identical, SLOWER (99-102 vs 80-83 us at 5 images, 635 vs
+                // 520 us at 40: a lone wave per SIMD has nobody to cover its conversion / epilogue phases; profiles/r06_stem_persist.txt)
+                static const bool form8 = [] { const char* e = getenv("BFLOW_STEM_PERSIST_FORM"); return !(e && !strcmp(e, "4")); }();
+                const int nwv = form8 ? 8 : 4;
+                const int p_lds = p_nkb * (2 * 2 * 2048) + nwv * p_slab;
+                const int per_wave = (int)bflow::ceil_div(n_slabs, (long long)CUS * nwv);
+                const int g = (int)bflow::ceil_div(n_slabs, (long long)per_wave * nwv);
+                if (form8) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_persist_kernel<CH, 8, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, p_lds);
+                    hipLaunchKernelGGL((conv_stem_persist_kernel<CH, 8, 0>), dim3(g), dim3(512), p_lds, (hipStream_t)stream, a, sa, (int)n_slabs, per_wave, tiles_x, rows2);
+                } else {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_persist_kernel<CH, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, p_lds);
+                    hipLaunchKernelGGL((conv_stem_persist_kernel<CH, 4, 1>), dim3(g), dim3(256), p_lds, (hipStream_t)stream, a, sa, (int)n_slabs, per_wave, tiles_x, rows2);
+                }
+                return bflow::launch_status("conv_stem(persistent)");
+            }
+        }
         const int epi = tr ? 2 * 4 * 64 * 4 : (2 * 4 * 64 + 4 * 2 * 32 * CONV_STG_STRIDE) * 4;
         const int lds1 = body > epi ? body : epi;
 #define LAUNCH_STEM_ROWS(TRR, GENN)                                                                                    \

@@ -211,7 +211,7 @@ class PackedStemWeight:
             cols = []
             w = weight.detach().float()
             for c0 in range(0, cin, chunk):
-                if self.layout == 1:
+                if self.layout >= 1:
                     blk = torch.nn.functional.pad(w[:, c0:c0 + chunk], (0, 0, 0, 0, 0, chunk - w[:, c0:c0 + chunk].shape[1]))   # missing channels: zero
                     rows = blk.permute(0, 2, 3, 1).reshape(cout, kh, kw * chunk)               # (r, q * chunk + c_local)
                     rows = torch.nn.functional.pad(rows, (0, (kw * chunk + 15) // 16 * 16 - kw * chunk)).reshape(cout, -1)
@@ -279,9 +279,10 @@ class StemInput:
 
 
 def conv_stem(x, packed, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-              stats: Optional[torch.Tensor] = None, want_split: bool = True, want_f32: bool = False):
+              stats: Optional[torch.Tensor] = None, want_split: bool = True, want_f32: bool = False, layout: Optional[int] = None):
     """7x7 / stride 2 / pad 3 convolution of a few-channel fp32 NCHW tensor or ChannelWindows (BasicEncoder.conv1) -> (split_out or
-    None, blocked fp32 or None), epilogue as `conv`.  `packed` = PackedStemWeight.get(weight)."""
+    None, blocked fp32 or None), epilogue as `conv`.  `packed` = PackedStemWeight.get(weight).  `layout` 2 / 3 forces the persistent /
+    the per-patch form of the row-window kernel (tests, A/B; same packed filter as layout 1)."""
     planes, (cout, cin, k_blocks, cout_pad) = packed[0], packed[1]
     windows = x if isinstance(x, ChannelWindows) else None
     general = x if isinstance(x, StemInput) else None
@@ -302,6 +303,9 @@ def conv_stem(x, packed, scale: Optional[torch.Tensor] = None, shift: Optional[t
     d.B, d.Cin, d.H, d.W, d.Cout, d.cout_pad, d.k_blocks = B, C, H, W, cout, cout_pad, k_blocks
     d.ksize, d.stride, d.pad = 7, 2, 3
     d.layout = STEM_LAYOUT if len(packed) < 3 else packed[2]
+    if layout is not None:
+        assert d.layout >= 1 and layout in (1, 2, 3), "forcing a form of the row-window kernel needs row-window weights"
+        d.layout = layout
     d.out_f32 = None if out_f32 is None else out_f32.data_ptr()
     d.out_hi = None if out_split is None else out_split.hi.data_ptr()
     d.out_lo = None if out_split is None else out_split.lo.data_ptr()

@@ -189,7 +189,12 @@ typedef struct bflow_stem_desc {
                                          1: (chunk, r, window) with window = q * chunk + c_local zero padded to a multiple of 16 per filter row,
                                             each chunk's 7 rows zero padded to a multiple of 32 -- the row-window kernel (round 3): the input
                                             patch is split once and laid out [row][column][channel], a filter row's 7 x chunk values of an
-                                            output pixel are contiguous and nothing is gathered                                              */
+                                            output pixel are contiguous and nothing is gathered.  The library picks the per-patch or the
+                                            PERSISTENT form of that kernel (round 6: weights resident in LDS, wave-private windows, no
+                                            barrier in the k-loop; fp32 + statistics output of a plain 5-channel input on >= 8192 slabs of
+                                            2 x 16 pixels) -- same packed filter, bit-identical outputs;
+                                         2 / 3: layout 1 with the persistent / the per-patch form FORCED (tests, A/B; 2 fails where the
+                                            persistent form cannot run)                                                                      */
     /* General input of the row-window kernel (layout 1; all zero / NULL = the plain fp32 input above).  Replaces the torch element-wise and
      * concatenation launches of raft.py:131-140: `images = [2 * (x.float() / 255) - 1 ...]`, `fnet_img(images)` (the encoder's torch.cat of the
      * list, extractor.py:106-110) and `context_input = cat((context_grid, images[0]))`.

@@ -1818,6 +1818,51 @@ def test_conv_stem_vs_fp64(cin, H, W, B):
     assert float(((gs - want).abs() / (mag * 1.5 + 1.0)).max()) < 1e-6
 
 
+@pytest.mark.parametrize("H,W,B,windows", [(96, 128, 2, False), (70, 90, 3, False), (136, 200, 2, True), (480, 640, 5, True)])
+def test_conv_stem_persistent_equals_per_patch_kernel(H, W, B, windows):
+    """conv_stem_persist_kernel (round 6: weights resident in LDS, a wave owns 2 x 16-pixel slabs with a private window image, no barrier in
+    the k-loop, stores drain under the next slab) == conv_stem_rows_kernel BIT FOR BIT (same fragments, same MFMA sequence per accumulator),
+    statistics to summation order; odd output sizes (a half-empty last row pair / column tile), channel windows read in place, and the
+    product's own launch (5 x 480 x 640: the default dispatch takes the persistent form there)."""
+    from bflow_amd import split as S
+    rs = np.random.RandomState(H + B)
+    w = cu((rs.standard_normal((64, 5, 7, 7)) / np.sqrt(5 * 49)).astype(np.float32))
+    pk = S.PackedStemWeight().get(w)
+    if windows:
+        src = cu(rs.standard_normal((max(B // 5, 1), 9, H, W)).astype(np.float32))
+        nb = src.shape[0]
+        starts = [0, 1, 2, 3, 4][:B // nb]
+        x = S.ChannelWindows(src, starts, 5)
+        dense = x.materialize()
+    else:
+        dense = cu(rs.standard_normal((B, 5, H, W)).astype(np.float32))
+        x = dense
+    n = dense.shape[0]
+    bias = cu(rs.standard_normal(64).astype(np.float32))
+
+    def run(layout):
+        st = torch.zeros((8, n, 64, 2), dtype=torch.float64, device=DEV)
+        _, f = S.conv_stem(x, pk, shift=bias, stats=st, want_split=False, want_f32=True, layout=layout)
+        return f, st.sum(0)
+    f2, s2 = run(2)
+    f2b, _ = run(2)
+    f3, s3 = run(3)
+    assert torch.equal(f2, f2b) and torch.equal(f2, f3)
+    np.testing.assert_allclose(s2.cpu().numpy(), s3.cpu().numpy(), rtol=2e-6, atol=1e-3)
+    f1, s1 = run(1)                                               # the library's own choice
+    assert torch.equal(f1, f3)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    ref = torch.nn.functional.conv2d(dense.double(), w.double(), bias.double(), stride=2, padding=3)
+    mag = torch.nn.functional.conv2d(dense.double().abs(), w.double().abs(), None, stride=2, padding=3) + 1.0 + bias.double().abs().view(1, -1, 1, 1)
+    got = S.blocked_f32_to_nhwc(f2, Ho, Wo, 64).permute(0, 3, 1, 2).double()
+    assert float(((got - ref).abs() / mag).max()) < 5e-7
+    np.testing.assert_allclose(s2[..., 0].cpu().numpy(), ref.sum(dim=(2, 3)).cpu().numpy(), rtol=1e-5, atol=5e-3)
+    np.testing.assert_allclose(s2[..., 1].cpu().numpy(), (ref * ref).sum(dim=(2, 3)).cpu().numpy(), rtol=1e-5, atol=5e-3)
+    with pytest.raises(hip.BflowHipError):                        # the persistent form is refused, not silently replaced, where it cannot run
+        S.conv_stem(cu(rs.standard_normal((1, 8, 64, 64)).astype(np.float32)), S.PackedStemWeight().get(cu(rs.standard_normal((64, 8, 7, 7)).astype(np.float32))),
+                    want_split=False, want_f32=True, layout=2)
+
+
 @pytest.mark.parametrize("case", ["two_images_u8", "two_images_f32", "ctx_plus_image_u8", "ctx41_plus_image_f32", "image_only_u8"])
 def test_conv_stem_general_input_equals_materialised(case):
     """The stem kernel assembles its input in its load (S.StemInput -> bflow_stem_desc_t.window_bases / x2 / *_dtype / *_image_norm): the two
