@@ -89,6 +89,8 @@ class TwoStepAssembler:
         self.normalize, self.merge_grids, self.version = normalize_voxel_grid, merge_grids, 1 if extended_voxel_grid else 0
         self.device = device
         self._bad = torch.zeros(1, dtype=torch.int32, device=device)
+        self.keep_last_window = True      # assemble(): reuse the last sample's current-window grid as this sample's previous one when it is the same window
+        self._kept = None
         # base.py:93-104 `load_voxel_grid`: per-window grids are cached as blosc-zstd HDF5 files (bflow_amd/voxel_cache.py)
         self.voxel_grid_dir = None
         if voxel_grid_dir is not None:
@@ -157,7 +159,15 @@ class TwoStepAssembler:
         (cf, ct), (pf, pt) = twostep_windows(forward_flow_timestamps, index)
         self._bad.zero_()     # the counter is per sample: one bad sample must not fail (or hide in) the following ones
         ev_cur = self.get_voxel_grid(events, cf, ct, flow_file_index)
-        ev_prev = self.get_voxel_grid(events, pf, pt, None if flow_file_index is None else flow_file_index - 2)
+        # In a 100-ms-step sequence the previous window of sample k + 1 is the current window of sample k (twostep.py:63-64): its grid is kept in
+        # memory (one 5-bin grid; the reference keeps the same per-window grids on disk, base.py:93-104) -- one K1 per sample instead of two.
+        key_prev = (id(events), int(pf), int(pt))
+        keep = self.keep_last_window and self.merge_grids          # (the unmerged form normalises the two grids in place)
+        if keep and self._kept is not None and self._kept[0] == key_prev:
+            ev_prev = self._kept[1]
+        else:
+            ev_prev = self.get_voxel_grid(events, pf, pt, None if flow_file_index is None else flow_file_index - 2)
+        self._kept = ((id(events), int(cf), int(ct)), ev_cur) if keep else None
         if check:
             # base.py:141-142: raw coordinates must lie inside the map (one device->host read, like the reference's x.max())
             assert int(self._bad) == 0, f"{int(self._bad)} events outside the {self.height}x{self.width} rectification map"

@@ -157,6 +157,9 @@ class EventFrameGraph:
 
     * serial (default): replay = 2 x K1 + merge + K2 of frame k, then frame k's forward.  No eager launch, no host gap between the
       assembly's ten launches, no frame of latency:      out = g(forward_flow_timestamps, index)
+      Consecutive frames of a 100-ms-step stream share a window (frame k + 1's previous window IS frame k's current one, twostep.py:63-64):
+      its 5-bin grid is kept and the replay runs ONE K1 (`reuse_windows`, decided on the host by comparing the window descriptors; the
+      reference caches the same per-window grids on disk, base.py:93-104).  Any other frame order falls back to both windows.
     * `overlap=True`: the assembly of frame k + 1 as a BRANCH of the graph that runs frame k's forward, on the forward's own side stream
       behind the context encoder (idle during the batch-1 GRU loop; the graph keeps two parallel chains -- more are not safe on this
       runtime: ConcurrentRunner); two graphs alternate (forward on grid[p], assembly into grid[1 - p]):
@@ -173,7 +176,8 @@ class EventFrameGraph:
 
     SURVEY 8(f-1) / twostep.py:44-100 feeding raft.py:101-200; measured by bench.py `pipeline_from_events`."""
 
-    def __init__(self, model, assembler, events, iters: int = 12, max_events: Optional[int] = None, overlap: bool = False):
+    def __init__(self, model, assembler, events, iters: int = 12, max_events: Optional[int] = None, overlap: bool = False,
+                 reuse_windows: bool = True):
         assert assembler.merge_grids and assembler.normalize and assembler.version == 1 and assembler.voxel_grid_dir is None, \
             "EventFrameGraph: merged, normalised, extended voxel grids built from the events (the DSEC two-step default)"
         self.model, self.asm, self.events, self.iters, self.overlap = model, assembler, events, iters, bool(overlap)
@@ -191,6 +195,11 @@ class EventFrameGraph:
         self._pin_ev = [None] * 4
         self._graphs = [None, None]
         self._outs = [None, None]
+        self.reuse_windows = bool(reuse_windows)
+        self._serial = {}           # serial form: previous window reused? -> (graph, static outputs)
+        self._last_cur = None       # descriptor of the window whose grid parts[1] holds (the last frame's current window)
+        self._rows = None
+        self.k1_launch_sets = 0     # K1 launch sequences replayed so far (2 per frame, 1 where the previous window was reused)
         self._p = 0                 # grid[_p] holds the frame whose forward runs next
         self._pending = False
         self._n = 0
@@ -198,17 +207,26 @@ class EventFrameGraph:
         self._weights = WeightsWatch(model)
 
     # -- the assembly as capturable launches: windows from self.win, everything else static
-    def _assemble(self, out: torch.Tensor):
+    def _assemble(self, out: torch.Tensor, reuse_prev: bool = False, keep: bool = False):
+        """The current window (descriptor row 0) -> parts[0]; the previous one (row 1) -> parts[1], unless `reuse_prev`: then parts[1] already
+        holds it (it was the current window of the frame before: twostep.py:63-64, 100-ms steps).  `keep`: the current window's grid is copied
+        to parts[1] behind the merge, for the next frame (6 MB device to device: ONE captured variant serves every consecutive frame --
+        alternating two executables with swapped slots instead measured slower than assembling both windows)."""
         a, ev = self.asm, self.events
         a._bad.zero_()
-        for j, part in ((0, self.parts[0]), (1, self.parts[1])):
-            hip.voxel_grid_rectified_window(ev.x, ev.y, ev.p, ev.t, self.win[j], self.max_events, a.rectify_events_map, part, self.ws, a._bad)
-        hip.voxel_merge_norm(self.parts[1], self.parts[0][1:], out, workspace=self.norm_ws)      # cat((previous, current[1:])), twostep.py:77-85
+        cur, prev = self.parts[0], self.parts[1]
+        hip.voxel_grid_rectified_window(ev.x, ev.y, ev.p, ev.t, self.win[0], self.max_events, a.rectify_events_map, cur, self.ws, a._bad)
+        if not reuse_prev:
+            hip.voxel_grid_rectified_window(ev.x, ev.y, ev.p, ev.t, self.win[1], self.max_events, a.rectify_events_map, prev, self.ws, a._bad)
+        hip.voxel_merge_norm(prev, cur[1:], out, workspace=self.norm_ws)      # cat((previous, current[1:])), twostep.py:77-85
+        if keep:
+            prev.copy_(cur)
 
     def _write_windows(self, forward_flow_timestamps, index: int):
         from .dsec import twostep_windows
         (cf, ct), (pf, pt) = twostep_windows(forward_flow_timestamps, index)
         rows = [self.asm.window_descriptor(self.events, cf, ct), self.asm.window_descriptor(self.events, pf, pt)]
+        self._rows = rows
         for r in rows:
             assert r[1] <= self.max_events, f"window of {r[1]} events: EventFrameGraph was planned for {self.max_events} (max_events)"
         slot = self._n & 3
@@ -222,7 +240,7 @@ class EventFrameGraph:
         e.record()
         self._pin_ev[slot] = e
 
-    def _capture(self, p: int):
+    def _capture(self, p: int, reuse_prev: bool = False, keep: bool = False):
         m = self.model
         assert not m.training, "inference only"
         with torch.inference_mode(False), torch.no_grad():
@@ -241,12 +259,12 @@ class EventFrameGraph:
                         low, ups = m._iterate(fr, self.iters, True)
                         br.join()
                     else:
-                        self._assemble(self.grid[p])
+                        self._assemble(self.grid[p], reuse_prev, keep)
                         low, ups = m._forward_impl(self.grid[p][None], None, self.iters, None, True)
             finally:
                 if gc_on:
                     gc.enable()
-        self._graphs[p], self._outs[p] = g, (low, ups[-1])
+        return g, (low, ups[-1])
 
     def __call__(self, forward_flow_timestamps, index: int):
         """Serial form (`overlap=False`, the default): ONE replay = assembly of frame `index` + its forward; returns its curves."""
@@ -255,12 +273,20 @@ class EventFrameGraph:
             if self._weights.changed():
                 self.close()
             self._write_windows(forward_flow_timestamps, index)
-            if self._graphs[0] is None:
+            # The previous window of this frame is the current window of the frame before (a 100-ms-step stream, twostep.py:63-64): its 5-bin
+            # grid is still in parts[last slot] -- ONE K1 per frame instead of two.  (The reference caches exactly these per-window grids,
+            # on disk: base.py:93-104.)  Two captured variants: both windows, or the current one only.
+            reuse = self.reuse_windows and self._last_cur is not None and self._rows[1] == self._last_cur
+            if not self._serial:
                 with torch.inference_mode(False):
                     self._assemble(self.grid[0])       # a real grid under the capture's warm-up forward
-                self._capture(0)
-            self._graphs[0].replay()
-            low, up = self._outs[0]
+                reuse = False                          # (parts[1] now holds THIS frame's previous window, not a kept one)
+            if reuse not in self._serial:
+                self._serial[reuse] = self._capture(0, reuse, self.reuse_windows)
+            g, (low, up) = self._serial[reuse]
+            g.replay()
+            self._last_cur = self._rows[0] if self.reuse_windows else None
+            self.k1_launch_sets += 1 if reuse else 2
             return BezierCurves(low.clone()), BezierCurves(up.clone())
 
     def submit(self, forward_flow_timestamps, index: int):
@@ -279,7 +305,7 @@ class EventFrameGraph:
             p = self._p
             if self._graphs[p] is None:
                 # the windows just written belong to the NEXT frame; the capture's warm-up forward reads grid[p] only
-                self._capture(p)
+                self._graphs[p], self._outs[p] = self._capture(p)
             self._graphs[p].replay()
             low, up = self._outs[p]
             self._p = 1 - p
@@ -298,9 +324,10 @@ class EventFrameGraph:
         return int(self.asm._bad)
 
     def close(self):
-        if any(g is not None for g in self._graphs):
+        if any(g is not None for g in self._graphs) or self._serial:
             torch.cuda.synchronize(self.device)        # (ConcurrentRunner.close: a graph is destroyed only after its last replay has finished)
         self._graphs, self._outs = [None, None], [None, None]
+        self._serial, self._last_cur = {}, None
 
     def __del__(self):
         try:

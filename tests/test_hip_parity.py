@@ -2022,6 +2022,8 @@ def test_event_frame_graph_matches_eager():
         for k, (low, up) in zip(frames, got):          # the serial form (one replay = this frame's assembly + forward)
             low1, up1 = gs(ts, k)
             assert torch.equal(low.get_params(), low1.get_params()) and torch.equal(up.get_params(), up1.get_params()), f"serial form, frame {k}"
+        # frames 1 -> 2 -> 3 are consecutive: the previous window's grid is reused (ONE K1 each); 3 -> 2, 2 -> 1, 1 -> 3 are not
+        assert gs.k1_launch_sets == 2 + 1 + 1 + 2 + 2 + 2
         m.enable_hipgraph(False)            # the reference chain: eager assembly (host-side windows), eager forward
         for k, (low, up) in zip(frames, got):
             vox = asm.assemble(stream, ts, k)

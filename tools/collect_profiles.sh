@@ -13,7 +13,7 @@ for t in fp8_cross store_patterns; do
   [ -x "$REPO/tools/micro/$t" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o "$REPO/tools/micro/$t" "$REPO/tools/micro/$t.hip" || { echo "collect_profiles: cannot build tools/micro/$t" >&2; exit 1; }
 done
 PROBE="python $REPO/tools/roofline_probe.py"
-KEYS="roofline roofline_update_conv roofline_corr_build roofline_corr_build_split roofline_lookup roofline_lookup_c4_shard roofline_corr_build_c5 roofline_conv3x3_c4 roofline_conv_stream_nin_c4 roofline_gru_conv_c4"
+KEYS="${KEYS:-roofline roofline_update_conv roofline_corr_build roofline_corr_build_split roofline_lookup roofline_lookup_c4_shard roofline_corr_build_c5 roofline_conv3x3_c4 roofline_conv_stream_nin_c4 roofline_gru_conv_c4}"     # (KEYS=... QUICK=1: a dry run of the counter passes on a subset, nothing copied to profiles/)
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
 
 # ---- (1) fabric traffic (FETCH_SIZE / WRITE_SIZE, separate passes: MI355X_MICROARCH.md, rocprofv3 PMC slots) and matrix-core busy cycles of
@@ -31,6 +31,7 @@ rm -rf /tmp/pmc; timeout 300 rocprofv3 --pmc $SQ --output-format csv -d /tmp/pmc
 f=$(find /tmp/pmc -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/calib_MFMA.csv"
 python "$REPO/tools/pmc_to_json.py" "$OUT" "$OUT/${R}_pmc.json" > "$OUT/${R}_pmc_summary.txt" || { echo "collect_profiles: counters incomplete" >&2; cat "$OUT/${R}_pmc_summary.txt"; exit 1; }
 # the bench quotes the PMC traffic of kernels built from the SAME sources (kernel_source_hash): counters first, then the bench reads them
+[ -n "${QUICK:-}" ] && { cat "$OUT/${R}_pmc_summary.txt"; ls -la "$OUT"; exit 0; }
 cp "$OUT/${R}_pmc.json" "$REPO/profiles/${R}_pmc.json"
 
 # ---- (2) the bench line, and the kernel traces: C2 ONLY (the frame's budget per kernel) and the full default command
