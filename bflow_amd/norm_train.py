@@ -127,7 +127,8 @@ def _norm_elementwise(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
 def norm_act(module: nn.Module, x: torch.Tensor, relu: bool) -> torch.Tensor:
     """[relu](module(x)) for the norm layers of the encoders: on the HIP kernels in GPU training mode; the GPU cases those kernels do not
     cover (eval-mode BatchNorm after `freeze_bn()`, unaligned planes, ...) as torch element-wise arithmetic (`_norm_elementwise`), never on
-    the vendor library; GroupNorm on a GPU tensor is refused (the engine has no GroupNorm, RAFTSpline.check_engine_support says so up front).
+    the vendor library; GroupNorm on a GPU tensor is refused (the TRAINING kernels have no GroupNorm: training.forward_train says so before the
+    first launch; the inference engine runs it, extractor.py BasicEncoder._group_stats).
     CPU tensors (the oracle tests) run the module itself."""
     mode = _supported(module, x)
     if mode is None:

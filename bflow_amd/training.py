@@ -363,6 +363,20 @@ def _update_block_train(ub, net, inp, corr, bezier, merged=None):
 def forward_train(model, voxel_grid: Optional[torch.Tensor], images: Optional[List[torch.Tensor]], iters: int,
                   flow_init: Optional[torch.Tensor]) -> Tuple[torch.Tensor, List[BezierCurves]]:
     """raft.py:101-200 under autograd: (low-resolution parameters, one up-sampled BezierCurves per GRU iteration)."""
+    # What the differentiable path does not run is refused HERE, before the first launch (the eval engine's check_engine_support covers more:
+    # GroupNorm encoders and zero-padded feature dims exist on the inference engine only).
+    bad = []
+    for name in ("fnet_ev", "fnet_img", "cnet"):
+        net_ = getattr(model, name)
+        if net_ is None:
+            continue
+        if net_.norm_fn == "group":
+            bad.append(f"{name}.norm_fn = 'group' (GroupNorm has no training kernels: norm_train.py)")
+        if name != "cnet" and net_.conv2.out_channels not in (64, 128, 256):
+            bad.append(f"{name} output dim {net_.conv2.out_channels} (the training correlation contracts 64, 128 or 256 feature channels; other dims are "
+                       "zero-padded on the inference engine only)")
+    if bad and (voxel_grid if voxel_grid is not None else images[0]).is_cuda:
+        raise hip.BflowHipError("RAFTSpline training forward on the GPU: not supported: " + "; ".join(bad))
     hdim, cdim = model.hidden_dim, model.context_dim
     groups = []
     context_input = None

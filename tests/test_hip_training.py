@@ -582,3 +582,27 @@ def test_adjoint_identities_at_dsec_size():
     gd, _ = hip.cvx_upsample_bwd(gu, data, mask)
     l3, r3 = float((up.double() * gu.double()).sum()), float((data.double() * gd.double()).sum())
     assert abs(l3 - r3) < 1e-5 * float(up.double().norm() * gu.double().norm())
+
+
+@pytest.mark.parametrize("what", ["group_norm", "feature_dim_96"])
+def test_training_forward_refuses_what_only_the_inference_engine_runs(what):
+    """GroupNorm encoders and zero-padded feature dims exist on the inference engine only (round 5): a training-mode forward on the GPU says so
+    BEFORE its first launch (training.forward_train) instead of failing inside a normalisation layer -- and the same model runs in eval()."""
+    import copy
+    from bflow_amd import configs, synthetic
+    cfg = copy.deepcopy(configs.model_config("E_LU4_BD2"))
+    if what == "group_norm":
+        cfg["feature"]["norm"] = "group"
+    else:
+        cfg["feature"]["dim"] = 96
+    m = bflow_amd.RAFTSpline(cfg)
+    m.load_state_dict(O.make_state_dict(cfg, seed=2, gain=0.35))
+    m.to(DEV)
+    vox = torch.from_numpy(synthetic.voxel_grid(1, 9, 64, 96, seed=3)).to(DEV)
+    m.train()
+    with pytest.raises(hip.BflowHipError, match="training forward"):
+        m(voxel_grid=vox, iters=2)
+    m.eval()
+    with torch.inference_mode():
+        low, up = m(voxel_grid=vox, iters=2, test_mode=True)
+    assert bool(torch.isfinite(up.get_params()).all())
