@@ -28,7 +28,7 @@ from .conv_train import Conv2d   # nn.Conv2d whose GPU training forward / backwa
 # 40 us at 38400 (batch 8) where its grid fills the chip -- measured cross-over near 24000 pixels.
 # Small-grid decisions (batch x h x w pixels), one constant each so that moving ONE cross-over for an A/B does not silently change the others.
 # SMALL_GRID_MAX_PIXELS (batch 1-4 at 60 x 80) is where they all sit today:
-SMALL_GRID_MAX_PIXELS = 20000
+SMALL_GRID_MAX_PIXELS = int(os.environ.get("BFLOW_SMALL_GRID_MAX_PIXELS", "20000"))     # (env: tools A/B, tools/c4_rank_probe.py)
 THIN_HEAD_MAX_PIXELS = int(os.environ.get("BFLOW_THIN_HEAD_MAX_PIXELS", str(SMALL_GRID_MAX_PIXELS)))   # thin Bezier head vs the MFMA halo kernel (env: tools A/B)
 ONE_QUEUE_MAX_PIXELS = SMALL_GRID_MAX_PIXELS     # the motion encoder's two branches as pair launches on one queue (else a side stream)
 MASK_TILE96_MAX_PIXELS = SMALL_GRID_MAX_PIXELS   # 96-channel tiles for the mask head's 1x1 (one round of 228 workgroups at batch 1)
