@@ -510,3 +510,31 @@ def test_split_tensor_pad_rows_and_the_lookup_callable():
     class Rows:                                        # a row-major pyramid has no rider
         def lookup_bezier_split(self, *a, **k): return None
     assert not SplitLookup(Rows(), 0, 0, 0).im2col_rider
+
+
+def test_window_descriptors_of_the_twostep_assembly_on_the_host():
+    """TwoStepAssembler.window_descriptor (what bflow_voxel_grid_rectified_window reads from device memory): the extended window of
+    base.py:165-200 as {first event, count, centres}, equal to the slice EventStream.window hands the plain K1 call; consecutive frames of a
+    100-ms-step sequence share a window (twostep.py:63-64) -- the condition EventFrameGraph / assemble() reuse a grid on.  Host logic only."""
+    import numpy as np
+    from bflow_amd.dsec import EventStream, TwoStepAssembler, event_window_indices, twostep_windows
+    rs = np.random.RandomState(3)
+    n = 20000
+    t = np.sort(rs.randint(1_000_000, 1_400_000, n)).astype(np.int64)
+    ev = EventStream.__new__(EventStream)              # host fields only (no device in the CPU tier)
+    ev.t_host = t
+    asm = TwoStepAssembler.__new__(TwoStepAssembler)
+    from bflow_amd.representations import VoxelGrid
+    asm.voxel_grid, asm.version = VoxelGrid(5, 48, 64), 1
+    ts = np.array([[1_030_000 + 100_000 * k, 1_130_000 + 100_000 * k] for k in range(3)], dtype=np.int64)
+    for k in range(3):
+        i0, cnt, t0c, t1c = asm.window_descriptor(ev, int(ts[k][0]), int(ts[k][1]))
+        ta, tb = asm.voxel_grid.get_extended_time_window(int(ts[k][0]), int(ts[k][1]))
+        ta, tb = max(ta, int(t[0])), min(tb, int(t[-1]))
+        assert (i0, i0 + cnt) == event_window_indices(t, ta, tb) and (t0c, t1c) == (int(ts[k][0]), int(ts[k][1]))
+        assert cnt > 0 and np.all(t[i0:i0 + cnt] >= ta) and np.all(t[i0:i0 + cnt] < tb)
+        assert (i0 == 0 or t[i0 - 1] < ta) and (i0 + cnt == n or t[i0 + cnt] >= tb)
+    assert twostep_windows(ts, 2)[1] == twostep_windows(ts, 1)[0]          # frame 2's previous window IS frame 1's current one
+    asm.version = 0
+    with pytest.raises(AssertionError, match="extended_voxel_grid"):
+        asm.window_descriptor(ev, int(ts[0][0]), int(ts[0][1]))
