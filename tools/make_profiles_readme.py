@@ -90,6 +90,7 @@ the sources still hash to the same value.  Every roofline entry of the bench lin
 | `r06_k7_valu_diet.txt`, `r06_k7_tp_cols.txt` | `tools/k7_ab.sh`, `tools/k7_abl.sh`, `tools/k7_tp.sh` | K7 against the round-5 kernel on one box (C2 11.6 → 10.5 µs, C4 shard 66–67 → 56.0 µs: per-pair gather instructions, both axes per tap thread with `exact_div`, two-pass packed interpolation, hardware split, trimmed gather), its phase ablations, pixels per workgroup × phase-C form |
 | `r06_stem_persist.txt` | `tools/stem_probe.py`, `tools/stem_ablate.sh`, `tools/ab_bench.sh "BFLOW_STEM_PERSIST=0" "" 3` | the stem: anatomy of the per-patch kernel (epilogue 58 + loads 34 + MFMA 31 + weight stream 17 of 120 µs), the persistent form (119 → 81 µs at 5 images, 640 → 520 µs at 40; bit-identical), its own ablations, the 4-wave weights-in-registers form (slower), frame A/B (`c4_strong` +1.05 %, batch 1 neutral) |
 | `r06_pipeline_graph.txt` | `tools/pipeline_probe.py`, `tools/pipeline_graph_probe.py` | raw events → flow as one replay per frame: serial vs branch form (the branch next to the GRU loop is SLOWER), eager assembly has no host gaps in steady state, one K1 per consecutive frame (3.60 → 3.48 ms) |
+| `r06_k1_place_ablation.txt` | `rocprofv3 --kernel-trace --stats -- python tools/k1_rect_probe.py`; `tools/k1_probe.py` with `BFLOW_VOXEL_STAGE=1 / 0` on the patched build | K1 on the DSEC two-step shape kernel by kernel (`place` 56 µs = loads 17 + map gather ≈ 20 + scattered record stores ≈ 30; `gather` 30; `count` 24) and the LDS-staged record placement: built, bit-identical, 7–17 % slower, not kept |
 | `r06_thin_head_b8_ab.txt`, `r06_direct_nt4_ab.txt` | `tools/ab_bench.sh …` | two batch-8 levers measured and not kept: the thin Bézier head above 20 000 pixels (slower), a 128-channel tile for the 1×1 direct kernel (no gain) |
 | `r06_mfma_clock_fp8_cross.txt`, `r06_store_patterns.txt`, `r06_k5_modes.txt`, `r06_corr_precision_e2e.txt`, `r06_k1_probe.txt` | as in round 5 (`README_r05.md`) | re-collected on this round's box (sustained clock of a pure MFMA stream, store ceilings, K5 per arithmetic, correlation precision end to end, K1) |
 
