@@ -5,7 +5,8 @@
 // 120 us = epilogue 58 + patch loads 34 + MFMAs 31 + weight stream 17, the parts ADD UP -- profiles/r06_stem_persist.txt): every workgroup
 // streams the whole 88-KB weight set through a two-slot ring with a full wait + barrier per k-block, loads its patch before its first MFMA
 // and drains its stores behind its last one.  Here:
-//   * ONE 8-wave workgroup per CU keeps the WHOLE packed weight set resident in LDS (CH = 5: 11 k-blocks x 8 KB), loaded once;
+//   * ONE 8-wave workgroup per CU keeps the WHOLE packed weight set resident in LDS (CH = 5: 11 k-blocks x 8 KB), loaded once (NWV = 8,
+//     WREG = 0: the product; the 4-wave forms with weight fragments in registers are tools variants, measured slower);
 //   * a WAVE is the unit of work: it owns slabs of 2 x 16 output pixels x 64 channels, with a PRIVATE LDS image of the slab's 9 x 37 x CH
 //     input window (split once into hi / lo planes, [row][column][channel] as in the row-window kernel: the same fragments, the same
 //     MFMA sequence per accumulator -> bit-identical outputs).  Nothing is shared between waves but the read-only weights: the k-loop has
@@ -16,8 +17,8 @@
 //     CU's vector cache), a wave keeps its InstanceNorm sums in fp64 registers and issues its atomics when the image changes or it is done;
 //   * the vector ALU work per slab is what the matrix work is measured against (one wave's MFMAs cover the other wave's VALU phases, not its
 //     own): interior slabs take per-lane offsets computed ONCE (window loads: 6 relative offsets + a scalar offset per channel; stores: one
-//     lane offset + 16 scalar offsets), and the hi / lo split is the hardware's (FP16_OVFL + flushed fp16 results, two values per
-//     instruction -- corr_lookup_tile.hip phase D: 3 instead of 12 instructions per value).
+//     lane offset + 16 scalar offsets), and the hi / lo split runs on packed conversions, two values per instruction, with the clamp as the
+//     hardware's (FP16_OVFL) and the "hi = 0 below 2^-14" select explicit: 5 instead of 12 instructions per value.
 #pragma once
 
 #ifndef STEMP_ABL
