@@ -29,3 +29,8 @@ with torch.inference_mode():
     print(f"   1 x 8  {timed(lambda: m(voxel_grid=v8, iters=12, test_mode=True), 8):.1f} frames/s", flush=True)
     v4s = vox(4, 0)
     print(f"   1 x 4  {timed(lambda: m(voxel_grid=v4s, iters=12, test_mode=True), 4):.1f} frames/s", flush=True)
+    for nb in (8, 16):
+        vv = [vox(nb, 0), vox(nb, 1)]
+        pr = ConcurrentRunner(m, 12, streams=2)
+        print(f"   2 x {nb} in flight  {timed(lambda: pr(vv), 2 * nb, k=6):.1f} frames/s", flush=True)
+        pr.close()
