@@ -1858,6 +1858,11 @@ def test_conv_stem_persistent_equals_per_patch_kernel(H, W, B, windows):
     assert float(((got - ref).abs() / mag).max()) < 5e-7
     np.testing.assert_allclose(s2[..., 0].cpu().numpy(), ref.sum(dim=(2, 3)).cpu().numpy(), rtol=1e-5, atol=5e-3)
     np.testing.assert_allclose(s2[..., 1].cpu().numpy(), (ref * ref).sum(dim=(2, 3)).cpu().numpy(), rtol=1e-5, atol=5e-3)
+    # the affine + ReLU epilogue (no statistics) through both forms
+    sc = cu(rs.uniform(0.5, 1.5, 64).astype(np.float32))
+    _, a2 = S.conv_stem(x, pk, scale=sc, shift=bias, act=S.ACT_RELU, want_split=False, want_f32=True, layout=2)
+    _, a3 = S.conv_stem(x, pk, scale=sc, shift=bias, act=S.ACT_RELU, want_split=False, want_f32=True, layout=3)
+    assert torch.equal(a2, a3) and float(a2.min()) >= 0.0 and float(a2.max()) > 0.5
     with pytest.raises(hip.BflowHipError):                        # the persistent form is refused, not silently replaced, where it cannot run
         S.conv_stem(cu(rs.standard_normal((1, 8, 64, 64)).astype(np.float32)), S.PackedStemWeight().get(cu(rs.standard_normal((64, 8, 7, 7)).astype(np.float32))),
                     want_split=False, want_f32=True, layout=2)
